@@ -1,0 +1,376 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own modules.
+
+Run in the authoring container only (needs /root/reference, which never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The fixtures hold DATA only -- inputs (or the seeds that regenerate them through
+oracle.*.synth_state / stcd_amd.synth), outputs, and gradient summaries.  Weights are
+not stored: both the generator and the tests rebuild them from the same numpy seed.
+
+Groups:
+  G1  per-op vectors through the torch.nn modules exactly as the reference configures them
+  G2  whole-model eval/train forward + loss + all parameter gradients (diff/conc/sub/SNUNet)
+  G3  config-1 step: SiamUnet_diff(3,2) [2,3,256,256], CE and sigmoid+cd_loss, Adam/AdamW deltas
+  G4  5-step loss trajectory
+  G5  confusion-matrix metrics (independent check through scikit-learn)
+  G6  odd-size (100x100) forward -- ReplicationPad2d branch
+"""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+sys.path.insert(1, "/root/reference")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from models.SiamUnet_diff import SiamUnet_diff      # noqa: E402  (reference)
+from models.SiamUnet_conc import SiamUnet_conc      # noqa: E402
+from models.SiamUnet_sub import SiamUnet_sub        # noqa: E402
+from models.SNUNet import SNUNet_ECAM               # noqa: E402
+from models import losses as ref_losses             # noqa: E402
+
+from oracle import fcsiam_ref, snunet_ref           # noqa: E402  (only for synth_state / synth_masks)
+from stcd_amd import synth                          # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+REF_CLS = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub}
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"  wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+class MaskFeeder(nn.Module):
+    """Stands in for nn.Dropout2d: multiplies by externally supplied [N,C] masks, B rows per call."""
+
+    def __init__(self, mask):
+        super().__init__()
+        self.mask, self.pos = mask, 0
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        b = x.shape[0]
+        m = self.mask[self.pos:self.pos + b]
+        self.pos += b
+        return x * m[:, :, None, None]
+
+
+def install_masks(model, masks):
+    for name, m in masks.items():
+        assert isinstance(getattr(model, name), nn.Dropout2d)
+        setattr(model, name, MaskFeeder(m))
+
+
+def unwrap(out):
+    return out[-1] if isinstance(out, (list, tuple)) else out
+
+
+def grad_summary(model, full_for=()):
+    """Per-parameter [sum, l2, first 8, 24 strided samples]; full tensors for a chosen few."""
+    out = {}
+    for name, p in model.named_parameters():
+        g = p.grad.detach().flatten().double()
+        n = g.numel()
+        idx = (np.arange(24) * max(n // 24, 1)) % n
+        summ = np.concatenate([[g.sum().item(), g.norm().item()], t2n(g[:8]) if n >= 8 else np.pad(t2n(g), (0, 8 - n)),
+                               t2n(g[idx])])
+        out["gs/" + name] = summ
+        if name in full_for:
+            out["gf/" + name] = t2n(p.grad)
+    return out
+
+
+def rand_pair(seed, n, h, w):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((n, 3, h, w)).astype(np.float32)
+    b = (a + 0.5 * rng.standard_normal((n, 3, h, w))).astype(np.float32)
+    return torch.from_numpy(a), torch.from_numpy(b)
+
+
+# ------------------------------------------------------------------------------ G1
+def g1_ops():
+    print("G1 per-op")
+    rng = np.random.default_rng(101)
+    r = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    d = {}
+
+    def run(tag, mod, x, extra=None):
+        x = x.clone().requires_grad_(True)
+        y = mod(x)
+        gy = r(*y.shape)
+        y.backward(gy)
+        d[f"{tag}/x"], d[f"{tag}/y"], d[f"{tag}/gy"], d[f"{tag}/dx"] = t2n(x), t2n(y), t2n(gy), t2n(x.grad)
+        for n_, p in mod.named_parameters():
+            d[f"{tag}/{n_}"] = t2n(p)
+            d[f"{tag}/d{n_}"] = t2n(p.grad)
+
+    run("conv_3_16", nn.Conv2d(3, 16, kernel_size=3, padding=1), r(2, 3, 8, 8))            # SiamUnet_diff.py:18
+    run("conv_16_32", nn.Conv2d(16, 32, kernel_size=3, padding=1), r(2, 16, 12, 10))       # :25
+    run("convT_s1_32_16", nn.ConvTranspose2d(32, 16, kernel_size=3, padding=1), r(2, 32, 8, 8))  # :87
+    run("convT_s2_16_16", nn.ConvTranspose2d(16, 16, kernel_size=3, padding=1, stride=2, output_padding=1),
+        r(2, 16, 6, 5))                                                                      # :85
+    run("convT_k2s2_32", nn.ConvTranspose2d(32, 32, 2, stride=2), r(2, 32, 4, 4))          # SNUNet.py:38
+    run("conv1x1_128_2", nn.Conv2d(128, 2, kernel_size=1), r(2, 128, 6, 6))                # SNUNet.py:106
+
+    # BatchNorm2d train step incl. running stats (SiamUnet_diff.py:19)
+    bn = nn.BatchNorm2d(16)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * r(16)); bn.bias.copy_(0.1 * r(16))
+        bn.running_mean.copy_(0.1 * r(16)); bn.running_var.copy_(1 + 0.2 * r(16).abs())
+    d["bn/rm0"], d["bn/rv0"] = t2n(bn.running_mean), t2n(bn.running_var)
+    bn.train()
+    run("bn", bn, 1.5 * r(2, 16, 8, 8) + 0.3)
+    d["bn/rm1"], d["bn/rv1"], d["bn/nbt1"] = t2n(bn.running_mean), t2n(bn.running_var), t2n(bn.num_batches_tracked)
+    bn.eval()
+    d["bn/y_eval"] = t2n(bn(torch.from_numpy(d["bn/x"])))
+
+    # max-pool with ties (post-ReLU zeros tie constantly)
+    x = torch.relu(r(2, 4, 8, 8)); x[0, 0, 0:2, 0:2] = 0.7
+    x = x.requires_grad_(True)
+    y = F.max_pool2d(x, kernel_size=2, stride=2); gy = r(*y.shape); y.backward(gy)
+    d["pool/x"], d["pool/y"], d["pool/gy"], d["pool/dx"] = t2n(x), t2n(y), t2n(gy), t2n(x.grad)
+    x = r(1, 2, 7, 5).requires_grad_(True)   # odd size: floor
+    y = F.max_pool2d(x, kernel_size=2, stride=2); gy = r(*y.shape); y.backward(gy)
+    d["pool_odd/x"], d["pool_odd/y"], d["pool_odd/gy"], d["pool_odd/dx"] = t2n(x), t2n(y), t2n(gy), t2n(x.grad)
+
+    # skip fusions (SiamUnet_diff.py:150, SiamUnet_sub.py:150)
+    a = r(2, 8, 4, 4).requires_grad_(True); b = r(2, 8, 4, 4)
+    with torch.no_grad():
+        b[0, 0] = a[0, 0]                     # exact ties -> abs' = 0
+    b = b.requires_grad_(True)
+    g = r(2, 8, 4, 4)
+    torch.abs(a - b).backward(g)
+    d["fuse/a"], d["fuse/b"], d["fuse/g"] = t2n(a), t2n(b), t2n(g)
+    d["fuse/abs"], d["fuse/abs_da"], d["fuse/abs_db"] = t2n(torch.abs(a - b)), t2n(a.grad), t2n(b.grad)
+
+    # ReplicationPad2d((0,1,0,1)) (SiamUnet_diff.py:149)
+    x = r(1, 3, 4, 5).requires_grad_(True)
+    y = nn.ReplicationPad2d((0, 1, 0, 1))(x); gy = r(*y.shape); y.backward(gy)
+    d["rpad/x"], d["rpad/y"], d["rpad/gy"], d["rpad/dx"] = t2n(x), t2n(y), t2n(gy), t2n(x.grad)
+
+    # losses (models/losses.py:6-21 and :24-34)
+    lg = (2 * r(2, 2, 8, 8)).requires_grad_(True)
+    tg = torch.from_numpy(rng.integers(0, 2, size=(2, 8, 8))).long()
+    tg[0, 0, :3] = 255
+    loss = ref_losses.cross_entropy(lg, tg.float().unsqueeze(1)); loss.backward()
+    d["ce/logits"], d["ce/target"], d["ce/loss"], d["ce/dlogits"] = t2n(lg), t2n(tg), loss.item(), t2n(lg.grad)
+    lg = (3 * r(2, 1, 8, 8)).requires_grad_(True)
+    tg = torch.from_numpy(rng.integers(0, 2, size=(2, 1, 8, 8))).float()
+    loss = ref_losses.cd_loss(torch.sigmoid(lg), tg); loss.backward()
+    d["cd/logits"], d["cd/target"], d["cd/loss"], d["cd/dlogits"] = t2n(lg), t2n(tg), loss.item(), t2n(lg.grad)
+    lg = torch.tensor([[[[60.0, -60.0, 120.0, -120.0]]]], requires_grad=True)  # saturation / clamp(-100) branch
+    tg = torch.tensor([[[[0.0, 1.0, 0.0, 1.0]]]])
+    loss = ref_losses.cd_loss(torch.sigmoid(lg), tg); loss.backward()
+    d["cd_sat/logits"], d["cd_sat/target"], d["cd_sat/loss"], d["cd_sat/dlogits"] = t2n(lg), t2n(tg), loss.item(), t2n(lg.grad)
+    save("g1_ops.npz", **d)
+
+
+# ------------------------------------------------------------------------------ G2
+FULL_GRADS = ("conv11.weight", "conv11.bias", "bn12.weight", "bn12.bias", "conv22.weight", "bn43.weight",
+              "upconv4.bias", "upconv1.weight", "conv12d.weight", "conv11d.weight", "conv11d.bias", "bn21d.bias")
+
+
+def g2_fcsiam():
+    for arch in ("diff", "conc", "sub"):
+        for label in (1, 2):
+            print(f"G2 {arch} label={label}")
+            seed = 200 + 10 * fcsiam_ref.ARCHS.index(arch) + label
+            d = {"seed": seed, "label": label}
+            x1, x2 = rand_pair(seed + 1, 2, 32, 32)
+            d["x1"], d["x2"] = t2n(x1), t2n(x2)
+            # eval with perturbed running stats
+            m = REF_CLS[arch](3, label)
+            m.load_state_dict(fcsiam_ref.synth_state(arch, 3, label, seed, perturb_running=True))
+            m.eval()
+            with torch.no_grad():
+                d["logits_eval"] = t2n(unwrap(m(x1, x2)))
+                y1, y2 = rand_pair(seed + 2, 1, 64, 64)
+                d["y1"], d["y2"] = t2n(y1), t2n(y2)
+                d["logits_eval_64"] = t2n(unwrap(m(y1, y2)))
+            # train step with supplied dropout masks
+            m = REF_CLS[arch](3, label)
+            m.load_state_dict(fcsiam_ref.synth_state(arch, 3, label, seed))
+            install_masks(m, fcsiam_ref.synth_masks(arch, 2, seed + 3))
+            m.train()
+            logits = unwrap(m(x1, x2))
+            rng = np.random.default_rng(seed + 4)
+            tgt = torch.from_numpy((rng.random((2, 32, 32)) < 0.2).astype(np.int64))
+            d["target"] = t2n(tgt)
+            if label == 2:
+                loss = ref_losses.cross_entropy(logits, tgt)
+            else:
+                loss = ref_losses.cd_loss(torch.sigmoid(logits), tgt.float().unsqueeze(1))
+            loss.backward()
+            d["logits_train"], d["loss"] = t2n(logits), loss.item()
+            d.update(grad_summary(m, FULL_GRADS))
+            sd = m.state_dict()
+            for k in ("bn11", "bn22", "bn43", "bn43d", "bn12d"):
+                d[f"rs/{k}.running_mean"] = t2n(sd[f"{k}.running_mean"])
+                d[f"rs/{k}.running_var"] = t2n(sd[f"{k}.running_var"])
+                d[f"rs/{k}.num_batches_tracked"] = t2n(sd[f"{k}.num_batches_tracked"])
+            save(f"g2_{arch}_{label}.npz", **d)
+
+
+def g2_snunet():
+    for label in (1, 2):
+        print(f"G2 snunet label={label}")
+        seed = 260 + label
+        d = {"seed": seed, "label": label}
+        x1, x2 = rand_pair(seed + 1, 2, 32, 32)
+        d["x1"], d["x2"] = t2n(x1), t2n(x2)
+        m = SNUNet_ECAM(3, label)
+        m.load_state_dict(snunet_ref.synth_state(3, label, seed, perturb_running=True))
+        m.eval()
+        with torch.no_grad():
+            d["logits_eval"] = t2n(m(x1, x2))
+        m = SNUNet_ECAM(3, label)
+        m.load_state_dict(snunet_ref.synth_state(3, label, seed))
+        m.train()
+        logits = m(x1, x2)
+        rng = np.random.default_rng(seed + 4)
+        tgt = torch.from_numpy((rng.random((2, 32, 32)) < 0.2).astype(np.int64))
+        d["target"] = t2n(tgt)
+        if label == 2:
+            loss = ref_losses.cross_entropy(logits, tgt)
+        else:
+            loss = ref_losses.cd_loss(torch.sigmoid(logits), tgt.float().unsqueeze(1))
+        loss.backward()
+        d["logits_train"], d["loss"] = t2n(logits), loss.item()
+        d.update(grad_summary(m, ("conv0_0.conv1.weight", "conv0_0.bn1.weight", "conv0_4.conv2.bias", "Up1_3.up.weight",
+                                  "Up4_0.up.bias", "ca.fc1.weight", "ca1.fc2.weight", "conv_final.weight",
+                                  "conv_final.bias", "conv4_0.bn2.bias")))
+        sd = m.state_dict()
+        for k in ("conv0_0.bn1", "conv3_0.bn2", "conv4_0.bn1", "conv0_4.bn2"):
+            d[f"rs/{k}.running_mean"] = t2n(sd[f"{k}.running_mean"])
+            d[f"rs/{k}.running_var"] = t2n(sd[f"{k}.running_var"])
+            d[f"rs/{k}.num_batches_tracked"] = t2n(sd[f"{k}.num_batches_tracked"])
+        save(f"g2_snunet_{label}.npz", **d)
+
+
+# ------------------------------------------------------------------------------ G3
+def g3_cfg1():
+    """BASELINE.json configs[0]: SiamUnet_diff 3-ch 256x256 synthetic pair, batch=2, one step."""
+    print("G3 config-1 step")
+    a, b, lab = synth.make_batch(2, 256, 256, seed=1337)
+    A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab)
+    d = {"data_seed": 1337, "label_pos_frac": float(lab.mean())}
+    samp = (np.arange(4096) * 31) % (2 * 256 * 256)
+    for tag, label, opt_name in (("ce", 2, "adamw"), ("cd", 1, "adam")):
+        seed = 300 + label
+        m = SiamUnet_diff(3, label)
+        m.load_state_dict(fcsiam_ref.synth_state("diff", 3, label, seed))
+        install_masks(m, fcsiam_ref.synth_masks("diff", 2, seed + 3))
+        m.train()
+        if opt_name == "adamw":   # trainer.py:48-50
+            opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+        else:                     # train_pse_cd.py:431
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        before = {k: v.detach().clone() for k, v in m.named_parameters()}
+        opt.zero_grad()
+        logits = m(A, B)
+        if label == 2:
+            loss = ref_losses.cross_entropy(logits, L)
+        else:
+            loss = ref_losses.cd_loss(torch.sigmoid(logits), L.float().unsqueeze(1))
+        loss.backward()
+        d[f"{tag}/seed"], d[f"{tag}/loss"] = seed, loss.item()
+        lf = logits.detach().flatten()
+        d[f"{tag}/logits_sum"], d[f"{tag}/logits_l2"] = lf.double().sum().item(), lf.double().norm().item()
+        d[f"{tag}/logits_sample_idx"] = samp[:lf.numel() if lf.numel() < 4096 else 4096] % lf.numel()
+        d[f"{tag}/logits_sample"] = t2n(lf[torch.from_numpy(d[f"{tag}/logits_sample_idx"])])
+        pred = (logits.argmax(1) if label == 2 else (torch.sigmoid(logits[:, 0]) > 0.5).long())
+        d[f"{tag}/mask_packed"] = np.packbits(t2n(pred).astype(np.uint8))
+        for k, v in grad_summary(m).items():
+            d[f"{tag}/{k}"] = v
+        opt.step()
+        for k in ("conv11.weight", "bn33.weight", "conv12d.weight"):
+            d[f"{tag}/delta/{k}"] = t2n(dict(m.named_parameters())[k].detach() - before[k])
+        sd = m.state_dict()
+        for k in ("bn11", "bn43", "bn12d"):
+            d[f"{tag}/rs/{k}.running_mean"] = t2n(sd[f"{k}.running_mean"])
+            d[f"{tag}/rs/{k}.running_var"] = t2n(sd[f"{k}.running_var"])
+    save("g3_cfg1.npz", **d)
+
+
+# ------------------------------------------------------------------------------ G4
+def g4_traj():
+    print("G4 5-step trajectory")
+    a, b, lab = synth.make_batch(2, 64, 64, seed=4242)
+    A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab)
+    seed = 400
+    m = SiamUnet_diff(3, 2)
+    m.load_state_dict(fcsiam_ref.synth_state("diff", 3, 2, seed))
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    losses = []
+    for step in range(5):
+        masks = fcsiam_ref.synth_masks("diff", 2, seed + 10 + step)
+        for name, mk in masks.items():
+            setattr(m, name, MaskFeeder(mk))
+        m.train()
+        opt.zero_grad()
+        loss = ref_losses.cross_entropy(m(A, B), L)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    print("   losses", losses)
+    save("g4_traj.npz", seed=seed, data_seed=4242, losses=np.array(losses))
+
+
+# ------------------------------------------------------------------------------ G5
+def g5_metric():
+    """The reference's SegmentationMetric lives in train_pse_cd.py (argparse + smp at import time, not
+    importable).  The fixture pins the formulae (train_pse_cd.py:313-368) through an independent
+    implementation: scikit-learn."""
+    print("G5 metrics")
+    from sklearn import metrics as skm
+
+    rng = np.random.default_rng(500)
+    lab = (rng.random((4, 1, 64, 64)) < 0.15).astype(np.int64)
+    pred = np.where(rng.random(lab.shape) < 0.85, lab, 1 - lab)
+    y, p = lab.ravel(), pred.ravel()
+    cm = skm.confusion_matrix(y, p, labels=[0, 1]).astype(np.float64)   # rows = label, cols = pred
+    save("g5_metric.npz", label=lab, pred=pred, cm=cm,
+         f1=skm.f1_score(y, p, average=None, labels=[0, 1]),
+         iou=skm.jaccard_score(y, p, average=None, labels=[0, 1]),
+         precision=skm.precision_score(y, p, average=None, labels=[0, 1]),
+         recall=skm.recall_score(y, p, average=None, labels=[0, 1]),
+         oa=skm.accuracy_score(y, p))
+
+
+# ------------------------------------------------------------------------------ G6
+def g6_odd():
+    print("G6 odd size 100x100")
+    d = {}
+    for arch in ("diff", "conc"):
+        seed = 600 + fcsiam_ref.ARCHS.index(arch)
+        x1, x2 = rand_pair(seed + 1, 1, 100, 100)
+        m = REF_CLS[arch](3, 2)
+        m.load_state_dict(fcsiam_ref.synth_state(arch, 3, 2, seed, perturb_running=True))
+        m.eval()
+        with torch.no_grad():
+            d[f"{arch}/logits"] = t2n(m(x1, x2))
+        d[f"{arch}/seed"] = seed
+    save("g6_odd.npz", **d)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6"]
+    fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd}
+    for w in which:
+        fn[w]()

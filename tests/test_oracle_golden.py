@@ -1,0 +1,142 @@
+"""The CPU oracle (oracle/*.py) against the golden vectors captured from the reference.
+
+This is what PINS the oracle: the reference has no tests of its own,
+so tests/golden/*.npz (made by tests/golden/make_golden.py from the reference's modules)
+are the only ground truth that travels.
+"""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fcsiam_ref as R
+from oracle import snunet_ref as S
+
+TOL = dict(rtol=1e-4, atol=2e-5)
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _grad_summary(g):
+    g = g.detach().flatten().double()
+    n = g.numel()
+    idx = (np.arange(24) * max(n // 24, 1)) % n
+    first = g[:8].numpy() if n >= 8 else np.pad(g.numpy(), (0, 8 - n))
+    return np.concatenate([[g.sum().item(), g.norm().item()], first, g[idx].numpy()])
+
+
+def _zero_grad_by_construction(name):
+    """A conv bias that feeds ONLY a train-mode BatchNorm has an exactly-zero gradient
+    (BN subtracts the batch mean); what autograd reports is rounding noise."""
+    if re.fullmatch(r"conv\d\dd?\.bias", name):
+        return name != "conv11d.bias"
+    return name.endswith(".conv2.bias")
+
+
+def _check_grad(name, got_t, g, rtol, atol):
+    ref = g["gs/" + name]
+    if _zero_grad_by_construction(name):
+        assert abs(ref[2:]).max() < 1e-5 and got_t.abs().max().item() < 1e-5, name
+        return
+    scale = max(ref[1], 1e-6)          # l2 of the tensor's gradient
+    np.testing.assert_allclose(_grad_summary(got_t) / scale, ref / scale, rtol=rtol, atol=atol, err_msg=name)
+    if "gf/" + name in g:
+        np.testing.assert_allclose(got_t.numpy(), g["gf/" + name], rtol=rtol, atol=atol * scale, err_msg=name)
+
+
+def _loss(label, logits, tgt):
+    if label == 2:
+        return R.cross_entropy(logits, tgt)
+    return R.cd_loss(torch.sigmoid(logits), tgt.float().unsqueeze(1))
+
+
+@pytest.mark.parametrize("arch", ["diff", "conc", "sub"])
+@pytest.mark.parametrize("label", [1, 2])
+def test_fcsiam_eval_and_train_step(golden, arch, label):
+    g = golden(f"g2_{arch}_{label}.npz")
+    seed = int(g["seed"])
+    x1, x2 = _t(g["x1"]), _t(g["x2"])
+    st = R.synth_state(arch, 3, label, seed, perturb_running=True)
+    with torch.no_grad():
+        np.testing.assert_allclose(R.forward(arch, st, x1, x2).numpy(), g["logits_eval"], **TOL)
+        np.testing.assert_allclose(R.forward(arch, st, _t(g["y1"]), _t(g["y2"])).numpy(), g["logits_eval_64"], **TOL)
+
+    st = R.synth_state(arch, 3, label, seed)
+    params = [k for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
+    for k in params:
+        st[k].requires_grad_(True)
+    masks = R.synth_masks(arch, 2, seed + 3)
+    logits = R.forward(arch, st, x1, x2, training=True, masks=masks)
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits_train"], **TOL)
+    loss = _loss(label, logits, _t(g["target"]))
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    loss.backward()
+    for k in params:
+        _check_grad(k, st[k].grad, g, 2e-3, 2e-4)
+    for k in [k for k in g if k.startswith("rs/")]:
+        np.testing.assert_allclose(st[k[3:]].detach().numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("label", [1, 2])
+def test_snunet_eval_and_train_step(golden, label):
+    g = golden(f"g2_snunet_{label}.npz")
+    seed = int(g["seed"])
+    x1, x2 = _t(g["x1"]), _t(g["x2"])
+    st = S.synth_state(3, label, seed, perturb_running=True)
+    with torch.no_grad():
+        np.testing.assert_allclose(S.forward(st, x1, x2).numpy(), g["logits_eval"], **TOL)
+    st = S.synth_state(3, label, seed)
+    params = [k for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
+    for k in params:
+        st[k].requires_grad_(True)
+    logits = S.forward(st, x1, x2, training=True)
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits_train"], rtol=2e-4, atol=5e-5)
+    loss = _loss(label, logits, _t(g["target"]))
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    loss.backward()
+    for k in params:
+        _check_grad(k, st[k].grad, g, 3e-3, 3e-4)
+    for k in [k for k in g if k.startswith("rs/")]:
+        np.testing.assert_allclose(st[k[3:]].detach().numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_odd_size_replication_pad(golden):
+    g = golden("g6_odd.npz")
+    for arch in ("diff", "conc"):
+        seed = int(g[f"{arch}/seed"])
+        rng = np.random.default_rng(seed + 1)
+        a = rng.standard_normal((1, 3, 100, 100)).astype(np.float32)
+        b = (a + 0.5 * rng.standard_normal((1, 3, 100, 100))).astype(np.float32)
+        st = R.synth_state(arch, 3, 2, seed, perturb_running=True)
+        with torch.no_grad():
+            out = R.forward(arch, st, _t(a), _t(b))
+        assert out.shape == (1, 2, 100, 100)
+        np.testing.assert_allclose(out.numpy(), g[f"{arch}/logits"], **TOL)
+
+
+def test_losses_against_reference_vectors(golden):
+    g = golden("g1_ops.npz")
+    lg = _t(g["ce/logits"]).requires_grad_(True)
+    loss = R.cross_entropy(lg, _t(g["ce/target"]))
+    loss.backward()
+    assert abs(loss.item() - float(g["ce/loss"])) < 1e-6
+    np.testing.assert_allclose(lg.grad.numpy(), g["ce/dlogits"], rtol=1e-5, atol=1e-7)
+    for tag in ("cd", "cd_sat"):
+        lg = _t(g[f"{tag}/logits"]).requires_grad_(True)
+        loss = R.cd_loss(torch.sigmoid(lg), _t(g[f"{tag}/target"]))
+        loss.backward()
+        assert abs(loss.item() - float(g[f"{tag}/loss"])) < 1e-5 * max(1, abs(float(g[f"{tag}/loss"])))
+        np.testing.assert_allclose(lg.grad.numpy(), g[f"{tag}/dlogits"], rtol=1e-4, atol=1e-7)
+
+
+def test_metrics_against_sklearn_vectors(golden):
+    g = golden("g5_metric.npz")
+    cm = R.confusion_matrix(_t(g["pred"]), _t(g["label"]))
+    np.testing.assert_array_equal(cm.numpy(), g["cm"])
+    sc = R.scores_from_cm(cm)
+    for k in ("f1", "iou", "precision", "recall"):
+        np.testing.assert_allclose(sc[k].numpy(), g[k], rtol=1e-12)
+    assert abs(sc["oa"].item() - float(g["oa"])) < 1e-12
