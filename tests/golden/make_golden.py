@@ -51,7 +51,7 @@ def save(name, **arrs):
 
 
 def t2n(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()   # copy: .numpy() aliases tensors that are later updated in place
 
 
 class MaskFeeder(nn.Module):
