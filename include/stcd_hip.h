@@ -1,0 +1,154 @@
+/* stcd_hip.h -- C ABI of the MI355X (gfx950) bi-temporal change-detection engine.
+ *
+ * The reference (VCISwang/STCD) has NO native interface: its hot path sits behind a Python
+ * torch.nn.Module duck-type built by a factory:
+ *     define_G(args)            /root/reference/models/networks.py:138-215
+ *     Module(input_nbr,label_nbr).forward(x1,x2) -> logits
+ *                               /root/reference/models/SiamUnet_diff.py:13,94-181
+ *                               /root/reference/models/SiamUnet_conc.py:94-181
+ *                               /root/reference/models/SiamUnet_sub.py:94-180
+ *                               /root/reference/models/SNUNet.py:63-152
+ *     loss(logits,label)        /root/reference/models/losses.py:6-21 (cross_entropy), :24-34 (cd_loss)
+ * This header is the boundary a maintainer would bind instead (ctypes stub: INTEGRATION.md): plain
+ * pointers and sizes, no torch types.  All pointers are DEVICE pointers unless a parameter says "host".
+ * Every entry point returns 0 on success; on failure it returns non-zero and stcd_last_error() gives
+ * the reason (thread-local).  No exceptions cross the ABI.  An engine handle is not thread-safe: one
+ * handle per process / per GPU (the reference pins nn.DataParallel to one device,
+ * /root/reference/train_pse_cd.py:405-417).
+ *
+ * Ownership: the caller owns inputs, parameters, gradients, outputs and the workspace; the engine borrows
+ * them for the duration of one call, enqueued on the caller's HIP stream.  The engine allocates no device
+ * memory and never synchronises the device.
+ */
+#ifndef STCD_HIP_H
+#define STCD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STCD_ABI_VERSION 1
+
+/* network family: replaces the class chosen by define_G (networks.py:145-169) */
+#define STCD_ARCH_DIFF 0   /* "SiamUnet_abs"  -> SiamUnet_diff  */
+#define STCD_ARCH_CONC 1   /* "SiamUnet_conc" -> SiamUnet_conc  */
+#define STCD_ARCH_SUB 2    /* "SiamUnet_sub"  -> SiamUnet_sub   */
+#define STCD_ARCH_SNUNET 3 /* "SNUNet"        -> SNUNet_ECAM    */
+
+/* arithmetic / storage type of activations. Parameters, gradients, BN statistics, logits: always fp32. */
+#define STCD_DTYPE_F32 0  /* parity mode: fp32 storage, fp32 FMA */
+#define STCD_DTYPE_BF16 1 /* production: bf16 storage, MFMA with fp32 accumulation */
+
+typedef struct stcd_engine stcd_engine;
+
+typedef struct stcd_tensor_info {
+    char name[64];    /* reference state_dict key, e.g. "conv43d.weight" */
+    int32_t ndim;
+    int64_t shape[4]; /* reference shape, e.g. (256,128,3,3) */
+    int64_t offset;   /* element offset into the flat fp32 parameter / gradient buffer */
+    int64_t numel;
+} stcd_tensor_info;
+
+typedef struct stcd_bn_info {
+    char name[64];           /* module name, e.g. "bn11": buffers are name.running_mean / name.running_var */
+    int32_t channels;
+    int32_t calls_per_forward; /* 2 for the shared encoder (T1 then T2), 1 otherwise: num_batches_tracked increment */
+    int64_t offset;          /* running_mean at offset, running_var at offset+channels, in the flat BN buffer */
+} stcd_bn_info;
+
+typedef struct stcd_dropout_info {
+    char name[64];   /* module name, e.g. "do11" */
+    int32_t rows;    /* 2*batch for encoder layers (T1 rows then T2 rows), batch for decoder layers */
+    int32_t channels;
+    int64_t offset;  /* element offset into the flat fp32 mask buffer; mask[row*channels + c] in {0, 1/(1-p)} */
+} stcd_dropout_info;
+
+const char* stcd_last_error(void);
+int stcd_abi_version(void);
+
+/* ---- engine lifecycle: replaces Module.__init__ (SiamUnet_diff.py:13-92, SNUNet.py:65-113) ---- */
+int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out);
+void stcd_destroy(stcd_engine* e);
+
+/* ---- parameter / buffer enumeration in the reference's registration order (state_dict compatibility,
+ *      /root/reference/models/trainer.py:138,183; basic_model.py:35) ---- */
+int stcd_num_params(const stcd_engine* e);
+int stcd_param_info(const stcd_engine* e, int i, stcd_tensor_info* info);
+int64_t stcd_param_floats(const stcd_engine* e);
+int stcd_num_bn(const stcd_engine* e);
+int stcd_bn_info_get(const stcd_engine* e, int i, stcd_bn_info* info);
+int64_t stcd_bn_floats(const stcd_engine* e);
+
+/* ---- shape binding: batch = image PAIRS per call; height/width as the reference accepts (any >= 16;
+ *      ReplicationPad2d branch, SiamUnet_diff.py:149, for sizes not divisible by 16) ---- */
+int stcd_configure(stcd_engine* e, int batch, int height, int width);
+int64_t stcd_workspace_bytes(const stcd_engine* e);
+int stcd_num_dropout(const stcd_engine* e);
+int stcd_dropout_info_get(const stcd_engine* e, int i, stcd_dropout_info* info);
+int64_t stcd_dropout_floats(const stcd_engine* e);
+/* Dropout2d probability (reference: 0.2, SiamUnet_diff.py:20); 0 disables dropout in training mode. */
+int stcd_set_dropout_p(stcd_engine* e, float p);
+
+/* ---- forward: replaces Module.forward(x1,x2) (SiamUnet_diff.py:94-181) ----
+ * x1,x2      fp32 NCHW [batch,in_ch,H,W]
+ * params     flat fp32 parameters (layout: stcd_param_info)
+ * bn_running flat fp32 running stats (layout: stcd_bn_info_get); updated in place when training != 0
+ * dropout_masks  nullable; when given (training only) these masks are used verbatim (parity tests);
+ *            when NULL and training, masks are drawn on-device from (dropout_seed) by a counter hash
+ * logits     fp32 NCHW [batch,label_ch,H,W]
+ */
+int stcd_forward(stcd_engine* e, const float* x1, const float* x2, const float* params, float* bn_running,
+                 const float* dropout_masks, uint64_t dropout_seed, int training, float* logits,
+                 void* workspace, void* hip_stream);
+
+/* ---- backward: replaces autograd through the module (loss.backward(), trainer.py:313) ----
+ * Must follow a training-mode stcd_forward on the same workspace.  grads (flat fp32, layout of params) is
+ * OVERWRITTEN with d loss / d param.  stage: -1 = whole backward; 0 = decoder half (its gradients are final
+ * when it returns, so a data-parallel caller may start reducing them), 1 = encoder half.
+ */
+int stcd_backward(stcd_engine* e, const float* grad_logits, const float* params, float* grads,
+                  void* workspace, int stage, void* hip_stream);
+/* [begin,end) element range of the flat gradient buffer that stage 0 finalises (the rest belongs to stage 1). */
+int stcd_grad_stage_range(const stcd_engine* e, int stage, int64_t* begin, int64_t* end);
+
+/* ---- losses, fused forward+backward: replace cross_entropy (losses.py:6-21) and
+ *      cd_loss(sigmoid(x),y) == BCE_DICE (losses.py:24-34; train_pse_cd.py:227-228,436-462) ----
+ * loss_out: one fp32 on the device.  dlogits nullable.  scratch: >= stcd_loss_scratch_bytes() bytes.
+ */
+int64_t stcd_loss_scratch_bytes(void);
+int stcd_loss_ce(const float* logits, const int64_t* target, int batch, int classes, int64_t hw, int ignore_index,
+                 float* loss_out, float* dlogits, void* scratch, void* hip_stream);
+int stcd_loss_bce_dice(const float* logits, const float* target, int64_t numel, float* loss_out, float* dlogits,
+                       void* scratch, void* hip_stream);
+/* ---- metric: replaces SegmentationMetric.genConfusionMatrix (train_pse_cd.py:361-368) without the
+ *      per-step .cpu() sync (train_pse_cd.py:231).  cm[2*label+pred] += count; cm is 4 int64 on the device.
+ *      pred = argmax over classes (classes==2) or logit > 0 (classes==1, i.e. sigmoid > 0.5). */
+int stcd_confusion_update(const float* logits, const int64_t* target, int batch, int classes, int64_t hw,
+                          int64_t* cm, void* hip_stream);
+
+/* ---- per-op entry points (NHWC, activation dtype per `dtype`); used by the parity tests.
+ *      Geometry is the engine's generic "tap list" convolution: see DESIGN.md section 3. ---- */
+typedef struct stcd_conv_geom {
+    int32_t n, hi, wi, ci, ldi;         /* input: images, spatial, channels (K per tap), pixel stride (elements) */
+    int32_t hm, wm, in_stride;          /* output-position grid per image; input pixel = m*in_stride + tap */
+    int32_t ho, wo, out_stride, oy0, ox0; /* output buffer dims; output pixel = m*out_stride + (oy0,ox0) */
+    int32_t co, ldo;                    /* output channels, output pixel stride (elements) */
+    int32_t ntaps;
+    int8_t dy[9], dx[9];
+    int8_t pad_[2];
+} stcd_conv_geom;
+
+/* w: fp32 [ntaps][ci][co]; bias: fp32 [co] or NULL; impl: 0 = reference FMA kernel, 1 = MFMA kernel (bf16 only) */
+int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, const float* w, const float* bias,
+                 void* out, void* scratch, int64_t scratch_bytes, void* hip_stream);
+/* dw: fp32 [ntaps][ci][co], overwritten */
+int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, const void* dout, float* dw,
+                  void* scratch, int64_t scratch_bytes, void* hip_stream);
+int64_t stcd_op_scratch_bytes(const stcd_conv_geom* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STCD_HIP_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of the C ABI in include/stcd_hip.h (stcd_amd/libstcd_hip.so).
+
+There is no fallback: if the shared library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstcd_hip.so")
+
+ARCH_DIFF, ARCH_CONC, ARCH_SUB, ARCH_SNUNET = 0, 1, 2, 3
+DTYPE_F32, DTYPE_BF16 = 0, 1
+ARCH_IDS = {"diff": ARCH_DIFF, "conc": ARCH_CONC, "sub": ARCH_SUB, "snunet": ARCH_SNUNET}
+DTYPE_IDS = {"fp32": DTYPE_F32, "f32": DTYPE_F32, "bf16": DTYPE_BF16}
+
+
+class TensorInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("ndim", C.c_int32), ("shape", C.c_int64 * 4), ("offset", C.c_int64),
+                ("numel", C.c_int64)]
+
+
+class BnInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("channels", C.c_int32), ("calls_per_forward", C.c_int32),
+                ("offset", C.c_int64)]
+
+
+class DropoutInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("rows", C.c_int32), ("channels", C.c_int32), ("offset", C.c_int64)]
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("n", C.c_int32), ("hi", C.c_int32), ("wi", C.c_int32), ("ci", C.c_int32), ("ldi", C.c_int32),
+                ("hm", C.c_int32), ("wm", C.c_int32), ("in_stride", C.c_int32),
+                ("ho", C.c_int32), ("wo", C.c_int32), ("out_stride", C.c_int32), ("oy0", C.c_int32), ("ox0", C.c_int32),
+                ("co", C.c_int32), ("ldo", C.c_int32), ("ntaps", C.c_int32),
+                ("dy", C.c_int8 * 9), ("dx", C.c_int8 * 9), ("pad_", C.c_int8 * 2)]
+
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_PROTOS = {
+    "stcd_last_error": (C.c_char_p, []),
+    "stcd_abi_version": (_i, []),
+    "stcd_create": (_i, [_i, _i, _i, _i, C.POINTER(_vp)]),
+    "stcd_destroy": (None, [_vp]),
+    "stcd_num_params": (_i, [_vp]),
+    "stcd_param_info": (_i, [_vp, _i, C.POINTER(TensorInfo)]),
+    "stcd_param_floats": (_i64, [_vp]),
+    "stcd_num_bn": (_i, [_vp]),
+    "stcd_bn_info_get": (_i, [_vp, _i, C.POINTER(BnInfo)]),
+    "stcd_bn_floats": (_i64, [_vp]),
+    "stcd_configure": (_i, [_vp, _i, _i, _i]),
+    "stcd_workspace_bytes": (_i64, [_vp]),
+    "stcd_num_dropout": (_i, [_vp]),
+    "stcd_dropout_info_get": (_i, [_vp, _i, C.POINTER(DropoutInfo)]),
+    "stcd_dropout_floats": (_i64, [_vp]),
+    "stcd_set_dropout_p": (_i, [_vp, _f]),
+    "stcd_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _i, _vp, _vp, _vp]),
+    "stcd_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "stcd_grad_stage_range": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "stcd_loss_scratch_bytes": (_i64, []),
+    "stcd_loss_ce": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp]),
+    "stcd_loss_bce_dice": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "stcd_confusion_update": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp]),
+    "stcd_op_conv": (_i, [_i, _i, C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "stcd_op_wgrad": (_i, [_i, _i, C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _i64, _vp]),
+    "stcd_op_scratch_bytes": (_i64, [C.POINTER(ConvGeom)]),
+}
+EXPORTS = tuple(_PROTOS)
+
+_lib = None
+
+
+class StcdError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libstcd_hip.so (once).  Raises if it has not been built -- there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StcdError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C stcd_amd/csrc`.  The engine has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        if l.stcd_abi_version() != 1:
+            raise StcdError("libstcd_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise StcdError(lib().stcd_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,179 @@
+// common.h -- shared declarations of the stcd HIP engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/stcd_hip.h"
+
+namespace stcd {
+
+typedef __bf16 bf16;
+
+enum DType { F32 = STCD_DTYPE_F32, BF16 = STCD_DTYPE_BF16 };
+inline size_t dsize(int dt) { return dt == BF16 ? 2 : 4; }
+
+void set_error(const std::string& msg);
+
+#define STCD_CHECK(cond, msg)                                              \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            ::stcd::set_error(std::string(__func__) + ": " + (msg));       \
+            return 1;                                                      \
+        }                                                                  \
+    } while (0)
+
+#define STCD_HIP(call)                                                                        \
+    do {                                                                                      \
+        hipError_t err_ = (call);                                                             \
+        if (err_ != hipSuccess) {                                                             \
+            ::stcd::set_error(std::string(__func__) + ": " #call ": " + hipGetErrorString(err_)); \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+// ------------------------------------------------------------------ device helpers
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v)[8]) {
+    uint4 r = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 t;
+    t[0] = (__bf16)lo;   // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+    t[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, t);
+}
+template <>
+__device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[8]) {
+    uint4 r;
+    r.x = pack_bf16x2(v[0], v[1]); r.y = pack_bf16x2(v[2], v[3]);
+    r.z = pack_bf16x2(v[4], v[5]); r.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = r;
+}
+// value as the kernel's activation type would store it (bf16 rounding in bf16 mode, identity in fp32 mode)
+template <typename T>
+__device__ __forceinline__ float round_as(float v) { return (float)(T)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ host launchers (kernels_*.hip)
+// All tensors NHWC with an explicit pixel stride ("ld", in elements); channel counts are multiples of 8.
+
+// x1,x2 fp32 NCHW [B,cin,H,W] -> X [2B,H,W,8] (channels >= cin zero)
+void launch_in_pack(int dt, const float* x1, const float* x2, void* X, int B, int cin, int H, int W, hipStream_t s);
+// g fp32 NCHW [B,L,H,W] -> G [B,H,W,8]
+void launch_gout_pack(int dt, const float* g, void* G, int B, int L, int H, int W, hipStream_t s);
+
+// generic tap-list convolution, reference FMA implementation.  w fp32 [ntaps][kpad][wld]; out_nchw_f32: write fp32
+// NCHW [n,co,ho,wo] instead of NHWC activations (network output).
+void launch_conv_ref(int dt, const stcd_conv_geom& g, const void* in, const float* w, int kpad, int wld,
+                     const float* bias, void* out, bool out_nchw_f32, hipStream_t s);
+// dw fp32 [ntaps][kpad][wld] += sum_pixels in(tap) * dout ; caller zeroes dw.
+void launch_wgrad_ref(int dt, const stcd_conv_geom& g, const void* in, const void* dout, float* dw, int kpad, int wld,
+                      hipStream_t s);
+
+// weight (un)packing between the reference layouts and the engine layout [tap][k][wld]
+struct PackSpec {
+    int ks;          // source kernel size (1,2,3)
+    int kn_major;    // 1: src[k][n][ks][ks] ; 0: src[n][k][ks][ks]
+    int K, N, wld;   // reduction channels, output channels, padded row length of the packed matrix
+    int kpad;        // packed rows per tap (>= K; rows >= K are zero)
+    int ntaps;
+    int8_t ky[9], kx[9];
+};
+void launch_pack_w(const PackSpec& ps, const float* src, float* dst, hipStream_t s);          // dst[t][k][n]
+void launch_unpack_dw(const PackSpec& ps, const float* dwe, float* gsrc, hipStream_t s);      // gsrc[src idx] = dwe[t][k][n]
+
+// batch-norm (train): per-(group, channel) sums over a group's pixels.
+// partial: fp32 [groups][nchunk][2][C]; chunking is decided by the launcher, nchunk returned.
+int bn_stats_chunks(int64_t pixels_per_group);
+void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t pixels_per_group, float* partial,
+                     hipStream_t s);
+// stat: fp32 [groups][4][C] = mean, invstd, scale, shift.  running (mean|var at +C) updated sequentially per group.
+void launch_bn_finalize(const float* partial, int nchunk, int C, int groups, int64_t pixels_per_group,
+                        const float* gamma, const float* beta, float* running_mean, float* running_var, float* stat,
+                        float momentum, float eps, hipStream_t s);
+void launch_bn_eval_prepare(int C, int groups, const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float* stat, float eps, hipStream_t s);
+// A = relu(Y*scale+shift) * mask ; optional fused 2x2 max-pool output P (floor).
+// Images [g*npg, (g+1)*npg) belong to group g; A for group g starts at A_base + g*a_group_off (elements).
+struct BnActArgs {
+    const void* Y; int ldy;
+    void* A; int lda; int64_t a_group_off;
+    void* P; int ldp;                       // nullable
+    const float* stat;                      // [groups][4][C]
+    const float* mask;                      // nullable, [groups*npg][C]
+    int C, groups, npg, H, W;
+    int relu;                               // 0: affine only
+};
+void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s);
+void launch_maxpool(int dt, const void* A, int lda, void* P, int ldp, int N, int H, int W, int C, hipStream_t s);
+
+// Grouped views: element (g, n_in_group, pix, c) of an activation lives at p + g*goff + (n_in_group*HW + pix)*ld + c.
+// A plain [groups*npg, HW, C] tensor has goff = npg*HW*ld; the conc variant keeps T1/T2 skips as channel slices of
+// the decoder's concat buffer (goff = C).
+// skip fusion: D[n][.., 0:C] = |a1-a2| (mode 0) or a2-a1 (mode 1); a1 = group 0 image n, a2 = group 1 image n
+void launch_fuse(int dt, int mode, const void* A, int lda, int64_t a_goff, void* D, int ldd, int B, int64_t HW, int C,
+                 hipStream_t s);
+void launch_fuse_bwd(int dt, int mode, const void* A, int lda, int64_t a_goff, const void* dD, int ldd, void* dA, int ldda,
+                     int64_t da_goff, int B, int64_t HW, int C, hipStream_t s);
+// replication pad of the last row/col of a channel slice (odd sizes): rows [h0,H) copy row h0-1, cols likewise
+void launch_rep_pad(int dt, void* D, int ld, int N, int H, int W, int h0, int w0, int C, hipStream_t s);
+void launch_rep_pad_bwd(int dt, void* dD, int ld, int N, int H, int W, int h0, int w0, int C, hipStream_t s);
+
+// backward of bn_act (train): dz = dA*mask*(z>0); sums of dz and dz*xhat per (group, channel)
+void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, const void* Y, int ldy, const float* stat,
+                          const float* mask, int C, int groups, int npg, int64_t HW, int relu, float* partial,
+                          hipStream_t s);
+// coef fp32 [groups][2][C] = (sum dz)/M, (sum dz*xhat)/M ; dgamma/dbeta summed over groups (overwritten)
+void launch_bn_bwd_finalize(const float* partial, int nchunk, int C, int groups, int64_t pixels_per_group,
+                            float* coef, float* dgamma, float* dbeta, hipStream_t s);
+// dY = scale*(dz - k1 - xhat*k2); dY is a plain tensor and may alias dA when dA is plain too
+void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
+                         const float* stat, const float* coef, const float* mask, int C, int groups, int npg, int64_t HW,
+                         int relu, hipStream_t s);
+// dA (+)= route(dP) to the first maximum of each 2x2 window of A
+void launch_pool_bwd(int dt, const void* A, int lda, int64_t a_goff, const void* dP, int ldp, void* dA, int ldda,
+                     int64_t da_goff, int groups, int npg, int H, int W, int C, int accumulate, hipStream_t s);
+// db[c] = sum over pixels of dY[.., c]  (db zeroed by caller; atomics)
+void launch_bias_grad(int dt, const void* dY, int ld, int64_t pixels, int C, float* db, hipStream_t s);
+// masks from a counter hash: mask[i] = (u(seed, i) >= p) / (1-p)
+void launch_dropout_gen(float* mask, int64_t n, uint64_t seed, float p, hipStream_t s);
+void launch_fill(float* p, int64_t n, float v, hipStream_t s);
+
+// losses / metric (kernels_loss.hip)
+int64_t loss_scratch_bytes();
+void launch_loss_ce(const float* logits, const int64_t* target, int B, int Cn, int64_t HW, int ignore, float* loss,
+                    float* dlogits, void* scratch, hipStream_t s);
+void launch_loss_bce_dice(const float* logits, const float* target, int64_t n, float* loss, float* dlogits,
+                          void* scratch, hipStream_t s);
+void launch_confusion(const float* logits, const int64_t* target, int B, int Cn, int64_t HW, int64_t* cm,
+                      hipStream_t s);
+
+}  // namespace stcd

@@ -1,0 +1,750 @@
+// engine.hip -- network plans, workspace layout and the C ABI (include/stcd_hip.h) of the stcd engine.
+//
+// The engine owns the *graph* of the FC-Siam family (and SNUNet, engine_snunet.hip): buffers are carved out of
+// one caller-provided workspace at stcd_configure() time, forward/backward are straight-line launch sequences
+// on the caller's stream (no allocation, no sync -> hipGraph-capturable).  Data layout in HBM:
+//   activations  NHWC, bf16 (or fp32 in parity mode), T1 images then T2 images in one batch of 2B for the
+//                shared encoder (BN statistics stay per date: "groups"),
+//   concat       never materialised by a copy: producers write channel slices of the decoder's input buffer,
+//   parameters   caller's flat fp32 buffer in the reference's layouts; repacked per call into [tap][K][N],
+//   gradients    caller's flat fp32 buffer, same layout as parameters.
+// Layer tables restate /root/reference/models/SiamUnet_diff.py:13-92 (+ SiamUnet_conc.py:54-87); the forward
+// order follows SiamUnet_diff.py:94-181.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+
+namespace stcd {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+enum ConvKind { K_CONV3 = 0, K_CONVT3_S1 = 1, K_UPCONV = 2 };
+
+struct TRef { int64_t off = -1; int ld = 0; };                 // byte offset in workspace, pixel stride (elements)
+struct GRef { int64_t off = -1; int ld = 0; int64_t goff = 0; }; // grouped view (see common.h)
+
+static inline int round8(int c) { return (c + 7) & ~7; }
+
+struct ConvW {
+    std::string name;
+    int kind = 0, cin = 0, cout = 0;
+    int kin_p = 0, nout_p = 0;       // padded K (input channels incl. zero pad) and N
+    int64_t w_off = 0, b_off = 0;    // into flat params (elements)
+    PackSpec fwd{}, dgrad{};         // dgrad.ntaps == 0: no data gradient needed
+    int64_t wpk_fwd = -1, wpk_dgrad = -1, dwe = -1;   // workspace byte offsets
+    int64_t dwe_floats = 0;
+};
+struct BnP {
+    std::string name;
+    int C = 0, calls = 1;
+    int64_t g_off = 0, b_off = 0;    // gamma/beta in flat params
+    int64_t run_off = 0;             // running mean (var at +C) in flat bn buffer
+};
+struct DropP { std::string name; int rows = 0, C = 0; int64_t off = 0; };
+
+struct Cbrd {                         // conv -> BN -> ReLU -> Dropout2d [-> pool]
+    int conv = -1, bn = -1, drop = -1;
+    int N = 0, H = 0, W = 0, groups = 1, npg = 0;
+    TRef in; int K = 0;               // input view and its channel count
+    TRef Y; GRef A; TRef P; TRef dPool; bool pool = false;
+    GRef dA; TRef dY; TRef dIn; bool has_dIn = false;
+    int64_t stat = -1, coef = -1;
+};
+struct UpConv {
+    int conv = -1, level = 0;
+    int N = 0, h = 0, w = 0, Ho = 0, Wo = 0, C = 0;   // input h x w, concat buffer Ho x Wo
+    TRef in, out, dOut, dIn;
+};
+
+struct stcd_engine_impl {
+    int arch = 0, in_ch = 3, label = 2, dt = F32;
+    float drop_p = 0.2f;
+    std::vector<stcd_tensor_info> params;
+    int64_t param_floats = 0, enc_param_end = 0;
+    std::vector<ConvW> convs;
+    std::vector<BnP> bns;
+    int64_t bn_floats = 0;
+    // shape-bound plan
+    bool configured = false, fwd_training = false;
+    int B = 0, H = 0, W = 0;
+    std::vector<DropP> drops;
+    int64_t drop_floats = 0;
+    int64_t ws_bytes = 0;
+    std::vector<Cbrd> enc, dec;
+    std::vector<UpConv> ups;
+    int final_conv = -1;
+    TRef X0, G, finalIn, dFinalIn;
+    int Hs[5] = {0}, Ws[5] = {0};
+    TRef D[4], dD[4], P[4], dP[4];
+    int64_t bn_partial = -1, masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
+    int use_mfma = 1;
+};
+
+}  // namespace stcd
+
+using namespace stcd;
+struct stcd_engine : stcd_engine_impl {};
+
+namespace stcd {
+
+// ------------------------------------------------------------------------------------------ model tables
+static const int ENC_STAGE_CONVS[4] = {2, 2, 3, 3};
+static const int ENC_C[4] = {16, 32, 64, 128};
+
+static void add_param(stcd_engine& e, const std::string& name, std::initializer_list<int64_t> shape, int64_t* off_out) {
+    stcd_tensor_info ti;
+    memset(&ti, 0, sizeof(ti));
+    snprintf(ti.name, sizeof(ti.name), "%s", name.c_str());
+    ti.ndim = (int)shape.size();
+    int64_t n = 1;
+    int i = 0;
+    for (auto s : shape) { ti.shape[i++] = s; n *= s; }
+    ti.numel = n;
+    ti.offset = e.param_floats;
+    *off_out = ti.offset;
+    e.param_floats += (n + 3) & ~(int64_t)3;   // keep every tensor 16-B aligned in the flat buffer
+    e.params.push_back(ti);
+}
+
+static void make_specs(ConvW& c, bool need_dgrad) {
+    PackSpec& f = c.fwd;
+    f.ks = 3;
+    f.K = c.cin; f.N = c.cout; f.kpad = c.kin_p; f.wld = c.nout_p;
+    PackSpec& d = c.dgrad;
+    d.ks = 3;
+    d.K = c.cout; d.N = c.cin; d.kpad = c.nout_p; d.wld = round8(c.cin);
+    d.ntaps = 0;
+    if (c.kind == K_CONV3 || c.kind == K_CONVT3_S1) {
+        f.ntaps = 9;
+        f.kn_major = c.kind == K_CONVT3_S1;       // ConvTranspose2d weights are [Cin][Cout][3][3]
+        for (int t = 0; t < 9; ++t) {
+            int dy = t / 3 - 1, dx = t % 3 - 1;
+            f.ky[t] = c.kind == K_CONV3 ? dy + 1 : 1 - dy;
+            f.kx[t] = c.kind == K_CONV3 ? dx + 1 : 1 - dx;
+        }
+        if (need_dgrad) {
+            d.ntaps = 9;
+            d.kn_major = c.kind == K_CONV3;
+            for (int t = 0; t < 9; ++t) {
+                int dy = t / 3 - 1, dx = t % 3 - 1;
+                d.ky[t] = c.kind == K_CONV3 ? 1 - dy : 1 + dy;
+                d.kx[t] = c.kind == K_CONV3 ? 1 - dx : 1 + dx;
+            }
+        }
+    } else {  // K_UPCONV: 4 sub-pixel phases, 1+2+2+4 taps, stored in phase order (py,px) = (0,0),(0,1),(1,0),(1,1)
+        f.ntaps = 9;
+        f.kn_major = 1;
+        int t = 0;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px)
+                for (int dy = 0; dy <= py; ++dy)
+                    for (int dx = 0; dx <= px; ++dx) {
+                        f.ky[t] = py + 1 - 2 * dy;
+                        f.kx[t] = px + 1 - 2 * dx;
+                        ++t;
+                    }
+        if (need_dgrad) {   // stride-2 3x3 conv over dOut
+            d.ntaps = 9;
+            d.kn_major = 0;
+            for (int k = 0; k < 9; ++k) { d.ky[k] = k / 3; d.kx[k] = k % 3; }
+        }
+    }
+}
+
+static int add_conv(stcd_engine& e, const std::string& name, int kind, int cin, int cout, bool need_dgrad) {
+    ConvW c;
+    c.name = name; c.kind = kind; c.cin = cin; c.cout = cout;
+    c.kin_p = round8(cin); c.nout_p = round8(cout);
+    if (kind == K_CONV3) add_param(e, name + ".weight", {cout, cin, 3, 3}, &c.w_off);
+    else add_param(e, name + ".weight", {cin, cout, 3, 3}, &c.w_off);
+    add_param(e, name + ".bias", {cout}, &c.b_off);
+    make_specs(c, need_dgrad);
+    e.convs.push_back(c);
+    return (int)e.convs.size() - 1;
+}
+static int add_bn(stcd_engine& e, const std::string& name, int C, int calls) {
+    BnP b;
+    b.name = name; b.C = C; b.calls = calls;
+    add_param(e, name + ".weight", {C}, &b.g_off);
+    add_param(e, name + ".bias", {C}, &b.b_off);
+    b.run_off = e.bn_floats;
+    e.bn_floats += 2 * C;
+    e.bns.push_back(b);
+    return (int)e.bns.size() - 1;
+}
+
+struct DecSpec { const char* up; int C; int n; const char* sfx[3]; int cout[3]; };
+static const DecSpec DEC[4] = {
+    {"upconv4", 128, 3, {"43d", "42d", "41d"}, {128, 128, 64}},
+    {"upconv3", 64, 3, {"33d", "32d", "31d"}, {64, 64, 32}},
+    {"upconv2", 32, 2, {"22d", "21d", nullptr}, {32, 16, 0}},
+    {"upconv1", 16, 2, {"12d", "11d", nullptr}, {16, -1, 0}},   // 11d -> label_nbr, no BN
+};
+
+static void build_fcsiam_tables(stcd_engine& e) {
+    // registration order of SiamUnet_*.__init__ (SiamUnet_diff.py:18-90): conv, bn per layer; upconv before its stage
+    for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < ENC_STAGE_CONVS[s]; ++j) {
+            std::string sfx = std::to_string(s + 1) + std::to_string(j + 1);
+            int cin = j == 0 ? (s == 0 ? e.in_ch : ENC_C[s - 1]) : ENC_C[s];
+            add_conv(e, "conv" + sfx, K_CONV3, cin, ENC_C[s], !(s == 0 && j == 0));
+            add_bn(e, "bn" + sfx, ENC_C[s], 2);
+        }
+    e.enc_param_end = e.param_floats;
+    for (int k = 0; k < 4; ++k) {
+        const DecSpec& d = DEC[k];
+        add_conv(e, d.up, K_UPCONV, d.C, d.C, true);
+        int skipc = e.arch == STCD_ARCH_CONC ? 2 * d.C : d.C;
+        int cin = d.C + skipc;
+        for (int j = 0; j < d.n; ++j) {
+            int cout = d.cout[j] < 0 ? e.label : d.cout[j];
+            add_conv(e, std::string("conv") + d.sfx[j], K_CONVT3_S1, cin, cout, true);
+            if (d.cout[j] >= 0) add_bn(e, std::string("bn") + d.sfx[j], cout, 1);
+            cin = cout;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ workspace plan
+struct Bump {
+    int64_t cur = 0;
+    int64_t take(int64_t bytes) {
+        int64_t o = cur;
+        cur += (bytes + 255) & ~(int64_t)255;
+        return o;
+    }
+};
+
+static int conv_index(const stcd_engine& e, const std::string& name) {
+    for (size_t i = 0; i < e.convs.size(); ++i)
+        if (e.convs[i].name == name) return (int)i;
+    return -1;
+}
+static int bn_index(const stcd_engine& e, const std::string& name) {
+    for (size_t i = 0; i < e.bns.size(); ++i)
+        if (e.bns[i].name == name) return (int)i;
+    return -1;
+}
+
+static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
+    const int64_t T = (int64_t)dsize(e.dt);
+    e.enc.clear(); e.dec.clear(); e.ups.clear(); e.drops.clear();
+    e.drop_floats = 0;
+    e.Hs[0] = H; e.Ws[0] = W;
+    for (int s = 0; s < 4; ++s) { e.Hs[s + 1] = e.Hs[s] / 2; e.Ws[s + 1] = e.Ws[s] / 2; }
+    Bump ws;
+    int64_t max_partial = 0;
+    auto add_drop = [&](const std::string& name, int rows, int C) {
+        DropP d; d.name = name; d.rows = rows; d.C = C; d.off = e.drop_floats;
+        e.drop_floats += (int64_t)rows * C;
+        e.drops.push_back(d);
+        return (int)e.drops.size() - 1;
+    };
+    auto plain = [&](int N, int h, int w, int C) { TRef t; t.off = ws.take((int64_t)N * h * w * C * T); t.ld = C; return t; };
+
+    e.X0 = plain(2 * B, H, W, 8);
+    // concat buffers first (conc keeps its skips inside them)
+    for (int s = 0; s < 4; ++s) {
+        int Cd = ENC_C[s] + (e.arch == STCD_ARCH_CONC ? 2 : 1) * ENC_C[s];
+        e.D[s] = plain(B, e.Hs[s], e.Ws[s], Cd);
+        e.dD[s] = plain(B, e.Hs[s], e.Ws[s], Cd);
+        e.P[s] = plain(2 * B, e.Hs[s + 1], e.Ws[s + 1], ENC_C[s]);
+        e.dP[s] = plain(2 * B, e.Hs[s + 1], e.Ws[s + 1], ENC_C[s]);
+    }
+    // ---- encoder
+    for (int s = 0; s < 4; ++s) {
+        const int C = ENC_C[s], h = e.Hs[s], w = e.Ws[s];
+        for (int j = 0; j < ENC_STAGE_CONVS[s]; ++j) {
+            std::string sfx = std::to_string(s + 1) + std::to_string(j + 1);
+            Cbrd L;
+            L.conv = conv_index(e, "conv" + sfx);
+            L.bn = bn_index(e, "bn" + sfx);
+            L.drop = add_drop("do" + sfx, 2 * B, C);
+            L.N = 2 * B; L.H = h; L.W = w; L.groups = 2; L.npg = B;
+            const bool first = j == 0, last = j == ENC_STAGE_CONVS[s] - 1;
+            if (first && s == 0) { L.in = e.X0; L.K = 8; }
+            else if (first) { L.in = e.P[s - 1]; L.K = ENC_C[s - 1]; }
+            else { L.in.off = e.enc.back().A.off; L.in.ld = C; L.K = C; }
+            L.Y = plain(2 * B, h, w, C);
+            if (last && e.arch == STCD_ARCH_CONC) {
+                L.A.off = e.D[s].off + C * T; L.A.ld = e.D[s].ld; L.A.goff = C;
+                L.dA.off = e.dD[s].off + C * T; L.dA.ld = e.dD[s].ld; L.dA.goff = C;
+                L.dY = plain(2 * B, h, w, C);
+            } else {
+                TRef a = plain(2 * B, h, w, C), da = plain(2 * B, h, w, C);
+                L.A.off = a.off; L.A.ld = C; L.A.goff = (int64_t)B * h * w * C;
+                L.dA.off = da.off; L.dA.ld = C; L.dA.goff = L.A.goff;
+                L.dY = da;   // in place
+            }
+            if (last) { L.pool = true; L.P = e.P[s]; L.dPool = e.dP[s]; }
+            if (first && s == 0) L.has_dIn = false;
+            else if (first) { L.has_dIn = true; L.dIn = e.dP[s - 1]; }
+            else { L.has_dIn = true; L.dIn.off = e.enc.back().dA.off; L.dIn.ld = C; }
+            L.stat = ws.take((int64_t)2 * 4 * C * 4);
+            L.coef = ws.take((int64_t)2 * 2 * C * 4);
+            max_partial = std::max<int64_t>(max_partial, (int64_t)2 * bn_stats_chunks((int64_t)B * h * w) * 2 * C);
+            e.enc.push_back(L);
+        }
+    }
+    // ---- decoder
+    TRef prevA = {e.P[3].off + (int64_t)B * e.Hs[4] * e.Ws[4] * ENC_C[3] * T, ENC_C[3]};    // T2 half of the last pool
+    TRef prevdA = {e.dP[3].off + (int64_t)B * e.Hs[4] * e.Ws[4] * ENC_C[3] * T, ENC_C[3]};
+    for (int k = 0; k < 4; ++k) {
+        const DecSpec& d = DEC[k];
+        const int s = 3 - k, h = e.Hs[s], w = e.Ws[s];
+        UpConv U;
+        U.conv = conv_index(e, d.up); U.level = s; U.N = B; U.h = e.Hs[s + 1]; U.w = e.Ws[s + 1]; U.Ho = h; U.Wo = w; U.C = d.C;
+        U.in = prevA; U.dIn = prevdA;
+        U.out = e.D[s]; U.dOut = e.dD[s];
+        e.ups.push_back(U);
+        TRef in = e.D[s], dIn = e.dD[s];
+        int K = e.D[s].ld;
+        for (int j = 0; j < d.n; ++j) {
+            if (d.cout[j] < 0) {   // conv11d: no BN, writes the logits
+                e.final_conv = conv_index(e, "conv11d");
+                e.finalIn = in; e.dFinalIn = dIn;
+                break;
+            }
+            Cbrd L;
+            L.conv = conv_index(e, std::string("conv") + d.sfx[j]);
+            L.bn = bn_index(e, std::string("bn") + d.sfx[j]);
+            L.drop = add_drop(std::string("do") + d.sfx[j], B, d.cout[j]);
+            const int C = d.cout[j];
+            L.N = B; L.H = h; L.W = w; L.groups = 1; L.npg = B;
+            L.in = in; L.K = K;
+            L.Y = plain(B, h, w, C);
+            TRef a = plain(B, h, w, C), da = plain(B, h, w, C);
+            L.A.off = a.off; L.A.ld = C; L.A.goff = 0;
+            L.dA.off = da.off; L.dA.ld = C; L.dA.goff = 0;
+            L.dY = da;
+            L.has_dIn = true; L.dIn = dIn;
+            L.stat = ws.take((int64_t)4 * C * 4);
+            L.coef = ws.take((int64_t)2 * C * 4);
+            max_partial = std::max<int64_t>(max_partial, (int64_t)bn_stats_chunks((int64_t)B * h * w) * 2 * C);
+            e.dec.push_back(L);
+            in = a; dIn = da; K = C;
+            prevA = a; prevdA = da;
+        }
+    }
+    e.G = plain(B, H, W, 8);
+    e.bn_partial = ws.take(max_partial * 4);
+    e.scratch8 = ws.take(256);
+    e.masks = ws.take(e.drop_floats * 4);
+    for (auto& c : e.convs) {
+        c.wpk_fwd = ws.take((int64_t)c.fwd.ntaps * c.fwd.kpad * c.fwd.wld * 4);
+        if (c.dgrad.ntaps) c.wpk_dgrad = ws.take((int64_t)c.dgrad.ntaps * c.dgrad.kpad * c.dgrad.wld * 4);
+    }
+    e.dwe_begin = ws.cur;
+    for (auto& c : e.convs) {
+        c.dwe_floats = (int64_t)c.fwd.ntaps * c.fwd.kpad * c.fwd.wld;
+        c.dwe = ws.take(c.dwe_floats * 4);
+    }
+    e.dwe_end = ws.cur;
+    e.ws_bytes = ws.cur;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ execution helpers
+struct Ctx {
+    stcd_engine& e;
+    char* ws;
+    const float* params;
+    float* grads;
+    hipStream_t s;
+    template <typename P = void> P* at(int64_t off) const { return (P*)(ws + off); }
+};
+
+static stcd_conv_geom geom3(int N, int H, int W, int K, int ldi, int co, int ldo) {
+    stcd_conv_geom g;
+    memset(&g, 0, sizeof(g));
+    g.n = N; g.hi = H; g.wi = W; g.ci = K; g.ldi = ldi;
+    g.hm = H; g.wm = W; g.in_stride = 1;
+    g.ho = H; g.wo = W; g.out_stride = 1; g.oy0 = 0; g.ox0 = 0;
+    g.co = co; g.ldo = ldo;
+    g.ntaps = 9;
+    for (int t = 0; t < 9; ++t) { g.dy[t] = (int8_t)(t / 3 - 1); g.dx[t] = (int8_t)(t % 3 - 1); }
+    return g;
+}
+
+static void run_conv(const Ctx& c, const stcd_conv_geom& g, const void* in, const float* w, int kpad, int wld,
+                     const float* bias, void* out, bool nchw) {
+    launch_conv_ref(c.e.dt, g, in, w, kpad, wld, bias, out, nchw, c.s);
+}
+static void run_wgrad(const Ctx& c, const stcd_conv_geom& g, const void* in, const void* dout, float* dw, int kpad, int wld) {
+    launch_wgrad_ref(c.e.dt, g, in, dout, dw, kpad, wld, c.s);
+}
+
+static void pack_all_weights(const Ctx& c, bool with_dgrad) {
+    for (auto& cv : c.e.convs) {
+        launch_pack_w(cv.fwd, c.params + cv.w_off, c.at<float>(cv.wpk_fwd), c.s);
+        if (with_dgrad && cv.dgrad.ntaps) launch_pack_w(cv.dgrad, c.params + cv.w_off, c.at<float>(cv.wpk_dgrad), c.s);
+    }
+}
+
+static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool training) {
+    stcd_engine& e = c.e;
+    const ConvW& cv = e.convs[L.conv];
+    const BnP& bn = e.bns[L.bn];
+    const int C = cv.cout;
+    stcd_conv_geom g = geom3(L.N, L.H, L.W, L.K, L.in.ld, C, L.Y.ld);
+    run_conv(c, g, c.at(L.in.off), c.at<float>(cv.wpk_fwd), cv.fwd.kpad, cv.fwd.wld, c.params + cv.b_off, c.at(L.Y.off), false);
+    const int64_t ppg = (int64_t)L.npg * L.H * L.W;
+    float* stat = c.at<float>(L.stat);
+    if (training) {
+        launch_bn_stats(e.dt, c.at(L.Y.off), L.Y.ld, C, L.groups, ppg, c.at<float>(e.bn_partial), c.s);
+        launch_bn_finalize(c.at<float>(e.bn_partial), bn_stats_chunks(ppg), C, L.groups, ppg, c.params + bn.g_off,
+                           c.params + bn.b_off, bn_running + bn.run_off, bn_running + bn.run_off + C, stat, 0.1f, 1e-5f, c.s);
+    } else {
+        launch_bn_eval_prepare(C, L.groups, c.params + bn.g_off, c.params + bn.b_off, bn_running + bn.run_off,
+                               bn_running + bn.run_off + C, stat, 1e-5f, c.s);
+    }
+    BnActArgs a;
+    a.Y = c.at(L.Y.off); a.ldy = L.Y.ld;
+    a.A = c.at(L.A.off); a.lda = L.A.ld; a.a_group_off = L.A.goff;
+    a.P = L.pool ? c.at(L.P.off) : nullptr; a.ldp = L.P.ld;
+    a.stat = stat;
+    a.mask = (training && e.drop_p > 0.f) ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
+    a.C = C; a.groups = L.groups; a.npg = L.npg; a.H = L.H; a.W = L.W; a.relu = 1;
+    launch_bn_act(e.dt, a, c.s);
+}
+
+static void cbrd_backward(const Ctx& c, const Cbrd& L) {
+    stcd_engine& e = c.e;
+    const ConvW& cv = e.convs[L.conv];
+    const BnP& bn = e.bns[L.bn];
+    const int C = cv.cout;
+    const int64_t HW = (int64_t)L.H * L.W, ppg = (int64_t)L.npg * HW;
+    const float* stat = c.at<float>(L.stat);
+    const float* mask = e.drop_p > 0.f ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
+    float* partial = c.at<float>(e.bn_partial);
+    launch_bn_bwd_reduce(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.Y.off), L.Y.ld, stat, mask, C, L.groups, L.npg, HW, 1,
+                         partial, c.s);
+    launch_bn_bwd_finalize(partial, bn_stats_chunks(ppg), C, L.groups, ppg, c.at<float>(L.coef), c.grads + bn.g_off,
+                           c.grads + bn.b_off, c.s);
+    launch_bn_bwd_apply(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.dY.off), L.dY.ld, c.at(L.Y.off), L.Y.ld, stat,
+                        c.at<float>(L.coef), mask, C, L.groups, L.npg, HW, 1, c.s);
+    // weight gradient (the conv bias feeds only a train-mode BN: its gradient is exactly zero and stays zero)
+    stcd_conv_geom g = geom3(L.N, L.H, L.W, L.K, L.in.ld, C, L.dY.ld);
+    run_wgrad(c, g, c.at(L.in.off), c.at(L.dY.off), c.at<float>(cv.dwe), cv.fwd.kpad, cv.fwd.wld);
+    launch_unpack_dw(cv.fwd, c.at<float>(cv.dwe), c.grads + cv.w_off, c.s);
+    if (L.has_dIn) {
+        stcd_conv_geom gd = geom3(L.N, L.H, L.W, cv.dgrad.kpad, L.dY.ld, cv.cin, L.dIn.ld);
+        run_conv(c, gd, c.at(L.dY.off), c.at<float>(cv.wpk_dgrad), cv.dgrad.kpad, cv.dgrad.wld, nullptr, c.at(L.dIn.off), false);
+    }
+}
+
+// 4 sub-pixel phases of ConvTranspose2d(k3,s2,p1,op1): out(2m+py, 2n+px) = sum_{dy<=py, dx<=px} in(m+dy, n+dx) W[py+1-2dy][px+1-2dx]
+static stcd_conv_geom geom_up_phase(const UpConv& U, int py, int px, int ldi, int ldo, int* tap0) {
+    stcd_conv_geom g;
+    memset(&g, 0, sizeof(g));
+    g.n = U.N; g.hi = U.h; g.wi = U.w; g.ci = U.C; g.ldi = ldi;
+    g.hm = U.h; g.wm = U.w; g.in_stride = 1;
+    g.ho = U.Ho; g.wo = U.Wo; g.out_stride = 2; g.oy0 = py; g.ox0 = px;
+    g.co = U.C; g.ldo = ldo;
+    int t = 0;
+    for (int dy = 0; dy <= py; ++dy)
+        for (int dx = 0; dx <= px; ++dx) { g.dy[t] = (int8_t)dy; g.dx[t] = (int8_t)dx; ++t; }
+    g.ntaps = t;
+    static const int start[4] = {0, 1, 3, 5};
+    *tap0 = start[py * 2 + px];
+    return g;
+}
+
+static void upconv_forward(const Ctx& c, const UpConv& U) {
+    stcd_engine& e = c.e;
+    const ConvW& cv = e.convs[U.conv];
+    for (int ph = 0; ph < 4; ++ph) {
+        int tap0;
+        stcd_conv_geom g = geom_up_phase(U, ph >> 1, ph & 1, U.in.ld, U.out.ld, &tap0);
+        const float* w = c.at<float>(cv.wpk_fwd) + (int64_t)tap0 * cv.fwd.kpad * cv.fwd.wld;
+        run_conv(c, g, c.at(U.in.off), w, cv.fwd.kpad, cv.fwd.wld, c.params + cv.b_off, c.at(U.out.off), false);
+    }
+    launch_rep_pad(e.dt, c.at(U.out.off), U.out.ld, U.N, U.Ho, U.Wo, 2 * U.h, 2 * U.w, U.C, c.s);
+}
+
+static void upconv_backward(const Ctx& c, const UpConv& U) {
+    stcd_engine& e = c.e;
+    const ConvW& cv = e.convs[U.conv];
+    launch_rep_pad_bwd(e.dt, c.at(U.dOut.off), U.dOut.ld, U.N, U.Ho, U.Wo, 2 * U.h, 2 * U.w, U.C, c.s);
+    // bias gradient over the un-padded 2h x 2w region == all phases' positions
+    if (2 * U.h == U.Ho && 2 * U.w == U.Wo) {
+        launch_bias_grad(e.dt, c.at(U.dOut.off), U.dOut.ld, (int64_t)U.N * U.Ho * U.Wo, U.C, c.grads + cv.b_off, c.s);
+    } else {
+        const int64_t T = (int64_t)dsize(e.dt);
+        for (int n = 0; n < U.N; ++n)
+            for (int y = 0; y < 2 * U.h; ++y)
+                launch_bias_grad(e.dt, c.at<char>(U.dOut.off) + ((int64_t)(n * U.Ho + y) * U.Wo) * U.dOut.ld * T, U.dOut.ld,
+                                 2 * U.w, U.C, c.grads + cv.b_off, c.s);
+    }
+    for (int ph = 0; ph < 4; ++ph) {
+        int tap0;
+        stcd_conv_geom g = geom_up_phase(U, ph >> 1, ph & 1, U.in.ld, U.dOut.ld, &tap0);
+        float* dw = c.at<float>(cv.dwe) + (int64_t)tap0 * cv.fwd.kpad * cv.fwd.wld;
+        run_wgrad(c, g, c.at(U.in.off), c.at(U.dOut.off), dw, cv.fwd.kpad, cv.fwd.wld);
+    }
+    launch_unpack_dw(cv.fwd, c.at<float>(cv.dwe), c.grads + cv.w_off, c.s);
+    // data gradient: 3x3 stride-2 conv over dOut
+    stcd_conv_geom gd;
+    memset(&gd, 0, sizeof(gd));
+    gd.n = U.N; gd.hi = 2 * U.h; gd.wi = 2 * U.w; gd.ci = cv.dgrad.kpad; gd.ldi = U.dOut.ld;
+    gd.hm = U.h; gd.wm = U.w; gd.in_stride = 2;
+    gd.ho = U.h; gd.wo = U.w; gd.out_stride = 1;
+    gd.co = U.C; gd.ldo = U.dIn.ld;
+    gd.ntaps = 9;
+    for (int t = 0; t < 9; ++t) { gd.dy[t] = (int8_t)(t / 3 - 1); gd.dx[t] = (int8_t)(t % 3 - 1); }
+    // dOut rows are Wo pixels apart while the conv sees a 2h x 2w image: only valid when the buffer is unpadded in W.
+    // (hi,wi) bound the taps; the row pitch must be the buffer's.  The reference kernel indexes rows by wi, so for
+    // padded buffers present the full buffer and bound by construction (taps never reach row/col 2h / 2w).
+    gd.hi = U.Ho; gd.wi = U.Wo;
+    run_conv(c, gd, c.at(U.dOut.off), c.at<float>(cv.wpk_dgrad), cv.dgrad.kpad, cv.dgrad.wld, nullptr, c.at(U.dIn.off), false);
+}
+
+static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, const float* params, float* bn_running,
+                          const float* masks, uint64_t seed, int training, float* logits, void* workspace, hipStream_t s) {
+    Ctx c{e, (char*)workspace, params, nullptr, s};
+    const int B = e.B, dt = e.dt;
+    const int64_t T = (int64_t)dsize(dt);
+    if (training && e.drop_p > 0.f) {
+        if (masks) STCD_HIP(hipMemcpyAsync(c.at(e.masks), masks, e.drop_floats * 4, hipMemcpyDeviceToDevice, s));
+        else launch_dropout_gen(c.at<float>(e.masks), e.drop_floats, seed, e.drop_p, s);
+    }
+    pack_all_weights(c, training != 0);
+    launch_in_pack(dt, x1, x2, c.at(e.X0.off), B, e.in_ch, e.H, e.W, s);
+    for (auto& L : e.enc) cbrd_forward(c, L, bn_running, training != 0);
+    size_t di = 0;
+    for (int k = 0; k < 4; ++k) {
+        const UpConv& U = e.ups[k];
+        const int s_ = U.level, C = ENC_C[s_];
+        upconv_forward(c, U);
+        const Cbrd& skip = e.enc[(s_ == 0 ? 1 : s_ == 1 ? 3 : s_ == 2 ? 6 : 9)];
+        if (e.arch != STCD_ARCH_CONC)
+            launch_fuse(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(skip.A.off), skip.A.ld, skip.A.goff,
+                        c.at<char>(e.D[s_].off) + C * T, e.D[s_].ld, B, (int64_t)e.Hs[s_] * e.Ws[s_], C, s);
+        for (int j = 0; j < DEC[k].n; ++j) {
+            if (DEC[k].cout[j] < 0) break;
+            cbrd_forward(c, e.dec[di++], bn_running, training != 0);
+        }
+    }
+    const ConvW& cv = e.convs[e.final_conv];
+    stcd_conv_geom g = geom3(B, e.H, e.W, cv.kin_p, e.finalIn.ld, e.label, e.label);
+    run_conv(c, g, c.at(e.finalIn.off), c.at<float>(cv.wpk_fwd), cv.fwd.kpad, cv.fwd.wld, params + cv.b_off, logits, true);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
+static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float* params, float* grads, void* workspace,
+                           int stage, hipStream_t s) {
+    Ctx c{e, (char*)workspace, params, grads, s};
+    const int B = e.B, dt = e.dt;
+    const int64_t T = (int64_t)dsize(dt);
+    static const int SKIP_IDX[4] = {1, 3, 6, 9};
+    if (stage <= 0) {
+        STCD_HIP(hipMemsetAsync(grads, 0, e.param_floats * 4, s));
+        STCD_HIP(hipMemsetAsync(c.at(e.dwe_begin), 0, e.dwe_end - e.dwe_begin, s));
+        // T1 half of the bottleneck pool is dead work in the reference (SiamUnet_diff.py:119 overwritten at :143)
+        STCD_HIP(hipMemsetAsync(c.at(e.dP[3].off), 0, (int64_t)B * e.Hs[4] * e.Ws[4] * ENC_C[3] * T, s));
+        launch_gout_pack(dt, grad_logits, c.at(e.G.off), B, e.label, e.H, e.W, s);
+        // conv11d: bias, weight and data gradients straight from the packed output gradient
+        const ConvW& cv = e.convs[e.final_conv];
+        STCD_HIP(hipMemsetAsync(c.at(e.scratch8), 0, 32, s));
+        launch_bias_grad(dt, c.at(e.G.off), 8, (int64_t)B * e.H * e.W, 8, c.at<float>(e.scratch8), s);
+        STCD_HIP(hipMemcpyAsync(grads + cv.b_off, c.at(e.scratch8), (size_t)e.label * 4, hipMemcpyDeviceToDevice, s));
+        stcd_conv_geom g = geom3(B, e.H, e.W, cv.kin_p, e.finalIn.ld, e.label, 8);
+        run_wgrad(c, g, c.at(e.finalIn.off), c.at(e.G.off), c.at<float>(cv.dwe), cv.fwd.kpad, cv.fwd.wld);
+        launch_unpack_dw(cv.fwd, c.at<float>(cv.dwe), grads + cv.w_off, s);
+        stcd_conv_geom gd = geom3(B, e.H, e.W, cv.dgrad.kpad, 8, cv.cin, e.dFinalIn.ld);
+        run_conv(c, gd, c.at(e.G.off), c.at<float>(cv.wpk_dgrad), cv.dgrad.kpad, cv.dgrad.wld, nullptr, c.at(e.dFinalIn.off), false);
+        int di = (int)e.dec.size() - 1;
+        for (int k = 3; k >= 0; --k) {
+            int nb = 0;
+            for (int j = 0; j < DEC[k].n; ++j) nb += DEC[k].cout[j] >= 0;
+            for (int j = 0; j < nb; ++j) cbrd_backward(c, e.dec[di--]);
+            const UpConv& U = e.ups[k];
+            const int s_ = U.level, C = ENC_C[s_];
+            upconv_backward(c, U);
+            const Cbrd& skip = e.enc[SKIP_IDX[s_]];
+            if (e.arch != STCD_ARCH_CONC)
+                launch_fuse_bwd(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(skip.A.off), skip.A.ld, skip.A.goff,
+                                c.at<char>(e.dD[s_].off) + C * T, e.dD[s_].ld, c.at(skip.dA.off), skip.dA.ld, skip.dA.goff, B,
+                                (int64_t)e.Hs[s_] * e.Ws[s_], C, s);
+        }
+    }
+    if (stage < 0 || stage == 1) {
+        for (int li = (int)e.enc.size() - 1; li >= 0; --li) {
+            const Cbrd& L = e.enc[li];
+            if (L.pool)   // dA_skip += gradient routed back through the 2x2 max-pool
+                launch_pool_bwd(dt, c.at(L.A.off), L.A.ld, L.A.goff, c.at(L.dPool.off), L.dPool.ld, c.at(L.dA.off), L.dA.ld,
+                                L.dA.goff, L.groups, L.npg, L.H, L.W, e.convs[L.conv].cout, 1, s);
+            cbrd_backward(c, L);
+        }
+    }
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace stcd
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char* stcd_last_error(void) { return stcd::g_err.c_str(); }
+int stcd_abi_version(void) { return STCD_ABI_VERSION; }
+
+int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out) {
+    STCD_CHECK(out != nullptr, "out is null");
+    STCD_CHECK(arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SNUNET, "unknown arch");
+    STCD_CHECK(arch != STCD_ARCH_SNUNET, "SNUNet plan is built by engine_snunet (not linked in this build)");
+    STCD_CHECK(in_ch >= 1 && in_ch <= 8, "in_ch must be in [1,8]");
+    STCD_CHECK(label_ch >= 1 && label_ch <= 8, "label_ch must be in [1,8]");
+    STCD_CHECK(dtype == STCD_DTYPE_F32 || dtype == STCD_DTYPE_BF16, "unknown dtype");
+    std::unique_ptr<stcd_engine> e(new stcd_engine());
+    e->arch = arch; e->in_ch = in_ch; e->label = label_ch; e->dt = dtype;
+    const char* env = getenv("STCD_FORCE_REF_KERNELS");
+    e->use_mfma = !(env && env[0] == '1');
+    build_fcsiam_tables(*e);
+    *out = e.release();
+    return 0;
+}
+void stcd_destroy(stcd_engine* e) { delete e; }
+
+int stcd_num_params(const stcd_engine* e) { return e ? (int)e->params.size() : 0; }
+int stcd_param_info(const stcd_engine* e, int i, stcd_tensor_info* info) {
+    STCD_CHECK(e && info && i >= 0 && i < (int)e->params.size(), "bad argument");
+    *info = e->params[i];
+    return 0;
+}
+int64_t stcd_param_floats(const stcd_engine* e) { return e ? e->param_floats : 0; }
+int stcd_num_bn(const stcd_engine* e) { return e ? (int)e->bns.size() : 0; }
+int stcd_bn_info_get(const stcd_engine* e, int i, stcd_bn_info* info) {
+    STCD_CHECK(e && info && i >= 0 && i < (int)e->bns.size(), "bad argument");
+    memset(info, 0, sizeof(*info));
+    snprintf(info->name, sizeof(info->name), "%s", e->bns[i].name.c_str());
+    info->channels = e->bns[i].C;
+    info->calls_per_forward = e->bns[i].calls;
+    info->offset = e->bns[i].run_off;
+    return 0;
+}
+int64_t stcd_bn_floats(const stcd_engine* e) { return e ? e->bn_floats : 0; }
+
+int stcd_configure(stcd_engine* e, int batch, int height, int width) {
+    STCD_CHECK(e != nullptr, "engine is null");
+    STCD_CHECK(batch >= 1, "batch must be >= 1");
+    STCD_CHECK(height >= 16 && width >= 16, "height and width must be >= 16 (four 2x2 pools)");
+    STCD_CHECK((int64_t)2 * batch * height * width * 16 < ((int64_t)1 << 31), "tensor too large for 32-bit pixel indexing");
+    e->configured = false;
+    e->B = batch; e->H = height; e->W = width;
+    if (configure_fcsiam(*e, batch, height, width)) return 1;
+    e->configured = true;
+    e->fwd_training = false;
+    return 0;
+}
+int64_t stcd_workspace_bytes(const stcd_engine* e) { return e && e->configured ? e->ws_bytes : 0; }
+int stcd_num_dropout(const stcd_engine* e) { return e && e->configured ? (int)e->drops.size() : 0; }
+int stcd_dropout_info_get(const stcd_engine* e, int i, stcd_dropout_info* info) {
+    STCD_CHECK(e && e->configured && info && i >= 0 && i < (int)e->drops.size(), "bad argument");
+    memset(info, 0, sizeof(*info));
+    snprintf(info->name, sizeof(info->name), "%s", e->drops[i].name.c_str());
+    info->rows = e->drops[i].rows;
+    info->channels = e->drops[i].C;
+    info->offset = e->drops[i].off;
+    return 0;
+}
+int64_t stcd_dropout_floats(const stcd_engine* e) { return e && e->configured ? e->drop_floats : 0; }
+int stcd_set_dropout_p(stcd_engine* e, float p) {
+    STCD_CHECK(e != nullptr, "engine is null");
+    STCD_CHECK(p >= 0.f && p < 1.f, "p must be in [0,1)");
+    e->drop_p = p;
+    return 0;
+}
+
+int stcd_forward(stcd_engine* e, const float* x1, const float* x2, const float* params, float* bn_running,
+                 const float* dropout_masks, uint64_t dropout_seed, int training, float* logits, void* workspace,
+                 void* hip_stream) {
+    STCD_CHECK(e && e->configured, "engine not configured");
+    STCD_CHECK(x1 && x2 && params && bn_running && logits && workspace, "null pointer argument");
+    e->fwd_training = false;
+    int rc = forward_fcsiam(*e, x1, x2, params, bn_running, dropout_masks, dropout_seed, training, logits, workspace,
+                            (hipStream_t)hip_stream);
+    if (rc == 0) e->fwd_training = training != 0;
+    return rc;
+}
+
+int stcd_backward(stcd_engine* e, const float* grad_logits, const float* params, float* grads, void* workspace, int stage,
+                  void* hip_stream) {
+    STCD_CHECK(e && e->configured, "engine not configured");
+    STCD_CHECK(e->fwd_training, "backward requires a preceding training-mode forward on this engine");
+    STCD_CHECK(grad_logits && params && grads && workspace, "null pointer argument");
+    STCD_CHECK(stage >= -1 && stage <= 1, "stage must be -1, 0 or 1");
+    return backward_fcsiam(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
+}
+
+int stcd_grad_stage_range(const stcd_engine* e, int stage, int64_t* begin, int64_t* end) {
+    STCD_CHECK(e && begin && end, "bad argument");
+    STCD_CHECK(stage == 0 || stage == 1, "stage must be 0 or 1");
+    if (stage == 0) { *begin = e->enc_param_end; *end = e->param_floats; }
+    else { *begin = 0; *end = e->enc_param_end; }
+    return 0;
+}
+
+int64_t stcd_loss_scratch_bytes(void) { return loss_scratch_bytes(); }
+int stcd_loss_ce(const float* logits, const int64_t* target, int batch, int classes, int64_t hw, int ignore_index,
+                 float* loss_out, float* dlogits, void* scratch, void* hip_stream) {
+    STCD_CHECK(logits && target && loss_out && scratch, "null pointer argument");
+    STCD_CHECK(batch >= 1 && classes >= 2 && classes <= 16 && hw >= 1, "bad shape");
+    launch_loss_ce(logits, target, batch, classes, hw, ignore_index, loss_out, dlogits, scratch, (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+int stcd_loss_bce_dice(const float* logits, const float* target, int64_t numel, float* loss_out, float* dlogits,
+                       void* scratch, void* hip_stream) {
+    STCD_CHECK(logits && target && loss_out && scratch, "null pointer argument");
+    STCD_CHECK(numel >= 1, "bad shape");
+    launch_loss_bce_dice(logits, target, numel, loss_out, dlogits, scratch, (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+int stcd_confusion_update(const float* logits, const int64_t* target, int batch, int classes, int64_t hw, int64_t* cm,
+                          void* hip_stream) {
+    STCD_CHECK(logits && target && cm, "null pointer argument");
+    STCD_CHECK(batch >= 1 && (classes == 1 || classes == 2) && hw >= 1, "bad shape (classes must be 1 or 2)");
+    launch_confusion(logits, target, batch, classes, hw, cm, (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
+static int check_geom(const stcd_conv_geom* g) {
+    STCD_CHECK(g != nullptr, "geometry is null");
+    STCD_CHECK(g->ntaps >= 1 && g->ntaps <= 9, "ntaps must be in [1,9]");
+    STCD_CHECK(g->ci >= 8 && g->ci % 8 == 0 && g->ldi >= g->ci && g->ldi % 8 == 0, "ci/ldi must be multiples of 8");
+    STCD_CHECK(g->co >= 1 && g->ldo >= g->co, "bad co/ldo");
+    STCD_CHECK(g->in_stride >= 1 && g->out_stride >= 1 && g->n >= 1 && g->hm >= 1 && g->wm >= 1, "bad sizes");
+    STCD_CHECK((g->hm - 1) * g->out_stride + g->oy0 < g->ho && (g->wm - 1) * g->out_stride + g->ox0 < g->wo,
+               "output positions exceed the output buffer");
+    return 0;
+}
+int64_t stcd_op_scratch_bytes(const stcd_conv_geom* g) { return g ? 1 << 20 : 0; }
+int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, const float* w, const float* bias,
+                 void* out, void* scratch, int64_t scratch_bytes, void* hip_stream) {
+    if (check_geom(g)) return 1;
+    STCD_CHECK(in && w && out, "null pointer argument");
+    STCD_CHECK(impl == 0, "MFMA implementation not linked in this build");
+    launch_conv_ref(dtype, *g, in, w, g->ci, g->co, bias, out, false, (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, const void* dout, float* dw, void* scratch,
+                  int64_t scratch_bytes, void* hip_stream) {
+    if (check_geom(g)) return 1;
+    STCD_CHECK(in && dout && dw, "null pointer argument");
+    STCD_CHECK(impl == 0, "MFMA implementation not linked in this build");
+    STCD_HIP(hipMemsetAsync(dw, 0, (size_t)g->ntaps * g->ci * g->co * 4, (hipStream_t)hip_stream));
+    launch_wgrad_ref(dtype, *g, in, dout, dw, g->ci, g->co, (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

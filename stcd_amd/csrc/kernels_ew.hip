@@ -1,0 +1,625 @@
+// kernels_ew.hip -- HBM-bound elementwise / reduction kernels of the change-detection engine (gfx950).
+//
+// Everything here is bandwidth work: every thread moves 8 channels (16 B in bf16, 32 B in fp32) per access,
+// consecutive lanes touch consecutive 16-B chunks of NHWC rows, reductions go wave -> LDS -> one partial per
+// block (no same-address atomics on the hot path).  Semantics restated from:
+//   BatchNorm2d + ReLU + Dropout2d   /root/reference/models/SiamUnet_diff.py:19-20, applied :99
+//   F.max_pool2d(2,2)                /root/reference/models/SiamUnet_diff.py:101
+//   |T1-T2| / T2-T1 skip fusion      SiamUnet_diff.py:150 / SiamUnet_sub.py:150
+//   ReplicationPad2d                 SiamUnet_diff.py:149
+#include "common.h"
+
+namespace stcd {
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// grouped view: element (g, n_in_group, pix, c) at p + g*goff + (n_in_group*HW + pix)*ld + c
+struct GV {
+    int ld;
+    int64_t goff;
+};
+
+// ------------------------------------------------------------------ pack / unpack at the NCHW fp32 boundary
+template <typename T>
+__global__ void k_in_pack(const float* __restrict__ x1, const float* __restrict__ x2, T* __restrict__ X, int B, int cin,
+                          int64_t HW) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * (int64_t)B * HW) return;
+    int n = (int)(i / HW);
+    int64_t p = i - (int64_t)n * HW;
+    const float* src = (n < B ? x1 + (int64_t)n * cin * HW : x2 + (int64_t)(n - B) * cin * HW) + p;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = c < cin ? src[(int64_t)c * HW] : 0.f;
+    store8<T>(X + i * 8, v);
+}
+
+void launch_in_pack(int dt, const float* x1, const float* x2, void* X, int B, int cin, int H, int W, hipStream_t s) {
+    int64_t HW = (int64_t)H * W, n = 2 * (int64_t)B * HW;
+    if (dt == BF16) k_in_pack<bf16><<<cdiv(n, 256), 256, 0, s>>>(x1, x2, (bf16*)X, B, cin, HW);
+    else k_in_pack<float><<<cdiv(n, 256), 256, 0, s>>>(x1, x2, (float*)X, B, cin, HW);
+}
+
+template <typename T>
+__global__ void k_gout_pack(const float* __restrict__ g, T* __restrict__ G, int B, int L, int64_t HW) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * HW) return;
+    int n = (int)(i / HW);
+    int64_t p = i - (int64_t)n * HW;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = c < L ? g[((int64_t)n * L + c) * HW + p] : 0.f;
+    store8<T>(G + i * 8, v);
+}
+
+void launch_gout_pack(int dt, const float* g, void* G, int B, int L, int H, int W, hipStream_t s) {
+    int64_t HW = (int64_t)H * W, n = (int64_t)B * HW;
+    if (dt == BF16) k_gout_pack<bf16><<<cdiv(n, 256), 256, 0, s>>>(g, (bf16*)G, B, L, HW);
+    else k_gout_pack<float><<<cdiv(n, 256), 256, 0, s>>>(g, (float*)G, B, L, HW);
+}
+
+// ------------------------------------------------------------------ weight pack / unpack (tiny)
+__global__ void k_pack_w(PackSpec ps, const float* __restrict__ src, float* __restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)ps.ntaps * ps.kpad * ps.wld;
+    if (i >= total) return;
+    int n = (int)(i % ps.wld);
+    int k = (int)((i / ps.wld) % ps.kpad);
+    int t = (int)(i / ((int64_t)ps.wld * ps.kpad));
+    float v = 0.f;
+    if (n < ps.N && k < ps.K) {
+        int64_t a = ps.kn_major ? ((int64_t)k * ps.N + n) : ((int64_t)n * ps.K + k);
+        v = src[(a * ps.ks + ps.ky[t]) * ps.ks + ps.kx[t]];
+    }
+    dst[i] = v;
+}
+void launch_pack_w(const PackSpec& ps, const float* src, float* dst, hipStream_t s) {
+    int64_t total = (int64_t)ps.ntaps * ps.kpad * ps.wld;
+    k_pack_w<<<cdiv(total, 256), 256, 0, s>>>(ps, src, dst);
+}
+__global__ void k_unpack_dw(PackSpec ps, const float* __restrict__ dwe, float* __restrict__ gsrc) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)ps.ntaps * ps.K * ps.N;
+    if (i >= total) return;
+    int n = (int)(i % ps.N);
+    int k = (int)((i / ps.N) % ps.K);
+    int t = (int)(i / ((int64_t)ps.N * ps.K));
+    int64_t a = ps.kn_major ? ((int64_t)k * ps.N + n) : ((int64_t)n * ps.K + k);
+    gsrc[(a * ps.ks + ps.ky[t]) * ps.ks + ps.kx[t]] = dwe[((int64_t)t * ps.kpad + k) * ps.wld + n];
+}
+void launch_unpack_dw(const PackSpec& ps, const float* dwe, float* gsrc, hipStream_t s) {
+    int64_t total = (int64_t)ps.ntaps * ps.K * ps.N;
+    k_unpack_dw<<<cdiv(total, 256), 256, 0, s>>>(ps, dwe, gsrc);
+}
+
+// ------------------------------------------------------------------ batch-norm statistics
+// One block = one contiguous pixel chunk of one group.  thread -> (pixel lane, channel block of 8).
+// MODE 0: sums of y and y^2.  MODE 1 (backward): sums of dz and dz*xhat with dz = dA*mask*(z>0).
+int bn_stats_chunks(int64_t ppg) {
+    int64_t c = ppg / 2048;
+    if (c < 1) c = 1;
+    if (c > 1024) c = 1024;
+    return (int)c;
+}
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256)
+k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, const float* __restrict__ stat,
+            const float* __restrict__ mask, int C, int npg, int64_t HW, int relu, int64_t ppg, int nchunk,
+            float* __restrict__ partial) {
+    __shared__ float red[256 * 16];
+    const int g = blockIdx.y, chunk = blockIdx.x;
+    const int cb = C >> 3;                   // channel blocks (power of two, <= 256)
+    const int lanes = 256 / cb;
+    const int mycb = threadIdx.x % cb, lane = threadIdx.x / cb;
+    const int64_t per = (ppg + nchunk - 1) / nchunk;
+    const int64_t p0 = (int64_t)chunk * per, p1 = min(ppg, p0 + per);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    float mean[8], invstd[8], scale[8], shift[8];
+    if (MODE == 1) {
+        const float* st = stat + (int64_t)g * 4 * C + mycb * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mean[j] = st[j]; invstd[j] = st[C + j]; scale[j] = st[2 * C + j]; shift[j] = st[3 * C + j];
+        }
+    }
+    const T* yb = Y + ((int64_t)g * ppg) * ldy + mycb * 8;
+    for (int64_t p = p0 + lane; p < p1; p += lanes) {
+        float y[8];
+        load8<T>(yb + p * ldy, y);
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += y[j]; s2[j] += y[j] * y[j]; }
+        } else {
+            float d[8];
+            int nig = (int)(p / HW);
+            load8<T>(dA + g * dav.goff + p * dav.ld + mycb * 8, d);
+            const float* mk = mask ? mask + ((int64_t)(g * npg + nig)) * C + mycb * 8 : nullptr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float z = y[j] * scale[j] + shift[j];
+                float dz = d[j] * (mk ? mk[j] : 1.f);
+                if (relu && !(z > 0.f)) dz = 0.f;
+                s1[j] += dz;
+                s2[j] += dz * (y[j] - mean[j]) * invstd[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s1[j]; red[threadIdx.x * 16 + 8 + j] = s2[j]; }
+    __syncthreads();
+    float* out = partial + ((int64_t)g * nchunk + chunk) * 2 * C;
+    for (int o = threadIdx.x; o < 2 * C; o += 256) {
+        int which = o / C, c = o - which * C;
+        float acc = 0.f;
+        for (int l = 0; l < lanes; ++l) acc += red[(l * cb + (c >> 3)) * 16 + which * 8 + (c & 7)];
+        out[o] = acc;
+    }
+}
+
+void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t ppg, float* partial, hipStream_t s) {
+    int nchunk = bn_stats_chunks(ppg);
+    dim3 grid(nchunk, groups);
+    GV z{0, 0};
+    if (dt == BF16)
+        k_bn_reduce<bf16, 0><<<grid, 256, 0, s>>>((const bf16*)Y, ld, nullptr, z, nullptr, nullptr, C, 0, 1, 0, ppg, nchunk, partial);
+    else
+        k_bn_reduce<float, 0><<<grid, 256, 0, s>>>((const float*)Y, ld, nullptr, z, nullptr, nullptr, C, 0, 1, 0, ppg, nchunk, partial);
+}
+
+void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, const void* Y, int ldy, const float* stat,
+                          const float* mask, int C, int groups, int npg, int64_t HW, int relu, float* partial,
+                          hipStream_t s);
+
+__global__ void k_bn_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+                              float* __restrict__ rvar, float* __restrict__ stat, float momentum, float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
+    for (int g = 0; g < groups; ++g) {   // sequential: the shared encoder BN sees T1 then T2 (SiamUnet_diff.py:99,123)
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            const float* p = partial + ((int64_t)g * nchunk + k) * 2 * C;
+            s1 += p[c];
+            s2 += p[C + c];
+        }
+        double mean = s1 / ppg, var = s2 / ppg - mean * mean;
+        if (var < 0.0) var = 0.0;
+        double invstd = 1.0 / sqrt(var + (double)eps);
+        float sc = (float)(gamma[c] * invstd);
+        float* st = stat + (int64_t)g * 4 * C;
+        st[c] = (float)mean;
+        st[C + c] = (float)invstd;
+        st[2 * C + c] = sc;
+        st[3 * C + c] = (float)(beta[c] - mean * gamma[c] * invstd);
+        double unb = ppg > 1 ? var * ((double)ppg / (double)(ppg - 1)) : var;
+        rm = (float)((1.0 - momentum) * rm + momentum * mean);
+        rv = (float)((1.0 - momentum) * rv + momentum * unb);
+    }
+    if (rmean) rmean[c] = rm;
+    if (rvar) rvar[c] = rv;
+}
+void launch_bn_finalize(const float* partial, int nchunk, int C, int groups, int64_t ppg, const float* gamma,
+                        const float* beta, float* rmean, float* rvar, float* stat, float momentum, float eps,
+                        hipStream_t s) {
+    k_bn_finalize<<<cdiv(C, 64), 64, 0, s>>>(partial, nchunk, C, groups, ppg, gamma, beta, rmean, rvar, stat, momentum, eps);
+}
+
+__global__ void k_bn_eval_prepare(int C, int groups, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  const float* __restrict__ rmean, const float* __restrict__ rvar, float* __restrict__ stat,
+                                  float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float invstd = 1.f / sqrtf(rvar[c] + eps);
+    for (int g = 0; g < groups; ++g) {
+        float* st = stat + (int64_t)g * 4 * C;
+        st[c] = rmean[c];
+        st[C + c] = invstd;
+        st[2 * C + c] = gamma[c] * invstd;
+        st[3 * C + c] = beta[c] - rmean[c] * gamma[c] * invstd;
+    }
+}
+void launch_bn_eval_prepare(int C, int groups, const float* gamma, const float* beta, const float* rmean,
+                            const float* rvar, float* stat, float eps, hipStream_t s) {
+    k_bn_eval_prepare<<<cdiv(C, 64), 64, 0, s>>>(C, groups, gamma, beta, rmean, rvar, stat, eps);
+}
+
+// ------------------------------------------------------------------ BN-apply + ReLU + Dropout2d (+ 2x2 max-pool)
+// thread -> (2x2 cell, channel block).  One pass: reads the raw conv output once, writes the activation once
+// and, when a pool follows, the pooled map too (saves re-reading the full-resolution tensor).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restrict__ P, int ldp,
+         const float* __restrict__ stat, const float* __restrict__ mask, int C, int npg, int H, int W, int relu,
+         int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
+    int c0 = (int)(i % cb) * 8;
+    int64_t r = i / cb;
+    int xc = (int)(r % Wc); r /= Wc;
+    int yc = (int)(r % Hc);
+    int n = (int)(r / Hc);
+    int g = n / npg, nig = n - g * npg;
+    const float* st = stat + (int64_t)g * 4 * C + c0;
+    float sc[8], sh[8], mk[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = st[2 * C + j];
+        sh[j] = st[3 * C + j];
+        mk[j] = mask ? mask[(int64_t)n * C + c0 + j] : 1.f;
+    }
+    float best[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+        if (y >= H || x >= W) continue;
+        float v[8];
+        load8<T>(Y + (((int64_t)n * H + y) * W + x) * ldy + c0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = v[j] * sc[j] + sh[j];
+            if (relu) z = fmaxf(z, 0.f);
+            v[j] = round_as<T>(z * mk[j]);
+            best[j] = k == 0 ? v[j] : fmaxf(best[j], v[j]);
+        }
+        store8<T>(A + g * av.goff + (((int64_t)nig * H + y) * W + x) * av.ld + c0, v);
+    }
+    if (P && yc < Hp && xc < Wp) store8<T>(P + (((int64_t)n * Hp + yc) * Wp + xc) * ldp + c0, best);
+}
+
+void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s) {
+    int64_t total = (int64_t)a.groups * a.npg * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.C / 8);
+    GV av{a.lda, a.a_group_off};
+    if (dt == BF16)
+        k_bn_act<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)a.Y, a.ldy, (bf16*)a.A, av, (bf16*)a.P, a.ldp, a.stat,
+                                                        a.mask, a.C, a.npg, a.H, a.W, a.relu, total);
+    else
+        k_bn_act<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)a.Y, a.ldy, (float*)a.A, av, (float*)a.P, a.ldp,
+                                                         a.stat, a.mask, a.C, a.npg, a.H, a.W, a.relu, total);
+}
+
+template <typename T>
+__global__ void k_maxpool(const T* __restrict__ A, int lda, T* __restrict__ P, int ldp, int H, int W, int C, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3, Hp = H >> 1, Wp = W >> 1;
+    int c0 = (int)(i % cb) * 8;
+    int64_t r = i / cb;
+    int xp = (int)(r % Wp); r /= Wp;
+    int yp = (int)(r % Hp);
+    int n = (int)(r / Hp);
+    float best[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v[8];
+        load8<T>(A + (((int64_t)n * H + 2 * yp + (k >> 1)) * W + 2 * xp + (k & 1)) * lda + c0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) best[j] = k == 0 ? v[j] : fmaxf(best[j], v[j]);
+    }
+    store8<T>(P + (((int64_t)n * Hp + yp) * Wp + xp) * ldp + c0, best);
+}
+void launch_maxpool(int dt, const void* A, int lda, void* P, int ldp, int N, int H, int W, int C, hipStream_t s) {
+    int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+    if (total == 0) return;
+    if (dt == BF16) k_maxpool<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)A, lda, (bf16*)P, ldp, H, W, C, total);
+    else k_maxpool<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)A, lda, (float*)P, ldp, H, W, C, total);
+}
+
+// dA (+)= dP routed to the FIRST maximum (scan order (0,0),(0,1),(1,0),(1,1)) of each window of A
+template <typename T>
+__global__ void k_pool_bwd(const T* __restrict__ A, GV av, const T* __restrict__ dP, int ldp, T* __restrict__ dA, GV dav,
+                           int npg, int H, int W, int C, int accumulate, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
+    int c0 = (int)(i % cb) * 8;
+    int64_t r = i / cb;
+    int xc = (int)(r % Wc); r /= Wc;
+    int yc = (int)(r % Hc);
+    int n = (int)(r / Hc);
+    int g = n / npg, nig = n - g * npg;
+    bool pooled = yc < Hp && xc < Wp;
+    float a[4][8], gp[8];
+    int arg[8];
+    if (pooled) {
+        load8<T>(dP + (((int64_t)n * Hp + yc) * Wp + xc) * ldp + c0, gp);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            load8<T>(A + g * av.goff + (((int64_t)nig * H + 2 * yc + (k >> 1)) * W + 2 * xc + (k & 1)) * av.ld + c0, a[k]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int b = 0;
+            float bv = a[0][j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (a[k][j] > bv) { bv = a[k][j]; b = k; }
+            arg[j] = b;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+        if (y >= H || x >= W) continue;
+        T* dst = dA + g * dav.goff + (((int64_t)nig * H + y) * W + x) * dav.ld + c0;
+        float v[8];
+        if (accumulate) load8<T>(dst, v);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+        if (pooled) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (arg[j] == k) v[j] += gp[j];
+        }
+        store8<T>(dst, v);
+    }
+}
+
+// ------------------------------------------------------------------ skip fusion
+template <typename T>
+__global__ void k_fuse(int mode, const T* __restrict__ A, GV av, T* __restrict__ D, int ldd, int64_t HW, int C, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3;
+    int c0 = (int)(i % cb) * 8;
+    int64_t p = i / cb;   // n*HW + pix over the B pairs
+    float a[8], b[8], o[8];
+    load8<T>(A + p * av.ld + c0, a);
+    load8<T>(A + av.goff + p * av.ld + c0, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = mode == 0 ? fabsf(a[j] - b[j]) : b[j] - a[j];
+    store8<T>(D + p * ldd + c0, o);
+}
+template <typename T>
+__global__ void k_fuse_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ dD, int ldd, T* __restrict__ dA,
+                           GV dav, int64_t HW, int C, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3;
+    int c0 = (int)(i % cb) * 8;
+    int64_t p = i / cb;
+    float a[8], b[8], g[8], da[8], db[8];
+    load8<T>(dD + p * ldd + c0, g);
+    if (mode == 0) {
+        load8<T>(A + p * av.ld + c0, a);
+        load8<T>(A + av.goff + p * av.ld + c0, b);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float sgn = mode == 0 ? (float)((a[j] > b[j]) - (a[j] < b[j])) : -1.f;
+        da[j] = sgn * g[j];
+        db[j] = -sgn * g[j];
+    }
+    store8<T>(dA + p * dav.ld + c0, da);
+    store8<T>(dA + dav.goff + p * dav.ld + c0, db);
+}
+
+// ------------------------------------------------------------------ replication pad of trailing rows / cols
+template <typename T>
+__global__ void k_rep_pad(T* __restrict__ D, int ld, int H, int W, int h0, int w0, int C, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3;
+    int c0 = (int)(i % cb) * 8;
+    int64_t r = i / cb;
+    int x = (int)(r % W); r /= W;
+    int y = (int)(r % H);
+    int n = (int)(r / H);
+    if (y < h0 && x < w0) return;
+    int ys = min(y, h0 - 1), xs = min(x, w0 - 1);
+    float v[8];
+    load8<T>(D + (((int64_t)n * H + ys) * W + xs) * ld + c0, v);
+    store8<T>(D + (((int64_t)n * H + y) * W + x) * ld + c0, v);
+}
+// backward: edge pixel (h0-1 / w0-1) accumulates the gradients of its replicas; thread per interior edge pixel
+template <typename T>
+__global__ void k_rep_pad_bwd(T* __restrict__ dD, int ld, int H, int W, int h0, int w0, int C, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3;
+    int c0 = (int)(i % cb) * 8;
+    int64_t r = i / cb;
+    int x = (int)(r % w0); r /= w0;
+    int y = (int)(r % h0);
+    int n = (int)(r / h0);
+    bool ey = (y == h0 - 1) && H > h0, ex = (x == w0 - 1) && W > w0;
+    if (!ey && !ex) return;
+    float acc[8], v[8];
+    load8<T>(dD + (((int64_t)n * H + y) * W + x) * ld + c0, acc);
+    for (int yy = y; yy < (ey ? H : y + 1); ++yy)
+        for (int xx = x; xx < (ex ? W : x + 1); ++xx) {
+            if (yy == y && xx == x) continue;
+            load8<T>(dD + (((int64_t)n * H + yy) * W + xx) * ld + c0, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+    store8<T>(dD + (((int64_t)n * H + y) * W + x) * ld + c0, acc);
+}
+
+// ------------------------------------------------------------------ BN backward: apply
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, const T* __restrict__ Y, int ldy,
+               const float* __restrict__ stat, const float* __restrict__ coef, const float* __restrict__ mask, int C, int npg,
+               int64_t HW, int relu, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3;
+    int c0 = (int)(i % cb) * 8;
+    int64_t p = i / cb;           // global pixel index over groups*npg images
+    int n = (int)(p / HW);
+    int g = n / npg;
+    int64_t pig = p - (int64_t)g * npg * HW;
+    const float* st = stat + (int64_t)g * 4 * C + c0;
+    const float* cf = coef + (int64_t)g * 2 * C + c0;
+    float y[8], d[8], o[8];
+    load8<T>(Y + p * ldy + c0, y);
+    load8<T>(dA + g * dav.goff + pig * dav.ld + c0, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float mean = st[j], invstd = st[C + j], scale = st[2 * C + j], shift = st[3 * C + j];
+        float z = y[j] * scale + shift;
+        float dz = d[j] * (mask ? mask[(int64_t)n * C + c0 + j] : 1.f);
+        if (relu && !(z > 0.f)) dz = 0.f;
+        float xh = (y[j] - mean) * invstd;
+        o[j] = scale * (dz - cf[j] - xh * cf[C + j]);
+    }
+    store8<T>(dY + p * lddy + c0, o);
+}
+
+__global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg,
+                                  float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double tg = 0.0, tb = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            const float* p = partial + ((int64_t)g * nchunk + k) * 2 * C;
+            s1 += p[c];
+            s2 += p[C + c];
+        }
+        coef[(int64_t)g * 2 * C + c] = (float)(s1 / ppg);
+        coef[(int64_t)g * 2 * C + C + c] = (float)(s2 / ppg);
+        tb += s1;
+        tg += s2;
+    }
+    dgamma[c] = (float)tg;
+    dbeta[c] = (float)tb;
+}
+void launch_bn_bwd_finalize(const float* partial, int nchunk, int C, int groups, int64_t ppg, float* coef, float* dgamma,
+                            float* dbeta, hipStream_t s) {
+    k_bn_bwd_finalize<<<cdiv(C, 64), 64, 0, s>>>(partial, nchunk, C, groups, ppg, coef, dgamma, dbeta);
+}
+
+// ------------------------------------------------------------------ bias gradient (layers without a following BN)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_bias_grad(const T* __restrict__ dY, int ld, int64_t pixels, int C, float* __restrict__ db) {
+    __shared__ float red[256 * 8];
+    const int cb = C >> 3, lanes = 256 / cb;
+    const int mycb = threadIdx.x % cb, lane = threadIdx.x / cb;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    for (int64_t p = (int64_t)blockIdx.x * lanes + lane; p < pixels; p += (int64_t)gridDim.x * lanes) {
+        float v[8];
+        load8<T>(dY + p * ld + mycb * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = s[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int l = 0; l < lanes; ++l) acc += red[(l * cb + (c >> 3)) * 8 + (c & 7)];
+        atomicAdd(db + c, acc);
+    }
+}
+void launch_bias_grad(int dt, const void* dY, int ld, int64_t pixels, int C, float* db, hipStream_t s) {
+    int lanes = 256 / (C / 8);
+    int grid = (int)std::min<int64_t>(512, (pixels + lanes - 1) / lanes);
+    if (grid < 1) grid = 1;
+    if (dt == BF16) k_bias_grad<bf16><<<grid, 256, 0, s>>>((const bf16*)dY, ld, pixels, C, db);
+    else k_bias_grad<float><<<grid, 256, 0, s>>>((const float*)dY, ld, pixels, C, db);
+}
+
+// ------------------------------------------------------------------ dropout masks, fill
+__global__ void k_dropout_gen(float* __restrict__ mask, int64_t n, uint64_t seed, float p) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);   // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+    mask[i] = u >= p ? 1.0f / (1.0f - p) : 0.f;
+}
+void launch_dropout_gen(float* mask, int64_t n, uint64_t seed, float p, hipStream_t s) {
+    if (n > 0) k_dropout_gen<<<cdiv(n, 256), 256, 0, s>>>(mask, n, seed, p);
+}
+__global__ void k_fill(float* p, int64_t n, float v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+void launch_fill(float* p, int64_t n, float v, hipStream_t s) {
+    if (n > 0) k_fill<<<cdiv(n, 256), 256, 0, s>>>(p, n, v);
+}
+
+// ------------------------------------------------------------------ typed launch wrappers using grouped views
+#define DISPATCH(dt, KERNEL, ...)                          \
+    do {                                                   \
+        if ((dt) == BF16) KERNEL(bf16, __VA_ARGS__);       \
+        else KERNEL(float, __VA_ARGS__);                   \
+    } while (0)
+
+void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, const void* Y, int ldy, const float* stat,
+                          const float* mask, int C, int groups, int npg, int64_t HW, int relu, float* partial,
+                          hipStream_t s) {
+    int64_t ppg = (int64_t)npg * HW;
+    int nchunk = bn_stats_chunks(ppg);
+    dim3 grid(nchunk, groups);
+    GV dav{ldda, da_goff};
+    if (dt == BF16)
+        k_bn_reduce<bf16, 1><<<grid, 256, 0, s>>>((const bf16*)Y, ldy, (const bf16*)dA, dav, stat, mask, C, npg, HW, relu, ppg, nchunk, partial);
+    else
+        k_bn_reduce<float, 1><<<grid, 256, 0, s>>>((const float*)Y, ldy, (const float*)dA, dav, stat, mask, C, npg, HW, relu, ppg, nchunk, partial);
+}
+
+void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
+                         const float* stat, const float* coef, const float* mask, int C, int groups, int npg, int64_t HW,
+                         int relu, hipStream_t s) {
+    int64_t total = (int64_t)groups * npg * HW * (C / 8);
+    GV dav{ldda, da_goff};
+    if (dt == BF16)
+        k_bn_bwd_apply<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)dA, dav, (bf16*)dY, lddy, (const bf16*)Y, ldy, stat, coef, mask, C, npg, HW, relu, total);
+    else
+        k_bn_bwd_apply<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)dA, dav, (float*)dY, lddy, (const float*)Y, ldy, stat, coef, mask, C, npg, HW, relu, total);
+}
+
+void launch_pool_bwd(int dt, const void* A, int lda, int64_t a_goff, const void* dP, int ldp, void* dA, int ldda,
+                     int64_t da_goff, int groups, int npg, int H, int W, int C, int accumulate, hipStream_t s) {
+    int64_t total = (int64_t)groups * npg * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+    GV av{lda, a_goff}, dav{ldda, da_goff};
+    if (dt == BF16)
+        k_pool_bwd<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)A, av, (const bf16*)dP, ldp, (bf16*)dA, dav, npg, H, W, C, accumulate, total);
+    else
+        k_pool_bwd<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)A, av, (const float*)dP, ldp, (float*)dA, dav, npg, H, W, C, accumulate, total);
+}
+
+void launch_fuse(int dt, int mode, const void* A, int lda, int64_t a_goff, void* D, int ldd, int B, int64_t HW, int C,
+                 hipStream_t s) {
+    int64_t total = (int64_t)B * HW * (C / 8);
+    GV av{lda, a_goff};
+    if (dt == BF16) k_fuse<bf16><<<cdiv(total, 256), 256, 0, s>>>(mode, (const bf16*)A, av, (bf16*)D, ldd, HW, C, total);
+    else k_fuse<float><<<cdiv(total, 256), 256, 0, s>>>(mode, (const float*)A, av, (float*)D, ldd, HW, C, total);
+}
+void launch_fuse_bwd(int dt, int mode, const void* A, int lda, int64_t a_goff, const void* dD, int ldd, void* dA, int ldda,
+                     int64_t da_goff, int B, int64_t HW, int C, hipStream_t s) {
+    int64_t total = (int64_t)B * HW * (C / 8);
+    GV av{lda, a_goff}, dav{ldda, da_goff};
+    if (dt == BF16)
+        k_fuse_bwd<bf16><<<cdiv(total, 256), 256, 0, s>>>(mode, (const bf16*)A, av, (const bf16*)dD, ldd, (bf16*)dA, dav, HW, C, total);
+    else
+        k_fuse_bwd<float><<<cdiv(total, 256), 256, 0, s>>>(mode, (const float*)A, av, (const float*)dD, ldd, (float*)dA, dav, HW, C, total);
+}
+void launch_rep_pad(int dt, void* D, int ld, int N, int H, int W, int h0, int w0, int C, hipStream_t s) {
+    if (h0 >= H && w0 >= W) return;
+    int64_t total = (int64_t)N * H * W * (C / 8);
+    if (dt == BF16) k_rep_pad<bf16><<<cdiv(total, 256), 256, 0, s>>>((bf16*)D, ld, H, W, h0, w0, C, total);
+    else k_rep_pad<float><<<cdiv(total, 256), 256, 0, s>>>((float*)D, ld, H, W, h0, w0, C, total);
+}
+void launch_rep_pad_bwd(int dt, void* dD, int ld, int N, int H, int W, int h0, int w0, int C, hipStream_t s) {
+    if (h0 >= H && w0 >= W) return;
+    int64_t total = (int64_t)N * h0 * w0 * (C / 8);
+    if (dt == BF16) k_rep_pad_bwd<bf16><<<cdiv(total, 256), 256, 0, s>>>((bf16*)dD, ld, H, W, h0, w0, C, total);
+    else k_rep_pad_bwd<float><<<cdiv(total, 256), 256, 0, s>>>((float*)dD, ld, H, W, h0, w0, C, total);
+}
+
+}  // namespace stcd

@@ -1,0 +1,191 @@
+// kernels_loss.hip -- fused loss forward+backward and the on-device confusion matrix (gfx950).
+//
+// Restated from (semantics, not code):
+//   cross_entropy(ignore_index=255)          /root/reference/models/losses.py:6-21
+//   cd_loss(sigmoid(x), y) == BCE_DICE       /root/reference/models/losses.py:24-34; train_pse_cd.py:227-228,436-462
+//   SegmentationMetric.genConfusionMatrix    /root/reference/train_pse_cd.py:361-368
+// The reference runs each of these as 3-8 tiny ATen kernels plus a host sync for the metric; here each loss is
+// reduce -> finalize -> gradient (three launches, wave-reduced, no host sync) and the metric is one launch.
+#include "common.h"
+
+namespace stcd {
+
+#define LOSS_BLOCKS 1024
+
+struct LossScratch {
+    double part[LOSS_BLOCKS][4];
+    double fin[4];
+};
+int64_t loss_scratch_bytes() { return (int64_t)sizeof(LossScratch); }
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// block-reduce up to 4 doubles; result valid in thread 0
+__device__ __forceinline__ void block_sum4(double (&v)[4], double* sm) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = wave_sum_d(v[k]);
+        if (lane == 0) sm[wid * 4 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double a = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += sm[w * 4 + k];
+            v[k] = a;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ cross entropy
+__global__ void __launch_bounds__(256)
+k_ce_reduce(const float* __restrict__ logits, const int64_t* __restrict__ target, int Cn, int64_t HW, int64_t npix, int ignore,
+            LossScratch* sc) {
+    __shared__ double sm[16];
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = target[i];
+        if (t == ignore) continue;
+        int64_t n = i / HW, p = i - n * HW;
+        const float* l = logits + n * Cn * HW + p;
+        float mx = l[0];
+        for (int c = 1; c < Cn; ++c) mx = fmaxf(mx, l[(int64_t)c * HW]);
+        float se = 0.f;
+        for (int c = 0; c < Cn; ++c) se += expf(l[(int64_t)c * HW] - mx);
+        float lse = mx + logf(se);
+        v[0] += (double)(lse - l[t * HW]);
+        v[1] += 1.0;
+    }
+    block_sum4(v, sm);
+    if (threadIdx.x == 0) { sc->part[blockIdx.x][0] = v[0]; sc->part[blockIdx.x][1] = v[1]; }
+}
+__global__ void k_ce_finalize(LossScratch* sc, int nblocks, float* loss) {
+    __shared__ double sm[16];
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) { v[0] += sc->part[b][0]; v[1] += sc->part[b][1]; }
+    block_sum4(v, sm);
+    if (threadIdx.x == 0) {
+        sc->fin[0] = v[0]; sc->fin[1] = v[1];
+        *loss = (float)(v[0] / v[1]);
+    }
+}
+__global__ void __launch_bounds__(256)
+k_ce_grad(const float* __restrict__ logits, const int64_t* __restrict__ target, int Cn, int64_t HW, int64_t npix, int ignore,
+          const LossScratch* sc, float* __restrict__ dlogits) {
+    const float inv = (float)(1.0 / sc->fin[1]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = target[i];
+        int64_t n = i / HW, p = i - n * HW;
+        const float* l = logits + n * Cn * HW + p;
+        float* d = dlogits + n * Cn * HW + p;
+        if (t == ignore) {
+            for (int c = 0; c < Cn; ++c) d[(int64_t)c * HW] = 0.f;
+            continue;
+        }
+        float mx = l[0];
+        for (int c = 1; c < Cn; ++c) mx = fmaxf(mx, l[(int64_t)c * HW]);
+        float se = 0.f;
+        for (int c = 0; c < Cn; ++c) se += expf(l[(int64_t)c * HW] - mx);
+        float rs = 1.f / se;
+        for (int c = 0; c < Cn; ++c)
+            d[(int64_t)c * HW] = (expf(l[(int64_t)c * HW] - mx) * rs - (c == t ? 1.f : 0.f)) * inv;
+    }
+}
+void launch_loss_ce(const float* logits, const int64_t* target, int B, int Cn, int64_t HW, int ignore, float* loss,
+                    float* dlogits, void* scratch, hipStream_t s) {
+    LossScratch* sc = (LossScratch*)scratch;
+    int64_t npix = (int64_t)B * HW;
+    int nb = (int)std::min<int64_t>(LOSS_BLOCKS, (npix + 255) / 256);
+    k_ce_reduce<<<nb, 256, 0, s>>>(logits, target, Cn, HW, npix, ignore, sc);
+    k_ce_finalize<<<1, 256, 0, s>>>(sc, nb, loss);
+    if (dlogits) k_ce_grad<<<nb, 256, 0, s>>>(logits, target, Cn, HW, npix, ignore, sc, dlogits);
+}
+
+// ------------------------------------------------------------------ sigmoid + BCE(mean) + Dice(smooth=1)
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void __launch_bounds__(256)
+k_bd_reduce(const float* __restrict__ logits, const float* __restrict__ target, int64_t n, LossScratch* sc) {
+    __shared__ double sm[16];
+    double v[4] = {0.0, 0.0, 0.0, 0.0};   // sum p, sum t, sum p*t, sum bce
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float p = sigmoidf(logits[i]), t = target[i];
+        float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);   // torch clamps log at -100
+        v[0] += p; v[1] += t; v[2] += (double)p * t;
+        v[3] -= (double)(t * lp + (1.f - t) * l1p);
+    }
+    block_sum4(v, sm);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 4; ++k) sc->part[blockIdx.x][k] = v[k];
+}
+__global__ void k_bd_finalize(LossScratch* sc, int nblocks, int64_t n, float* loss) {
+    __shared__ double sm[16];
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+        for (int k = 0; k < 4; ++k) v[k] += sc->part[b][k];
+    block_sum4(v, sm);
+    if (threadIdx.x == 0) {
+        double den = v[0] + v[1] + 1.0, num = 2.0 * v[2] + 1.0;
+        sc->fin[0] = den; sc->fin[1] = num;
+        *loss = (float)(v[3] / (double)n + 1.0 - num / den);
+    }
+}
+__global__ void __launch_bounds__(256)
+k_bd_grad(const float* __restrict__ logits, const float* __restrict__ target, int64_t n, const LossScratch* sc,
+          float* __restrict__ dlogits) {
+    const float den = (float)sc->fin[0], num = (float)sc->fin[1], invn = 1.f / (float)n, invd2 = 1.f / (den * den);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float p = sigmoidf(logits[i]), t = target[i];
+        float q = p * (1.f - p);
+        float dbce = (p - t) / fmaxf(q, 1e-12f) * invn;          // ATen binary_cross_entropy_backward (EPSILON 1e-12)
+        float ddice = -(2.f * t * den - num) * invd2;
+        dlogits[i] = (dbce + ddice) * q;
+    }
+}
+void launch_loss_bce_dice(const float* logits, const float* target, int64_t n, float* loss, float* dlogits, void* scratch,
+                          hipStream_t s) {
+    LossScratch* sc = (LossScratch*)scratch;
+    int nb = (int)std::min<int64_t>(LOSS_BLOCKS, (n + 255) / 256);
+    k_bd_reduce<<<nb, 256, 0, s>>>(logits, target, n, sc);
+    k_bd_finalize<<<1, 256, 0, s>>>(sc, nb, n, loss);
+    if (dlogits) k_bd_grad<<<nb, 256, 0, s>>>(logits, target, n, sc, dlogits);
+}
+
+// ------------------------------------------------------------------ 2x2 confusion matrix: cm[2*label+pred] += count
+__global__ void __launch_bounds__(256)
+k_confusion(const float* __restrict__ logits, const int64_t* __restrict__ target, int Cn, int64_t HW, int64_t npix,
+            unsigned long long* __restrict__ cm) {
+    __shared__ unsigned int bins[4];
+    if (threadIdx.x < 4) bins[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned int loc[4] = {0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = target[i];
+        if (t < 0 || t > 1) continue;
+        int64_t n = i / HW, p = i - n * HW;
+        const float* l = logits + n * Cn * HW + p;
+        int pred = Cn == 1 ? (l[0] > 0.f) : (l[HW] > l[0]);   // argmax picks class 0 on ties, sigmoid(x) > 0.5 <=> x > 0
+        loc[2 * (int)t + pred]++;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned int v = loc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&bins[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && bins[threadIdx.x]) atomicAdd(cm + threadIdx.x, (unsigned long long)bins[threadIdx.x]);
+}
+void launch_confusion(const float* logits, const int64_t* target, int B, int Cn, int64_t HW, int64_t* cm, hipStream_t s) {
+    int64_t npix = (int64_t)B * HW;
+    int nb = (int)std::min<int64_t>(512, (npix + 255) / 256);
+    k_confusion<<<nb, 256, 0, s>>>(logits, target, Cn, HW, npix, (unsigned long long*)cm);
+}
+
+}  // namespace stcd

@@ -1,0 +1,130 @@
+"""Python handle over the C-ABI engine (include/stcd_hip.h).
+
+torch is plumbing here: it owns device memory (parameters, workspace, outputs) and the HIP stream the
+engine enqueues on.  All arithmetic happens in libstcd_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class ParamInfo:
+    name: str
+    shape: Tuple[int, ...]
+    offset: int
+    numel: int
+
+
+@dataclass
+class BnInfo:
+    name: str
+    channels: int
+    calls_per_forward: int
+    offset: int
+
+
+@dataclass
+class DropoutInfo:
+    name: str
+    rows: int
+    channels: int
+    offset: int
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    def __init__(self, arch: str, in_ch: int, label_ch: int, dtype: str = "bf16"):
+        self._l = _lib.lib()
+        self.arch, self.in_ch, self.label_ch, self.dtype = arch, in_ch, label_ch, dtype
+        h = C.c_void_p()
+        _lib.check(self._l.stcd_create(_lib.ARCH_IDS[arch], in_ch, label_ch, _lib.DTYPE_IDS[dtype], C.byref(h)))
+        self._h = h
+        self.params: List[ParamInfo] = []
+        ti = _lib.TensorInfo()
+        for i in range(self._l.stcd_num_params(h)):
+            _lib.check(self._l.stcd_param_info(h, i, C.byref(ti)))
+            self.params.append(ParamInfo(ti.name.decode(), tuple(ti.shape[k] for k in range(ti.ndim)), ti.offset, ti.numel))
+        self.param_floats = self._l.stcd_param_floats(h)
+        self.bns: List[BnInfo] = []
+        bi = _lib.BnInfo()
+        for i in range(self._l.stcd_num_bn(h)):
+            _lib.check(self._l.stcd_bn_info_get(h, i, C.byref(bi)))
+            self.bns.append(BnInfo(bi.name.decode(), bi.channels, bi.calls_per_forward, bi.offset))
+        self.bn_floats = self._l.stcd_bn_floats(h)
+        b, e = C.c_int64(), C.c_int64()
+        _lib.check(self._l.stcd_grad_stage_range(h, 0, C.byref(b), C.byref(e)))
+        self.stage0_range = (b.value, e.value)     # decoder gradients: final after backward stage 0
+        _lib.check(self._l.stcd_grad_stage_range(h, 1, C.byref(b), C.byref(e)))
+        self.stage1_range = (b.value, e.value)
+        self.shape: Optional[Tuple[int, int, int]] = None
+        self.dropouts: List[DropoutInfo] = []
+        self.dropout_floats = 0
+        self.workspace: Optional[torch.Tensor] = None
+        self.ticket = 0
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._l.stcd_destroy(h)
+
+    # pickling / deepcopy re-create the native handle (it is process-local)
+    def __getstate__(self):
+        return {"arch": self.arch, "in_ch": self.in_ch, "label_ch": self.label_ch, "dtype": self.dtype}
+
+    def __setstate__(self, st):
+        self.__init__(st["arch"], st["in_ch"], st["label_ch"], st["dtype"])
+
+    def __deepcopy__(self, memo):
+        return Engine(self.arch, self.in_ch, self.label_ch, self.dtype)
+
+    def set_dropout_p(self, p: float):
+        _lib.check(self._l.stcd_set_dropout_p(self._h, C.c_float(p)))
+
+    def configure(self, batch: int, height: int, width: int, device: torch.device):
+        if self.shape == (batch, height, width) and self.workspace is not None and self.workspace.device == device:
+            return
+        _lib.check(self._l.stcd_configure(self._h, batch, height, width))
+        self.shape = (batch, height, width)
+        self.dropouts = []
+        di = _lib.DropoutInfo()
+        for i in range(self._l.stcd_num_dropout(self._h)):
+            _lib.check(self._l.stcd_dropout_info_get(self._h, i, C.byref(di)))
+            self.dropouts.append(DropoutInfo(di.name.decode(), di.rows, di.channels, di.offset))
+        self.dropout_floats = self._l.stcd_dropout_floats(self._h)
+        self.workspace = None   # release before re-allocating
+        self.workspace = torch.empty(self._l.stcd_workspace_bytes(self._h), dtype=torch.uint8, device=device)
+
+    def pack_masks(self, masks: dict, device) -> torch.Tensor:
+        """name -> [rows, C] tensors (oracle convention) into the engine's flat mask buffer."""
+        flat = torch.empty(self.dropout_floats, dtype=torch.float32, device=device)
+        for d in self.dropouts:
+            m = masks[d.name]
+            assert tuple(m.shape) == (d.rows, d.channels), (d.name, tuple(m.shape), d.rows, d.channels)
+            flat[d.offset:d.offset + d.rows * d.channels] = m.reshape(-1).to(device)
+        return flat
+
+    def forward(self, x1, x2, flat_params, flat_bn, logits, training: bool, masks: Optional[torch.Tensor] = None,
+                seed: int = 0):
+        self.ticket += 1
+        _lib.check(self._l.stcd_forward(self._h, _ptr(x1), _ptr(x2), _ptr(flat_params), _ptr(flat_bn), _ptr(masks),
+                                        C.c_uint64(seed & (2 ** 64 - 1)), int(training), _ptr(logits),
+                                        _ptr(self.workspace), _stream()))
+        return self.ticket
+
+    def backward(self, grad_logits, flat_params, flat_grads, stage: int = -1):
+        _lib.check(self._l.stcd_backward(self._h, _ptr(grad_logits), _ptr(flat_params), _ptr(flat_grads),
+                                         _ptr(self.workspace), stage, _stream()))

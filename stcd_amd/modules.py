@@ -1,0 +1,259 @@
+"""Drop-in ``torch.nn.Module`` boundary over the HIP engine.
+
+Same constructor signatures, ``forward(x1, x2)`` contract, parameter / buffer names and shapes as the
+reference classes, so ``state_dict`` files interchange both ways and ``define_G`` / ``init_weights`` /
+optimizers / ``nn.DataParallel([0])`` work unchanged:
+
+    SiamUnet_diff(input_nbr, label_nbr)   /root/reference/models/SiamUnet_diff.py:13,94   -> tensor
+    SiamUnet_conc(input_nbr, label_nbr)   /root/reference/models/SiamUnet_conc.py:13,94   -> tensor
+    SiamUnet_sub(input_nbr, label_nbr)    /root/reference/models/SiamUnet_sub.py:13,94    -> [tensor]
+
+The sub-modules (``conv11``, ``bn11``, ``do11`` ...) are ordinary torch layer objects used purely as
+parameter holders -- they are never called.  All arithmetic of forward and backward runs in
+libstcd_hip.so; there is no eager/PyTorch fallback, and CPU tensors are rejected.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from ._lib import StcdError
+from .engine import Engine
+
+_ENC = ((("11", None, 16), ("12", 16, 16)),
+        (("21", 16, 32), ("22", 32, 32)),
+        (("31", 32, 64), ("32", 64, 64), ("33", 64, 64)),
+        (("41", 64, 128), ("42", 128, 128), ("43", 128, 128)))
+_DEC = (("upconv4", 128, (("43d", 128), ("42d", 128), ("41d", 64))),
+        ("upconv3", 64, (("33d", 64), ("32d", 64), ("31d", 32))),
+        ("upconv2", 32, (("22d", 32), ("21d", 16))),
+        ("upconv1", 16, (("12d", 16), ("11d", None))))
+
+
+def default_dtype() -> str:
+    return os.environ.get("STCD_DTYPE", "bf16")
+
+
+class _EngineFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward and backward are single engine calls."""
+
+    @staticmethod
+    def forward(ctx, model, anchor, x1, x2):
+        logits = model._run_forward(x1, x2, True)
+        ctx.model = model
+        ctx.ticket = model._engine.ticket
+        return logits
+
+    @staticmethod
+    def backward(ctx, grad_logits):
+        model = ctx.model
+        if ctx.ticket != model._engine.ticket:
+            raise StcdError("backward() for a forward pass whose saved activations were overwritten by a later "
+                            "forward of the same module (the engine keeps one step of activations)")
+        model._run_backward(grad_logits.contiguous())
+        return None, None, None, None
+
+
+class HipChangeDetector(nn.Module):
+    """Common machinery: flat parameter / gradient / BN buffers shared with the engine."""
+
+    ARCH = None
+    RETURNS_LIST = False
+
+    def __init__(self, in_ch: int, label_ch: int, dtype: Optional[str] = None):
+        super().__init__()
+        self._engine = Engine(self.ARCH, in_ch, label_ch, dtype or default_dtype())
+        self._flat_params: Optional[torch.Tensor] = None
+        self._flat_grads: Optional[torch.Tensor] = None
+        self._flat_bn: Optional[torch.Tensor] = None
+        self._anchor: Optional[torch.Tensor] = None
+        self._grad_views: List[torch.Tensor] = []
+        self._next_masks: Optional[torch.Tensor] = None
+        self._seed = int(os.environ.get("STCD_DROPOUT_SEED", "1337"))
+        self._steps = 0
+        self.grad_stage_hook: Optional[Callable[[int, torch.Tensor], None]] = None
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _check_layout(self):
+        names = [n for n, _ in self.named_parameters()]
+        want = [p.name for p in self._engine.params]
+        if names != want:
+            raise StcdError(f"module/engine parameter order mismatch: {names[:4]}... vs {want[:4]}...")
+        for (n, p), info in zip(self.named_parameters(), self._engine.params):
+            if tuple(p.shape) != info.shape:
+                raise StcdError(f"shape mismatch for {n}: {tuple(p.shape)} vs {info.shape}")
+
+    def _bn_modules(self):
+        mods = dict(self.named_modules())
+        return [(b, mods[b.name]) for b in self._engine.bns]
+
+    def _views_ok(self, device) -> bool:
+        fp = self._flat_params
+        if fp is None or fp.device != device:
+            return False
+        ps = list(self.parameters())
+        infos = self._engine.params
+        for p, info in ((ps[0], infos[0]), (ps[-1], infos[-1])):
+            if p.data_ptr() != fp.data_ptr() + 4 * info.offset or p.dtype != torch.float32:
+                return False
+        b, m = self._bn_modules()[-1]
+        return m.running_mean.data_ptr() == self._flat_bn.data_ptr() + 4 * b.offset
+
+    def _ensure_flat(self, device):
+        if self._views_ok(device):
+            return
+        eng = self._engine
+        flat = torch.zeros(eng.param_floats, dtype=torch.float32, device=device)
+        for p, info in zip(self.parameters(), eng.params):
+            v = flat[info.offset:info.offset + info.numel].view(info.shape)
+            v.copy_(p.data.to(device=device, dtype=torch.float32))
+            p.data = v
+            p.grad = None
+        self._flat_params = flat
+        self._flat_grads = torch.zeros_like(flat)
+        self._grad_views = [self._flat_grads[i.offset:i.offset + i.numel].view(i.shape) for i in eng.params]
+        fbn = torch.zeros(eng.bn_floats, dtype=torch.float32, device=device)
+        for b, m in self._bn_modules():
+            for k, name in enumerate(("running_mean", "running_var")):
+                v = fbn[b.offset + k * b.channels:b.offset + (k + 1) * b.channels]
+                v.copy_(getattr(m, name).to(device=device, dtype=torch.float32))
+                m._buffers[name] = v
+            m._buffers["num_batches_tracked"] = m.num_batches_tracked.to(device)
+        self._flat_bn = fbn
+        self._nbt = [m.num_batches_tracked for _, m in self._bn_modules()]
+        self._nbt_inc = [b.calls_per_forward for b, _ in self._bn_modules()]
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._flat_params = None   # .to()/.cuda()/.float() re-created the tensors: re-flatten lazily
+        return out
+
+    def __deepcopy__(self, memo):
+        new = type(self)(self._engine.in_ch, self._engine.label_ch, self._engine.dtype)
+        new.load_state_dict({k: v.detach().clone() for k, v in self.state_dict().items()})
+        new.train(self.training)
+        new._engine_dropout_p(getattr(self, "_drop_p", 0.2))
+        if self._flat_params is not None:
+            new.to(self._flat_params.device)
+        return new
+
+    # ------------------------------------------------------------------ knobs
+    def _engine_dropout_p(self, p: float):
+        self._drop_p = p
+        self._engine.set_dropout_p(p)
+
+    def set_dropout_p(self, p: float):
+        """Dropout2d probability (reference: 0.2); also reflected in the holder modules."""
+        self._engine_dropout_p(p)
+        for m in self.modules():
+            if isinstance(m, nn.Dropout2d):
+                m.p = p
+
+    def set_dropout_masks(self, masks: Optional[Dict[str, torch.Tensor]]):
+        """Use these [rows, C] masks ({0, 1/(1-p)}) verbatim for the NEXT training forward (parity tests)."""
+        self._pending_masks = masks
+
+    # ------------------------------------------------------------------ execution
+    def _run_forward(self, x1, x2, training: bool):
+        eng = self._engine
+        B, _, H, W = x1.shape
+        logits = torch.empty((B, eng.label_ch, H, W), dtype=torch.float32, device=x1.device)
+        masks = None
+        pend = getattr(self, "_pending_masks", None)
+        if training and pend is not None:
+            masks = eng.pack_masks(pend, x1.device)
+            self._pending_masks = None
+        self._steps += 1
+        eng.forward(x1, x2, self._flat_params, self._flat_bn, logits, training, masks,
+                    seed=self._seed * 1000003 + self._steps)
+        if training:
+            torch._foreach_add_(self._nbt, self._nbt_inc)
+        return logits
+
+    def _run_backward(self, grad_logits):
+        eng = self._engine
+        params = list(self.parameters())
+        accumulate = any(p.grad is not None for p in params)
+        target = torch.empty_like(self._flat_grads) if accumulate else self._flat_grads
+        hook = self.grad_stage_hook
+        if hook is None:
+            eng.backward(grad_logits, self._flat_params, target, -1)
+        else:
+            eng.backward(grad_logits, self._flat_params, target, 0)
+            hook(0, target[eng.stage0_range[0]:eng.stage0_range[1]])
+            eng.backward(grad_logits, self._flat_params, target, 1)
+            hook(1, target[eng.stage1_range[0]:eng.stage1_range[1]])
+        if accumulate:
+            for p, info in zip(params, eng.params):
+                g = target[info.offset:info.offset + info.numel].view(info.shape)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.add_(g)
+        else:
+            for p, v in zip(params, self._grad_views):
+                p.grad = v
+
+    def forward(self, x1, x2):
+        if not (x1.is_cuda and x2.is_cuda):
+            raise StcdError("the HIP engine needs inputs on a GPU (cuda/HIP device); there is no CPU fallback")
+        if x1.shape != x2.shape or x1.dim() != 4 or x1.shape[1] != self._engine.in_ch:
+            raise StcdError(f"expected two [B,{self._engine.in_ch},H,W] tensors, got {tuple(x1.shape)} and {tuple(x2.shape)}")
+        dev = x1.device
+        self._ensure_flat(dev)
+        x1 = x1.detach().contiguous().float()
+        x2 = x2.detach().contiguous().float()
+        B, _, H, W = x1.shape
+        with torch.cuda.device(dev):
+            self._engine.configure(B, H, W, dev)
+            if self.training and torch.is_grad_enabled():
+                out = _EngineFn.apply(self, self._anchor, x1, x2)
+            else:
+                out = self._run_forward(x1, x2, self.training)
+        return [out] if self.RETURNS_LIST else out
+
+
+class _FCSiam(HipChangeDetector):
+    """Layer holders in the reference's registration order (SiamUnet_diff.py:18-90)."""
+
+    def __init__(self, input_nbr, label_nbr, dtype: Optional[str] = None):
+        super().__init__(input_nbr, label_nbr, dtype)
+        self.input_nbr = input_nbr
+        for stage in _ENC:
+            for sfx, ci, co in stage:
+                ci = input_nbr if ci is None else ci
+                setattr(self, f"conv{sfx}", nn.Conv2d(ci, co, kernel_size=3, padding=1))
+                setattr(self, f"bn{sfx}", nn.BatchNorm2d(co))
+                setattr(self, f"do{sfx}", nn.Dropout2d(p=0.2))
+        for up, c, convs in _DEC:
+            setattr(self, up, nn.ConvTranspose2d(c, c, kernel_size=3, padding=1, stride=2, output_padding=1))
+            ci = c + (2 * c if self.ARCH == "conc" else c)
+            for sfx, co in convs:
+                co_ = label_nbr if co is None else co
+                setattr(self, f"conv{sfx}", nn.ConvTranspose2d(ci, co_, kernel_size=3, padding=1))
+                if co is not None:
+                    setattr(self, f"bn{sfx}", nn.BatchNorm2d(co))
+                    setattr(self, f"do{sfx}", nn.Dropout2d(p=0.2))
+                ci = co_
+        self.sm = nn.LogSoftmax(dim=1)   # present (unused) in the reference too: SiamUnet_diff.py:92
+        self._check_layout()
+
+
+class SiamUnet_diff(_FCSiam):
+    """FC-Siam-diff: skips = |f1 - f2| (SiamUnet_diff.py:150)."""
+    ARCH = "diff"
+
+
+class SiamUnet_conc(_FCSiam):
+    """FC-Siam-conc: skips = cat(f1, f2) (SiamUnet_conc.py:149)."""
+    ARCH = "conc"
+
+
+class SiamUnet_sub(_FCSiam):
+    """Signed skips f2 - f1; returns a one-element list like the reference (SiamUnet_sub.py:150,177-180)."""
+    ARCH = "sub"
+    RETURNS_LIST = True

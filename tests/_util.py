@@ -1,0 +1,38 @@
+"""Shared helpers of the parity tests."""
+import re
+
+import numpy as np
+import torch
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def grad_summary(g):
+    g = g.detach().flatten().double().cpu()
+    n = g.numel()
+    idx = (np.arange(24) * max(n // 24, 1)) % n
+    first = g[:8].numpy() if n >= 8 else np.pad(g.numpy(), (0, 8 - n))
+    return np.concatenate([[g.sum().item(), g.norm().item()], first, g[idx].numpy()])
+
+
+def zero_grad_by_construction(name):
+    """A conv bias that feeds ONLY a train-mode BatchNorm has an exactly-zero gradient (BN subtracts the
+    batch mean); autograd reports rounding noise, the engine reports 0."""
+    if re.fullmatch(r"conv\d\dd?\.bias", name):
+        return name != "conv11d.bias"
+    return name.endswith(".conv2.bias")
+
+
+def check_grad(name, got, g, rtol, atol):
+    """got: gradient tensor; g: golden dict with 'gs/<name>' summaries and optional 'gf/<name>' full tensors."""
+    ref = g["gs/" + name]
+    got = got.detach().float().cpu()
+    if zero_grad_by_construction(name):
+        assert abs(ref[2:]).max() < 1e-5 and got.abs().max().item() < 1e-5, name
+        return
+    scale = max(ref[1], 1e-6)
+    np.testing.assert_allclose(grad_summary(got) / scale, ref / scale, rtol=rtol, atol=atol, err_msg=name)
+    if "gf/" + name in g:
+        np.testing.assert_allclose(got.numpy(), g["gf/" + name], rtol=rtol, atol=atol * scale, err_msg=name)

@@ -1,0 +1,74 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol the header declares,
+the engine's parameter table is the reference's state_dict layout, and the product fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import fcsiam_ref as R
+from stcd_amd import _lib
+from stcd_amd.modules import SiamUnet_conc, SiamUnet_diff, SiamUnet_sub
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "stcd_hip.h")).read()
+    declared = set(re.findall(r"\b(stcd_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in stcd_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert _lib.lib().stcd_abi_version() == 1
+
+
+@pytest.mark.parametrize("cls,arch", [(SiamUnet_diff, "diff"), (SiamUnet_conc, "conc"), (SiamUnet_sub, "sub")])
+@pytest.mark.parametrize("label", [1, 2])
+def test_state_dict_layout_is_the_reference_layout(cls, arch, label):
+    m = cls(3, label)
+    sd = m.state_dict()
+    specs = R.param_specs(arch, 3, label)          # pinned against the reference by tests/golden (oracle tests)
+    assert list(sd.keys()) == [n for n, _, _ in specs]
+    for (n, shape, _), v in zip(specs, sd.values()):
+        assert tuple(v.shape) == tuple(shape), n
+    # loading a reference-shaped state dict works strictly, and round-trips
+    st = R.synth_state(arch, 3, label, seed=5, perturb_running=True)
+    m.load_state_dict(st, strict=True)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, st[k]), k
+
+
+def test_init_weights_style_apply_sees_reference_class_names():
+    m = SiamUnet_diff(3, 2)
+    seen = {"Conv": 0, "BatchNorm2d": 0}
+
+    def fn(mod):
+        name = mod.__class__.__name__
+        if hasattr(mod, "weight") and name.find("Conv") != -1:
+            seen["Conv"] += 1
+        elif name.find("BatchNorm2d") != -1:
+            seen["BatchNorm2d"] += 1
+
+    m.apply(fn)
+    assert seen == {"Conv": 24, "BatchNorm2d": 19}
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    m = SiamUnet_diff(3, 2)
+    x = torch.zeros(1, 3, 32, 32)
+    with pytest.raises(_lib.StcdError):
+        m(x, x)
+
+
+def test_error_reporting_through_the_abi():
+    l = _lib.lib()
+    h = ctypes.c_void_p()
+    assert l.stcd_create(99, 3, 2, 0, ctypes.byref(h)) != 0
+    assert b"arch" in l.stcd_last_error()
+    assert l.stcd_create(0, 3, 2, 0, ctypes.byref(h)) == 0
+    assert l.stcd_configure(h, 1, 8, 8) != 0 and b">= 16" in l.stcd_last_error()
+    assert l.stcd_configure(h, 2, 100, 100) == 0 and l.stcd_workspace_bytes(h) > 0
+    l.stcd_destroy(h)

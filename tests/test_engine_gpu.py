@@ -1,0 +1,195 @@
+"""Parity of the HIP engine (through the nn.Module boundary -> C ABI) against the golden vectors captured
+from the reference and against the CPU oracle.  fp32 mode carries the 1e-3 bar of BASELINE.json;
+bf16 mode is checked against the same vectors at a bf16-sized tolerance (stated per test)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fcsiam_ref as R
+from stcd_amd.modules import SiamUnet_conc, SiamUnet_diff, SiamUnet_sub
+from tests._util import check_grad, t
+
+pytestmark = pytest.mark.gpu
+CLS = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub}
+DEV = "cuda:0"
+
+
+def unwrap(o):
+    return o[-1] if isinstance(o, (list, tuple)) else o
+
+
+def loss_fn(label, logits, tgt):
+    if label == 2:
+        return torch.nn.functional.cross_entropy(logits, tgt)
+    p = torch.sigmoid(logits)
+    y = tgt.float().unsqueeze(1)
+    bce = torch.nn.functional.binary_cross_entropy(p, y)
+    dice = 1 - (2 * (p * y).sum() + 1) / (p.sum() + y.sum() + 1)
+    return bce + dice
+
+
+@pytest.mark.parametrize("arch", ["diff", "conc", "sub"])
+@pytest.mark.parametrize("label", [1, 2])
+def test_fp32_matches_reference_vectors(golden, arch, label):
+    g = golden(f"g2_{arch}_{label}.npz")
+    seed = int(g["seed"])
+    x1, x2 = t(g["x1"]).to(DEV), t(g["x2"]).to(DEV)
+    m = CLS[arch](3, label, dtype="fp32")
+    m.load_state_dict(R.synth_state(arch, 3, label, seed, perturb_running=True))
+    m.to(DEV).eval()
+    with torch.no_grad():
+        out = unwrap(m(x1, x2)).cpu().numpy()
+        np.testing.assert_allclose(out, g["logits_eval"], rtol=1e-3, atol=1e-4)
+        out64 = unwrap(m(t(g["y1"]).to(DEV), t(g["y2"]).to(DEV))).cpu().numpy()
+        np.testing.assert_allclose(out64, g["logits_eval_64"], rtol=1e-3, atol=1e-4)
+
+    m = CLS[arch](3, label, dtype="fp32")
+    m.load_state_dict(R.synth_state(arch, 3, label, seed))
+    m.to(DEV).train()
+    m.set_dropout_masks(R.synth_masks(arch, 2, seed + 3))
+    logits = unwrap(m(x1, x2))
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits_train"], rtol=1e-3, atol=1e-4)
+    loss = loss_fn(label, logits, t(g["target"]).to(DEV))
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    for name, p in m.named_parameters():
+        check_grad(name, p.grad, g, 3e-3, 3e-4)
+    sd = m.state_dict()
+    for k in [k for k in g if k.startswith("rs/")]:
+        np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("arch", ["diff", "conc"])
+def test_fp32_odd_size_replication_pad(golden, arch):
+    g = golden("g6_odd.npz")
+    seed = int(g[f"{arch}/seed"])
+    rng = np.random.default_rng(seed + 1)
+    a = rng.standard_normal((1, 3, 100, 100)).astype(np.float32)
+    b = (a + 0.5 * rng.standard_normal((1, 3, 100, 100))).astype(np.float32)
+    m = CLS[arch](3, 2, dtype="fp32")
+    m.load_state_dict(R.synth_state(arch, 3, 2, seed, perturb_running=True))
+    m.to(DEV).eval()
+    with torch.no_grad():
+        out = m(t(a).to(DEV), t(b).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(out, g[f"{arch}/logits"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("arch", ["diff", "conc", "sub"])
+def test_fp32_odd_size_backward_matches_oracle(arch):
+    """ReplicationPad2d branch in training (36x44 -> pool chain 18x22, 9x11, 4x5, 2x2: two padded levels)."""
+    seed, label = 77, 2
+    rng = np.random.default_rng(seed)
+    x1 = t(rng.standard_normal((2, 3, 36, 44)).astype(np.float32))
+    x2 = t(rng.standard_normal((2, 3, 36, 44)).astype(np.float32))
+    tgt = t((rng.random((2, 36, 44)) < 0.3).astype(np.int64))
+    masks = R.synth_masks(arch, 2, seed + 1)
+    st = R.synth_state(arch, 3, label, seed)
+    m = CLS[arch](3, label, dtype="fp32")
+    m.load_state_dict(st)
+    m.to(DEV).train()
+    m.set_dropout_masks(masks)
+    loss = torch.nn.functional.cross_entropy(unwrap(m(x1.to(DEV), x2.to(DEV))), tgt.to(DEV))
+    loss.backward()
+    ref = {k: v.clone() for k, v in st.items()}
+    names = [k for k, v in ref.items() if v.dtype.is_floating_point and "running" not in k]
+    for k in names:
+        ref[k].requires_grad_(True)
+    rl = R.cross_entropy(R.forward(arch, ref, x1, x2, training=True, masks=masks), tgt)
+    rl.backward()
+    assert abs(loss.item() - rl.item()) < 1e-4
+    for name, p in m.named_parameters():
+        r = ref[name].grad
+        scale = r.abs().max().item() + 1e-7
+        if scale < 1e-5:
+            assert p.grad.abs().max().item() < 1e-5, name
+        else:
+            np.testing.assert_allclose(p.grad.cpu().numpy() / scale, r.numpy() / scale, atol=2e-3, err_msg=name)
+
+
+@pytest.mark.parametrize("arch", ["diff", "conc"])
+def test_bf16_tracks_reference_vectors(golden, arch):
+    """bf16 storage + fp32 accumulation through ~20 layers: logits within 6e-2 absolute (|logit| ~ 1),
+    loss within 2e-2, gradient direction cosine > 0.99 for the big tensors."""
+    label = 2
+    g = golden(f"g2_{arch}_{label}.npz")
+    seed = int(g["seed"])
+    x1, x2 = t(g["x1"]).to(DEV), t(g["x2"]).to(DEV)
+    m = CLS[arch](3, label, dtype="bf16")
+    m.load_state_dict(R.synth_state(arch, 3, label, seed))
+    m.to(DEV).train()
+    m.set_dropout_masks(R.synth_masks(arch, 2, seed + 3))
+    logits = m(x1, x2)
+    assert np.abs(logits.detach().cpu().numpy() - g["logits_train"]).max() < 6e-2
+    loss = loss_fn(label, logits, t(g["target"]).to(DEV))
+    assert abs(loss.item() - float(g["loss"])) < 2e-2
+    loss.backward()
+    for name, p in m.named_parameters():
+        if "gf/" + name in g and p.numel() >= 256:
+            a, b = p.grad.flatten().cpu().double(), t(g["gf/" + name]).flatten().double()
+            cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+            assert cos > 0.99, (name, cos)
+
+
+def test_fp32_config1_step(golden):
+    """BASELINE.json configs[0]: SiamUnet_diff 3-ch 256x256 pair, batch 2, one optimizer step -- loss and change
+    mask against the reference's CPU run (1e-3), gradient norms, AdamW/Adam deltas, BN running stats."""
+    from stcd_amd import synth
+
+    g = golden("g3_cfg1.npz")
+    a, b, lab = synth.make_batch(2, 256, 256, seed=int(g["data_seed"]))
+    A, B, L = t(a).to(DEV), t(b).to(DEV), t(lab).to(DEV)
+    for tag, label, opt_name in (("ce", 2, "adamw"), ("cd", 1, "adam")):
+        seed = int(g[f"{tag}/seed"])
+        m = SiamUnet_diff(3, label, dtype="fp32")
+        m.load_state_dict(R.synth_state("diff", 3, label, seed))
+        m.to(DEV).train()
+        m.set_dropout_masks(R.synth_masks("diff", 2, seed + 3))
+        if opt_name == "adamw":
+            opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+        else:
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        before = {k: v.detach().clone() for k, v in m.named_parameters()}
+        opt.zero_grad()
+        logits = m(A, B)
+        loss = loss_fn(label, logits, L)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"{tag}/loss"])) < 1e-3
+        lf = logits.detach().flatten().cpu()
+        np.testing.assert_allclose(lf[t(g[f"{tag}/logits_sample_idx"])].numpy(), g[f"{tag}/logits_sample"], rtol=1e-3, atol=1e-3)
+        pred = (logits.argmax(1) if label == 2 else (torch.sigmoid(logits[:, 0]) > 0.5).long()).cpu().numpy().astype(np.uint8)
+        ref_mask = np.unpackbits(g[f"{tag}/mask_packed"])[:pred.size].reshape(pred.shape)
+        assert (pred != ref_mask).mean() < 1e-3, "change mask differs from the reference on more than 0.1% of pixels"
+        for name, p in m.named_parameters():
+            check_grad(name, p.grad, {"gs/" + name: g[f"{tag}/gs/{name}"]}, 5e-3, 5e-4)
+        opt.step()
+        for k in ("conv11.weight", "bn33.weight", "conv12d.weight"):
+            d = (dict(m.named_parameters())[k].detach() - before[k]).cpu().numpy()
+            # Adam's first step is lr*sign-like (|delta| ~ 1e-3): compare where the reference moved clearly
+            ref = g[f"{tag}/delta/{k}"]
+            np.testing.assert_allclose(d, ref, atol=2.5e-4, err_msg=k)
+        sd = m.state_dict()
+        for k in ("bn11", "bn43", "bn12d"):
+            np.testing.assert_allclose(sd[f"{k}.running_mean"].cpu().numpy(), g[f"{tag}/rs/{k}.running_mean"], rtol=1e-3, atol=1e-5)
+            np.testing.assert_allclose(sd[f"{k}.running_var"].cpu().numpy(), g[f"{tag}/rs/{k}.running_var"], rtol=1e-3, atol=1e-5)
+
+
+def test_fp32_five_step_trajectory(golden):
+    from stcd_amd import synth
+
+    g = golden("g4_traj.npz")
+    a, b, lab = synth.make_batch(2, 64, 64, seed=int(g["data_seed"]))
+    A, B, L = t(a).to(DEV), t(b).to(DEV), t(lab).to(DEV)
+    seed = int(g["seed"])
+    m = SiamUnet_diff(3, 2, dtype="fp32")
+    m.load_state_dict(R.synth_state("diff", 3, 2, seed))
+    m.to(DEV).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    losses = []
+    for step in range(5):
+        m.set_dropout_masks(R.synth_masks("diff", 2, seed + 10 + step))
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(m(A, B), L)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, g["losses"], atol=5e-3)
