@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- image-pairs/sec of full SiamUnet training steps through the HIP engine (BASELINE.json's metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad -> forward -> cross-entropy -> backward -> (gradient all-reduce) -> AdamW, on a synthetic
+LEVIR-CD-shaped batch already resident in HBM (stcd_amd/synth.py).  Weak scaling: the per-GPU batch is fixed.
+Rank 0 prints ONE JSON line.  At N=1 the line also carries
+  roofline      the dominant kernel class, timed live with HIP events on the engine's stream
+                (stcd_profile_* in include/stcd_hip.h) over instrumented steps of the same workload,
+  cpu_baseline  the oracle (oracle/fcsiam_ref.py: a CPU PyTorch restatement pinned to the reference's golden
+                vectors) timed on this box's host cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+MFMA_F32_PEAK_TF = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub"])
+    ap.add_argument("--batch", type=int, default=16, help="image pairs per GPU per step")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--label", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(arch, label, size, pairs, steps):
+    """The oracle timed on the host: same step (fwd + CE + bwd + AdamW), fp32, all host threads."""
+    from oracle import fcsiam_ref as R
+    from stcd_amd import synth
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    a, b, lab = synth.make_batch(pairs, size, size, seed=1337)
+    A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab)
+    st = R.synth_state(arch, 3, label, seed=1)
+    params = [v.requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
+    opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    masks = R.synth_masks(arch, pairs, seed=2)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = R.cross_entropy(R.forward(arch, st, A, B, training=True, masks=masks), L)
+        loss.backward()
+        opt.step()
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(pairs / med, 3), "unit": "image-pairs/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/fcsiam_ref.py SiamUnet_{arch}(3,{label}) fp32, {pairs} pairs {size}x{size}, "
+                      f"median of {steps} full steps after 1 warm-up ({med * 1e3:.0f} ms/step)"}
+
+
+def main():
+    args = parse()
+    from stcd_amd import synth
+    from stcd_amd.ddp import FlatGradReducer, broadcast_parameters, init_distributed
+    from stcd_amd.losses import bce_dice_with_logits, cross_entropy
+    from stcd_amd.modules import SiamUnet_conc, SiamUnet_diff, SiamUnet_sub
+
+    rank, local_rank, world = init_distributed()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU fallback"
+    dev = torch.device("cuda", local_rank)
+    cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub}[args.model]
+
+    torch.manual_seed(1337)
+    model = cls(3, args.label, dtype=args.dtype).to(dev).train()
+    broadcast_parameters(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, fused=True)
+    reducer = FlatGradReducer(model)  # noqa: F841  (installs the gradient hook when world > 1)
+
+    a, b, lab = synth.make_batch(args.batch, args.size, args.size, seed=1337 + rank)
+    A, B, L = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(lab).to(dev)
+    Lf = L.float().unsqueeze(1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(A, B)
+        out = out[-1] if isinstance(out, list) else out
+        loss = cross_entropy(out, L) if args.label == 2 else bce_dice_with_logits(out, Lf)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    last_loss = loss.item()
+
+    result = {
+        "metric": "image-pairs/sec (256x256 bf16 SiamUnet_diff train)" if (args.model, args.size, args.dtype) == ("diff", 256, "bf16")
+        else f"image-pairs/sec ({args.size}x{args.size} {args.dtype} SiamUnet_{args.model} train)",
+        "value": round(world * args.batch * args.steps / elapsed, 2),
+        "unit": "image-pairs/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"SiamUnet_{args.model}(3,{args.label}) {args.size}x{args.size} full training step "
+                               f"(fwd + {'cross_entropy' if args.label == 2 else 'sigmoid+cd_loss'} + bwd + AdamW), "
+                               f"{args.batch} pairs/GPU, synthetic LEVIR-CD-shaped pairs resident in HBM",
+                   "global_batch": world * args.batch, "image": args.size, "parallelism": f"dp{world}",
+                   "last_loss": round(last_loss, 5)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        eng = model._engine
+        nprof = 3
+        eng.profile_enable(True)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        p = prof[dom]
+        secs = p["ms"] * 1e-3
+        hbm_frac = p["bytes"] / secs / 1e9 / HBM_PEAK_GBS if secs > 0 else 0.0
+        peak_tf = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
+        mfma_frac = p["flops"] / secs / 1e12 / peak_tf if secs > 0 else 0.0
+        bound = "mfma" if mfma_frac > hbm_frac else "hbm"
+        if bound == "hbm":
+            ach, peak, unit = p["bytes"] / secs / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = p["flops"] / secs / 1e12, peak_tf, "TFLOP/s"
+        tot_ms = sum(v["ms"] for v in prof.values())
+        result["roofline"] = {
+            "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+            "traffic": None,
+            "kernel": dom, "avg_launch_us": round(p["ms"] * 1e3 / max(p["launches"], 1), 3),
+            "launches_per_step": p["launches"] // nprof,
+            "alg_bytes_per_launch": round(p["bytes"] / max(p["launches"], 1)),
+            "alg_flops_per_launch": round(p["flops"] / max(p["launches"], 1)),
+            "other_bound_frac": round(min(hbm_frac, mfma_frac), 4),
+            "class_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in prof.items()},
+            "instrumented_ms_per_step": round(tot_ms / nprof, 4),
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.model, args.label, args.size, args.cpu_pairs, args.cpu_steps)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,6 +113,15 @@ int stcd_backward(stcd_engine* e, const float* grad_logits, const float* params,
 /* [begin,end) element range of the flat gradient buffer that stage 0 finalises (the rest belongs to stage 1). */
 int stcd_grad_stage_range(const stcd_engine* e, int stage, int64_t* begin, int64_t* end);
 
+/* ---- measurement aid (bench.py): when enabled, every launch of the engine's kernel classes is bracketed by a
+ *      hipEvent pair on the caller's stream; stcd_profile_read sums one class (it synchronises those events) and
+ *      reports the ALGORITHMIC work of the same launches (each tensor counted once).
+ *      Classes: 0 conv/dgrad  1 wgrad  2 bn-stats  3 bn+relu+dropout(+pool)  4 bn-backward reduce
+ *               5 bn-backward apply  6 pool/fusion backward  7 packing. */
+#define STCD_PROFILE_CLASSES 8
+int stcd_profile_enable(stcd_engine* e, int on);
+int stcd_profile_read(stcd_engine* e, int klass, double* total_ms, int64_t* launches, double* flops, double* bytes);
+
 /* ---- losses, fused forward+backward: replace cross_entropy (losses.py:6-21) and
  *      cd_loss(sigmoid(x),y) == BCE_DICE (losses.py:24-34; train_pse_cd.py:227-228,436-462) ----
  * loss_out: one fp32 on the device.  dlogits nullable.  scratch: >= stcd_loss_scratch_bytes() bytes.
@@ -120,7 +129,9 @@ int stcd_grad_stage_range(const stcd_engine* e, int stage, int64_t* begin, int64
 int64_t stcd_loss_scratch_bytes(void);
 int stcd_loss_ce(const float* logits, const int64_t* target, int batch, int classes, int64_t hw, int ignore_index,
                  float* loss_out, float* dlogits, void* scratch, void* hip_stream);
-int stcd_loss_bce_dice(const float* logits, const float* target, int64_t numel, float* loss_out, float* dlogits,
+/* from_logits != 0: x are logits, the loss is cd_loss(sigmoid(x), y) and dx is d loss / d logits (fused form used by the
+ * script-shaped loop); from_logits == 0: x are probabilities, exactly cd_loss(x, y) with dx = d loss / d probability. */
+int stcd_loss_bce_dice(const float* x, const float* target, int64_t numel, int from_logits, float* loss_out, float* dx,
                        void* scratch, void* hip_stream);
 /* ---- metric: replaces SegmentationMetric.genConfusionMatrix (train_pse_cd.py:361-368) without the
  *      per-step .cpu() sync (train_pse_cd.py:231).  cm[2*label+pred] += count; cm is 4 int64 on the device.

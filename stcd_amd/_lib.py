@@ -7,6 +7,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch wheels bundle their own libamdhip64; it must be the HIP runtime this process uses (device memory and
+# streams come from torch).  Importing torch first makes the dynamic linker resolve our library's
+# libamdhip64 dependency to that already-loaded runtime instead of a second copy from /opt/rocm.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstcd_hip.so")
 
@@ -59,9 +64,11 @@ _PROTOS = {
     "stcd_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _i, _vp, _vp, _vp]),
     "stcd_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "stcd_grad_stage_range": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "stcd_profile_enable": (_i, [_vp, _i]),
+    "stcd_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "stcd_loss_scratch_bytes": (_i64, []),
     "stcd_loss_ce": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp]),
-    "stcd_loss_bce_dice": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "stcd_loss_bce_dice": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "stcd_confusion_update": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp]),
     "stcd_op_conv": (_i, [_i, _i, C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "stcd_op_wgrad": (_i, [_i, _i, C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _i64, _vp]),

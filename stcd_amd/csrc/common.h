@@ -171,8 +171,8 @@ void launch_fill(float* p, int64_t n, float v, hipStream_t s);
 int64_t loss_scratch_bytes();
 void launch_loss_ce(const float* logits, const int64_t* target, int B, int Cn, int64_t HW, int ignore, float* loss,
                     float* dlogits, void* scratch, hipStream_t s);
-void launch_loss_bce_dice(const float* logits, const float* target, int64_t n, float* loss, float* dlogits,
-                          void* scratch, hipStream_t s);
+void launch_loss_bce_dice(const float* logits, const float* target, int64_t n, int from_logits, float* loss,
+                          float* dlogits, void* scratch, hipStream_t s);
 void launch_confusion(const float* logits, const int64_t* target, int B, int Cn, int64_t HW, int64_t* cm,
                       hipStream_t s);
 

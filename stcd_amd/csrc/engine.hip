@@ -60,7 +60,25 @@ struct UpConv {
     TRef in, out, dOut, dIn;
 };
 
+// ---- optional event instrumentation: one hipEvent pair around every launch of a kernel class (bench.py's live
+//      roofline measurement; off by default, adds nothing to the normal path)
+enum ProfClass { PC_CONV = 0, PC_WGRAD = 1, PC_BN_STATS = 2, PC_BN_ACT = 3, PC_BN_BWD_REDUCE = 4, PC_BN_BWD_APPLY = 5,
+                 PC_POOL_FUSE = 6, PC_PACK = 7, PC_COUNT = 8 };
+struct ProfRec { hipEvent_t a, b; int klass; double flops, bytes; };
+struct Prof {
+    bool on = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t ev; (void)hipEventCreate(&ev); pool.push_back(ev); }
+        return pool[used++];
+    }
+    ~Prof() { for (auto ev : pool) (void)hipEventDestroy(ev); }
+};
+
 struct stcd_engine_impl {
+    Prof prof;
     int arch = 0, in_ch = 3, label = 2, dt = F32;
     float drop_p = 0.2f;
     std::vector<stcd_tensor_info> params;
@@ -358,6 +376,21 @@ struct Ctx {
     template <typename P = void> P* at(int64_t off) const { return (P*)(ws + off); }
 };
 
+struct ProfScope {
+    Prof& p; hipStream_t s; bool on; hipEvent_t b;
+    ProfScope(const Ctx& c, int klass, double flops, double bytes);
+    ~ProfScope() { if (on) (void)hipEventRecord(b, s); }
+};
+
+ProfScope::ProfScope(const Ctx& c, int klass, double flops, double bytes) : p(c.e.prof), s(c.s), on(c.e.prof.on), b(nullptr) {
+    if (!on) return;
+    ProfRec r;
+    r.a = p.get(); r.b = p.get(); r.klass = klass; r.flops = flops; r.bytes = bytes;
+    b = r.b;
+    p.recs.push_back(r);
+    (void)hipEventRecord(r.a, s);
+}
+
 static stcd_conv_geom geom3(int N, int H, int W, int K, int ldi, int co, int ldo) {
     stcd_conv_geom g;
     memset(&g, 0, sizeof(g));
@@ -370,11 +403,27 @@ static stcd_conv_geom geom3(int N, int H, int W, int K, int ldi, int co, int ldo
     return g;
 }
 
+// algorithmic work of one conv-like launch: flops = 2 MACs over real channels,
+// bytes = (input + output + weights) * sizeof(T), each tensor counted once.
+static void conv_work(const stcd_engine& e, const stcd_conv_geom& g, int kreal, int nreal, double* flops, double* bytes) {
+    double pos = (double)g.n * g.hm * g.wm;
+    *flops = 2.0 * pos * g.ntaps * kreal * nreal;
+    double in_px = (double)g.n * (g.in_stride == 1 ? (double)g.hm * g.wm : (double)g.hi * g.wi);
+    *bytes = (in_px * kreal + pos * nreal + (double)g.ntaps * kreal * nreal) * (double)dsize(e.dt);
+}
+
 static void run_conv(const Ctx& c, const stcd_conv_geom& g, const void* in, const float* w, int kpad, int wld,
-                     const float* bias, void* out, bool nchw) {
+                     const float* bias, void* out, bool nchw, int kreal, int nreal) {
+    double fl, by;
+    conv_work(c.e, g, kreal, nreal, &fl, &by);
+    ProfScope ps(c, PC_CONV, fl, by);
     launch_conv_ref(c.e.dt, g, in, w, kpad, wld, bias, out, nchw, c.s);
 }
-static void run_wgrad(const Ctx& c, const stcd_conv_geom& g, const void* in, const void* dout, float* dw, int kpad, int wld) {
+static void run_wgrad(const Ctx& c, const stcd_conv_geom& g, const void* in, const void* dout, float* dw, int kpad, int wld,
+                      int kreal, int nreal) {
+    double fl, by;
+    conv_work(c.e, g, kreal, nreal, &fl, &by);
+    ProfScope ps(c, PC_WGRAD, fl, by);
     launch_wgrad_ref(c.e.dt, g, in, dout, dw, kpad, wld, c.s);
 }
 
@@ -391,11 +440,16 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     const BnP& bn = e.bns[L.bn];
     const int C = cv.cout;
     stcd_conv_geom g = geom3(L.N, L.H, L.W, L.K, L.in.ld, C, L.Y.ld);
-    run_conv(c, g, c.at(L.in.off), c.at<float>(cv.wpk_fwd), cv.fwd.kpad, cv.fwd.wld, c.params + cv.b_off, c.at(L.Y.off), false);
+    run_conv(c, g, c.at(L.in.off), c.at<float>(cv.wpk_fwd), cv.fwd.kpad, cv.fwd.wld, c.params + cv.b_off, c.at(L.Y.off), false,
+             cv.cin, C);
     const int64_t ppg = (int64_t)L.npg * L.H * L.W;
+    const double act_bytes = (double)L.N * L.H * L.W * C * (double)dsize(e.dt);
     float* stat = c.at<float>(L.stat);
     if (training) {
-        launch_bn_stats(e.dt, c.at(L.Y.off), L.Y.ld, C, L.groups, ppg, c.at<float>(e.bn_partial), c.s);
+        {
+            ProfScope ps(c, PC_BN_STATS, 0.0, act_bytes);
+            launch_bn_stats(e.dt, c.at(L.Y.off), L.Y.ld, C, L.groups, ppg, c.at<float>(e.bn_partial), c.s);
+        }
         launch_bn_finalize(c.at<float>(e.bn_partial), bn_stats_chunks(ppg), C, L.groups, ppg, c.params + bn.g_off,
                            c.params + bn.b_off, bn_running + bn.run_off, bn_running + bn.run_off + C, stat, 0.1f, 1e-5f, c.s);
     } else {
@@ -409,6 +463,7 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     a.stat = stat;
     a.mask = (training && e.drop_p > 0.f) ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
     a.C = C; a.groups = L.groups; a.npg = L.npg; a.H = L.H; a.W = L.W; a.relu = 1;
+    ProfScope ps(c, PC_BN_ACT, 0.0, act_bytes * (L.pool ? 2.25 : 2.0));
     launch_bn_act(e.dt, a, c.s);
 }
 
@@ -421,19 +476,27 @@ static void cbrd_backward(const Ctx& c, const Cbrd& L) {
     const float* stat = c.at<float>(L.stat);
     const float* mask = e.drop_p > 0.f ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
     float* partial = c.at<float>(e.bn_partial);
-    launch_bn_bwd_reduce(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.Y.off), L.Y.ld, stat, mask, C, L.groups, L.npg, HW, 1,
-                         partial, c.s);
+    const double act_bytes = (double)L.N * HW * C * (double)dsize(e.dt);
+    {
+        ProfScope ps(c, PC_BN_BWD_REDUCE, 0.0, 2.0 * act_bytes);
+        launch_bn_bwd_reduce(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.Y.off), L.Y.ld, stat, mask, C, L.groups, L.npg, HW, 1,
+                             partial, c.s);
+    }
     launch_bn_bwd_finalize(partial, bn_stats_chunks(ppg), C, L.groups, ppg, c.at<float>(L.coef), c.grads + bn.g_off,
                            c.grads + bn.b_off, c.s);
-    launch_bn_bwd_apply(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.dY.off), L.dY.ld, c.at(L.Y.off), L.Y.ld, stat,
-                        c.at<float>(L.coef), mask, C, L.groups, L.npg, HW, 1, c.s);
+    {
+        ProfScope ps(c, PC_BN_BWD_APPLY, 0.0, 3.0 * act_bytes);
+        launch_bn_bwd_apply(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.dY.off), L.dY.ld, c.at(L.Y.off), L.Y.ld, stat,
+                            c.at<float>(L.coef), mask, C, L.groups, L.npg, HW, 1, c.s);
+    }
     // weight gradient (the conv bias feeds only a train-mode BN: its gradient is exactly zero and stays zero)
     stcd_conv_geom g = geom3(L.N, L.H, L.W, L.K, L.in.ld, C, L.dY.ld);
-    run_wgrad(c, g, c.at(L.in.off), c.at(L.dY.off), c.at<float>(cv.dwe), cv.fwd.kpad, cv.fwd.wld);
+    run_wgrad(c, g, c.at(L.in.off), c.at(L.dY.off), c.at<float>(cv.dwe), cv.fwd.kpad, cv.fwd.wld, cv.cin, C);
     launch_unpack_dw(cv.fwd, c.at<float>(cv.dwe), c.grads + cv.w_off, c.s);
     if (L.has_dIn) {
         stcd_conv_geom gd = geom3(L.N, L.H, L.W, cv.dgrad.kpad, L.dY.ld, cv.cin, L.dIn.ld);
-        run_conv(c, gd, c.at(L.dY.off), c.at<float>(cv.wpk_dgrad), cv.dgrad.kpad, cv.dgrad.wld, nullptr, c.at(L.dIn.off), false);
+        run_conv(c, gd, c.at(L.dY.off), c.at<float>(cv.wpk_dgrad), cv.dgrad.kpad, cv.dgrad.wld, nullptr, c.at(L.dIn.off), false,
+                 C, cv.cin);
     }
 }
 
@@ -461,7 +524,7 @@ static void upconv_forward(const Ctx& c, const UpConv& U) {
         int tap0;
         stcd_conv_geom g = geom_up_phase(U, ph >> 1, ph & 1, U.in.ld, U.out.ld, &tap0);
         const float* w = c.at<float>(cv.wpk_fwd) + (int64_t)tap0 * cv.fwd.kpad * cv.fwd.wld;
-        run_conv(c, g, c.at(U.in.off), w, cv.fwd.kpad, cv.fwd.wld, c.params + cv.b_off, c.at(U.out.off), false);
+        run_conv(c, g, c.at(U.in.off), w, cv.fwd.kpad, cv.fwd.wld, c.params + cv.b_off, c.at(U.out.off), false, U.C, U.C);
     }
     launch_rep_pad(e.dt, c.at(U.out.off), U.out.ld, U.N, U.Ho, U.Wo, 2 * U.h, 2 * U.w, U.C, c.s);
 }
@@ -484,7 +547,7 @@ static void upconv_backward(const Ctx& c, const UpConv& U) {
         int tap0;
         stcd_conv_geom g = geom_up_phase(U, ph >> 1, ph & 1, U.in.ld, U.dOut.ld, &tap0);
         float* dw = c.at<float>(cv.dwe) + (int64_t)tap0 * cv.fwd.kpad * cv.fwd.wld;
-        run_wgrad(c, g, c.at(U.in.off), c.at(U.dOut.off), dw, cv.fwd.kpad, cv.fwd.wld);
+        run_wgrad(c, g, c.at(U.in.off), c.at(U.dOut.off), dw, cv.fwd.kpad, cv.fwd.wld, U.C, U.C);
     }
     launch_unpack_dw(cv.fwd, c.at<float>(cv.dwe), c.grads + cv.w_off, c.s);
     // data gradient: 3x3 stride-2 conv over dOut
@@ -500,7 +563,8 @@ static void upconv_backward(const Ctx& c, const UpConv& U) {
     // (hi,wi) bound the taps; the row pitch must be the buffer's.  The reference kernel indexes rows by wi, so for
     // padded buffers present the full buffer and bound by construction (taps never reach row/col 2h / 2w).
     gd.hi = U.Ho; gd.wi = U.Wo;
-    run_conv(c, gd, c.at(U.dOut.off), c.at<float>(cv.wpk_dgrad), cv.dgrad.kpad, cv.dgrad.wld, nullptr, c.at(U.dIn.off), false);
+    run_conv(c, gd, c.at(U.dOut.off), c.at<float>(cv.wpk_dgrad), cv.dgrad.kpad, cv.dgrad.wld, nullptr, c.at(U.dIn.off), false,
+             U.C, U.C);
 }
 
 static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, const float* params, float* bn_running,
@@ -531,7 +595,8 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
     }
     const ConvW& cv = e.convs[e.final_conv];
     stcd_conv_geom g = geom3(B, e.H, e.W, cv.kin_p, e.finalIn.ld, e.label, e.label);
-    run_conv(c, g, c.at(e.finalIn.off), c.at<float>(cv.wpk_fwd), cv.fwd.kpad, cv.fwd.wld, params + cv.b_off, logits, true);
+    run_conv(c, g, c.at(e.finalIn.off), c.at<float>(cv.wpk_fwd), cv.fwd.kpad, cv.fwd.wld, params + cv.b_off, logits, true, cv.cin,
+             e.label);
     STCD_HIP(hipGetLastError());
     return 0;
 }
@@ -554,10 +619,11 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
         launch_bias_grad(dt, c.at(e.G.off), 8, (int64_t)B * e.H * e.W, 8, c.at<float>(e.scratch8), s);
         STCD_HIP(hipMemcpyAsync(grads + cv.b_off, c.at(e.scratch8), (size_t)e.label * 4, hipMemcpyDeviceToDevice, s));
         stcd_conv_geom g = geom3(B, e.H, e.W, cv.kin_p, e.finalIn.ld, e.label, 8);
-        run_wgrad(c, g, c.at(e.finalIn.off), c.at(e.G.off), c.at<float>(cv.dwe), cv.fwd.kpad, cv.fwd.wld);
+        run_wgrad(c, g, c.at(e.finalIn.off), c.at(e.G.off), c.at<float>(cv.dwe), cv.fwd.kpad, cv.fwd.wld, cv.cin, e.label);
         launch_unpack_dw(cv.fwd, c.at<float>(cv.dwe), grads + cv.w_off, s);
         stcd_conv_geom gd = geom3(B, e.H, e.W, cv.dgrad.kpad, 8, cv.cin, e.dFinalIn.ld);
-        run_conv(c, gd, c.at(e.G.off), c.at<float>(cv.wpk_dgrad), cv.dgrad.kpad, cv.dgrad.wld, nullptr, c.at(e.dFinalIn.off), false);
+        run_conv(c, gd, c.at(e.G.off), c.at<float>(cv.wpk_dgrad), cv.dgrad.kpad, cv.dgrad.wld, nullptr, c.at(e.dFinalIn.off), false,
+                 e.label, cv.cin);
         int di = (int)e.dec.size() - 1;
         for (int k = 3; k >= 0; --k) {
             int nb = 0;
@@ -690,6 +756,27 @@ int stcd_grad_stage_range(const stcd_engine* e, int stage, int64_t* begin, int64
     return 0;
 }
 
+int stcd_profile_enable(stcd_engine* e, int on) {
+    STCD_CHECK(e != nullptr, "engine is null");
+    e->prof.on = on != 0;
+    e->prof.recs.clear();
+    e->prof.used = 0;
+    return 0;
+}
+int stcd_profile_read(stcd_engine* e, int klass, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+    STCD_CHECK(e && total_ms && launches && flops && bytes, "bad argument");
+    STCD_CHECK(klass >= 0 && klass < PC_COUNT, "unknown kernel class");
+    *total_ms = 0.0; *launches = 0; *flops = 0.0; *bytes = 0.0;
+    for (auto& r : e->prof.recs) {
+        if (r.klass != klass) continue;
+        STCD_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        STCD_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        *total_ms += ms; *launches += 1; *flops += r.flops; *bytes += r.bytes;
+    }
+    return 0;
+}
+
 int64_t stcd_loss_scratch_bytes(void) { return loss_scratch_bytes(); }
 int stcd_loss_ce(const float* logits, const int64_t* target, int batch, int classes, int64_t hw, int ignore_index,
                  float* loss_out, float* dlogits, void* scratch, void* hip_stream) {
@@ -699,11 +786,11 @@ int stcd_loss_ce(const float* logits, const int64_t* target, int batch, int clas
     STCD_HIP(hipGetLastError());
     return 0;
 }
-int stcd_loss_bce_dice(const float* logits, const float* target, int64_t numel, float* loss_out, float* dlogits,
-                       void* scratch, void* hip_stream) {
+int stcd_loss_bce_dice(const float* logits, const float* target, int64_t numel, int from_logits, float* loss_out,
+                       float* dlogits, void* scratch, void* hip_stream) {
     STCD_CHECK(logits && target && loss_out && scratch, "null pointer argument");
     STCD_CHECK(numel >= 1, "bad shape");
-    launch_loss_bce_dice(logits, target, numel, loss_out, dlogits, scratch, (hipStream_t)hip_stream);
+    launch_loss_bce_dice(logits, target, numel, from_logits, loss_out, dlogits, scratch, (hipStream_t)hip_stream);
     STCD_HIP(hipGetLastError());
     return 0;
 }

@@ -110,11 +110,11 @@ void launch_loss_ce(const float* logits, const int64_t* target, int B, int Cn, i
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
 __global__ void __launch_bounds__(256)
-k_bd_reduce(const float* __restrict__ logits, const float* __restrict__ target, int64_t n, LossScratch* sc) {
+k_bd_reduce(const float* __restrict__ logits, const float* __restrict__ target, int64_t n, int from_logits, LossScratch* sc) {
     __shared__ double sm[16];
     double v[4] = {0.0, 0.0, 0.0, 0.0};   // sum p, sum t, sum p*t, sum bce
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float p = sigmoidf(logits[i]), t = target[i];
+        float p = from_logits ? sigmoidf(logits[i]) : logits[i], t = target[i];
         float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);   // torch clamps log at -100
         v[0] += p; v[1] += t; v[2] += (double)p * t;
         v[3] -= (double)(t * lp + (1.f - t) * l1p);
@@ -136,24 +136,24 @@ __global__ void k_bd_finalize(LossScratch* sc, int nblocks, int64_t n, float* lo
     }
 }
 __global__ void __launch_bounds__(256)
-k_bd_grad(const float* __restrict__ logits, const float* __restrict__ target, int64_t n, const LossScratch* sc,
-          float* __restrict__ dlogits) {
+k_bd_grad(const float* __restrict__ logits, const float* __restrict__ target, int64_t n, int from_logits,
+          const LossScratch* sc, float* __restrict__ dlogits) {
     const float den = (float)sc->fin[0], num = (float)sc->fin[1], invn = 1.f / (float)n, invd2 = 1.f / (den * den);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float p = sigmoidf(logits[i]), t = target[i];
+        float p = from_logits ? sigmoidf(logits[i]) : logits[i], t = target[i];
         float q = p * (1.f - p);
         float dbce = (p - t) / fmaxf(q, 1e-12f) * invn;          // ATen binary_cross_entropy_backward (EPSILON 1e-12)
         float ddice = -(2.f * t * den - num) * invd2;
-        dlogits[i] = (dbce + ddice) * q;
+        dlogits[i] = from_logits ? (dbce + ddice) * q : (dbce + ddice);   // chain through sigmoid only for logits
     }
 }
-void launch_loss_bce_dice(const float* logits, const float* target, int64_t n, float* loss, float* dlogits, void* scratch,
-                          hipStream_t s) {
+void launch_loss_bce_dice(const float* logits, const float* target, int64_t n, int from_logits, float* loss, float* dlogits,
+                          void* scratch, hipStream_t s) {
     LossScratch* sc = (LossScratch*)scratch;
     int nb = (int)std::min<int64_t>(LOSS_BLOCKS, (n + 255) / 256);
-    k_bd_reduce<<<nb, 256, 0, s>>>(logits, target, n, sc);
+    k_bd_reduce<<<nb, 256, 0, s>>>(logits, target, n, from_logits, sc);
     k_bd_finalize<<<1, 256, 0, s>>>(sc, nb, n, loss);
-    if (dlogits) k_bd_grad<<<nb, 256, 0, s>>>(logits, target, n, sc, dlogits);
+    if (dlogits) k_bd_grad<<<nb, 256, 0, s>>>(logits, target, n, from_logits, sc, dlogits);
 }
 
 // ------------------------------------------------------------------ 2x2 confusion matrix: cm[2*label+pred] += count

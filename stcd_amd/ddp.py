@@ -1,0 +1,86 @@
+"""Data-parallel training over the 8 GPUs of one node: one process per GPU, torch.distributed (backend "nccl" is
+RCCL on ROCm, over xGMI), image pairs sharded across ranks, ONE flat-bucket gradient all-reduce per backward stage.
+
+The reference has no distributed code (nn.DataParallel pinned to one device,
+/root/reference/train_pse_cd.py:405-417), so this is new capability judged against the oracle: N ranks must equal
+the average of N sequential micro-batches on one device (BatchNorm statistics stay per replica, like the
+reference's DataParallel).
+
+The engine finishes the decoder's gradients first (backward stage 0): their all-reduce is launched on a side
+stream while the encoder's backward (stage 1) still runs; the encoder's bucket follows, and the compute stream
+waits for both before ``loss.backward()`` returns control to the optimizer.  Two collectives per step
+(diff: 3.5 MB + 1.9 MB fp32) -- latency-bound on xGMI either way, so they are not split further.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None):
+    """Rendezvous from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
+    Returns (rank, local_rank, world_size).  A single process needs no env and no process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous, even split of a global batch / index list (remainder to the first ranks)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class FlatGradReducer:
+    """Averages gradients across ranks through the model's ``grad_stage_hook`` protocol
+    (stcd_amd.modules.HipChangeDetector): hook(stage, flat_gradient_slice) is called when that slice is final."""
+
+    def __init__(self, model, group=None, overlap: bool = True):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.overlap = overlap
+        self._comm = None
+        self._pending = False
+        if self.world > 1:
+            model.grad_stage_hook = self._hook
+
+    def _hook(self, stage: int, g: torch.Tensor):
+        if g.numel() == 0:
+            return
+        if g.is_cuda and self.overlap:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=g.device)
+            cur = torch.cuda.current_stream(g.device)
+            self._comm.wait_stream(cur)
+            with torch.cuda.stream(self._comm):
+                g.mul_(1.0 / self.world)
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            if stage == 1:                      # last bucket: order the compute stream after both collectives
+                cur.wait_stream(self._comm)
+        else:
+            g.mul_(1.0 / self.world)
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+
+
+def broadcast_parameters(model, src: int = 0, group=None):
+    """Same initial replica everywhere (parameters and BN buffers)."""
+    if not dist.is_initialized():
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

@@ -128,3 +128,18 @@ class Engine:
     def backward(self, grad_logits, flat_params, flat_grads, stage: int = -1):
         _lib.check(self._l.stcd_backward(self._h, _ptr(grad_logits), _ptr(flat_params), _ptr(flat_grads),
                                          _ptr(self.workspace), stage, _stream()))
+
+    # ------------------------------------------------------------------ measurement aid (bench.py)
+    PROFILE_CLASSES = ("conv", "wgrad", "bn_stats", "bn_act", "bn_bwd_reduce", "bn_bwd_apply", "pool_fuse_bwd", "pack")
+
+    def profile_enable(self, on: bool):
+        _lib.check(self._l.stcd_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """-> {class: dict(ms, launches, flops, bytes)} for the launches recorded since profile_enable(True)."""
+        out = {}
+        for k, name in enumerate(self.PROFILE_CLASSES):
+            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            _lib.check(self._l.stcd_profile_read(self._h, k, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+            out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        return out

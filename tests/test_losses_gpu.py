@@ -1,0 +1,80 @@
+"""HIP loss / metric kernels (through stcd_amd.losses / metrics -> C ABI) against the reference vectors (G1, G5)
+and the C oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_c as O
+from stcd_amd import losses, metrics
+from tests._util import t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_cross_entropy_value_and_gradient(golden):
+    g = golden("g1_ops.npz")
+    lg = t(g["ce/logits"]).to(DEV).requires_grad_(True)
+    tgt = t(g["ce/target"]).to(DEV)
+    loss = losses.cross_entropy(lg, tgt.float().unsqueeze(1))      # the trainer hands a float N*1*H*W label
+    loss.backward()
+    assert abs(loss.item() - float(g["ce/loss"])) < 1e-6
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), g["ce/dlogits"], rtol=1e-5, atol=1e-8)
+    # upstream gradient is honoured
+    lg2 = t(g["ce/logits"]).to(DEV).requires_grad_(True)
+    (3.0 * losses.cross_entropy(lg2, tgt)).backward()
+    np.testing.assert_allclose(lg2.grad.cpu().numpy(), 3.0 * g["ce/dlogits"], rtol=1e-5, atol=1e-8)
+
+
+def test_cross_entropy_large_random_vs_c_oracle():
+    rng = np.random.default_rng(3)
+    lg = (3 * rng.standard_normal((3, 2, 64, 48))).astype(np.float32)
+    tg = rng.integers(0, 2, size=(3, 64, 48)).astype(np.int64)
+    tg[rng.random(tg.shape) < 0.05] = 255
+    ref_loss, ref_d = O.ce_fwd_bwd(lg, tg)
+    x = t(lg).to(DEV).requires_grad_(True)
+    loss = losses.cross_entropy(x, t(tg).to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref_loss) < 1e-5
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref_d, rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("tag", ["cd", "cd_sat"])
+def test_cd_loss_probability_form_and_fused_logit_form(golden, tag):
+    g = golden("g1_ops.npz")
+    ref_loss = float(g[f"{tag}/loss"])
+    # reference call form: cd_loss(sigmoid(x), y)
+    lg = t(g[f"{tag}/logits"]).to(DEV).requires_grad_(True)
+    tgt = t(g[f"{tag}/target"]).to(DEV)
+    loss = losses.cd_loss(torch.sigmoid(lg), tgt)
+    loss.backward()
+    assert abs(loss.item() - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), g[f"{tag}/dlogits"], rtol=2e-4, atol=1e-7)
+    # fused form
+    lg2 = t(g[f"{tag}/logits"]).to(DEV).requires_grad_(True)
+    loss2 = losses.bce_dice_with_logits(lg2, tgt)
+    loss2.backward()
+    assert abs(loss2.item() - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
+    np.testing.assert_allclose(lg2.grad.cpu().numpy(), g[f"{tag}/dlogits"], rtol=2e-4, atol=1e-7)
+    assert isinstance(losses.BCE_DICE()(torch.sigmoid(lg2.detach()), tgt).item(), float)
+
+
+def test_confusion_matrix_on_device(golden):
+    g = golden("g5_metric.npz")
+    lab, pred = t(g["label"]).to(DEV), t(g["pred"]).to(DEV)
+    # two-class logits whose argmax is `pred`, and one-class logits whose sign is `pred`
+    l2 = torch.stack([1.0 - pred[:, 0].float(), pred[:, 0].float()], 1).contiguous()
+    l1 = (pred.float() * 2 - 1).contiguous()
+    for logits in (l2, l1):
+        m = metrics.SegmentationMetric(2, DEV)
+        m.add_logits(logits[:2], lab[:2])
+        m.add_logits(logits[2:], lab[2:])          # accumulates across batches
+        np.testing.assert_array_equal(m.confusionMatrix.cpu().numpy(), g["cm"])
+        np.testing.assert_allclose(m.F1score(), g["f1"], rtol=1e-12)
+        np.testing.assert_allclose(m.IntersectionOverUnion(), g["iou"], rtol=1e-12)
+        np.testing.assert_allclose(m.Precision(), g["precision"], rtol=1e-12)
+        np.testing.assert_allclose(m.Recall(), g["recall"], rtol=1e-12)
+        assert abs(m.OverallAccuracy() - float(g["oa"])) < 1e-12
+    cm = metrics.ConfuseMatrixMeter(2)
+    cm.update_cm(g["pred"], g["label"])
+    assert abs(cm.get_scores()["mf1"] - float(np.mean(g["f1"]))) < 1e-12
