@@ -98,6 +98,31 @@ void launch_conv_ref(int dt, const stcd_conv_geom& g, const void* in, const floa
 void launch_wgrad_ref(int dt, const stcd_conv_geom& g, const void* in, const void* dout, float* dw, int kpad, int wld,
                       hipStream_t s);
 
+// ---- MFMA (bf16) implementations, kernels_conv_mfma.hip
+struct ConvMfmaPlan {
+    int CiB = 0, nchunks = 0, KS = 0, modeB = 0, NT = 0, NTtot = 0;
+    int64_t wf_elems = 0;   // bf16 elements of the fragment-order weight image
+    bool ok = false;
+};
+ConvMfmaPlan conv_mfma_plan(const stcd_conv_geom& g);
+// w fp32 [ntaps][kpad][wld] (the engine's packed layout) -> fragment-order bf16 image
+void launch_pack_frag(const stcd_conv_geom& g, const ConvMfmaPlan& p, const float* w, int kpad, int wld, void* dst,
+                      hipStream_t s);
+int launch_conv_mfma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const void* in, const void* wf, const float* bias,
+                     void* out, bool out_nchw_f32, hipStream_t s);
+struct WgradMfmaPlan {
+    int WCI = 1, NTW = 1, gx = 1, gy = 1, gz = 1;
+    int64_t slab_floats = 0;
+    bool ok = false;
+};
+WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld);
+int launch_wgrad_mfma(const stcd_conv_geom& g, const WgradMfmaPlan& p, const void* in, const void* dout, float* slab,
+                      int kpad, int wld, hipStream_t s);
+struct PackSpec;
+// out = sum of the gx slabs; ps == nullptr: engine layout [tap][kpad][wld], else scattered into the reference layout
+void launch_reduce_dw(const float* slab, int gx, const stcd_conv_geom& g, int K, int N, int kpad, int wld,
+                      const PackSpec* ps, float* out, hipStream_t s);
+
 // weight (un)packing between the reference layouts and the engine layout [tap][k][wld]
 struct PackSpec {
     int ks;          // source kernel size (1,2,3)

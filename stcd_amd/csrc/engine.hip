@@ -46,7 +46,22 @@ struct BnP {
 };
 struct DropP { std::string name; int rows = 0, C = 0; int64_t off = 0; };
 
+// one conv-shaped launch, fully bound at configure time
+struct ConvOp {
+    stcd_conv_geom g{};
+    int conv = -1; bool dgrad = false;   // which packed filter of which ConvW
+    int tap0 = 0;                        // first tap inside that filter's PackSpec (sub-pixel phases)
+    int kreal = 0, nreal = 0;            // un-padded channels (algorithmic work accounting)
+    ConvMfmaPlan plan; int64_t wf = -1;  // MFMA path: plan + fragment-order weight image (workspace offset)
+};
+struct WgradOp {
+    stcd_conv_geom g{};
+    int conv = -1, tap0 = 0, kreal = 0, nreal = 0;
+    WgradMfmaPlan plan;
+};
+
 struct Cbrd {                         // conv -> BN -> ReLU -> Dropout2d [-> pool]
+    ConvOp fwd, dgr; WgradOp wg;
     int conv = -1, bn = -1, drop = -1;
     int N = 0, H = 0, W = 0, groups = 1, npg = 0;
     TRef in; int K = 0;               // input view and its channel count
@@ -58,6 +73,7 @@ struct UpConv {
     int conv = -1, level = 0;
     int N = 0, h = 0, w = 0, Ho = 0, Wo = 0, C = 0;   // input h x w, concat buffer Ho x Wo
     TRef in, out, dOut, dIn;
+    ConvOp fwd[4], dgr; WgradOp wg[4];
 };
 
 // ---- optional event instrumentation: one hipEvent pair around every launch of a kernel class (bench.py's live
@@ -95,6 +111,9 @@ struct stcd_engine_impl {
     std::vector<Cbrd> enc, dec;
     std::vector<UpConv> ups;
     int final_conv = -1;
+    ConvOp final_fwd, final_dgr; WgradOp final_wg;
+    std::vector<ConvOp*> conv_ops;      // every ConvOp of the plan (weight-image packing walks this)
+    int64_t slab = -1, slab_floats = 0;
     TRef X0, G, finalIn, dFinalIn;
     int Hs[5] = {0}, Ws[5] = {0};
     TRef D[4], dD[4], P[4], dP[4];
@@ -248,6 +267,35 @@ static int bn_index(const stcd_engine& e, const std::string& name) {
     return -1;
 }
 
+static stcd_conv_geom geom3(int N, int H, int W, int K, int ldi, int co, int ldo) {
+    stcd_conv_geom g;
+    memset(&g, 0, sizeof(g));
+    g.n = N; g.hi = H; g.wi = W; g.ci = K; g.ldi = ldi;
+    g.hm = H; g.wm = W; g.in_stride = 1;
+    g.ho = H; g.wo = W; g.out_stride = 1; g.oy0 = 0; g.ox0 = 0;
+    g.co = co; g.ldo = ldo;
+    g.ntaps = 9;
+    for (int t = 0; t < 9; ++t) { g.dy[t] = (int8_t)(t / 3 - 1); g.dx[t] = (int8_t)(t % 3 - 1); }
+    return g;
+}
+
+// 4 sub-pixel phases of ConvTranspose2d(k3,s2,p1,op1): out(2m+py, 2n+px) = sum_{dy<=py, dx<=px} in(m+dy, n+dx) W[py+1-2dy][px+1-2dx]
+static stcd_conv_geom geom_up_phase(const UpConv& U, int py, int px, int ldi, int ldo, int* tap0) {
+    stcd_conv_geom g;
+    memset(&g, 0, sizeof(g));
+    g.n = U.N; g.hi = U.h; g.wi = U.w; g.ci = U.C; g.ldi = ldi;
+    g.hm = U.h; g.wm = U.w; g.in_stride = 1;
+    g.ho = U.Ho; g.wo = U.Wo; g.out_stride = 2; g.oy0 = py; g.ox0 = px;
+    g.co = U.C; g.ldo = ldo;
+    int t = 0;
+    for (int dy = 0; dy <= py; ++dy)
+        for (int dx = 0; dx <= px; ++dx) { g.dy[t] = (int8_t)dy; g.dx[t] = (int8_t)dx; ++t; }
+    g.ntaps = t;
+    static const int start[4] = {0, 1, 3, 5};
+    *tap0 = start[py * 2 + px];
+    return g;
+}
+
 static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     const int64_t T = (int64_t)dsize(e.dt);
     e.enc.clear(); e.dec.clear(); e.ups.clear(); e.drops.clear();
@@ -362,6 +410,63 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         c.dwe = ws.take(c.dwe_floats * 4);
     }
     e.dwe_end = ws.cur;
+
+    // ---- bind every conv-shaped launch (geometry, filter, MFMA plan); the layer vectors are final from here on
+    e.conv_ops.clear();
+    e.slab_floats = 0;
+    auto bind_conv = [&](ConvOp& op, const stcd_conv_geom& g, int conv, bool dgrad, int tap0, int kreal, int nreal) {
+        op.g = g; op.conv = conv; op.dgrad = dgrad; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
+        op.plan = ConvMfmaPlan(); op.wf = -1;
+        if (e.dt == BF16) {
+            op.plan = conv_mfma_plan(g);
+            if (op.plan.ok) op.wf = ws.take(op.plan.wf_elems * 2);
+        }
+        e.conv_ops.push_back(&op);
+    };
+    auto bind_wgrad = [&](WgradOp& op, const stcd_conv_geom& g, int conv, int tap0, int kreal, int nreal) {
+        op.g = g; op.conv = conv; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
+        op.plan = WgradMfmaPlan();
+        if (e.dt == BF16) {
+            op.plan = wgrad_mfma_plan(g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
+            e.slab_floats = std::max(e.slab_floats, op.plan.slab_floats);
+        }
+    };
+    auto bind_cbrd = [&](Cbrd& L) {
+        const ConvW& cv = e.convs[L.conv];
+        bind_conv(L.fwd, geom3(L.N, L.H, L.W, L.K, L.in.ld, cv.cout, L.Y.ld), L.conv, false, 0, cv.cin, cv.cout);
+        bind_wgrad(L.wg, geom3(L.N, L.H, L.W, L.K, L.in.ld, cv.cout, L.dY.ld), L.conv, 0, cv.cin, cv.cout);
+        if (L.has_dIn)
+            bind_conv(L.dgr, geom3(L.N, L.H, L.W, cv.dgrad.kpad, L.dY.ld, cv.cin, L.dIn.ld), L.conv, true, 0, cv.cout, cv.cin);
+    };
+    for (auto& L : e.enc) bind_cbrd(L);
+    for (auto& L : e.dec) bind_cbrd(L);
+    for (auto& U : e.ups) {
+        const ConvW& cv = e.convs[U.conv];
+        for (int ph = 0; ph < 4; ++ph) {
+            int tap0;
+            stcd_conv_geom g = geom_up_phase(U, ph >> 1, ph & 1, U.in.ld, U.out.ld, &tap0);
+            bind_conv(U.fwd[ph], g, U.conv, false, tap0, U.C, U.C);
+            bind_wgrad(U.wg[ph], g, U.conv, tap0, U.C, U.C);
+        }
+        // data gradient: 3x3 stride-2 conv over dOut.  (hi,wi) are the BUFFER dims (row pitch); taps reach at most
+        // row 2h-1 / col 2w-1, so replication-padded rows/cols are never read.
+        stcd_conv_geom gd;
+        memset(&gd, 0, sizeof(gd));
+        gd.n = U.N; gd.hi = U.Ho; gd.wi = U.Wo; gd.ci = cv.dgrad.kpad; gd.ldi = U.dOut.ld;
+        gd.hm = U.h; gd.wm = U.w; gd.in_stride = 2;
+        gd.ho = U.h; gd.wo = U.w; gd.out_stride = 1;
+        gd.co = U.C; gd.ldo = U.dIn.ld;
+        gd.ntaps = 9;
+        for (int t = 0; t < 9; ++t) { gd.dy[t] = (int8_t)(t / 3 - 1); gd.dx[t] = (int8_t)(t % 3 - 1); }
+        bind_conv(U.dgr, gd, U.conv, true, 0, U.C, U.C);
+    }
+    {
+        const ConvW& cv = e.convs[e.final_conv];
+        bind_conv(e.final_fwd, geom3(B, H, W, cv.kin_p, e.finalIn.ld, e.label, e.label), e.final_conv, false, 0, cv.cin, e.label);
+        bind_wgrad(e.final_wg, geom3(B, H, W, cv.kin_p, e.finalIn.ld, e.label, 8), e.final_conv, 0, cv.cin, e.label);
+        bind_conv(e.final_dgr, geom3(B, H, W, cv.dgrad.kpad, 8, cv.cin, e.dFinalIn.ld), e.final_conv, true, 0, e.label, cv.cin);
+    }
+    e.slab = ws.take(e.slab_floats * 4);
     e.ws_bytes = ws.cur;
     return 0;
 }
@@ -391,46 +496,71 @@ ProfScope::ProfScope(const Ctx& c, int klass, double flops, double bytes) : p(c.
     (void)hipEventRecord(r.a, s);
 }
 
-static stcd_conv_geom geom3(int N, int H, int W, int K, int ldi, int co, int ldo) {
-    stcd_conv_geom g;
-    memset(&g, 0, sizeof(g));
-    g.n = N; g.hi = H; g.wi = W; g.ci = K; g.ldi = ldi;
-    g.hm = H; g.wm = W; g.in_stride = 1;
-    g.ho = H; g.wo = W; g.out_stride = 1; g.oy0 = 0; g.ox0 = 0;
-    g.co = co; g.ldo = ldo;
-    g.ntaps = 9;
-    for (int t = 0; t < 9; ++t) { g.dy[t] = (int8_t)(t / 3 - 1); g.dx[t] = (int8_t)(t % 3 - 1); }
-    return g;
-}
-
 // algorithmic work of one conv-like launch: flops = 2 MACs over real channels,
 // bytes = (input + output + weights) * sizeof(T), each tensor counted once.
 static void conv_work(const stcd_engine& e, const stcd_conv_geom& g, int kreal, int nreal, double* flops, double* bytes) {
     double pos = (double)g.n * g.hm * g.wm;
     *flops = 2.0 * pos * g.ntaps * kreal * nreal;
-    double in_px = (double)g.n * (g.in_stride == 1 ? (double)g.hm * g.wm : (double)g.hi * g.wi);
+    double in_px = g.in_stride == 1 ? pos : (double)g.n * (2.0 * g.hm) * (2.0 * g.wm);
     *bytes = (in_px * kreal + pos * nreal + (double)g.ntaps * kreal * nreal) * (double)dsize(e.dt);
 }
 
-static void run_conv(const Ctx& c, const stcd_conv_geom& g, const void* in, const float* w, int kpad, int wld,
-                     const float* bias, void* out, bool nchw, int kreal, int nreal) {
+static bool mfma_on(const stcd_engine& e) { return e.dt == BF16 && e.use_mfma; }
+
+static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const float* bias, void* out, bool nchw) {
+    const ConvW& cv = c.e.convs[op.conv];
+    const PackSpec& ps = op.dgrad ? cv.dgrad : cv.fwd;
     double fl, by;
-    conv_work(c.e, g, kreal, nreal, &fl, &by);
-    ProfScope ps(c, PC_CONV, fl, by);
-    launch_conv_ref(c.e.dt, g, in, w, kpad, wld, bias, out, nchw, c.s);
+    conv_work(c.e, op.g, op.kreal, op.nreal, &fl, &by);
+    ProfScope prof(c, PC_CONV, fl, by);
+    if (mfma_on(c.e) && op.plan.ok && op.wf >= 0 &&
+        launch_conv_mfma(op.g, op.plan, in, c.at(op.wf), bias, out, nchw, c.s) == 0)
+        return;
+    const float* w = c.at<float>(op.dgrad ? cv.wpk_dgrad : cv.wpk_fwd) + (int64_t)op.tap0 * ps.kpad * ps.wld;
+    launch_conv_ref(c.e.dt, op.g, in, w, ps.kpad, ps.wld, bias, out, nchw, c.s);
 }
-static void run_wgrad(const Ctx& c, const stcd_conv_geom& g, const void* in, const void* dout, float* dw, int kpad, int wld,
-                      int kreal, int nreal) {
+
+// weight gradient of one launch, delivered straight into the reference-layout gradient tensor
+static void exec_wgrad(const Ctx& c, const WgradOp& op, const void* in, const void* dout) {
+    const ConvW& cv = c.e.convs[op.conv];
+    PackSpec sub = cv.fwd;                 // this launch's taps of the filter
+    sub.ntaps = op.g.ntaps;
+    for (int t = 0; t < op.g.ntaps; ++t) { sub.ky[t] = cv.fwd.ky[op.tap0 + t]; sub.kx[t] = cv.fwd.kx[op.tap0 + t]; }
     double fl, by;
-    conv_work(c.e, g, kreal, nreal, &fl, &by);
-    ProfScope ps(c, PC_WGRAD, fl, by);
-    launch_wgrad_ref(c.e.dt, g, in, dout, dw, kpad, wld, c.s);
+    conv_work(c.e, op.g, op.kreal, op.nreal, &fl, &by);
+    if (mfma_on(c.e) && op.plan.ok) {
+        int rc;
+        {
+            ProfScope prof(c, PC_WGRAD, fl, by);
+            rc = launch_wgrad_mfma(op.g, op.plan, in, dout, c.at<float>(c.e.slab), sub.kpad, sub.wld, c.s);
+        }
+        if (rc == 0) {
+            ProfScope prof(c, PC_PACK, 0.0, 0.0);
+            launch_reduce_dw(c.at<float>(c.e.slab), op.plan.gx, op.g, cv.cin, cv.cout, sub.kpad, sub.wld, &sub, c.grads + cv.w_off, c.s);
+            return;
+        }
+    }
+    float* dwe = c.at<float>(cv.dwe) + (int64_t)op.tap0 * sub.kpad * sub.wld;
+    {
+        ProfScope prof(c, PC_WGRAD, fl, by);
+        launch_wgrad_ref(c.e.dt, op.g, in, dout, dwe, sub.kpad, sub.wld, c.s);
+    }
+    launch_unpack_dw(sub, dwe, c.grads + cv.w_off, c.s);
 }
 
 static void pack_all_weights(const Ctx& c, bool with_dgrad) {
+    ProfScope prof(c, PC_PACK, 0.0, 0.0);
     for (auto& cv : c.e.convs) {
         launch_pack_w(cv.fwd, c.params + cv.w_off, c.at<float>(cv.wpk_fwd), c.s);
         if (with_dgrad && cv.dgrad.ntaps) launch_pack_w(cv.dgrad, c.params + cv.w_off, c.at<float>(cv.wpk_dgrad), c.s);
+    }
+    if (!mfma_on(c.e)) return;
+    for (const ConvOp* op : c.e.conv_ops) {
+        if (!op->plan.ok || op->wf < 0 || (op->dgrad && !with_dgrad)) continue;
+        const ConvW& cv = c.e.convs[op->conv];
+        const PackSpec& ps = op->dgrad ? cv.dgrad : cv.fwd;
+        const float* w = c.at<float>(op->dgrad ? cv.wpk_dgrad : cv.wpk_fwd) + (int64_t)op->tap0 * ps.kpad * ps.wld;
+        launch_pack_frag(op->g, op->plan, w, ps.kpad, ps.wld, c.at(op->wf), c.s);
     }
 }
 
@@ -439,9 +569,7 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     const ConvW& cv = e.convs[L.conv];
     const BnP& bn = e.bns[L.bn];
     const int C = cv.cout;
-    stcd_conv_geom g = geom3(L.N, L.H, L.W, L.K, L.in.ld, C, L.Y.ld);
-    run_conv(c, g, c.at(L.in.off), c.at<float>(cv.wpk_fwd), cv.fwd.kpad, cv.fwd.wld, c.params + cv.b_off, c.at(L.Y.off), false,
-             cv.cin, C);
+    exec_conv(c, L.fwd, c.at(L.in.off), c.params + cv.b_off, c.at(L.Y.off), false);
     const int64_t ppg = (int64_t)L.npg * L.H * L.W;
     const double act_bytes = (double)L.N * L.H * L.W * C * (double)dsize(e.dt);
     float* stat = c.at<float>(L.stat);
@@ -490,42 +618,14 @@ static void cbrd_backward(const Ctx& c, const Cbrd& L) {
                             c.at<float>(L.coef), mask, C, L.groups, L.npg, HW, 1, c.s);
     }
     // weight gradient (the conv bias feeds only a train-mode BN: its gradient is exactly zero and stays zero)
-    stcd_conv_geom g = geom3(L.N, L.H, L.W, L.K, L.in.ld, C, L.dY.ld);
-    run_wgrad(c, g, c.at(L.in.off), c.at(L.dY.off), c.at<float>(cv.dwe), cv.fwd.kpad, cv.fwd.wld, cv.cin, C);
-    launch_unpack_dw(cv.fwd, c.at<float>(cv.dwe), c.grads + cv.w_off, c.s);
-    if (L.has_dIn) {
-        stcd_conv_geom gd = geom3(L.N, L.H, L.W, cv.dgrad.kpad, L.dY.ld, cv.cin, L.dIn.ld);
-        run_conv(c, gd, c.at(L.dY.off), c.at<float>(cv.wpk_dgrad), cv.dgrad.kpad, cv.dgrad.wld, nullptr, c.at(L.dIn.off), false,
-                 C, cv.cin);
-    }
-}
-
-// 4 sub-pixel phases of ConvTranspose2d(k3,s2,p1,op1): out(2m+py, 2n+px) = sum_{dy<=py, dx<=px} in(m+dy, n+dx) W[py+1-2dy][px+1-2dx]
-static stcd_conv_geom geom_up_phase(const UpConv& U, int py, int px, int ldi, int ldo, int* tap0) {
-    stcd_conv_geom g;
-    memset(&g, 0, sizeof(g));
-    g.n = U.N; g.hi = U.h; g.wi = U.w; g.ci = U.C; g.ldi = ldi;
-    g.hm = U.h; g.wm = U.w; g.in_stride = 1;
-    g.ho = U.Ho; g.wo = U.Wo; g.out_stride = 2; g.oy0 = py; g.ox0 = px;
-    g.co = U.C; g.ldo = ldo;
-    int t = 0;
-    for (int dy = 0; dy <= py; ++dy)
-        for (int dx = 0; dx <= px; ++dx) { g.dy[t] = (int8_t)dy; g.dx[t] = (int8_t)dx; ++t; }
-    g.ntaps = t;
-    static const int start[4] = {0, 1, 3, 5};
-    *tap0 = start[py * 2 + px];
-    return g;
+    exec_wgrad(c, L.wg, c.at(L.in.off), c.at(L.dY.off));
+    if (L.has_dIn) exec_conv(c, L.dgr, c.at(L.dY.off), nullptr, c.at(L.dIn.off), false);
 }
 
 static void upconv_forward(const Ctx& c, const UpConv& U) {
     stcd_engine& e = c.e;
     const ConvW& cv = e.convs[U.conv];
-    for (int ph = 0; ph < 4; ++ph) {
-        int tap0;
-        stcd_conv_geom g = geom_up_phase(U, ph >> 1, ph & 1, U.in.ld, U.out.ld, &tap0);
-        const float* w = c.at<float>(cv.wpk_fwd) + (int64_t)tap0 * cv.fwd.kpad * cv.fwd.wld;
-        run_conv(c, g, c.at(U.in.off), w, cv.fwd.kpad, cv.fwd.wld, c.params + cv.b_off, c.at(U.out.off), false, U.C, U.C);
-    }
+    for (int ph = 0; ph < 4; ++ph) exec_conv(c, U.fwd[ph], c.at(U.in.off), c.params + cv.b_off, c.at(U.out.off), false);
     launch_rep_pad(e.dt, c.at(U.out.off), U.out.ld, U.N, U.Ho, U.Wo, 2 * U.h, 2 * U.w, U.C, c.s);
 }
 
@@ -543,28 +643,8 @@ static void upconv_backward(const Ctx& c, const UpConv& U) {
                 launch_bias_grad(e.dt, c.at<char>(U.dOut.off) + ((int64_t)(n * U.Ho + y) * U.Wo) * U.dOut.ld * T, U.dOut.ld,
                                  2 * U.w, U.C, c.grads + cv.b_off, c.s);
     }
-    for (int ph = 0; ph < 4; ++ph) {
-        int tap0;
-        stcd_conv_geom g = geom_up_phase(U, ph >> 1, ph & 1, U.in.ld, U.dOut.ld, &tap0);
-        float* dw = c.at<float>(cv.dwe) + (int64_t)tap0 * cv.fwd.kpad * cv.fwd.wld;
-        run_wgrad(c, g, c.at(U.in.off), c.at(U.dOut.off), dw, cv.fwd.kpad, cv.fwd.wld, U.C, U.C);
-    }
-    launch_unpack_dw(cv.fwd, c.at<float>(cv.dwe), c.grads + cv.w_off, c.s);
-    // data gradient: 3x3 stride-2 conv over dOut
-    stcd_conv_geom gd;
-    memset(&gd, 0, sizeof(gd));
-    gd.n = U.N; gd.hi = 2 * U.h; gd.wi = 2 * U.w; gd.ci = cv.dgrad.kpad; gd.ldi = U.dOut.ld;
-    gd.hm = U.h; gd.wm = U.w; gd.in_stride = 2;
-    gd.ho = U.h; gd.wo = U.w; gd.out_stride = 1;
-    gd.co = U.C; gd.ldo = U.dIn.ld;
-    gd.ntaps = 9;
-    for (int t = 0; t < 9; ++t) { gd.dy[t] = (int8_t)(t / 3 - 1); gd.dx[t] = (int8_t)(t % 3 - 1); }
-    // dOut rows are Wo pixels apart while the conv sees a 2h x 2w image: only valid when the buffer is unpadded in W.
-    // (hi,wi) bound the taps; the row pitch must be the buffer's.  The reference kernel indexes rows by wi, so for
-    // padded buffers present the full buffer and bound by construction (taps never reach row/col 2h / 2w).
-    gd.hi = U.Ho; gd.wi = U.Wo;
-    run_conv(c, gd, c.at(U.dOut.off), c.at<float>(cv.wpk_dgrad), cv.dgrad.kpad, cv.dgrad.wld, nullptr, c.at(U.dIn.off), false,
-             U.C, U.C);
+    for (int ph = 0; ph < 4; ++ph) exec_wgrad(c, U.wg[ph], c.at(U.in.off), c.at(U.dOut.off));
+    exec_conv(c, U.dgr, c.at(U.dOut.off), nullptr, c.at(U.dIn.off), false);
 }
 
 static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, const float* params, float* bn_running,
@@ -572,6 +652,7 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
     Ctx c{e, (char*)workspace, params, nullptr, s};
     const int B = e.B, dt = e.dt;
     const int64_t T = (int64_t)dsize(dt);
+    static const int SKIP_IDX[4] = {1, 3, 6, 9};
     if (training && e.drop_p > 0.f) {
         if (masks) STCD_HIP(hipMemcpyAsync(c.at(e.masks), masks, e.drop_floats * 4, hipMemcpyDeviceToDevice, s));
         else launch_dropout_gen(c.at<float>(e.masks), e.drop_floats, seed, e.drop_p, s);
@@ -584,19 +665,18 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
         const UpConv& U = e.ups[k];
         const int s_ = U.level, C = ENC_C[s_];
         upconv_forward(c, U);
-        const Cbrd& skip = e.enc[(s_ == 0 ? 1 : s_ == 1 ? 3 : s_ == 2 ? 6 : 9)];
-        if (e.arch != STCD_ARCH_CONC)
+        const Cbrd& skip = e.enc[SKIP_IDX[s_]];
+        if (e.arch != STCD_ARCH_CONC) {
+            ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.0 * B * e.Hs[s_] * e.Ws[s_] * C * (double)T);
             launch_fuse(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(skip.A.off), skip.A.ld, skip.A.goff,
                         c.at<char>(e.D[s_].off) + C * T, e.D[s_].ld, B, (int64_t)e.Hs[s_] * e.Ws[s_], C, s);
+        }
         for (int j = 0; j < DEC[k].n; ++j) {
             if (DEC[k].cout[j] < 0) break;
             cbrd_forward(c, e.dec[di++], bn_running, training != 0);
         }
     }
-    const ConvW& cv = e.convs[e.final_conv];
-    stcd_conv_geom g = geom3(B, e.H, e.W, cv.kin_p, e.finalIn.ld, e.label, e.label);
-    run_conv(c, g, c.at(e.finalIn.off), c.at<float>(cv.wpk_fwd), cv.fwd.kpad, cv.fwd.wld, params + cv.b_off, logits, true, cv.cin,
-             e.label);
+    exec_conv(c, e.final_fwd, c.at(e.finalIn.off), params + e.convs[e.final_conv].b_off, logits, true);
     STCD_HIP(hipGetLastError());
     return 0;
 }
@@ -609,7 +689,7 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
     static const int SKIP_IDX[4] = {1, 3, 6, 9};
     if (stage <= 0) {
         STCD_HIP(hipMemsetAsync(grads, 0, e.param_floats * 4, s));
-        STCD_HIP(hipMemsetAsync(c.at(e.dwe_begin), 0, e.dwe_end - e.dwe_begin, s));
+        if (!mfma_on(e)) STCD_HIP(hipMemsetAsync(c.at(e.dwe_begin), 0, e.dwe_end - e.dwe_begin, s));
         // T1 half of the bottleneck pool is dead work in the reference (SiamUnet_diff.py:119 overwritten at :143)
         STCD_HIP(hipMemsetAsync(c.at(e.dP[3].off), 0, (int64_t)B * e.Hs[4] * e.Ws[4] * ENC_C[3] * T, s));
         launch_gout_pack(dt, grad_logits, c.at(e.G.off), B, e.label, e.H, e.W, s);
@@ -618,12 +698,8 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
         STCD_HIP(hipMemsetAsync(c.at(e.scratch8), 0, 32, s));
         launch_bias_grad(dt, c.at(e.G.off), 8, (int64_t)B * e.H * e.W, 8, c.at<float>(e.scratch8), s);
         STCD_HIP(hipMemcpyAsync(grads + cv.b_off, c.at(e.scratch8), (size_t)e.label * 4, hipMemcpyDeviceToDevice, s));
-        stcd_conv_geom g = geom3(B, e.H, e.W, cv.kin_p, e.finalIn.ld, e.label, 8);
-        run_wgrad(c, g, c.at(e.finalIn.off), c.at(e.G.off), c.at<float>(cv.dwe), cv.fwd.kpad, cv.fwd.wld, cv.cin, e.label);
-        launch_unpack_dw(cv.fwd, c.at<float>(cv.dwe), grads + cv.w_off, s);
-        stcd_conv_geom gd = geom3(B, e.H, e.W, cv.dgrad.kpad, 8, cv.cin, e.dFinalIn.ld);
-        run_conv(c, gd, c.at(e.G.off), c.at<float>(cv.wpk_dgrad), cv.dgrad.kpad, cv.dgrad.wld, nullptr, c.at(e.dFinalIn.off), false,
-                 e.label, cv.cin);
+        exec_wgrad(c, e.final_wg, c.at(e.finalIn.off), c.at(e.G.off));
+        exec_conv(c, e.final_dgr, c.at(e.G.off), nullptr, c.at(e.dFinalIn.off), false);
         int di = (int)e.dec.size() - 1;
         for (int k = 3; k >= 0; --k) {
             int nb = 0;
@@ -633,18 +709,23 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
             const int s_ = U.level, C = ENC_C[s_];
             upconv_backward(c, U);
             const Cbrd& skip = e.enc[SKIP_IDX[s_]];
-            if (e.arch != STCD_ARCH_CONC)
+            if (e.arch != STCD_ARCH_CONC) {
+                ProfScope ps(c, PC_POOL_FUSE, 0.0, (e.arch == STCD_ARCH_DIFF ? 5.0 : 3.0) * B * e.Hs[s_] * e.Ws[s_] * C * (double)T);
                 launch_fuse_bwd(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(skip.A.off), skip.A.ld, skip.A.goff,
                                 c.at<char>(e.dD[s_].off) + C * T, e.dD[s_].ld, c.at(skip.dA.off), skip.dA.ld, skip.dA.goff, B,
                                 (int64_t)e.Hs[s_] * e.Ws[s_], C, s);
+            }
         }
     }
     if (stage < 0 || stage == 1) {
         for (int li = (int)e.enc.size() - 1; li >= 0; --li) {
             const Cbrd& L = e.enc[li];
-            if (L.pool)   // dA_skip += gradient routed back through the 2x2 max-pool
+            if (L.pool) {  // dA_skip += gradient routed back through the 2x2 max-pool
+                const int C = e.convs[L.conv].cout;
+                ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.25 * L.N * L.H * L.W * C * (double)T);
                 launch_pool_bwd(dt, c.at(L.A.off), L.A.ld, L.A.goff, c.at(L.dPool.off), L.dPool.ld, c.at(L.dA.off), L.dA.ld,
-                                L.dA.goff, L.groups, L.npg, L.H, L.W, e.convs[L.conv].cout, 1, s);
+                                L.dA.goff, L.groups, L.npg, L.H, L.W, C, 1, s);
+            }
             cbrd_backward(c, L);
         }
     }
@@ -813,12 +894,27 @@ static int check_geom(const stcd_conv_geom* g) {
                "output positions exceed the output buffer");
     return 0;
 }
-int64_t stcd_op_scratch_bytes(const stcd_conv_geom* g) { return g ? 1 << 20 : 0; }
+int64_t stcd_op_scratch_bytes(const stcd_conv_geom* g) {
+    if (!g) return 0;
+    ConvMfmaPlan p = conv_mfma_plan(*g);
+    WgradMfmaPlan w = wgrad_mfma_plan(*g, g->ci, g->co);
+    return std::max<int64_t>(p.wf_elems * 2, w.slab_floats * 4) + 256;
+}
 int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, const float* w, const float* bias,
                  void* out, void* scratch, int64_t scratch_bytes, void* hip_stream) {
     if (check_geom(g)) return 1;
     STCD_CHECK(in && w && out, "null pointer argument");
-    STCD_CHECK(impl == 0, "MFMA implementation not linked in this build");
+    if (impl == 1) {
+        STCD_CHECK(dtype == STCD_DTYPE_BF16, "the MFMA implementation is bf16 only");
+        ConvMfmaPlan p = conv_mfma_plan(*g);
+        STCD_CHECK(p.ok, "geometry not supported by the MFMA kernel");
+        STCD_CHECK(scratch && scratch_bytes >= p.wf_elems * 2, "scratch too small for the fragment-order filter");
+        launch_pack_frag(*g, p, w, g->ci, g->co, scratch, (hipStream_t)hip_stream);
+        STCD_CHECK(launch_conv_mfma(*g, p, in, scratch, bias, out, false, (hipStream_t)hip_stream) == 0, "LDS budget exceeded");
+        STCD_HIP(hipGetLastError());
+        return 0;
+    }
+    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA) or 1 (MFMA)");
     launch_conv_ref(dtype, *g, in, w, g->ci, g->co, bias, out, false, (hipStream_t)hip_stream);
     STCD_HIP(hipGetLastError());
     return 0;
@@ -827,7 +923,17 @@ int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, 
                   int64_t scratch_bytes, void* hip_stream) {
     if (check_geom(g)) return 1;
     STCD_CHECK(in && dout && dw, "null pointer argument");
-    STCD_CHECK(impl == 0, "MFMA implementation not linked in this build");
+    if (impl == 1) {
+        STCD_CHECK(dtype == STCD_DTYPE_BF16, "the MFMA implementation is bf16 only");
+        WgradMfmaPlan p = wgrad_mfma_plan(*g, g->ci, g->co);
+        STCD_CHECK(p.ok, "geometry not supported by the MFMA kernel");
+        STCD_CHECK(scratch && scratch_bytes >= p.slab_floats * 4, "scratch too small for the partial slabs");
+        STCD_CHECK(launch_wgrad_mfma(*g, p, in, dout, (float*)scratch, g->ci, g->co, (hipStream_t)hip_stream) == 0, "LDS budget exceeded");
+        launch_reduce_dw((const float*)scratch, p.gx, *g, g->ci, g->co, g->ci, g->co, nullptr, dw, (hipStream_t)hip_stream);
+        STCD_HIP(hipGetLastError());
+        return 0;
+    }
+    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA) or 1 (MFMA)");
     STCD_HIP(hipMemsetAsync(dw, 0, (size_t)g->ntaps * g->ci * g->co * 4, (hipStream_t)hip_stream));
     launch_wgrad_ref(dtype, *g, in, dout, dw, g->ci, g->co, (hipStream_t)hip_stream);
     STCD_HIP(hipGetLastError());

@@ -1,0 +1,546 @@
+// kernels_conv_mfma.hip -- bf16 implicit-GEMM "tap-list" convolution on the CDNA4 matrix cores (gfx950).
+//
+// One kernel family serves every conv-shaped op of the path (same geometry struct as the reference FMA kernel in
+// kernels_conv_ref.hip, which is its on-device cross-check):
+//   Conv2d 3x3 fwd / dgrad, ConvTranspose2d 3x3 (s=1) fwd / dgrad        SiamUnet_diff.py:18-48, 54-90
+//   ConvTranspose2d 3x3 s=2 as 4 sub-pixel phases, its dgrad as a stride-2 conv   SiamUnet_diff.py:52
+//
+// GEMM view per block:  D[co][pos] = sum_k W[co][k] * X[pos][k],  k = (tap, ci)
+//   * block = 256 threads = 4 waves, output tile 8 rows x 16 positions; wave w owns rows 2w, 2w+1
+//   * v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand (rows = co) and the ACTIVATIONS as the B operand
+//     (cols = positions): the accumulator then holds 4 consecutive channels of one position per lane, so the NHWC
+//     store is 8 contiguous bytes per lane and bias / BN-statistics are per-register constants
+//   * activations: an input halo tile (all taps of the output tile) is staged ONCE per channel chunk in LDS as
+//     [pixel][CiB] bf16 with the 16-B chunk index XOR-swizzled by the pixel column (ds_read_b128 conflicts)
+//   * weights: pre-packed on the device in MFMA-fragment order ([k-step][n-tile][lane][8]) so a wave's read of one
+//     fragment is 1 KiB contiguous; streamed tap by tap through a double-buffered LDS image, the next tap's
+//     global loads in flight in registers while the current tap's MFMAs run (one barrier per tap)
+//   * small-Ci layers (Ci in {8,16,48}: first layer, 16-channel stages) use a flattened k = tap*Ci + c walk with the
+//     whole weight image resident in LDS -- they are HBM-bound, the matrix cores just ride along
+#include "common.h"
+
+namespace stcd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct ConvMfmaArgs {
+    stcd_conv_geom g;
+    const bf16* in;
+    const bf16* wf;        // fragment-order weights
+    const float* bias;     // nullable
+    void* out;
+    int out_nchw;          // 1: fp32 NCHW [n][co][ho][wo]
+    int CiB, nchunks, KS;  // channel chunk, chunks per Ci, k-steps per tap (mode A) / per chunk (mode B)
+    int modeB;
+    int NTtot;             // ceil(co/16)
+    int dymin, dxmin, HH, HWp, swmask;
+    int tiles_x, tiles_y;
+    int halo_bytes, wbuf_bytes;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+k_conv_mfma(const ConvMfmaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int q = lane >> 4, r = lane & 15;
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int n = bid / a.tiles_y;
+    const int my0 = ty * 8, mx0 = tx * 16;
+    const int cob = blockIdx.y;
+    const int is = a.g.in_stride;
+    const int CiB = a.CiB, nch8 = CiB >> 3, swmask = a.swmask, HWp = a.HWp;
+    bf16* halo = reinterpret_cast<bf16*>(smem);
+    bf16* wl = reinterpret_cast<bf16*>(smem + a.halo_bytes);
+    int* tapoff = reinterpret_cast<int*>(smem + a.halo_bytes + 2 * a.wbuf_bytes);   // [9] pixel offset, [9] dx (mode B)
+    if (tid < a.g.ntaps) {
+        tapoff[tid] = (a.g.dy[tid] - a.dymin) * HWp + (a.g.dx[tid] - a.dxmin);
+        tapoff[9 + tid] = a.g.dx[tid] - a.dxmin;
+    }
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int WP = (2 * NT + 3) / 4;   // 16-B weight pieces per thread per tap (KS <= 2)
+    const int w_pieces = a.KS * NT * 64;   // per tap (mode A)
+    const int ntaps = a.g.ntaps;
+
+    for (int cc = 0; cc < a.nchunks; ++cc) {
+        __syncthreads();   // everyone is done reading the previous chunk's halo / weights
+        // ---- stage the input halo tile of this channel chunk
+        const int npieces = a.HH * HWp * nch8;
+        for (int i = tid; i < npieces; i += 256) {
+            const int ch = i % nch8, pix = i / nch8;
+            const int hx = pix % HWp, hy = pix / HWp;
+            const int gy = my0 * is + a.dymin + hy, gx = mx0 * is + a.dxmin + hx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gy >= 0 && gy < a.g.hi && gx >= 0 && gx < a.g.wi)
+                v = *reinterpret_cast<const uint4*>(a.in + (((int64_t)n * a.g.hi + gy) * a.g.wi + gx) * a.g.ldi + cc * CiB + ch * 8);
+            *reinterpret_cast<uint4*>(halo + (pix * nch8 + (ch ^ ((hx >> 1) & swmask))) * 8) = v;
+        }
+        if (a.modeB) {
+            // ---- whole weight image of the (single) chunk: KS x NT fragments
+            const bf16* wsrc = a.wf;
+            for (int i = tid; i < a.KS * NT * 64; i += 256) {
+                const int ks = i / (NT * 64), rem = i - ks * NT * 64;
+                *reinterpret_cast<uint4*>(wl + (int64_t)i * 8) =
+                    *reinterpret_cast<const uint4*>(wsrc + ((int64_t)(ks * a.NTtot + cob * NT) * 64 + rem) * 8);
+            }
+            __syncthreads();
+            for (int ks = 0; ks < a.KS; ++ks) {
+                const int kl = ks * 32 + 8 * q;
+                int t = kl / CiB, c = kl - t * CiB;
+                if (t >= ntaps) { t = 0; c = 0; }    // zero weights there; keep the address valid
+                const int toff = tapoff[t], tdx = tapoff[9 + t];
+                bf16x8 af[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int hx = r * is + tdx;
+                    const int pix = (wid * 2 + m) * is * HWp + r * is + toff;
+                    af[m] = *reinterpret_cast<const bf16x8*>(halo + (pix * nch8 + ((c >> 3) ^ ((hx >> 1) & swmask))) * 8);
+                }
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) {
+                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(wl + ((ks * NT + t2) * 64 + lane) * 8);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[m][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[m], acc[m][t2], 0, 0, 0);
+                }
+            }
+        } else {
+            // ---- mode A: stream the weights tap by tap through two LDS buffers
+            uint4 wreg[WP];
+            auto load_w = [&](int t) {
+                const bf16* wsrc = a.wf + ((int64_t)(cc * ntaps + t) * a.KS) * a.NTtot * 512;
+#pragma unroll
+                for (int p = 0; p < WP; ++p) {
+                    const int i = tid + p * 256;
+                    if (i < w_pieces) {
+                        const int ks = i / (NT * 64), rem = i - ks * NT * 64;
+                        wreg[p] = *reinterpret_cast<const uint4*>(wsrc + ((int64_t)(ks * a.NTtot + cob * NT) * 64 + rem) * 8);
+                    }
+                }
+            };
+            auto store_w = [&](int buf) {
+                bf16* dst = wl + (int64_t)buf * (a.wbuf_bytes >> 1);
+#pragma unroll
+                for (int p = 0; p < WP; ++p) {
+                    const int i = tid + p * 256;
+                    if (i < w_pieces) *reinterpret_cast<uint4*>(dst + (int64_t)i * 8) = wreg[p];
+                }
+            };
+            load_w(0);
+            store_w(0);
+            __syncthreads();
+            for (int t = 0; t < ntaps; ++t) {
+                if (t + 1 < ntaps) load_w(t + 1);
+                const bf16* wb = wl + (int64_t)(t & 1) * (a.wbuf_bytes >> 1);
+                const int tdy = a.g.dy[t] - a.dymin, tdx = a.g.dx[t] - a.dxmin;
+                for (int ks = 0; ks < a.KS; ++ks) {
+                    bf16x8 af[2];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int hx = r * is + tdx;
+                        const int pix = ((wid * 2 + m) * is + tdy) * HWp + hx;
+                        af[m] = *reinterpret_cast<const bf16x8*>(halo + (pix * nch8 + ((ks * 4 + q) ^ ((hx >> 1) & swmask))) * 8);
+                    }
+#pragma unroll
+                    for (int t2 = 0; t2 < NT; ++t2) {
+                        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(wb + ((ks * NT + t2) * 64 + lane) * 8);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            acc[m][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[m], acc[m][t2], 0, 0, 0);
+                    }
+                }
+                if (t + 1 < ntaps) store_w((t + 1) & 1);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: lane (q, r) holds, for position r of row (wid*2+m), channels nt*16 + 4q + j
+    const int mx = mx0 + r;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int my = my0 + wid * 2 + m;
+        if (my >= a.g.hm || mx >= a.g.wm) continue;
+        const int oy = my * a.g.out_stride + a.g.oy0, ox = mx * a.g.out_stride + a.g.ox0;
+#pragma unroll
+        for (int t2 = 0; t2 < NT; ++t2) {
+            const int cb = (cob * NT + t2) * 16 + 4 * q;
+            if (cb >= a.g.co) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[m][t2][j] + ((a.bias && cb + j < a.g.co) ? a.bias[cb + j] : 0.f);
+            if (a.out_nchw) {
+                float* o = reinterpret_cast<float*>(a.out);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (cb + j < a.g.co) o[(((int64_t)n * a.g.co + cb + j) * a.g.ho + oy) * a.g.wo + ox] = v[j];
+            } else {
+                bf16* o = reinterpret_cast<bf16*>(a.out) + (((int64_t)n * a.g.ho + oy) * a.g.wo + ox) * a.g.ldo + cb;
+                if (cb + 3 < a.g.co) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(o) = pk;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (cb + j < a.g.co) o[j] = (bf16)v[j];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static void taps_extent(const stcd_conv_geom& g, int* dymin, int* dymax, int* dxmin, int* dxmax) {
+    *dymin = *dxmin = 127; *dymax = *dxmax = -127;
+    for (int t = 0; t < g.ntaps; ++t) {
+        *dymin = std::min<int>(*dymin, g.dy[t]); *dymax = std::max<int>(*dymax, g.dy[t]);
+        *dxmin = std::min<int>(*dxmin, g.dx[t]); *dxmax = std::max<int>(*dxmax, g.dx[t]);
+    }
+}
+
+ConvMfmaPlan conv_mfma_plan(const stcd_conv_geom& g) {
+    ConvMfmaPlan p;
+    const int Ci = g.ci;
+    if (Ci % 64 == 0) p.CiB = 64;
+    else if (Ci % 32 == 0) p.CiB = 32;
+    else p.CiB = Ci;
+    p.modeB = (p.CiB % 32) != 0;
+    p.nchunks = Ci / p.CiB;
+    p.KS = p.modeB ? (g.ntaps * Ci + 31) / 32 : p.CiB / 32;
+    p.NTtot = (g.co + 15) / 16;
+    p.NT = p.NTtot >= 8 ? 8 : p.NTtot >= 4 ? 4 : p.NTtot >= 2 ? 2 : 1;
+    p.NTtot = ((p.NTtot + p.NT - 1) / p.NT) * p.NT;     // pad the n-tiles to whole blocks
+    p.wf_elems = p.modeB ? (int64_t)p.KS * p.NTtot * 512 : (int64_t)p.nchunks * g.ntaps * p.KS * p.NTtot * 512;
+    p.ok = (Ci % 8 == 0) && (p.modeB ? (Ci <= 64 && p.KS <= 24) : true) && g.ldi % 8 == 0;
+    return p;
+}
+
+// fp32 [tap][kpad][wld] -> bf16 fragment order
+__global__ void k_pack_frag(const float* __restrict__ w, int kpad, int wld, int ntaps, int Ci, int Co, int CiB, int nchunks,
+                            int KS, int NTtot, int modeB, bf16* __restrict__ dst, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    int64_t f = i >> 9;                                // fragment index
+    const int nt = (int)(f % NTtot); f /= NTtot;
+    const int ks = (int)(f % KS); f /= KS;
+    const int co = nt * 16 + (lane & 15);
+    int t, ci;
+    if (modeB) {
+        const int kf = ks * 32 + 8 * (lane >> 4) + j;
+        t = kf / Ci; ci = kf - t * Ci;
+    } else {
+        t = (int)(f % ntaps);
+        const int cc = (int)(f / ntaps);
+        ci = cc * CiB + ks * 32 + 8 * (lane >> 4) + j;
+    }
+    float v = 0.f;
+    if (t < ntaps && ci < Ci && co < Co) v = w[((int64_t)t * kpad + ci) * wld + co];
+    dst[i] = (bf16)v;
+}
+
+void launch_pack_frag(const stcd_conv_geom& g, const ConvMfmaPlan& p, const float* w, int kpad, int wld, void* dst,
+                      hipStream_t s) {
+    k_pack_frag<<<(unsigned)((p.wf_elems + 255) / 256), 256, 0, s>>>(w, kpad, wld, g.ntaps, g.ci, g.co, p.CiB, p.nchunks, p.KS,
+                                                                      p.NTtot, p.modeB, (bf16*)dst, p.wf_elems);
+}
+
+int launch_conv_mfma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const void* in, const void* wf, const float* bias,
+                     void* out, bool out_nchw, hipStream_t s) {
+    ConvMfmaArgs a;
+    a.g = g;
+    a.in = (const bf16*)in; a.wf = (const bf16*)wf; a.bias = bias; a.out = out; a.out_nchw = out_nchw ? 1 : 0;
+    a.CiB = p.CiB; a.nchunks = p.nchunks; a.KS = p.KS; a.modeB = p.modeB; a.NTtot = p.NTtot;
+    int dymax, dxmax;
+    taps_extent(g, &a.dymin, &dymax, &a.dxmin, &dxmax);
+    a.HH = 7 * g.in_stride + (dymax - a.dymin) + 1;
+    a.HWp = 15 * g.in_stride + (dxmax - a.dxmin) + 1;
+    const int nch8 = p.CiB / 8;
+    a.swmask = (nch8 & (nch8 - 1)) == 0 ? nch8 - 1 : 0;
+    a.tiles_x = (g.wm + 15) / 16;
+    a.tiles_y = (g.hm + 7) / 8;
+    a.halo_bytes = (a.HH * a.HWp * p.CiB * 2 + 255) & ~255;
+    a.wbuf_bytes = p.modeB ? ((p.KS * p.NT * 1024 + 1) / 2 + 255) & ~255 : (p.KS * p.NT * 1024 + 255) & ~255;
+    const size_t lds = (size_t)a.halo_bytes + 2 * (size_t)a.wbuf_bytes + 128;
+    if (lds > 160 * 1024) return 1;
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * g.n), (unsigned)(p.NTtot / p.NT));
+#define LAUNCH_NT(N_)                                                                                             \
+    do {                                                                                                          \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute((const void*)k_conv_mfma<N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        k_conv_mfma<N_><<<grid, 256, lds, s>>>(a);                                                                \
+    } while (0)
+    switch (p.NT) {
+        case 1: LAUNCH_NT(1); break;
+        case 2: LAUNCH_NT(2); break;
+        case 4: LAUNCH_NT(4); break;
+        default: LAUNCH_NT(8); break;
+    }
+#undef LAUNCH_NT
+    return 0;
+}
+
+
+// =====================================================================================================
+// Weight gradient on the matrix cores:  dW[t][ci][co] = sum_pos X[pos*is + tap_t][ci] * dY[pos][co]
+//
+// GEMM per tap: M = ci, N = co, K = positions.  Both operands are stored position-major in NHWC, i.e. K is the slow
+// axis of both -- exactly what ds_read_b64_tr_b16 is for: each 16-lane group reads a 4-position x 16-channel block and
+// gets it channel-major, two reads make one 8-deep MFMA fragment.  The dY fragment is read once per k-step and reused
+// by all 9 taps; the X fragment comes from the same halo tile shifted by the tap.
+//   block  = 4 waves; WCI waves side by side over 16-channel ci tiles, the other 4/WCI waves split the k-steps
+//            (position rows) of each tile; every wave keeps 9 x NTW accumulators for the whole block lifetime
+//   grid.x = position blocks, each walks tiles t = bx, bx+gx, ... and finally writes ONE fp32 slab
+//            [tap][ci][co] (plain coalesced stores, no global atomics: deterministic, and far cheaper than 1.3 TB/s
+//            atomics); k_reduce_dw sums the slabs straight into the reference-layout gradient.
+struct WgradArgs {
+    stcd_conv_geom g;
+    const bf16* in;
+    const bf16* dout;
+    float* slab;           // [gx][ntaps][kpad][wld]
+    int kpad, wld;
+    int dymin, dxmin, HH, HWp;
+    int tiles_x, tiles_y, ntiles;
+    int x_bytes;           // LDS bytes of the X halo tile
+    int co_valid;          // channels of dout that exist in memory (round8(co))
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* base0, const bf16* base1) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)base0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)base1);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+template <int WCI, int NTW>
+__global__ void __launch_bounds__(256)
+k_wgrad_mfma(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WK = 4 / WCI, CIB = WCI * 16, COB = NTW * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wci = wid % WCI, wk = wid / WCI;
+    const int grp = lane >> 4, li = lane & 15, qrow = li >> 2, pcol = li & 3;
+    const int is = a.g.in_stride, HWp = a.HWp;
+    const int ci0 = blockIdx.y * CIB, co0 = blockIdx.z * COB;
+    bf16* xs = reinterpret_cast<bf16*>(smem);
+    bf16* ys = reinterpret_cast<bf16*>(smem + a.x_bytes);
+
+    f32x4 acc[9][NTW];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int n_ = 0; n_ < NTW; ++n_) acc[t][n_] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane position of the two half-fragments inside a k-step (32 positions = 2 tile rows of 16)
+    // half h: k = 8*grp + 4*h + qrow  ->  row (k>>4) = grp>>1, x = 8*(grp&1) + 4*h + qrow
+    const int frow = grp >> 1;
+    const int fx0 = 8 * (grp & 1) + qrow, fx1 = fx0 + 4;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int tt = tile;
+        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+        const int ty = tt % a.tiles_y;
+        const int n = tt / a.tiles_y;
+        const int my0 = ty * 8, mx0 = tx * 16;
+        __syncthreads();
+        // ---- X halo tile, channels [ci0, ci0+CIB)
+        constexpr int XCH = CIB / 8;
+        const int nx = a.HH * HWp * XCH;
+        for (int i = tid; i < nx; i += 256) {
+            const int ch = i % XCH, pix = i / XCH;
+            const int hx = pix % HWp, hy = pix / HWp;
+            const int gy = my0 * is + a.dymin + hy, gx = mx0 * is + a.dxmin + hx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gy >= 0 && gy < a.g.hi && gx >= 0 && gx < a.g.wi && ci0 + ch * 8 < a.g.ci)
+                v = *reinterpret_cast<const uint4*>(a.in + (((int64_t)n * a.g.hi + gy) * a.g.wi + gx) * a.g.ldi + ci0 + ch * 8);
+            *reinterpret_cast<uint4*>(xs + (int64_t)i * 8) = v;
+        }
+        // ---- dY tile, channels [co0, co0+COB)
+        constexpr int YCH = COB / 8;
+        for (int i = tid; i < 128 * YCH; i += 256) {
+            const int ch = i % YCH, pix = i / YCH;
+            const int my = my0 + (pix >> 4), mx = mx0 + (pix & 15);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (my < a.g.hm && mx < a.g.wm && co0 + ch * 8 < a.co_valid) {
+                const int oy = my * a.g.out_stride + a.g.oy0, ox = mx * a.g.out_stride + a.g.ox0;
+                v = *reinterpret_cast<const uint4*>(a.dout + (((int64_t)n * a.g.ho + oy) * a.g.wo + ox) * a.g.ldo + co0 + ch * 8);
+            }
+            *reinterpret_cast<uint4*>(ys + (int64_t)i * 8) = v;
+        }
+        __syncthreads();
+        for (int ks = wk; ks < 4; ks += WK) {
+            const int row = ks * 2 + frow;
+            bf16x8 bfr[NTW];
+#pragma unroll
+            for (int n_ = 0; n_ < NTW; ++n_) {
+                const bf16* b0 = ys + ((row * 16 + fx0) * COB + n_ * 16 + 4 * pcol);
+                const bf16* b1 = ys + ((row * 16 + fx1) * COB + n_ * 16 + 4 * pcol);
+                bfr[n_] = tr_frag(b0, b1);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t < a.g.ntaps) {
+                    const int hy = row * is + (a.g.dy[t] - a.dymin);
+                    const int hxo = a.g.dx[t] - a.dxmin;
+                    const bf16* a0 = xs + ((hy * HWp + fx0 * is + hxo) * CIB + wci * 16 + 4 * pcol);
+                    const bf16* a1 = xs + ((hy * HWp + fx1 * is + hxo) * CIB + wci * 16 + 4 * pcol);
+                    const bf16x8 afr = tr_frag(a0, a1);
+#pragma unroll
+                    for (int n_ = 0; n_ < NTW; ++n_)
+                        acc[t][n_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[n_], acc[t][n_], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- block result -> slab[bx][t][ci][co]; lane holds D[ci_local = 4*grp + j][co_local = li]
+    float* slab = a.slab + (int64_t)blockIdx.x * a.g.ntaps * a.kpad * a.wld;
+    if (WK > 1) {
+        float* red = reinterpret_cast<float*>(smem);
+        __syncthreads();
+        for (int i = tid; i < 9 * CIB * COB; i += 256) red[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (t < a.g.ntaps)
+#pragma unroll
+                for (int n_ = 0; n_ < NTW; ++n_)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        atomicAdd(&red[(t * CIB + wci * 16 + 4 * grp + j) * COB + n_ * 16 + li], acc[t][n_][j]);
+        __syncthreads();
+        for (int i = tid; i < a.g.ntaps * CIB * COB; i += 256) {
+            const int co = i % COB, ci = (i / COB) % CIB, t = i / (COB * CIB);
+            if (ci0 + ci < a.kpad && co0 + co < a.wld)
+                slab[((int64_t)t * a.kpad + ci0 + ci) * a.wld + co0 + co] = red[i];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (t < a.g.ntaps)
+#pragma unroll
+                for (int n_ = 0; n_ < NTW; ++n_)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ci = ci0 + wci * 16 + 4 * grp + j, co = co0 + n_ * 16 + li;
+                        if (ci < a.kpad && co < a.wld) slab[((int64_t)t * a.kpad + ci) * a.wld + co] = acc[t][n_][j];
+                    }
+    }
+}
+
+// sum the slabs; out[t][k][n] (engine layout, same as the slab) or, with a PackSpec, straight into the reference layout
+__global__ void __launch_bounds__(256)
+k_reduce_dw(const float* __restrict__ slab, int gx, int64_t slab_stride, int ntaps, int K, int N, int kpad, int wld,
+            PackSpec ps, int use_ps, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int o = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int total = ntaps * K * N;
+    float acc = 0.f;
+    int n = 0, k = 0, t = 0;
+    if (o < total) {
+        n = o % N; k = (o / N) % K; t = o / (N * K);
+        const float* p = slab + ((int64_t)t * kpad + k) * wld + n;
+        for (int b = part; b < gx; b += 4) acc += p[(int64_t)b * slab_stride];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (part == 0 && o < total) {
+        acc = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+        if (use_ps) {
+            const int64_t a_ = ps.kn_major ? ((int64_t)k * ps.N + n) : ((int64_t)n * ps.K + k);
+            out[(a_ * ps.ks + ps.ky[t]) * ps.ks + ps.kx[t]] = acc;
+        } else {
+            out[((int64_t)t * kpad + k) * wld + n] = acc;
+        }
+    }
+}
+
+WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld) {
+    WgradMfmaPlan p;
+    p.WCI = g.ci >= 64 ? 4 : g.ci >= 32 ? 2 : 1;
+    p.NTW = g.co >= 64 ? 4 : g.co >= 32 ? 2 : 1;
+    p.gy = (g.ci + p.WCI * 16 - 1) / (p.WCI * 16);
+    p.gz = (g.co + p.NTW * 16 - 1) / (p.NTW * 16);
+    const int tiles_x = (g.wm + 15) / 16, tiles_y = (g.hm + 7) / 8;
+    const int64_t ntiles = (int64_t)g.n * tiles_x * tiles_y;
+    const int64_t slab_bytes = (int64_t)g.ntaps * kpad * wld * 4;
+    int64_t gx = std::max<int64_t>(1, 1024 / (p.gy * p.gz));
+    gx = std::min<int64_t>(gx, std::max<int64_t>(1, ((int64_t)24 << 20) / slab_bytes));
+    gx = std::min<int64_t>(gx, ntiles);
+    p.gx = (int)gx;
+    p.slab_floats = (int64_t)p.gx * g.ntaps * kpad * wld;
+    p.ok = g.ci % 8 == 0 && g.ldi % 8 == 0 && g.ldo % 8 == 0;
+    return p;
+}
+
+int launch_wgrad_mfma(const stcd_conv_geom& g, const WgradMfmaPlan& p, const void* in, const void* dout, float* slab,
+                      int kpad, int wld, hipStream_t s) {
+    WgradArgs a;
+    a.g = g;
+    a.in = (const bf16*)in; a.dout = (const bf16*)dout; a.slab = slab; a.kpad = kpad; a.wld = wld;
+    int dymax, dxmax;
+    taps_extent(g, &a.dymin, &dymax, &a.dxmin, &dxmax);
+    a.HH = 7 * g.in_stride + (dymax - a.dymin) + 1;
+    a.HWp = 15 * g.in_stride + (dxmax - a.dxmin) + 1;
+    a.tiles_x = (g.wm + 15) / 16;
+    a.tiles_y = (g.hm + 7) / 8;
+    a.ntiles = g.n * a.tiles_x * a.tiles_y;
+    const int CIB = p.WCI * 16, COB = p.NTW * 16;
+    a.x_bytes = (a.HH * a.HWp * CIB * 2 + 255) & ~255;
+    a.co_valid = (g.co + 7) & ~7;
+    size_t lds = (size_t)a.x_bytes + (size_t)128 * COB * 2;
+    if (p.WCI < 4) lds = std::max<size_t>(lds, (size_t)9 * CIB * COB * 4);
+    if (lds > 160 * 1024) return 1;
+    dim3 grid((unsigned)p.gx, (unsigned)p.gy, (unsigned)p.gz);
+#define LAUNCH_WG(W_, N_)                                                                                           \
+    do {                                                                                                            \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            (void)hipFuncSetAttribute((const void*)k_wgrad_mfma<W_, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        k_wgrad_mfma<W_, N_><<<grid, 256, lds, s>>>(a);                                                             \
+    } while (0)
+    const int key = p.WCI * 10 + p.NTW;
+    switch (key) {
+        case 11: LAUNCH_WG(1, 1); break;
+        case 12: LAUNCH_WG(1, 2); break;
+        case 14: LAUNCH_WG(1, 4); break;
+        case 21: LAUNCH_WG(2, 1); break;
+        case 22: LAUNCH_WG(2, 2); break;
+        case 24: LAUNCH_WG(2, 4); break;
+        case 41: LAUNCH_WG(4, 1); break;
+        case 42: LAUNCH_WG(4, 2); break;
+        default: LAUNCH_WG(4, 4); break;
+    }
+#undef LAUNCH_WG
+    return 0;
+}
+
+void launch_reduce_dw(const float* slab, int gx, const stcd_conv_geom& g, int K, int N, int kpad, int wld,
+                      const PackSpec* ps, float* out, hipStream_t s) {
+    const int total = g.ntaps * K * N;
+    PackSpec dummy{};
+    k_reduce_dw<<<(total + 63) / 64, 256, 0, s>>>(slab, gx, (int64_t)g.ntaps * kpad * wld, g.ntaps, K, N, kpad, wld,
+                                                  ps ? *ps : dummy, ps ? 1 : 0, out);
+}
+
+}  // namespace stcd

@@ -33,6 +33,10 @@ def check_grad(name, got, g, rtol, atol):
         assert abs(ref[2:]).max() < 1e-5 and got.abs().max().item() < 1e-5, name
         return
     scale = max(ref[1], 1e-6)
-    np.testing.assert_allclose(grad_summary(got) / scale, ref / scale, rtol=rtol, atol=atol, err_msg=name)
+    gs = grad_summary(got)
+    # entry 0 is the plain sum of all elements: a cancellation-prone statistic (|sum| << l2 * sqrt(n)), so it only
+    # gets a loose bound; entry 1 (l2) and the 32 sampled elements carry the real check
+    assert abs(gs[0] - ref[0]) / scale < max(20 * atol, 5e-3), (name, gs[0], ref[0])
+    np.testing.assert_allclose(gs[1:] / scale, ref[1:] / scale, rtol=rtol, atol=atol, err_msg=name)
     if "gf/" + name in g:
         np.testing.assert_allclose(got.numpy(), g["gf/" + name], rtol=rtol, atol=atol * scale, err_msg=name)

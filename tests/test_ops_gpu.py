@@ -1,0 +1,149 @@
+"""Per-op parity of the hand-written conv kernels through the C ABI (stcd_op_conv / stcd_op_wgrad).
+
+Inputs and filters are bf16-representable, accumulation is fp32 in every implementation, so the MFMA kernel
+(impl=1), the reference FMA kernel (impl=0) and the plain-C oracle (double accumulation) must agree to the rounding
+of the bf16 OUTPUT (one ulp = 2^-8 relative) for conv, and to fp32 summation-order noise for the weight gradient."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_c as O
+from stcd_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def geom(n, hi, wi, ci, ldi, hm, wm, in_stride, ho, wo, out_stride, oy0, ox0, co, ldo, taps):
+    g = _lib.ConvGeom()
+    g.n, g.hi, g.wi, g.ci, g.ldi = n, hi, wi, ci, ldi
+    g.hm, g.wm, g.in_stride = hm, wm, in_stride
+    g.ho, g.wo, g.out_stride, g.oy0, g.ox0 = ho, wo, out_stride, oy0, ox0
+    g.co, g.ldo, g.ntaps = co, ldo, len(taps)
+    for i, (dy, dx) in enumerate(taps):
+        g.dy[i], g.dx[i] = dy, dx
+    return g
+
+
+TAPS3 = [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+
+
+def run_conv(impl, g, x, w, bias, out):
+    l = _lib.lib()
+    nbytes = l.stcd_op_scratch_bytes(C.byref(g))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    _lib.check(l.stcd_op_conv(_lib.DTYPE_BF16, impl, C.byref(g), C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()),
+                              C.c_void_p(bias.data_ptr()) if bias is not None else None, C.c_void_p(out.data_ptr()),
+                              C.c_void_p(scratch.data_ptr()), nbytes, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+
+
+def run_wgrad(impl, g, x, dout):
+    l = _lib.lib()
+    nbytes = l.stcd_op_scratch_bytes(C.byref(g))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw = torch.full((g.ntaps, g.ci, g.co), float("nan"), dtype=torch.float32, device=DEV)
+    _lib.check(l.stcd_op_wgrad(_lib.DTYPE_BF16, impl, C.byref(g), C.c_void_p(x.data_ptr()), C.c_void_p(dout.data_ptr()),
+                               C.c_void_p(dw.data_ptr()), C.c_void_p(scratch.data_ptr()), nbytes,
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    return dw
+
+
+def rnd(rng, *shape, scale=1.0):
+    return torch.from_numpy((scale * rng.standard_normal(shape)).astype(np.float32)).bfloat16()
+
+
+CONV_CASES = [  # n, h, w, ci, co   (ci includes the engine's zero padding to 8)
+    (2, 16, 16, 8, 16), (2, 16, 32, 16, 16), (1, 24, 16, 16, 32), (2, 16, 16, 32, 32), (1, 16, 16, 32, 64),
+    (2, 8, 16, 64, 64), (1, 16, 16, 64, 128), (1, 8, 16, 128, 128), (1, 8, 16, 256, 128), (1, 8, 16, 384, 128),
+    (1, 16, 16, 48, 16), (1, 16, 16, 96, 32), (1, 16, 16, 192, 64), (2, 16, 16, 16, 2), (1, 16, 16, 16, 1),
+    (1, 20, 18, 16, 16), (1, 9, 11, 64, 64), (1, 25, 7, 32, 32),
+]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", CONV_CASES)
+def test_conv3x3_mfma_vs_ref_vs_oracle(n, h, w, ci, co):
+    rng = np.random.default_rng(ci * 1000 + co + h)
+    x = rnd(rng, n, h, w, ci).to(DEV)
+    wt = rnd(rng, 9, ci, co, scale=1.0 / np.sqrt(9 * ci)).float().to(DEV)
+    bias = torch.from_numpy(rng.standard_normal(co).astype(np.float32)).to(DEV)
+    ldo = (co + 7) // 8 * 8
+    g = geom(n, h, w, ci, ci, h, w, 1, h, w, 1, 0, 0, co, ldo, TAPS3)
+    outs = []
+    for impl in (0, 1):
+        out = torch.zeros(n, h, w, ldo, dtype=torch.bfloat16, device=DEV)
+        run_conv(impl, g, x, wt, bias, out)
+        outs.append(out[..., :co].float().cpu())
+    # oracle: NCHW, weight [co][ci][ky][kx] with tap (dy,dx) -> (ky,kx) = (dy+1, dx+1)
+    w_ref = wt.cpu().numpy().reshape(3, 3, ci, co).transpose(3, 2, 0, 1)
+    ref = O.conv2d_fwd(x.float().cpu().numpy().transpose(0, 3, 1, 2), w_ref, bias.cpu().numpy(), 1).transpose(0, 2, 3, 1)
+    for name, o in (("ref-kernel", outs[0]), ("mfma", outs[1])):
+        np.testing.assert_allclose(o.numpy(), ref, rtol=2 ** -7, atol=2e-3, err_msg=name)
+    np.testing.assert_allclose(outs[1].numpy(), outs[0].numpy(), rtol=2 ** -7, atol=2e-3)
+
+
+WGRAD_CASES = [(2, 16, 16, 8, 16), (2, 16, 32, 16, 16), (1, 24, 16, 16, 32), (2, 16, 16, 32, 32), (2, 8, 16, 64, 64),
+               (1, 16, 16, 64, 128), (1, 8, 16, 128, 128), (1, 8, 16, 256, 128), (1, 16, 16, 48, 16), (1, 16, 16, 96, 32),
+               (2, 16, 16, 16, 2), (1, 20, 18, 16, 16), (1, 9, 11, 64, 64), (4, 32, 32, 16, 16)]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", WGRAD_CASES)
+def test_wgrad_mfma_vs_ref_vs_oracle(n, h, w, ci, co):
+    rng = np.random.default_rng(7 * ci + co + w)
+    x = rnd(rng, n, h, w, ci).to(DEV)
+    ldo = (co + 7) // 8 * 8
+    dout = torch.zeros(n, h, w, ldo, dtype=torch.bfloat16, device=DEV)
+    dout[..., :co] = rnd(rng, n, h, w, co).to(DEV)
+    g = geom(n, h, w, ci, ci, h, w, 1, h, w, 1, 0, 0, co, ldo, TAPS3)
+    dw0, dw1 = run_wgrad(0, g, x, dout).cpu().numpy(), run_wgrad(1, g, x, dout).cpu().numpy()
+    _, dw_ref, _ = O.conv2d_bwd(x.float().cpu().numpy().transpose(0, 3, 1, 2), np.zeros((co, ci, 3, 3), np.float32),
+                                dout[..., :co].float().cpu().numpy().transpose(0, 3, 1, 2), 1)
+    ref = dw_ref.transpose(2, 3, 1, 0).reshape(9, ci, co)       # [co][ci][ky][kx] -> [tap][ci][co]
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(dw0 / scale, ref / scale, atol=2e-4, err_msg="ref-kernel")
+    np.testing.assert_allclose(dw1 / scale, ref / scale, atol=2e-4, err_msg="mfma")
+
+
+def up_phase_taps(py, px):
+    return [(dy, dx) for dy in range(py + 1) for dx in range(px + 1)]
+
+
+@pytest.mark.parametrize("c", [16, 32, 64, 128])
+def test_upconv_phases_and_stride2_dgrad(c):
+    """ConvTranspose2d(k3,s2,p1,op1) as 4 sub-pixel phase launches writing a channel slice of a wider concat buffer,
+    and its data gradient as a stride-2 conv: MFMA vs reference kernel (the reference kernel's whole-model use is
+    pinned to the reference vectors in test_engine_gpu.py)."""
+    rng = np.random.default_rng(c)
+    n, h, w, ldcat = 2, 8, 16, 2 * c
+    x = rnd(rng, n, h, w, c).to(DEV)
+    outs = []
+    for impl in (0, 1):
+        cat = torch.zeros(n, 2 * h, 2 * w, ldcat, dtype=torch.bfloat16, device=DEV)
+        for py in (0, 1):
+            for px in (0, 1):
+                taps = up_phase_taps(py, px)
+                wt = rnd(np.random.default_rng(c + 10 * py + px), len(taps), c, c, scale=0.1).float().to(DEV)
+                g = geom(n, h, w, c, c, h, w, 1, 2 * h, 2 * w, 2, py, px, c, ldcat, taps)
+                run_conv(impl, g, x, wt, None, cat)
+        assert cat[..., c:].abs().max().item() == 0.0           # the neighbouring slice is untouched
+        outs.append(cat[..., :c].float().cpu().numpy())
+    np.testing.assert_allclose(outs[1], outs[0], rtol=2 ** -7, atol=2e-3)
+    # stride-2 3x3 conv over a [2h,2w] gradient held in a wider buffer
+    dy_ = torch.zeros(n, 2 * h, 2 * w, ldcat, dtype=torch.bfloat16, device=DEV)
+    dy_[..., :c] = rnd(rng, n, 2 * h, 2 * w, c).to(DEV)
+    wt = rnd(rng, 9, c, c, scale=0.05).float().to(DEV)
+    g = geom(n, 2 * h, 2 * w, c, ldcat, h, w, 2, h, w, 1, 0, 0, c, c, TAPS3)
+    res = []
+    for impl in (0, 1):
+        o = torch.zeros(n, h, w, c, dtype=torch.bfloat16, device=DEV)
+        run_conv(impl, g, dy_, wt, None, o)
+        res.append(o.float().cpu().numpy())
+    np.testing.assert_allclose(res[1], res[0], rtol=2 ** -7, atol=2e-3)
+    # weight gradient of one phase (tap offsets on the input side, stride-2 offsets on the dY side)
+    taps = up_phase_taps(1, 1)
+    g = geom(n, h, w, c, c, h, w, 1, 2 * h, 2 * w, 2, 1, 1, c, ldcat, taps)
+    d0, d1 = run_wgrad(0, g, x, dy_).cpu().numpy(), run_wgrad(1, g, x, dy_).cpu().numpy()
+    np.testing.assert_allclose(d1 / np.abs(d0).max(), d0 / np.abs(d0).max(), atol=2e-4)
