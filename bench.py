@@ -53,7 +53,8 @@ def cpu_baseline(arch, label, size, pairs, steps):
     from oracle import fcsiam_ref as R
     from stcd_amd import synth
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(ncpu, int(os.environ.get("STCD_CPU_THREADS", "16")))))
     a, b, lab = synth.make_batch(pairs, size, size, seed=1337)
     A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab)
     st = R.synth_state(arch, 3, label, seed=1)

@@ -451,19 +451,21 @@ __global__ void __launch_bounds__(256)
 k_reduce_dw(const float* __restrict__ slab, int gx, int64_t slab_stride, int ntaps, int K, int N, int kpad, int wld,
             PackSpec ps, int use_ps, float* __restrict__ out) {
     __shared__ float red[256];
-    const int o = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int o = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
     const int total = ntaps * K * N;
     float acc = 0.f;
     int n = 0, k = 0, t = 0;
     if (o < total) {
         n = o % N; k = (o / N) % K; t = o / (N * K);
         const float* p = slab + ((int64_t)t * kpad + k) * wld + n;
-        for (int b = part; b < gx; b += 4) acc += p[(int64_t)b * slab_stride];
+        for (int b = part; b < gx; b += 16) acc += p[(int64_t)b * slab_stride];
     }
     red[threadIdx.x] = acc;
     __syncthreads();
     if (part == 0 && o < total) {
-        acc = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+        acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += red[q * 16 + threadIdx.x];
         if (use_ps) {
             const int64_t a_ = ps.kn_major ? ((int64_t)k * ps.N + n) : ((int64_t)n * ps.K + k);
             out[(a_ * ps.ks + ps.ky[t]) * ps.ks + ps.kx[t]] = acc;
@@ -482,7 +484,7 @@ WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld) {
     const int tiles_x = (g.wm + 15) / 16, tiles_y = (g.hm + 7) / 8;
     const int64_t ntiles = (int64_t)g.n * tiles_x * tiles_y;
     const int64_t slab_bytes = (int64_t)g.ntaps * kpad * wld * 4;
-    int64_t gx = std::max<int64_t>(1, 1024 / (p.gy * p.gz));
+    int64_t gx = std::max<int64_t>(1, std::min<int64_t>(512, 1024 / (p.gy * p.gz)));
     gx = std::min<int64_t>(gx, std::max<int64_t>(1, ((int64_t)24 << 20) / slab_bytes));
     gx = std::min<int64_t>(gx, ntiles);
     p.gx = (int)gx;
@@ -539,7 +541,7 @@ void launch_reduce_dw(const float* slab, int gx, const stcd_conv_geom& g, int K,
                       const PackSpec* ps, float* out, hipStream_t s) {
     const int total = g.ntaps * K * N;
     PackSpec dummy{};
-    k_reduce_dw<<<(total + 63) / 64, 256, 0, s>>>(slab, gx, (int64_t)g.ntaps * kpad * wld, g.ntaps, K, N, kpad, wld,
+    k_reduce_dw<<<(total + 15) / 16, 256, 0, s>>>(slab, gx, (int64_t)g.ntaps * kpad * wld, g.ntaps, K, N, kpad, wld,
                                                   ps ? *ps : dummy, ps ? 1 : 0, out);
 }
 

@@ -126,6 +126,11 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
         }
     }
     const T* yb = Y + ((int64_t)g * ppg) * ldy + mycb * 8;
+    int nig = 0, pin = 0;                       // image-in-group and pixel-in-image of the current pixel (MODE 1)
+    if (MODE == 1) {
+        nig = (int)((uint32_t)(p0 + lane) / (uint32_t)HW);
+        pin = (int)((p0 + lane) - (int64_t)nig * HW);
+    }
     for (int64_t p = p0 + lane; p < p1; p += lanes) {
         float y[8];
         load8<T>(yb + p * ldy, y);
@@ -134,7 +139,6 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
             for (int j = 0; j < 8; ++j) { s1[j] += y[j]; s2[j] += y[j] * y[j]; }
         } else {
             float d[8];
-            int nig = (int)(p / HW);
             load8<T>(dA + g * dav.goff + p * dav.ld + mycb * 8, d);
             const float* mk = mask ? mask + ((int64_t)(g * npg + nig)) * C + mycb * 8 : nullptr;
 #pragma unroll
@@ -145,6 +149,8 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
                 s1[j] += dz;
                 s2[j] += dz * (y[j] - mean[j]) * invstd[j];
             }
+            pin += lanes;
+            while (pin >= HW) { pin -= (int)HW; ++nig; }
         }
     }
 #pragma unroll
@@ -173,19 +179,38 @@ void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, con
                           const float* mask, int C, int groups, int npg, int64_t HW, int relu, float* partial,
                           hipStream_t s);
 
-__global__ void k_bn_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg,
-                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
-                              float* __restrict__ rvar, float* __restrict__ stat, float momentum, float eps) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
-    for (int g = 0; g < groups; ++g) {   // sequential: the shared encoder BN sees T1 then T2 (SiamUnet_diff.py:99,123)
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < nchunk; ++k) {
+// sum the per-chunk partials of 16 channels with 16 threads each; result for (group g, which) in sm[..] of part 0
+__device__ __forceinline__ void chunk_sums(const float* __restrict__ partial, int nchunk, int C, int g, int c, int part,
+                                           double* sm, double* s1, double* s2) {
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C)
+        for (int k = part; k < nchunk; k += 16) {
             const float* p = partial + ((int64_t)g * nchunk + k) * 2 * C;
-            s1 += p[c];
-            s2 += p[C + c];
+            a1 += p[c];
+            a2 += p[C + c];
         }
+    __syncthreads();
+    sm[threadIdx.x] = a1;
+    sm[256 + threadIdx.x] = a2;
+    __syncthreads();
+    a1 = 0.0; a2 = 0.0;
+    if (part == 0)
+        for (int q = 0; q < 16; ++q) { a1 += sm[q * 16 + (threadIdx.x & 15)]; a2 += sm[256 + q * 16 + (threadIdx.x & 15)]; }
+    *s1 = a1; *s2 = a2;
+}
+
+__global__ void __launch_bounds__(256)
+k_bn_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg,
+              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+              float* __restrict__ rvar, float* __restrict__ stat, float momentum, float eps) {
+    __shared__ double sm[512];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+    const bool owner = part == 0 && c < C;
+    float rm = (owner && rmean) ? rmean[c] : 0.f, rv = (owner && rvar) ? rvar[c] : 0.f;
+    for (int g = 0; g < groups; ++g) {   // sequential: the shared encoder BN sees T1 then T2 (SiamUnet_diff.py:99,123)
+        double s1, s2;
+        chunk_sums(partial, nchunk, C, g, c, part, sm, &s1, &s2);
+        if (!owner) continue;
         double mean = s1 / ppg, var = s2 / ppg - mean * mean;
         if (var < 0.0) var = 0.0;
         double invstd = 1.0 / sqrt(var + (double)eps);
@@ -199,13 +224,13 @@ __global__ void k_bn_finalize(const float* __restrict__ partial, int nchunk, int
         rm = (float)((1.0 - momentum) * rm + momentum * mean);
         rv = (float)((1.0 - momentum) * rv + momentum * unb);
     }
-    if (rmean) rmean[c] = rm;
-    if (rvar) rvar[c] = rv;
+    if (owner && rmean) rmean[c] = rm;
+    if (owner && rvar) rvar[c] = rv;
 }
 void launch_bn_finalize(const float* partial, int nchunk, int C, int groups, int64_t ppg, const float* gamma,
                         const float* beta, float* rmean, float* rvar, float* stat, float momentum, float eps,
                         hipStream_t s) {
-    k_bn_finalize<<<cdiv(C, 64), 64, 0, s>>>(partial, nchunk, C, groups, ppg, gamma, beta, rmean, rvar, stat, momentum, eps);
+    k_bn_finalize<<<cdiv(C, 16), 256, 0, s>>>(partial, nchunk, C, groups, ppg, gamma, beta, rmean, rvar, stat, momentum, eps);
 }
 
 __global__ void k_bn_eval_prepare(int C, int groups, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -450,9 +475,10 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int cb = C >> 3;
-    int c0 = (int)(i % cb) * 8;
-    int64_t p = i / cb;           // global pixel index over groups*npg images
-    int n = (int)(p / HW);
+    const uint32_t iu = (uint32_t)i;               // launcher guarantees total < 2^31
+    int c0 = (int)(iu % (uint32_t)cb) * 8;
+    int64_t p = iu / (uint32_t)cb;                 // global pixel index over groups*npg images
+    int n = (int)((uint32_t)p / (uint32_t)HW);
     int g = n / npg;
     int64_t pig = p - (int64_t)g * npg * HW;
     const float* st = stat + (int64_t)g * 4 * C + c0;
@@ -472,29 +498,30 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
     store8<T>(dY + p * lddy + c0, o);
 }
 
-__global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg,
-                                  float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ void __launch_bounds__(256)
+k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg,
+                  float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double sm[512];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+    const bool owner = part == 0 && c < C;
     double tg = 0.0, tb = 0.0;
     for (int g = 0; g < groups; ++g) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < nchunk; ++k) {
-            const float* p = partial + ((int64_t)g * nchunk + k) * 2 * C;
-            s1 += p[c];
-            s2 += p[C + c];
-        }
+        double s1, s2;
+        chunk_sums(partial, nchunk, C, g, c, part, sm, &s1, &s2);
+        if (!owner) continue;
         coef[(int64_t)g * 2 * C + c] = (float)(s1 / ppg);
         coef[(int64_t)g * 2 * C + C + c] = (float)(s2 / ppg);
         tb += s1;
         tg += s2;
     }
-    dgamma[c] = (float)tg;
-    dbeta[c] = (float)tb;
+    if (owner) {
+        dgamma[c] = (float)tg;
+        dbeta[c] = (float)tb;
+    }
 }
 void launch_bn_bwd_finalize(const float* partial, int nchunk, int C, int groups, int64_t ppg, float* coef, float* dgamma,
                             float* dbeta, hipStream_t s) {
-    k_bn_bwd_finalize<<<cdiv(C, 64), 64, 0, s>>>(partial, nchunk, C, groups, ppg, coef, dgamma, dbeta);
+    k_bn_bwd_finalize<<<cdiv(C, 16), 256, 0, s>>>(partial, nchunk, C, groups, ppg, coef, dgamma, dbeta);
 }
 
 // ------------------------------------------------------------------ bias gradient (layers without a following BN)
