@@ -135,9 +135,21 @@ struct PackSpec {
 void launch_pack_w(const PackSpec& ps, const float* src, float* dst, hipStream_t s);          // dst[t][k][n]
 void launch_unpack_dw(const PackSpec& ps, const float* dwe, float* gsrc, hipStream_t s);      // gsrc[src idx] = dwe[t][k][n]
 
+// One launch repacks every filter of the network straight from the reference-layout parameters:
+// job kind 0 -> fp32 [tap][kpad][wld] (reference kernels), kind 1 -> bf16 MFMA-fragment image.
+struct PackJob {
+    int64_t start, count;     // range of this job in the launch's global element index space
+    int64_t src_off;          // float offset of the filter in the flat parameter buffer
+    int64_t dst_off;          // byte offset of the image in the workspace
+    int kind;
+    PackSpec ps;              // reference index map restricted to the launch's taps
+    int Ci, Co, CiB, nchunks, KS, NTtot, modeB;   // fragment-image parameters (kind 1)
+};
+void launch_pack_jobs(const PackJob* jobs_dev, int njobs, int64_t total, const float* params, char* ws, hipStream_t s);
+
 // batch-norm (train): per-(group, channel) sums over a group's pixels.
 // partial: fp32 [groups][nchunk][2][C]; chunking is decided by the launcher, nchunk returned.
-int bn_stats_chunks(int64_t pixels_per_group);
+int bn_stats_chunks(int64_t pixels_per_group, int C);
 void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t pixels_per_group, float* partial,
                      hipStream_t s);
 // stat: fp32 [groups][4][C] = mean, invstd, scale, shift.  running (mean|var at +C) updated sequentially per group.
@@ -176,9 +188,9 @@ void launch_rep_pad_bwd(int dt, void* dD, int ld, int N, int H, int W, int h0, i
 void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, const void* Y, int ldy, const float* stat,
                           const float* mask, int C, int groups, int npg, int64_t HW, int relu, float* partial,
                           hipStream_t s);
-// coef fp32 [groups][2][C] = (sum dz)/M, (sum dz*xhat)/M ; dgamma/dbeta summed over groups (overwritten)
+// coef fp32 [groups][4][C] = (scale, shift, b, c) with dY = scale*dz + b*y + c ; dgamma/dbeta summed over groups
 void launch_bn_bwd_finalize(const float* partial, int nchunk, int C, int groups, int64_t pixels_per_group,
-                            float* coef, float* dgamma, float* dbeta, hipStream_t s);
+                            const float* stat, float* coef, float* dgamma, float* dbeta, hipStream_t s);
 // dY = scale*(dz - k1 - xhat*k2); dY is a plain tensor and may alias dA when dA is plain too
 void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
                          const float* stat, const float* coef, const float* mask, int C, int groups, int npg, int64_t HW,

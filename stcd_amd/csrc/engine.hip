@@ -114,6 +114,10 @@ struct stcd_engine_impl {
     ConvOp final_fwd, final_dgr; WgradOp final_wg;
     std::vector<ConvOp*> conv_ops;      // every ConvOp of the plan (weight-image packing walks this)
     int64_t slab = -1, slab_floats = 0;
+    // batched filter repacking: [0] = forward-only job list (eval), [1] = forward + data-gradient filters (training)
+    std::vector<PackJob> jobs[2];
+    int64_t jobs_total[2] = {0, 0}, jobs_off[2] = {-1, -1};
+    const void* jobs_uploaded_ws = nullptr;
     TRef X0, G, finalIn, dFinalIn;
     int Hs[5] = {0}, Ws[5] = {0};
     TRef D[4], dD[4], P[4], dP[4];
@@ -351,8 +355,8 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             else if (first) { L.has_dIn = true; L.dIn = e.dP[s - 1]; }
             else { L.has_dIn = true; L.dIn.off = e.enc.back().dA.off; L.dIn.ld = C; }
             L.stat = ws.take((int64_t)2 * 4 * C * 4);
-            L.coef = ws.take((int64_t)2 * 2 * C * 4);
-            max_partial = std::max<int64_t>(max_partial, (int64_t)2 * bn_stats_chunks((int64_t)B * h * w) * 2 * C);
+            L.coef = ws.take((int64_t)2 * 4 * C * 4);
+            max_partial = std::max<int64_t>(max_partial, (int64_t)2 * bn_stats_chunks((int64_t)B * h * w, C) * 2 * C);
             e.enc.push_back(L);
         }
     }
@@ -389,8 +393,8 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             L.dY = da;
             L.has_dIn = true; L.dIn = dIn;
             L.stat = ws.take((int64_t)4 * C * 4);
-            L.coef = ws.take((int64_t)2 * C * 4);
-            max_partial = std::max<int64_t>(max_partial, (int64_t)bn_stats_chunks((int64_t)B * h * w) * 2 * C);
+            L.coef = ws.take((int64_t)4 * C * 4);
+            max_partial = std::max<int64_t>(max_partial, (int64_t)bn_stats_chunks((int64_t)B * h * w, C) * 2 * C);
             e.dec.push_back(L);
             in = a; dIn = da; K = C;
             prevA = a; prevdA = da;
@@ -467,6 +471,50 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         bind_conv(e.final_dgr, geom3(B, H, W, cv.dgrad.kpad, 8, cv.cin, e.dFinalIn.ld), e.final_conv, true, 0, e.label, cv.cin);
     }
     e.slab = ws.take(e.slab_floats * 4);
+
+    // ---- one repack launch per forward: job tables (uploaded to the workspace on first use)
+    for (int with_dgrad = 0; with_dgrad < 2; ++with_dgrad) {
+        std::vector<PackJob>& jobs = e.jobs[with_dgrad];
+        jobs.clear();
+        int64_t cur = 0;
+        auto push = [&](PackJob j) { j.start = cur; cur += j.count; jobs.push_back(j); };
+        const bool mfma = e.dt == BF16 && e.use_mfma;
+        if (!mfma) {
+            for (auto& cv : e.convs)
+                for (int d = 0; d <= with_dgrad; ++d) {
+                    const PackSpec& ps = d ? cv.dgrad : cv.fwd;
+                    if (!ps.ntaps) continue;
+                    PackJob j{};
+                    j.kind = 0; j.ps = ps; j.src_off = cv.w_off; j.dst_off = d ? cv.wpk_dgrad : cv.wpk_fwd;
+                    j.count = (int64_t)ps.ntaps * ps.kpad * ps.wld;
+                    push(j);
+                }
+        } else {
+            for (const ConvOp* op : e.conv_ops) {
+                if (op->dgrad && !with_dgrad) continue;
+                const ConvW& cv = e.convs[op->conv];
+                const PackSpec& full = op->dgrad ? cv.dgrad : cv.fwd;
+                PackJob j{};
+                j.ps = full;
+                j.ps.ntaps = op->g.ntaps;
+                for (int t = 0; t < op->g.ntaps; ++t) { j.ps.ky[t] = full.ky[op->tap0 + t]; j.ps.kx[t] = full.kx[op->tap0 + t]; }
+                j.src_off = cv.w_off;
+                if (op->plan.ok && op->wf >= 0) {
+                    j.kind = 1; j.dst_off = op->wf; j.count = op->plan.wf_elems;
+                    j.Ci = op->g.ci; j.Co = op->g.co; j.CiB = op->plan.CiB; j.nchunks = op->plan.nchunks; j.KS = op->plan.KS;
+                    j.NTtot = op->plan.NTtot; j.modeB = op->plan.modeB;
+                } else {   // no MFMA plan for this launch: it runs on the reference kernel and needs the fp32 image
+                    j.kind = 0;
+                    j.dst_off = (op->dgrad ? cv.wpk_dgrad : cv.wpk_fwd) + (int64_t)op->tap0 * full.kpad * full.wld * 4;
+                    j.count = (int64_t)j.ps.ntaps * full.kpad * full.wld;
+                }
+                push(j);
+            }
+        }
+        e.jobs_total[with_dgrad] = cur;
+        e.jobs_off[with_dgrad] = ws.take((int64_t)jobs.size() * sizeof(PackJob) + 16);
+    }
+    e.jobs_uploaded_ws = nullptr;
     e.ws_bytes = ws.cur;
     return 0;
 }
@@ -548,20 +596,19 @@ static void exec_wgrad(const Ctx& c, const WgradOp& op, const void* in, const vo
     launch_unpack_dw(sub, dwe, c.grads + cv.w_off, c.s);
 }
 
-static void pack_all_weights(const Ctx& c, bool with_dgrad) {
+static int pack_all_weights(const Ctx& c, bool with_dgrad) {
+    stcd_engine& e = c.e;
+    if (e.jobs_uploaded_ws != (const void*)c.ws) {      // first use of this workspace: upload both job tables
+        for (int k = 0; k < 2; ++k)
+            if (!e.jobs[k].empty())
+                STCD_HIP(hipMemcpyAsync(c.at(e.jobs_off[k]), e.jobs[k].data(), e.jobs[k].size() * sizeof(PackJob),
+                                        hipMemcpyHostToDevice, c.s));
+        e.jobs_uploaded_ws = c.ws;
+    }
+    const int k = with_dgrad ? 1 : 0;
     ProfScope prof(c, PC_PACK, 0.0, 0.0);
-    for (auto& cv : c.e.convs) {
-        launch_pack_w(cv.fwd, c.params + cv.w_off, c.at<float>(cv.wpk_fwd), c.s);
-        if (with_dgrad && cv.dgrad.ntaps) launch_pack_w(cv.dgrad, c.params + cv.w_off, c.at<float>(cv.wpk_dgrad), c.s);
-    }
-    if (!mfma_on(c.e)) return;
-    for (const ConvOp* op : c.e.conv_ops) {
-        if (!op->plan.ok || op->wf < 0 || (op->dgrad && !with_dgrad)) continue;
-        const ConvW& cv = c.e.convs[op->conv];
-        const PackSpec& ps = op->dgrad ? cv.dgrad : cv.fwd;
-        const float* w = c.at<float>(op->dgrad ? cv.wpk_dgrad : cv.wpk_fwd) + (int64_t)op->tap0 * ps.kpad * ps.wld;
-        launch_pack_frag(op->g, op->plan, w, ps.kpad, ps.wld, c.at(op->wf), c.s);
-    }
+    launch_pack_jobs(c.at<PackJob>(e.jobs_off[k]), (int)e.jobs[k].size(), e.jobs_total[k], c.params, c.ws, c.s);
+    return 0;
 }
 
 static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool training) {
@@ -578,7 +625,7 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
             ProfScope ps(c, PC_BN_STATS, 0.0, act_bytes);
             launch_bn_stats(e.dt, c.at(L.Y.off), L.Y.ld, C, L.groups, ppg, c.at<float>(e.bn_partial), c.s);
         }
-        launch_bn_finalize(c.at<float>(e.bn_partial), bn_stats_chunks(ppg), C, L.groups, ppg, c.params + bn.g_off,
+        launch_bn_finalize(c.at<float>(e.bn_partial), bn_stats_chunks(ppg, C), C, L.groups, ppg, c.params + bn.g_off,
                            c.params + bn.b_off, bn_running + bn.run_off, bn_running + bn.run_off + C, stat, 0.1f, 1e-5f, c.s);
     } else {
         launch_bn_eval_prepare(C, L.groups, c.params + bn.g_off, c.params + bn.b_off, bn_running + bn.run_off,
@@ -610,7 +657,7 @@ static void cbrd_backward(const Ctx& c, const Cbrd& L) {
         launch_bn_bwd_reduce(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.Y.off), L.Y.ld, stat, mask, C, L.groups, L.npg, HW, 1,
                              partial, c.s);
     }
-    launch_bn_bwd_finalize(partial, bn_stats_chunks(ppg), C, L.groups, ppg, c.at<float>(L.coef), c.grads + bn.g_off,
+    launch_bn_bwd_finalize(partial, bn_stats_chunks(ppg, C), C, L.groups, ppg, stat, c.at<float>(L.coef), c.grads + bn.g_off,
                            c.grads + bn.b_off, c.s);
     {
         ProfScope ps(c, PC_BN_BWD_APPLY, 0.0, 3.0 * act_bytes);
@@ -657,7 +704,7 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
         if (masks) STCD_HIP(hipMemcpyAsync(c.at(e.masks), masks, e.drop_floats * 4, hipMemcpyDeviceToDevice, s));
         else launch_dropout_gen(c.at<float>(e.masks), e.drop_floats, seed, e.drop_p, s);
     }
-    pack_all_weights(c, training != 0);
+    if (pack_all_weights(c, training != 0)) return 1;
     launch_in_pack(dt, x1, x2, c.at(e.X0.off), B, e.in_ch, e.H, e.W, s);
     for (auto& L : e.enc) cbrd_forward(c, L, bn_running, training != 0);
     size_t di = 0;

@@ -220,6 +220,10 @@ ConvMfmaPlan conv_mfma_plan(const stcd_conv_geom& g) {
     p.KS = p.modeB ? (g.ntaps * Ci + 31) / 32 : p.CiB / 32;
     p.NTtot = (g.co + 15) / 16;
     p.NT = p.NTtot >= 8 ? 8 : p.NTtot >= 4 ? 4 : p.NTtot >= 2 ? 2 : 1;
+    {   // small-spatial, wide layers: halve the co block so the grid covers the chip with >= 2 blocks per CU
+        const int64_t tiles = (int64_t)g.n * ((g.hm + 7) / 8) * ((g.wm + 15) / 16);
+        while (p.NT > 2 && tiles * ((p.NTtot + p.NT - 1) / p.NT) < 512) p.NT /= 2;
+    }
     p.NTtot = ((p.NTtot + p.NT - 1) / p.NT) * p.NT;     // pad the n-tiles to whole blocks
     p.wf_elems = p.modeB ? (int64_t)p.KS * p.NTtot * 512 : (int64_t)p.nchunks * g.ntaps * p.KS * p.NTtot * 512;
     p.ok = (Ci % 8 == 0) && (p.modeB ? (Ci <= 64 && p.KS <= 24) : true) && g.ldi % 8 == 0;
@@ -248,6 +252,52 @@ __global__ void k_pack_frag(const float* __restrict__ w, int kpad, int wld, int 
     float v = 0.f;
     if (t < ntaps && ci < Ci && co < Co) v = w[((int64_t)t * kpad + ci) * wld + co];
     dst[i] = (bf16)v;
+}
+
+__device__ __forceinline__ float ref_weight(const PackSpec& ps, const float* src, int t, int k, int n) {
+    if (n >= ps.N || k >= ps.K) return 0.f;
+    const int64_t a_ = ps.kn_major ? ((int64_t)k * ps.N + n) : ((int64_t)n * ps.K + k);
+    return src[(a_ * ps.ks + ps.ky[t]) * ps.ks + ps.kx[t]];
+}
+
+__global__ void __launch_bounds__(256)
+k_pack_jobs(const PackJob* __restrict__ jobs, int njobs, int64_t total, const float* __restrict__ params, char* __restrict__ ws) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = njobs - 1;            // last job with start <= i
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const PackJob& jb = jobs[lo];
+    const int64_t e = i - jb.start;
+    const float* src = params + jb.src_off;
+    if (jb.kind == 0) {
+        const int n = (int)(e % jb.ps.wld);
+        const int k = (int)((e / jb.ps.wld) % jb.ps.kpad);
+        const int t = (int)(e / ((int64_t)jb.ps.wld * jb.ps.kpad));
+        reinterpret_cast<float*>(ws + jb.dst_off)[e] = ref_weight(jb.ps, src, t, k, n);
+    } else {
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        int64_t f = e >> 9;
+        const int nt = (int)(f % jb.NTtot); f /= jb.NTtot;
+        const int ks = (int)(f % jb.KS); f /= jb.KS;
+        const int co = nt * 16 + (lane & 15);
+        int t, ci;
+        if (jb.modeB) {
+            const int kf = ks * 32 + 8 * (lane >> 4) + j;
+            t = kf / jb.Ci; ci = kf - t * jb.Ci;
+        } else {
+            t = (int)(f % jb.ps.ntaps);
+            ci = (int)(f / jb.ps.ntaps) * jb.CiB + ks * 32 + 8 * (lane >> 4) + j;
+        }
+        float v = 0.f;
+        if (t < jb.ps.ntaps && ci < jb.Ci && co < jb.Co) v = ref_weight(jb.ps, src, t, ci, co);
+        reinterpret_cast<bf16*>(ws + jb.dst_off)[e] = (bf16)v;
+    }
+}
+void launch_pack_jobs(const PackJob* jobs_dev, int njobs, int64_t total, const float* params, char* ws, hipStream_t s) {
+    if (njobs > 0 && total > 0) k_pack_jobs<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(jobs_dev, njobs, total, params, ws);
 }
 
 void launch_pack_frag(const stcd_conv_geom& g, const ConvMfmaPlan& p, const float* w, int kpad, int wld, void* dst,

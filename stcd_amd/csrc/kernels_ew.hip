@@ -95,8 +95,10 @@ void launch_unpack_dw(const PackSpec& ps, const float* dwe, float* gsrc, hipStre
 // ------------------------------------------------------------------ batch-norm statistics
 // One block = one contiguous pixel chunk of one group.  thread -> (pixel lane, channel block of 8).
 // MODE 0: sums of y and y^2.  MODE 1 (backward): sums of dz and dz*xhat with dz = dA*mask*(z>0).
-int bn_stats_chunks(int64_t ppg) {
-    int64_t c = ppg / 2048;
+// chunks per group: ~2048 16-byte pieces (8 per thread) per block, so small-spatial / wide-channel layers still
+// spread over the whole chip (a 32x32x128-channel map used to get 16 blocks)
+int bn_stats_chunks(int64_t ppg, int C) {
+    int64_t c = ppg * (C / 8) / 2048;
     if (c < 1) c = 1;
     if (c > 1024) c = 1024;
     return (int)c;
@@ -166,7 +168,7 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
 }
 
 void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t ppg, float* partial, hipStream_t s) {
-    int nchunk = bn_stats_chunks(ppg);
+    int nchunk = bn_stats_chunks(ppg, C);
     dim3 grid(nchunk, groups);
     GV z{0, 0};
     if (dt == BF16)
@@ -467,39 +469,48 @@ __global__ void k_rep_pad_bwd(T* __restrict__ dD, int ld, int H, int W, int h0, 
 }
 
 // ------------------------------------------------------------------ BN backward: apply
-template <typename T>
+// dY = scale*(dz - k1 - xhat*k2) = a*dz + b*y + c with per-(group,channel) constants prepared by
+// k_bn_bwd_finalize: bw[g][0..3][C] = (scale, shift, b = -scale*k2*invstd, c = scale*(k2*invstd*mean - k1)).
+// thread -> (4 consecutive pixels, 8 channels): the 4x8 constants are loaded once as float4s.
+__device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <typename T, int PX>
 __global__ void __launch_bounds__(256)
 k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, const T* __restrict__ Y, int ldy,
-               const float* __restrict__ stat, const float* __restrict__ coef, const float* __restrict__ mask, int C, int npg,
-               int64_t HW, int relu, int64_t total) {
+               const float* __restrict__ bw, const float* __restrict__ mask, int C, int npg, int64_t HW, int relu,
+               int64_t total) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int cb = C >> 3;
     const uint32_t iu = (uint32_t)i;               // launcher guarantees total < 2^31
-    int c0 = (int)(iu % (uint32_t)cb) * 8;
-    int64_t p = iu / (uint32_t)cb;                 // global pixel index over groups*npg images
-    int n = (int)((uint32_t)p / (uint32_t)HW);
-    int g = n / npg;
-    int64_t pig = p - (int64_t)g * npg * HW;
-    const float* st = stat + (int64_t)g * 4 * C + c0;
-    const float* cf = coef + (int64_t)g * 2 * C + c0;
-    float y[8], d[8], o[8];
-    load8<T>(Y + p * ldy + c0, y);
-    load8<T>(dA + g * dav.goff + pig * dav.ld + c0, d);
+    const int c0 = (int)(iu % (uint32_t)cb) * 8;
+    const int64_t p0 = (int64_t)(iu / (uint32_t)cb) * PX;  // first of PX pixels (PX > 1 only when HW % PX == 0: same image)
+    const int n = (int)((uint32_t)p0 / (uint32_t)HW);
+    const int g = n / npg;
+    const int64_t pig0 = p0 - (int64_t)g * npg * HW;
+    float sc[8], sh[8], kb[8], kc[8], mk[8];
+    const float* w = bw + (int64_t)g * 4 * C + c0;
+    ld8f(w, sc); ld8f(w + C, sh); ld8f(w + 2 * C, kb); ld8f(w + 3 * C, kc);
+    if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float mean = st[j], invstd = st[C + j], scale = st[2 * C + j], shift = st[3 * C + j];
-        float z = y[j] * scale + shift;
-        float dz = d[j] * (mask ? mask[(int64_t)n * C + c0 + j] : 1.f);
-        if (relu && !(z > 0.f)) dz = 0.f;
-        float xh = (y[j] - mean) * invstd;
-        o[j] = scale * (dz - cf[j] - xh * cf[C + j]);
+    for (int k = 0; k < PX; ++k) {
+        float y[8], d[8], o[8];
+        load8<T>(Y + (p0 + k) * ldy + c0, y);
+        load8<T>(dA + g * dav.goff + (pig0 + k) * dav.ld + c0, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float dz = mask ? d[j] * mk[j] : d[j];
+            if (relu && !(y[j] * sc[j] + sh[j] > 0.f)) dz = 0.f;
+            o[j] = sc[j] * dz + kb[j] * y[j] + kc[j];
+        }
+        store8<T>(dY + (p0 + k) * lddy + c0, o);
     }
-    store8<T>(dY + p * lddy + c0, o);
 }
 
 __global__ void __launch_bounds__(256)
-k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg,
+k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg, const float* __restrict__ stat,
                   float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ double sm[512];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
@@ -509,8 +520,16 @@ k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int grou
         double s1, s2;
         chunk_sums(partial, nchunk, C, g, c, part, sm, &s1, &s2);
         if (!owner) continue;
-        coef[(int64_t)g * 2 * C + c] = (float)(s1 / ppg);
-        coef[(int64_t)g * 2 * C + C + c] = (float)(s2 / ppg);
+        {   // coefficients of dY = a*dz + b*y + c  (see k_bn_bwd_apply)
+            const float* st = stat + (int64_t)g * 4 * C;
+            const double mean = st[c], invstd = st[C + c], scale = st[2 * C + c];
+            const double k1 = s1 / ppg, k2 = s2 / ppg;
+            float* bw = coef + (int64_t)g * 4 * C;
+            bw[c] = (float)scale;
+            bw[C + c] = st[3 * C + c];
+            bw[2 * C + c] = (float)(-scale * k2 * invstd);
+            bw[3 * C + c] = (float)(scale * (k2 * invstd * mean - k1));
+        }
         tb += s1;
         tg += s2;
     }
@@ -519,9 +538,9 @@ k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int grou
         dbeta[c] = (float)tb;
     }
 }
-void launch_bn_bwd_finalize(const float* partial, int nchunk, int C, int groups, int64_t ppg, float* coef, float* dgamma,
-                            float* dbeta, hipStream_t s) {
-    k_bn_bwd_finalize<<<cdiv(C, 16), 256, 0, s>>>(partial, nchunk, C, groups, ppg, coef, dgamma, dbeta);
+void launch_bn_bwd_finalize(const float* partial, int nchunk, int C, int groups, int64_t ppg, const float* stat, float* coef,
+                            float* dgamma, float* dbeta, hipStream_t s) {
+    k_bn_bwd_finalize<<<cdiv(C, 16), 256, 0, s>>>(partial, nchunk, C, groups, ppg, stat, coef, dgamma, dbeta);
 }
 
 // ------------------------------------------------------------------ bias gradient (layers without a following BN)
@@ -590,7 +609,7 @@ void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, con
                           const float* mask, int C, int groups, int npg, int64_t HW, int relu, float* partial,
                           hipStream_t s) {
     int64_t ppg = (int64_t)npg * HW;
-    int nchunk = bn_stats_chunks(ppg);
+    int nchunk = bn_stats_chunks(ppg, C);
     dim3 grid(nchunk, groups);
     GV dav{ldda, da_goff};
     if (dt == BF16)
@@ -602,12 +621,14 @@ void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, con
 void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
                          const float* stat, const float* coef, const float* mask, int C, int groups, int npg, int64_t HW,
                          int relu, hipStream_t s) {
-    int64_t total = (int64_t)groups * npg * HW * (C / 8);
     GV dav{ldda, da_goff};
-    if (dt == BF16)
-        k_bn_bwd_apply<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)dA, dav, (bf16*)dY, lddy, (const bf16*)Y, ldy, stat, coef, mask, C, npg, HW, relu, total);
-    else
-        k_bn_bwd_apply<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)dA, dav, (float*)dY, lddy, (const float*)Y, ldy, stat, coef, mask, C, npg, HW, relu, total);
+    (void)stat;
+    const int px = (HW % 4 == 0) ? 4 : 1;        // odd-sized maps (ReplicationPad2d branch): one pixel per thread
+    int64_t total = (int64_t)groups * npg * HW / px * (C / 8);
+#define BWD_APPLY(T_, PX_) k_bn_bwd_apply<T_, PX_><<<cdiv(total, 256), 256, 0, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, coef, mask, C, npg, HW, relu, total)
+    if (dt == BF16) { if (px == 4) BWD_APPLY(bf16, 4); else BWD_APPLY(bf16, 1); }
+    else { if (px == 4) BWD_APPLY(float, 4); else BWD_APPLY(float, 1); }
+#undef BWD_APPLY
 }
 
 void launch_pool_bwd(int dt, const void* A, int lda, int64_t a_goff, const void* dP, int ldp, void* dA, int ldda,

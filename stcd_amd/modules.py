@@ -121,10 +121,14 @@ class HipChangeDetector(nn.Module):
                 v = fbn[b.offset + k * b.channels:b.offset + (k + 1) * b.channels]
                 v.copy_(getattr(m, name).to(device=device, dtype=torch.float32))
                 m._buffers[name] = v
-            m._buffers["num_batches_tracked"] = m.num_batches_tracked.to(device)
+        # num_batches_tracked: 0-dim views of one int64 vector, bumped by ONE add per training forward
+        bnm = self._bn_modules()
+        nbt = torch.stack([m.num_batches_tracked.to(device=device, dtype=torch.int64).reshape(()) for _, m in bnm])
+        for i, (_, m) in enumerate(bnm):
+            m._buffers["num_batches_tracked"] = nbt[i]
         self._flat_bn = fbn
-        self._nbt = [m.num_batches_tracked for _, m in self._bn_modules()]
-        self._nbt_inc = [b.calls_per_forward for b, _ in self._bn_modules()]
+        self._nbt = nbt
+        self._nbt_inc = torch.tensor([b.calls_per_forward for b, _ in bnm], dtype=torch.int64, device=device)
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
 
     def _apply(self, fn, *args, **kwargs):
@@ -171,7 +175,7 @@ class HipChangeDetector(nn.Module):
         eng.forward(x1, x2, self._flat_params, self._flat_bn, logits, training, masks,
                     seed=self._seed * 1000003 + self._steps)
         if training:
-            torch._foreach_add_(self._nbt, self._nbt_inc)
+            self._nbt.add_(self._nbt_inc)
         return logits
 
     def _run_backward(self, grad_logits):
