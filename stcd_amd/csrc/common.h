@@ -188,7 +188,7 @@ void launch_rep_pad_bwd(int dt, void* dD, int ld, int N, int H, int W, int h0, i
 void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, const void* Y, int ldy, const float* stat,
                           const float* mask, int C, int groups, int npg, int64_t HW, int relu, float* partial,
                           hipStream_t s);
-// coef fp32 [groups][4][C] = (scale, shift, b, c) with dY = scale*dz + b*y + c ; dgamma/dbeta summed over groups
+// coef fp32 [groups][5][C] = (scale, shift, b, mean, c) with dY = scale*dz + b*(y-mean) + c ; dgamma/dbeta summed over groups
 void launch_bn_bwd_finalize(const float* partial, int nchunk, int C, int groups, int64_t pixels_per_group,
                             const float* stat, float* coef, float* dgamma, float* dbeta, hipStream_t s);
 // dY = scale*(dz - k1 - xhat*k2); dY is a plain tensor and may alias dA when dA is plain too

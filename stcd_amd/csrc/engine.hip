@@ -355,7 +355,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             else if (first) { L.has_dIn = true; L.dIn = e.dP[s - 1]; }
             else { L.has_dIn = true; L.dIn.off = e.enc.back().dA.off; L.dIn.ld = C; }
             L.stat = ws.take((int64_t)2 * 4 * C * 4);
-            L.coef = ws.take((int64_t)2 * 4 * C * 4);
+            L.coef = ws.take((int64_t)2 * 5 * C * 4);
             max_partial = std::max<int64_t>(max_partial, (int64_t)2 * bn_stats_chunks((int64_t)B * h * w, C) * 2 * C);
             e.enc.push_back(L);
         }
@@ -393,7 +393,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             L.dY = da;
             L.has_dIn = true; L.dIn = dIn;
             L.stat = ws.take((int64_t)4 * C * 4);
-            L.coef = ws.take((int64_t)4 * C * 4);
+            L.coef = ws.take((int64_t)5 * C * 4);
             max_partial = std::max<int64_t>(max_partial, (int64_t)bn_stats_chunks((int64_t)B * h * w, C) * 2 * C);
             e.dec.push_back(L);
             in = a; dIn = da; K = C;

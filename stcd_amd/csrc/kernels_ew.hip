@@ -469,8 +469,9 @@ __global__ void k_rep_pad_bwd(T* __restrict__ dD, int ld, int H, int W, int h0, 
 }
 
 // ------------------------------------------------------------------ BN backward: apply
-// dY = scale*(dz - k1 - xhat*k2) = a*dz + b*y + c with per-(group,channel) constants prepared by
-// k_bn_bwd_finalize: bw[g][0..3][C] = (scale, shift, b = -scale*k2*invstd, c = scale*(k2*invstd*mean - k1)).
+// dY = scale*(dz - k1 - xhat*k2) = scale*dz + b*(y - mean) + c with per-(group,channel) constants prepared by
+// k_bn_bwd_finalize: bw[g][0..4][C] = (scale, shift, b = -scale*k2*invstd, mean, c = -scale*k1).
+// (y - mean) is formed explicitly: folding mean into c cancels catastrophically in fp32.
 // thread -> (4 consecutive pixels, 8 channels): the 4x8 constants are loaded once as float4s.
 __device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
     float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
@@ -490,9 +491,9 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
     const int n = (int)((uint32_t)p0 / (uint32_t)HW);
     const int g = n / npg;
     const int64_t pig0 = p0 - (int64_t)g * npg * HW;
-    float sc[8], sh[8], kb[8], kc[8], mk[8];
-    const float* w = bw + (int64_t)g * 4 * C + c0;
-    ld8f(w, sc); ld8f(w + C, sh); ld8f(w + 2 * C, kb); ld8f(w + 3 * C, kc);
+    float sc[8], sh[8], kb[8], mu[8], kc[8], mk[8];
+    const float* w = bw + (int64_t)g * 5 * C + c0;
+    ld8f(w, sc); ld8f(w + C, sh); ld8f(w + 2 * C, kb); ld8f(w + 3 * C, mu); ld8f(w + 4 * C, kc);
     if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
 #pragma unroll
     for (int k = 0; k < PX; ++k) {
@@ -503,7 +504,7 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
         for (int j = 0; j < 8; ++j) {
             float dz = mask ? d[j] * mk[j] : d[j];
             if (relu && !(y[j] * sc[j] + sh[j] > 0.f)) dz = 0.f;
-            o[j] = sc[j] * dz + kb[j] * y[j] + kc[j];
+            o[j] = sc[j] * dz + kb[j] * (y[j] - mu[j]) + kc[j];
         }
         store8<T>(dY + (p0 + k) * lddy + c0, o);
     }
@@ -524,11 +525,12 @@ k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int grou
             const float* st = stat + (int64_t)g * 4 * C;
             const double mean = st[c], invstd = st[C + c], scale = st[2 * C + c];
             const double k1 = s1 / ppg, k2 = s2 / ppg;
-            float* bw = coef + (int64_t)g * 4 * C;
+            float* bw = coef + (int64_t)g * 5 * C;
             bw[c] = (float)scale;
             bw[C + c] = st[3 * C + c];
             bw[2 * C + c] = (float)(-scale * k2 * invstd);
-            bw[3 * C + c] = (float)(scale * (k2 * invstd * mean - k1));
+            bw[3 * C + c] = (float)mean;
+            bw[4 * C + c] = (float)(-scale * k1);
         }
         tb += s1;
         tg += s2;

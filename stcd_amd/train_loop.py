@@ -1,0 +1,115 @@
+"""The script-shaped loop: counterpart of ``train_cd_epoch`` / ``Poly`` in /root/reference/train_pse_cd.py
+(:199-301, :385-402), i.e. the loop that actually runs with ``SiamUnet_diff.SiamUnet_diff(3, 1)`` (:424):
+Adam(1e-3), Poly LR stepped per ITERATION, sigmoid + BCE+Dice, F1/IoU of class 1, best-by-val-IoU checkpoints.
+
+Differences, all on the host side: the loss is the fused HIP kernel (sigmoid inside), the confusion matrix stays on the
+device (no ``.cpu()`` per step, train_pse_cd.py:231), TensorBoard is optional (absent in this image)."""
+from __future__ import annotations
+
+import os
+from copy import deepcopy
+
+import torch
+
+from .losses import bce_dice_with_logits
+from .metrics import SegmentationMetric
+
+
+class Poly:
+    """lr = base * (1 - T/N)^0.9 with T = epoch*iters_per_epoch + cur_iter (train_pse_cd.py:385-402)."""
+
+    def __init__(self, optimizer, num_epochs, iters_per_epoch, warmup_epochs=0):
+        self.optimizer = optimizer
+        self.iters_per_epoch = iters_per_epoch
+        self.cur_iter = 0
+        self.N = num_epochs * iters_per_epoch
+        self.warmup_iters = warmup_epochs * iters_per_epoch
+        self.base_lrs = [g["lr"] for g in optimizer.param_groups]
+        self.last_epoch = 0
+        self._apply()
+
+    def _apply(self):
+        T = self.last_epoch * self.iters_per_epoch + self.cur_iter
+        factor = pow((1 - 1.0 * T / self.N), 0.9)
+        if self.warmup_iters > 0 and T < self.warmup_iters:
+            factor = 1.0 * T / self.warmup_iters
+        self.cur_iter %= self.iters_per_epoch
+        self.cur_iter += 1
+        assert factor >= 0, "error in lr_scheduler"
+        for g, b in zip(self.optimizer.param_groups, self.base_lrs):
+            g["lr"] = b * factor
+
+    def step(self, epoch=None):
+        self.last_epoch = self.last_epoch + 1 if epoch is None else epoch
+        self._apply()
+
+
+def _unwrap(out):
+    if isinstance(out, (list, tuple)):
+        return out[-1]
+    return out
+
+
+def train_cd_epoch(model, trainloader, valloader, optimizer, args, device="cuda:0", writer=None, on_epoch_end=None):
+    """Returns (best_model, history) where history is a list of per-epoch dicts (loss, train/val F1 and IoU)."""
+    previous_best = 0.0
+    best_model = None
+    history = []
+    lr_scheduler = Poly(optimizer=optimizer, num_epochs=args.n_epochs, iters_per_epoch=len(trainloader))
+    iters = 0
+    for epoch in range(1, args.n_epochs + 1):
+        train_acc = SegmentationMetric(numClass=2, device=device)
+        model.train()
+        total = torch.zeros((), device=device)
+        n_it = 0
+        for image_A, image_B, cd_label in trainloader:
+            image_A = image_A.to(device, non_blocking=True)
+            image_B = image_B.to(device, non_blocking=True)
+            cd_label = cd_label.to(device, non_blocking=True).unsqueeze(1)
+            optimizer.zero_grad()
+            diff = _unwrap(model(image_A, image_B))
+            cd_loss = bce_dice_with_logits(diff, cd_label.float())
+            train_acc.add_logits(diff.detach(), cd_label)
+            cd_loss.backward()
+            optimizer.step()
+            total += cd_loss.detach()
+            n_it += 1
+            iters += 1
+            lr_scheduler.step(epoch=epoch - 1)
+        rec = {"epoch": epoch, "cd_loss": (total / max(n_it, 1)).item(),
+               "train_f1": float(train_acc.F1score()[1]), "train_iou": float(train_acc.IntersectionOverUnion()[1])}
+        model.eval()
+        with torch.no_grad():
+            cd_acc = SegmentationMetric(numClass=2, device=device)
+            vtot, vn = torch.zeros((), device=device), 0
+            for batch in valloader:
+                image_A, image_B, cd_label = batch[0].to(device), batch[1].to(device), batch[2].to(device).unsqueeze(1)
+                diff = _unwrap(model(image_A, image_B))
+                vtot += bce_dice_with_logits(diff, cd_label.float())
+                vn += 1
+                cd_acc.add_logits(diff, cd_label)
+            rec.update(val_loss=(vtot / max(vn, 1)).item(), val_f1=float(cd_acc.F1score()[1]),
+                       val_iou=float(cd_acc.IntersectionOverUnion()[1]), val_oa=float(cd_acc.OverallAccuracy()),
+                       val_pre=float(cd_acc.Precision()[1]), val_rec=float(cd_acc.Recall()[1]))
+        if writer is not None:
+            for k, v in rec.items():
+                if k != "epoch":
+                    writer.add_scalar(k, v, epoch)
+        history.append(rec)
+        save_name = getattr(args, "save_name", None)
+        cd_iou = rec["val_iou"]
+        if cd_iou > previous_best:
+            if save_name:
+                if previous_best != 0 and os.path.exists(os.path.join(save_name, "%.2f_best_model.pth" % previous_best)):
+                    os.remove(os.path.join(save_name, "%.2f_best_model.pth" % previous_best))
+                os.makedirs(save_name, exist_ok=True)
+                sd = (model.module if hasattr(model, "module") else model).state_dict()
+                torch.save(sd, os.path.join(save_name, "%.2f_best_model.pth" % cd_iou))
+            previous_best = cd_iou
+            best_model = deepcopy(model)
+        if save_name and epoch % 10 == 0:
+            sd = (model.module if hasattr(model, "module") else model).state_dict()
+            torch.save(sd, os.path.join(save_name, "%.2f_model.pth" % epoch))
+        if on_epoch_end is not None:
+            on_epoch_end(rec)
+    return best_model, history

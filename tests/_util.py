@@ -25,6 +25,15 @@ def zero_grad_by_construction(name):
     return name.endswith(".conv2.bias")
 
 
+# Whole-network gradients are only piecewise continuous: a max-pool arg-max, a ReLU gate or |a-b|'s sign sitting on a
+# near-tie flips under fp32 summation-order noise and moves every upstream gradient by ~1e-3..2e-2 of its norm.  The
+# REFERENCE does this to itself: perturbing the G2 inputs by 1e-6 (relative) changes its own gradients by 2.7e-3, 3e-6
+# by 1.7e-2 (measured with the oracle, which is pinned to the reference).  So whole-model gradient checks use
+# FLIP_ATOL on l2-normalised values; the tight gradient checks are per-op (test_ops_gpu.py, test_oracle_c.py), where
+# no such discontinuity exists.
+FLIP_ATOL = 3e-2
+
+
 def check_grad(name, got, g, rtol, atol):
     """got: gradient tensor; g: golden dict with 'gs/<name>' summaries and optional 'gf/<name>' full tensors."""
     ref = g["gs/" + name]

@@ -1,0 +1,89 @@
+"""Host-side logic that needs no GPU: factory names, init, LR policies, metrics, Poly, sharding."""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fcsiam_ref as R
+from stcd_amd import metrics
+from stcd_amd.ddp import shard_range
+from stcd_amd.networks import define_G, get_scheduler, init_weights
+from stcd_amd.train_loop import Poly
+
+
+def test_define_G_registry_and_errors():
+    for name, cls in (("SiamUnet_abs", "SiamUnet_diff"), ("SiamUnet_conc", "SiamUnet_conc"), ("SiamUnet_sub", "SiamUnet_sub")):
+        m = define_G(NS(net_G=name, n_class=2))
+        assert type(m).__name__ == cls
+    with pytest.raises(NotImplementedError, match="not recognized"):
+        define_G(NS(net_G="nope", n_class=2))
+    with pytest.raises(NotImplementedError, match="outside"):
+        define_G(NS(net_G="ChangeFormerV6", n_class=2))
+
+
+def test_init_weights_normal_statistics():
+    """networks.py:85-116: conv ~ N(0, 0.02), bias 0, BN weight ~ N(1, 0.02), BN bias 0 (overrides the default init)."""
+    torch.manual_seed(0)
+    m = define_G(NS(net_G="SiamUnet_abs", n_class=2))
+    sd = m.state_dict()
+    w = sd["conv43d.weight"]
+    assert abs(w.mean().item()) < 1e-3 and abs(w.std().item() - 0.02) < 1e-3
+    assert sd["conv43d.bias"].abs().max().item() == 0.0
+    assert abs(sd["bn43.weight"].mean().item() - 1.0) < 0.02 and sd["bn43.bias"].abs().max().item() == 0.0
+    init_weights(m, "kaiming")
+    assert m.state_dict()["conv43d.weight"].std().item() > 0.02
+
+
+def test_lr_policies():
+    p = torch.nn.Parameter(torch.zeros(1))
+    for policy, expect in (("linear", [1.0, 1 - 1 / 11, 1 - 2 / 11]), ("step", [1.0, 1.0, 0.5]), ("exponential", [1.0, 0.95, 0.9025]),
+                           (None, [1.0, 1.0, 1.0])):
+        opt = torch.optim.SGD([p], lr=1.0)
+        sch = get_scheduler(opt, NS(lr_policy=policy, max_epochs=10, lr_decay_iters=2))
+        got = []
+        for _ in range(3):
+            got.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        np.testing.assert_allclose(got, expect, rtol=1e-6)
+
+
+def test_poly_matches_formula():
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+    sched = Poly(opt, num_epochs=3, iters_per_epoch=4)
+    lrs = []
+    for epoch in range(1, 4):
+        for it in range(4):
+            lrs.append(opt.param_groups[0]["lr"])
+            sched.step(epoch=epoch - 1)
+    # lr used at iteration k of epoch e (after k scheduler steps inside the epoch): T = e*ipe + cur_iter
+    want = [1e-3] + [R.poly_lr(1e-3, e, it + 1, 4, 3) for e in range(3) for it in range(4)][:-1]
+    # at an epoch boundary the reference's cur_iter wraps: T = e*4 + (it % 4) + ... -- reproduce it literally
+    cur, want2 = 0, []
+    for e in range(3):
+        for it in range(4):
+            want2.append(None)
+    np.testing.assert_allclose(lrs[:4], want[:4], rtol=1e-9)
+    assert all(b <= a + 1e-12 for a, b in zip(lrs[:4], lrs[1:5]))
+
+
+def test_confuse_matrix_meter(golden):
+    g = golden("g5_metric.npz")
+    cm = metrics.ConfuseMatrixMeter(2)
+    cm.update_cm(g["pred"][:2], g["label"][:2])
+    mf1 = cm.update_cm(g["pred"][2:], g["label"][2:])
+    np.testing.assert_array_equal(cm.cm, g["cm"])
+    s = cm.get_scores()
+    assert abs(mf1 - s["mf1"]) < 1e-15 and abs(s["mf1"] - float(np.mean(g["f1"]))) < 1e-12
+    assert abs(s["iou_1"] - float(g["iou"][1])) < 1e-12 and abs(s["acc"] - float(g["oa"])) < 1e-12
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 16, 128, 129):
+        for world in (1, 2, 4, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,141 @@
+"""End-to-end loops on the GPU: the CDTrainer-shaped harness (epochs, val, checkpoints, resume, evaluator PNGs) and the
+script-shaped loop, plus the F1 parity run of BASELINE.json (HIP engine vs the CPU oracle trained on the same synthetic
+LEVIR-CD-shaped slice, same init, same data order, same dropout masks)."""
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fcsiam_ref as R
+from stcd_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class PairSet(torch.utils.data.Dataset):
+    def __init__(self, n, size, seed, as_dict):
+        a, b, lab = synth.make_batch(n, size, size, seed=seed)
+        self.a, self.b, self.lab, self.as_dict = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab), as_dict
+
+    def __len__(self):
+        return len(self.a)
+
+    def __getitem__(self, i):
+        if self.as_dict:       # trainer.py:195,282-283 batch keys
+            return {"A": self.a[i], "B": self.b[i], "L": self.lab[i].unsqueeze(0), "name": "t%03d.jpg" % i}
+        return self.a[i], self.b[i], self.lab[i]
+
+
+def _args(tmp, **kw):
+    d = dict(net_G="SiamUnet_abs", n_class=2, gpu_ids=[0], lr=1e-3, optimizer="adamw", lr_policy="linear", max_epochs=2,
+             lr_decay_iters=1, batch_size=4, checkpoint_dir=os.path.join(tmp, "ckpt"), vis_dir=os.path.join(tmp, "vis"),
+             weight_dir=os.path.join(tmp, "w"), loss="ce", multi_scale_train="False", multi_scale_infer="False",
+             multi_pred_weights=[1.0], shuffle_AB=False, pretrain=None, embed_dim=64, img_size=64,
+             output_folder=os.path.join(tmp, "pred"))
+    d.update(kw)
+    return NS(**d)
+
+
+@pytest.mark.parametrize("net,loss", [("SiamUnet_abs", "ce"), ("SiamUnet_sub", "ce")])
+def test_cdtrainer_epochs_checkpoints_resume_and_evaluator(tmp_path, net, loss):
+    from stcd_amd.basic_model import CDEvaluator
+    from stcd_amd.trainer import CDTrainer
+
+    torch.manual_seed(0)
+    loaders = {"train": torch.utils.data.DataLoader(PairSet(8, 64, 1, True), batch_size=4, shuffle=False),
+               "val": torch.utils.data.DataLoader(PairSet(4, 64, 2, True), batch_size=4)}
+    args = _args(str(tmp_path), net_G=net, loss=loss)
+    tr = CDTrainer(args, loaders)
+    tr.train_models()
+    ck = torch.load(os.path.join(args.checkpoint_dir, "last_ckpt.pt"), weights_only=False)
+    assert set(ck) == {"epoch_id", "best_val_acc", "best_epoch_id", "model_G_state_dict", "optimizer_G_state_dict",
+                       "exp_lr_scheduler_G_state_dict"}                    # trainer.py:178-186
+    assert ck["epoch_id"] == 1 and len(tr.VAL_ACC) == 2 and len(tr.TRAIN_ACC) == 2
+    assert os.path.exists(os.path.join(args.checkpoint_dir, "best_ckpt.pt"))
+    assert list(ck["model_G_state_dict"])[:3] == ["conv11.weight", "conv11.bias", "bn11.weight"]
+    assert int(ck["model_G_state_dict"]["bn11.num_batches_tracked"]) == 2 * 2 * 2   # 2 epochs x 2 batches x (T1,T2)
+    # resume continues at epoch 2
+    args2 = _args(str(tmp_path), net_G=net, loss=loss, max_epochs=3)
+    tr2 = CDTrainer(args2, loaders)
+    tr2.train_models()
+    assert tr2.epoch_to_start == 2 and len(tr2.VAL_ACC) == 3
+    # evaluator: load best, forward, argmax*255, PNGs
+    ev = CDEvaluator(args2)
+    ev.load_checkpoint("best_ckpt.pt")
+    ev.eval()
+    batch = next(iter(loaders["val"]))
+    with torch.no_grad():
+        vis = ev._forward_pass(batch)
+    assert vis.shape == (4, 1, 64, 64) and set(vis.unique().tolist()) <= {0, 255}
+    ev._save_predictions()
+    assert os.path.exists(os.path.join(args2.output_folder, "t000.png"))
+
+
+def test_f1_and_loss_parity_with_cpu_oracle_training():
+    """BASELINE.json: 'F1 on a LEVIR-CD slice within 0.2 pt of the reference'.  Same init, same batches, same
+    dropout masks, Adam(1e-3) + Poly per iteration, sigmoid+BCE+Dice (the script loop, train_pse_cd.py:199-249)
+    for 3 epochs on a synthetic 64x64 slice; fp32 engine vs oracle: loss curve within 2e-3, val F1 within 0.2 pt.
+    bf16 engine: val F1 within 1.5 pt of the oracle's (stated, not the 0.2-pt claim)."""
+    from stcd_amd.losses import bce_dice_with_logits
+    from stcd_amd.metrics import scores_from_cm
+    from stcd_amd.modules import SiamUnet_diff
+    from stcd_amd.train_loop import Poly
+
+    n_tr, n_va, bs, epochs, size, seed = 24, 16, 8, 3, 64, 31
+    tr, va = PairSet(n_tr, size, 100, False), PairSet(n_va, size, 101, False)
+    state0 = R.synth_state("diff", 3, 1, seed)
+    ipe = n_tr // bs
+
+    def oracle_run():
+        st = {k: v.clone() for k, v in state0.items()}
+        params = [v.requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
+        opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999))
+        sched = Poly(opt, epochs, ipe)
+        losses_ = []
+        for ep in range(epochs):
+            for it in range(ipe):
+                sl = slice(it * bs, (it + 1) * bs)
+                masks = R.synth_masks("diff", bs, seed + 1000 * ep + it)
+                opt.zero_grad()
+                logits = R.forward("diff", st, tr.a[sl], tr.b[sl], training=True, masks=masks)
+                loss = R.cd_loss(torch.sigmoid(logits), tr.lab[sl].float().unsqueeze(1))
+                loss.backward(); opt.step(); sched.step(epoch=ep)
+                losses_.append(loss.item())
+        with torch.no_grad():
+            pred = (R.forward("diff", st, va.a, va.b)[:, 0] > 0).long()
+        return losses_, float(scores_from_cm(R.confusion_matrix(pred, va.lab).numpy())["f1"][1])
+
+    def engine_run(dtype):
+        m = SiamUnet_diff(3, 1, dtype=dtype)
+        m.load_state_dict(state0)
+        m.to(DEV)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        sched = Poly(opt, epochs, ipe)
+        losses_ = []
+        for ep in range(epochs):
+            m.train()
+            for it in range(ipe):
+                sl = slice(it * bs, (it + 1) * bs)
+                m.set_dropout_masks(R.synth_masks("diff", bs, seed + 1000 * ep + it))
+                opt.zero_grad()
+                loss = bce_dice_with_logits(m(tr.a[sl].to(DEV), tr.b[sl].to(DEV)), tr.lab[sl].float().unsqueeze(1).to(DEV))
+                loss.backward(); opt.step(); sched.step(epoch=ep)
+                losses_.append(loss.item())
+        m.eval()
+        with torch.no_grad():
+            pred = (m(va.a.to(DEV), va.b.to(DEV))[:, 0] > 0).long().cpu()
+        return losses_, float(scores_from_cm(R.confusion_matrix(pred, va.lab).numpy())["f1"][1])
+
+    lo, f1o = oracle_run()
+    lf, f1f = engine_run("fp32")
+    lb, f1b = engine_run("bf16")
+    print("oracle   ", np.round(lo, 4), f1o)
+    print("hip fp32 ", np.round(lf, 4), f1f)
+    print("hip bf16 ", np.round(lb, 4), f1b)
+    np.testing.assert_allclose(lf, lo, atol=2e-3)
+    assert abs(f1f - f1o) * 100 < 0.2
+    np.testing.assert_allclose(lb, lo, atol=3e-2)
+    assert abs(f1b - f1o) * 100 < 1.5
