@@ -49,38 +49,56 @@ def shard_range(n_items: int, rank: int, world: int):
 
 class FlatGradReducer:
     """Averages gradients across ranks through the model's ``grad_stage_hook`` protocol
-    (stcd_amd.modules.HipChangeDetector): hook(stage, flat_gradient_slice) is called when that slice is final."""
+    (stcd_amd.modules.HipChangeDetector): hook(stage, flat_gradient_slice) is called when that slice is final.
+
+    RCCL path (backend "nccl", GPU tensors): each bucket's all-reduce (ReduceOp.AVG, no extra scaling kernel) is issued
+    asynchronously from a side stream that first waits for the compute stream, so the decoder bucket travels over xGMI
+    while the encoder's backward kernels run; after the last bucket the compute stream waits on both collectives
+    (stream-side wait, the host never blocks).  gloo path (CPU tests, or GPU tensors in a CPU-transport test):
+    staged through host memory, synchronous."""
 
     def __init__(self, model, group=None, overlap: bool = True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
         self.overlap = overlap
         self._comm = None
-        self._pending = False
+        self._works = []
         if self.world > 1:
             model.grad_stage_hook = self._hook
 
     def _hook(self, stage: int, g: torch.Tensor):
-        if g.numel() == 0:
-            return
-        if g.is_cuda and self.overlap:
-            if self._comm is None:
-                self._comm = torch.cuda.Stream(device=g.device)
-            cur = torch.cuda.current_stream(g.device)
-            self._comm.wait_stream(cur)
-            with torch.cuda.stream(self._comm):
-                g.mul_(1.0 / self.world)
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-            if stage == 1:                      # last bucket: order the compute stream after both collectives
-                cur.wait_stream(self._comm)
-        else:
-            g.mul_(1.0 / self.world)
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        if g.numel() > 0:
+            if g.is_cuda and self.backend == "nccl":
+                if self.overlap:
+                    if self._comm is None:
+                        self._comm = torch.cuda.Stream(device=g.device)
+                    self._comm.wait_stream(torch.cuda.current_stream(g.device))
+                    with torch.cuda.stream(self._comm):
+                        self._works.append(dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+                else:
+                    dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                t = g.cpu() if g.is_cuda else g
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                t.mul_(1.0 / self.world)
+                if g.is_cuda:
+                    g.copy_(t)
+        if stage == 1:                          # last bucket: order the compute stream after every collective
+            for w in self._works:
+                w.wait()
+            self._works.clear()
 
 
 def broadcast_parameters(model, src: int = 0, group=None):
     """Same initial replica everywhere (parameters and BN buffers)."""
     if not dist.is_initialized():
         return
+    staged = dist.get_backend(group) != "nccl"
     for t in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        if staged and t.is_cuda:
+            h = t.data.cpu()
+            dist.broadcast(h, src=src, group=group)
+            t.data.copy_(h)
+        else:
+            dist.broadcast(t.data, src=src, group=group)

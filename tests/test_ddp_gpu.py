@@ -63,7 +63,7 @@ def test_two_ranks_equal_mean_of_micro_batches():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, state)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=240) for _ in range(2))
+    got = dict(q.get(timeout=120) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
