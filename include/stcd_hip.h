@@ -151,7 +151,8 @@ typedef struct stcd_conv_geom {
     int8_t pad_[2];
 } stcd_conv_geom;
 
-/* w: fp32 [ntaps][ci][co]; bias: fp32 [co] or NULL; impl: 0 = reference FMA kernel, 1 = MFMA kernel (bf16 only) */
+/* w: fp32 [ntaps][ci][co]; bias: fp32 [co] or NULL; impl: 0 = reference FMA kernel, 1 = MFMA (bf16 only; the
+ * small-channel persistent kernel when the geometry is eligible, else the generic one), 2 = generic MFMA kernel */
 int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, const float* w, const float* bias,
                  void* out, void* scratch, int64_t scratch_bytes, void* hip_stream);
 /* dw: fp32 [ntaps][ci][co], overwritten */

@@ -110,6 +110,12 @@ void launch_pack_frag(const stcd_conv_geom& g, const ConvMfmaPlan& p, const floa
                       hipStream_t s);
 int launch_conv_mfma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const void* in, const void* wf, const float* bias,
                      void* out, bool out_nchw_f32, hipStream_t s);
+// small-channel persistent kernel (filter in registers, double-buffered halo, optional fused BN statistics);
+// uses the mode-B fragment image of conv_mfma_plan.
+bool conv_small_ok(const stcd_conv_geom& g, const ConvMfmaPlan& p);
+int conv_small_blocks(const stcd_conv_geom& g, int groups);
+int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_modeB, const float* bias, void* out,
+                      bool out_nchw_f32, int groups, float* stat_partial, int cpad, hipStream_t s);
 struct WgradMfmaPlan {
     int WCI = 1, NTW = 1, gx = 1, gy = 1, gz = 1;
     int64_t slab_floats = 0;

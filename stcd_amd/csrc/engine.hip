@@ -53,6 +53,7 @@ struct ConvOp {
     int tap0 = 0;                        // first tap inside that filter's PackSpec (sub-pixel phases)
     int kreal = 0, nreal = 0;            // un-padded channels (algorithmic work accounting)
     ConvMfmaPlan plan; int64_t wf = -1;  // MFMA path: plan + fragment-order weight image (workspace offset)
+    bool small = false;                  // eligible for the small-channel persistent kernel
 };
 struct WgradOp {
     stcd_conv_geom g{};
@@ -121,8 +122,9 @@ struct stcd_engine_impl {
     TRef X0, G, finalIn, dFinalIn;
     int Hs[5] = {0}, Ws[5] = {0};
     TRef D[4], dD[4], P[4], dP[4];
+    int64_t bn_partial2 = -1;
     int64_t bn_partial = -1, masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
-    int use_mfma = 1;
+    int use_mfma = 1, use_small = 1;
 };
 
 }  // namespace stcd
@@ -424,6 +426,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         if (e.dt == BF16) {
             op.plan = conv_mfma_plan(g);
             if (op.plan.ok) op.wf = ws.take(op.plan.wf_elems * 2);
+            op.small = conv_small_ok(g, op.plan);
         }
         e.conv_ops.push_back(&op);
     };
@@ -469,6 +472,16 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         bind_conv(e.final_fwd, geom3(B, H, W, cv.kin_p, e.finalIn.ld, e.label, e.label), e.final_conv, false, 0, cv.cin, e.label);
         bind_wgrad(e.final_wg, geom3(B, H, W, cv.kin_p, e.finalIn.ld, e.label, 8), e.final_conv, 0, cv.cin, e.label);
         bind_conv(e.final_dgr, geom3(B, H, W, cv.dgrad.kpad, 8, cv.cin, e.dFinalIn.ld), e.final_conv, true, 0, e.label, cv.cin);
+    }
+    {   // the fused-statistics conv kernels write one partial row per block: make sure the shared slab holds them
+        int64_t need = 0;
+        auto rows = [&](const Cbrd& L) {
+            if (L.fwd.small) need = std::max<int64_t>(need, (int64_t)conv_small_blocks(L.fwd.g, L.groups) * 2 * L.fwd.g.co);
+        };
+        for (auto& L : e.enc) rows(L);
+        for (auto& L : e.dec) rows(L);
+        e.bn_partial2 = need > max_partial ? ws.take(need * 4) : -1;
+        if (e.bn_partial2 >= 0) e.bn_partial = e.bn_partial2;
     }
     e.slab = ws.take(e.slab_floats * 4);
 
@@ -555,12 +568,24 @@ static void conv_work(const stcd_engine& e, const stcd_conv_geom& g, int kreal, 
 
 static bool mfma_on(const stcd_engine& e) { return e.dt == BF16 && e.use_mfma; }
 
-static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const float* bias, void* out, bool nchw) {
+// stat_groups > 0 asks for fused BN statistics (partials into e.bn_partial); *stat_chunks receives the number of
+// partial rows per group when the kernel delivered them, 0 when the caller must run the separate statistics pass.
+static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const float* bias, void* out, bool nchw,
+                      int stat_groups = 0, int* stat_chunks = nullptr) {
     const ConvW& cv = c.e.convs[op.conv];
     const PackSpec& ps = op.dgrad ? cv.dgrad : cv.fwd;
     double fl, by;
     conv_work(c.e, op.g, op.kreal, op.nreal, &fl, &by);
     ProfScope prof(c, PC_CONV, fl, by);
+    if (stat_chunks) *stat_chunks = 0;
+    if (mfma_on(c.e) && op.small && op.wf >= 0 && c.e.use_small) {
+        const int groups = stat_groups > 0 ? stat_groups : 1;
+        float* sp = stat_groups > 0 ? c.at<float>(c.e.bn_partial) : nullptr;
+        if (launch_conv_small(op.g, in, c.at(op.wf), bias, out, nchw, groups, sp, op.g.co, c.s) == 0) {
+            if (stat_chunks && stat_groups > 0) *stat_chunks = conv_small_blocks(op.g, groups) / groups;
+            return;
+        }
+    }
     if (mfma_on(c.e) && op.plan.ok && op.wf >= 0 &&
         launch_conv_mfma(op.g, op.plan, in, c.at(op.wf), bias, out, nchw, c.s) == 0)
         return;
@@ -616,16 +641,17 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     const ConvW& cv = e.convs[L.conv];
     const BnP& bn = e.bns[L.bn];
     const int C = cv.cout;
-    exec_conv(c, L.fwd, c.at(L.in.off), c.params + cv.b_off, c.at(L.Y.off), false);
+    int fused_chunks = 0;
+    exec_conv(c, L.fwd, c.at(L.in.off), c.params + cv.b_off, c.at(L.Y.off), false, training ? L.groups : 0, &fused_chunks);
     const int64_t ppg = (int64_t)L.npg * L.H * L.W;
     const double act_bytes = (double)L.N * L.H * L.W * C * (double)dsize(e.dt);
     float* stat = c.at<float>(L.stat);
     if (training) {
-        {
+        if (!fused_chunks) {
             ProfScope ps(c, PC_BN_STATS, 0.0, act_bytes);
             launch_bn_stats(e.dt, c.at(L.Y.off), L.Y.ld, C, L.groups, ppg, c.at<float>(e.bn_partial), c.s);
         }
-        launch_bn_finalize(c.at<float>(e.bn_partial), bn_stats_chunks(ppg, C), C, L.groups, ppg, c.params + bn.g_off,
+        launch_bn_finalize(c.at<float>(e.bn_partial), fused_chunks ? fused_chunks : bn_stats_chunks(ppg, C), C, L.groups, ppg, c.params + bn.g_off,
                            c.params + bn.b_off, bn_running + bn.run_off, bn_running + bn.run_off + C, stat, 0.1f, 1e-5f, c.s);
     } else {
         launch_bn_eval_prepare(C, L.groups, c.params + bn.g_off, c.params + bn.b_off, bn_running + bn.run_off,
@@ -799,6 +825,8 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
     e->arch = arch; e->in_ch = in_ch; e->label = label_ch; e->dt = dtype;
     const char* env = getenv("STCD_FORCE_REF_KERNELS");
     e->use_mfma = !(env && env[0] == '1');
+    env = getenv("STCD_NO_SMALL_KERNEL");
+    e->use_small = !(env && env[0] == '1');
     build_fcsiam_tables(*e);
     *out = e.release();
     return 0;
@@ -951,17 +979,23 @@ int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, c
                  void* out, void* scratch, int64_t scratch_bytes, void* hip_stream) {
     if (check_geom(g)) return 1;
     STCD_CHECK(in && w && out, "null pointer argument");
-    if (impl == 1) {
+    if (impl == 1 || impl == 2) {
         STCD_CHECK(dtype == STCD_DTYPE_BF16, "the MFMA implementation is bf16 only");
         ConvMfmaPlan p = conv_mfma_plan(*g);
         STCD_CHECK(p.ok, "geometry not supported by the MFMA kernel");
         STCD_CHECK(scratch && scratch_bytes >= p.wf_elems * 2, "scratch too small for the fragment-order filter");
         launch_pack_frag(*g, p, w, g->ci, g->co, scratch, (hipStream_t)hip_stream);
+        if (impl == 1 && conv_small_ok(*g, p)) {
+            STCD_CHECK(launch_conv_small(*g, in, scratch, bias, out, false, 1, nullptr, g->co, (hipStream_t)hip_stream) == 0,
+                       "small-channel kernel rejected the geometry");
+            STCD_HIP(hipGetLastError());
+            return 0;
+        }
         STCD_CHECK(launch_conv_mfma(*g, p, in, scratch, bias, out, false, (hipStream_t)hip_stream) == 0, "LDS budget exceeded");
         STCD_HIP(hipGetLastError());
         return 0;
     }
-    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA) or 1 (MFMA)");
+    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA), 1 (MFMA, auto-selected kernel) or 2 (generic MFMA kernel)");
     launch_conv_ref(dtype, *g, in, w, g->ci, g->co, bias, out, false, (hipStream_t)hip_stream);
     STCD_HIP(hipGetLastError());
     return 0;

@@ -595,4 +595,250 @@ void launch_reduce_dw(const float* slab, int gx, const stcd_conv_geom& g, int K,
                                                   ps ? *ps : dummy, ps ? 1 : 0, out);
 }
 
+// =====================================================================================================
+// Small-channel convolution (ntaps*Ci <= 288: the 256^2 / 128^2 layers, i.e. the HBM-bound bulk of the network).
+//   * the whole filter lives in REGISTERS as MFMA A-fragments (KS x NT x 4 VGPRs), loaded once per wave
+//   * a block is persistent over tiles (t = b, b + blocks, ...): the next tile's halo is fetched global -> registers
+//     while the current tile's MFMAs run, then dropped into the other LDS buffer -- one barrier per tile, no
+//     per-tile filter traffic, no per-tile index divisions (per-lane tap offsets are precomputed)
+//   * optional fused BatchNorm statistics: per-channel sum / sum-of-squares of the (rounded) outputs accumulate in
+//     registers across the block's tiles and leave as ONE partial row per block: the separate full-tensor
+//     statistics pass disappears.  Blocks are split evenly over the BN groups (T1 / T2 halves of the batch).
+struct ConvSmallArgs {
+    stcd_conv_geom g;
+    const bf16* in;
+    const bf16* wf;        // fragment-order weights [KS][NTtot][64][8] (mode-B image)
+    const float* bias;
+    void* out;
+    int out_nchw;
+    int KS, NTtot, Ci;
+    int dymin, dxmin, HH, HWp;
+    int tiles_x, tiles_y, ntiles, groups;
+    int halo_bytes;
+    float* stat_partial;   // nullable: [groups][blocks_per_group][2][cpad]
+    int cpad;
+};
+
+template <int NT, int KSMAX>
+__global__ void __launch_bounds__(256)
+k_conv_small(const ConvSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int q = lane >> 4, r = lane & 15;
+    const int is = a.g.in_stride, HWp = a.HWp, Ci = a.Ci, nch8 = Ci >> 3;
+    const int KS = a.KS;
+    bf16* halo[2] = {reinterpret_cast<bf16*>(smem), reinterpret_cast<bf16*>(smem + a.halo_bytes)};
+
+    // ---- filter fragments -> registers; per-lane LDS offset of each k-step's 8-channel piece
+    bf16x8 wreg[KSMAX][NT];
+    int aoff[KSMAX];
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ++ks) {
+        if (ks < KS) {
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2)
+                wreg[ks][t2] = *reinterpret_cast<const bf16x8*>(a.wf + ((int64_t)(ks * a.NTtot + t2) * 64 + lane) * 8);
+            const int kl = ks * 32 + 8 * q;
+            int t = kl / Ci, c = kl - t * Ci;
+            if (t >= a.g.ntaps) { t = 0; c = 0; }
+            aoff[ks] = ((a.g.dy[t] - a.dymin) * HWp + (a.g.dx[t] - a.dxmin)) * Ci + c;
+        } else {
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2) wreg[ks][t2] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            aoff[ks] = 0;
+        }
+    }
+
+    const int bpg = gridDim.x / a.groups, grp = blockIdx.x / bpg, bl = blockIdx.x - grp * bpg;
+    const int tpg = a.ntiles / a.groups;             // tiles per group (images are split evenly over groups)
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s1[t2][j] = s2[t2][j] = 0.f;
+
+    // ---- halo staging: piece i of the tile = pixel (i / nch8), 16-B chunk (i % nch8); <= 3 pieces per thread
+    const int npieces = a.HH * HWp * nch8;
+    constexpr int MAXP = 3;
+    uint4 pre[MAXP];
+    auto fetch = [&](int tile) {
+        int tt = tile;
+        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+        const int ty = tt % a.tiles_y;
+        const int n = tt / a.tiles_y;
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            const int i = tid + p * 256;
+            pre[p] = make_uint4(0, 0, 0, 0);
+            if (i < npieces) {
+                const int ch = i % nch8, pix = i / nch8;
+                const int hx = pix % HWp, hy = pix / HWp;
+                const int gy = ty * 8 * is + a.dymin + hy, gx = tx * 16 * is + a.dxmin + hx;
+                if (gy >= 0 && gy < a.g.hi && gx >= 0 && gx < a.g.wi)
+                    pre[p] = *reinterpret_cast<const uint4*>(a.in + (((int64_t)n * a.g.hi + gy) * a.g.wi + gx) * a.g.ldi + ch * 8);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            const int i = tid + p * 256;
+            if (i < npieces) *reinterpret_cast<uint4*>(halo[buf] + (int64_t)i * 8) = pre[p];
+        }
+    };
+
+    int tile = grp * tpg + bl;
+    const int tile_end = (grp + 1) * tpg;
+    int buf = 0;
+    if (tile < tile_end) { fetch(tile); stash(0); }
+    __syncthreads();
+    for (; tile < tile_end; tile += bpg, buf ^= 1) {
+        const int next = tile + bpg;
+        if (next < tile_end) fetch(next);
+        // ---- MFMAs of this tile
+        f32x4 acc[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2) acc[m][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bf16* hb = halo[buf];
+        const int base0 = ((wid * 2) * is * HWp + r * is) * Ci, rowstep = is * HWp * Ci;
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            if (ks < KS) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(hb + base0 + aoff[ks]);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(hb + base0 + rowstep + aoff[ks]);
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) {
+                    acc[0][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ks][t2], a0, acc[0][t2], 0, 0, 0);
+                    acc[1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[ks][t2], a1, acc[1][t2], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue of this tile
+        int tt = tile;
+        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+        const int ty = tt % a.tiles_y;
+        const int n = tt / a.tiles_y;
+        const int mx = tx * 16 + r;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int my = ty * 8 + wid * 2 + m;
+            if (my >= a.g.hm || mx >= a.g.wm) continue;
+            const int oy = my * a.g.out_stride + a.g.oy0, ox = mx * a.g.out_stride + a.g.ox0;
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2) {
+                const int cb = t2 * 16 + 4 * q;
+                if (cb >= a.g.co) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[m][t2][j] + ((a.bias && cb + j < a.g.co) ? a.bias[cb + j] : 0.f);
+                if (a.out_nchw) {
+                    float* o = reinterpret_cast<float*>(a.out);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (cb + j < a.g.co) o[(((int64_t)n * a.g.co + cb + j) * a.g.ho + oy) * a.g.wo + ox] = v[j];
+                } else {
+                    bf16* o = reinterpret_cast<bf16*>(a.out) + (((int64_t)n * a.g.ho + oy) * a.g.wo + ox) * a.g.ldo + cb;
+                    if (cb + 3 < a.g.co) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(v[0], v[1]);
+                        pk.y = pack_bf16x2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(o) = pk;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (cb + j < a.g.co) o[j] = (bf16)v[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float rv = round_as<bf16>(v[j]);
+                        s1[t2][j] += rv;
+                        s2[t2][j] += rv * rv;
+                    }
+                }
+            }
+        }
+        if (next < tile_end) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- fused BN statistics: lanes sharing q hold the same 4 channels -> xor-reduce over r, then over the 4 waves
+    if (a.stat_partial) {
+        float* red = reinterpret_cast<float*>(smem);     // [4 waves][NT][4 q][4 j][2]
+#pragma unroll
+        for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = s1[t2][j], y = s2[t2][j];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); }
+                if (r == 0) {
+                    red[(((wid * NT + t2) * 4 + q) * 4 + j) * 2] = x;
+                    red[(((wid * NT + t2) * 4 + q) * 4 + j) * 2 + 1] = y;
+                }
+            }
+        __syncthreads();
+        float* outp = a.stat_partial + ((int64_t)grp * bpg + bl) * 2 * a.cpad;
+        for (int i = tid; i < NT * 16 * 2; i += 256) {
+            const int which = i / (NT * 16), c = i - which * NT * 16;
+            const int t2 = c >> 4, qq = (c >> 2) & 3, j = c & 3;
+            float acc_ = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) acc_ += red[(((w * NT + t2) * 4 + qq) * 4 + j) * 2 + which];
+            if (c < a.cpad) outp[which * a.cpad + c] = acc_;
+        }
+    }
+}
+
+bool conv_small_ok(const stcd_conv_geom& g, const ConvMfmaPlan& p) {
+    if (!p.ok || (!p.modeB && p.nchunks != 1)) return false;
+    const int K = g.ntaps * g.ci;
+    const int ks = (K + 31) / 32;
+    const int nt = (g.co + 15) / 16;
+    int dymin, dymax, dxmin, dxmax;
+    taps_extent(g, &dymin, &dymax, &dxmin, &dxmax);
+    const int HH = 7 * g.in_stride + (dymax - dymin) + 1, HWp = 15 * g.in_stride + (dxmax - dxmin) + 1;
+    return ks <= 9 && nt <= 2 && g.ci <= 32 && HH * HWp * (g.ci / 8) <= 3 * 256;
+}
+
+// blocks the launcher will use (the BN-partial slab is sized from this)
+int conv_small_blocks(const stcd_conv_geom& g, int groups) {
+    const int64_t ntiles = (int64_t)g.n * ((g.hm + 7) / 8) * ((g.wm + 15) / 16);
+    int64_t per_group = ntiles / groups;
+    int64_t bpg = std::min<int64_t>(per_group, 2048 / groups);
+    if (bpg < 1) bpg = 1;
+    return (int)(bpg * groups);
+}
+
+int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_modeB, const float* bias, void* out,
+                      bool out_nchw, int groups, float* stat_partial, int cpad, hipStream_t s) {
+    ConvSmallArgs a;
+    a.g = g;
+    a.in = (const bf16*)in; a.wf = (const bf16*)wf_modeB; a.bias = bias; a.out = out; a.out_nchw = out_nchw ? 1 : 0;
+    a.Ci = g.ci;
+    a.KS = (g.ntaps * g.ci + 31) / 32;
+    const int nt = (g.co + 15) / 16;
+    a.NTtot = nt;
+    int dymax, dxmax;
+    taps_extent(g, &a.dymin, &dymax, &a.dxmin, &dxmax);
+    a.HH = 7 * g.in_stride + (dymax - a.dymin) + 1;
+    a.HWp = 15 * g.in_stride + (dxmax - a.dxmin) + 1;
+    a.tiles_x = (g.wm + 15) / 16;
+    a.tiles_y = (g.hm + 7) / 8;
+    a.ntiles = g.n * a.tiles_x * a.tiles_y;
+    a.groups = groups;
+    a.halo_bytes = (a.HH * a.HWp * g.ci * 2 + 255) & ~255;
+    a.stat_partial = stat_partial;
+    a.cpad = cpad;
+    if (g.n % groups != 0) return 1;
+    const int blocks = conv_small_blocks(g, groups);
+    size_t lds = std::max<size_t>(2 * (size_t)a.halo_bytes, 4 * 2 * 16 * 2 * 4 * 2);
+#define LAUNCH_SMALL(N_, K_) k_conv_small<N_, K_><<<blocks, 256, lds, s>>>(a)
+    if (nt == 1) { if (a.KS <= 5) LAUNCH_SMALL(1, 5); else LAUNCH_SMALL(1, 9); }
+    else { if (a.KS <= 5) LAUNCH_SMALL(2, 5); else LAUNCH_SMALL(2, 9); }
+#undef LAUNCH_SMALL
+    return 0;
+}
+
 }  // namespace stcd

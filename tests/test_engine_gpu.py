@@ -196,3 +196,42 @@ def test_fp32_five_step_trajectory(golden):
         opt.step()
         losses.append(loss.item())
     np.testing.assert_allclose(losses, g["losses"], atol=5e-3)
+
+
+def test_bf16_kernel_families_agree():
+    """The same bf16 step through (a) the reference FMA kernels, (b) the generic MFMA kernels with the separate
+    BN-statistics pass, (c) the default path (small-channel persistent kernel with fused statistics where eligible):
+    identical math up to summation order and an occasional 1-ulp bf16 flip, so logits agree to 2e-2 and the loss to 2e-3."""
+    import os
+
+    seed, label = 123, 2
+    rng = np.random.default_rng(seed)
+    x1 = t(rng.standard_normal((4, 3, 64, 64)).astype(np.float32)).to(DEV)
+    x2 = t(rng.standard_normal((4, 3, 64, 64)).astype(np.float32)).to(DEV)
+    tgt = t((rng.random((4, 64, 64)) < 0.3).astype(np.int64)).to(DEV)
+    st = R.synth_state("diff", 3, label, seed)
+    masks = R.synth_masks("diff", 4, seed + 1)
+    res = {}
+    for tag, env in (("ref", {"STCD_FORCE_REF_KERNELS": "1"}), ("generic", {"STCD_NO_SMALL_KERNEL": "1"}), ("default", {})):
+        for k in ("STCD_FORCE_REF_KERNELS", "STCD_NO_SMALL_KERNEL"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            m = SiamUnet_diff(3, label, dtype="bf16")
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        m.load_state_dict(st)
+        m.to(DEV).train()
+        m.set_dropout_masks(masks)
+        logits = m(x1, x2)
+        loss = torch.nn.functional.cross_entropy(logits, tgt)
+        loss.backward()
+        g = torch.cat([p.grad.flatten() for p in m.parameters()]).cpu().double()
+        res[tag] = (logits.detach().cpu(), loss.item(), g, m.state_dict()["bn12.running_var"].cpu())
+    for tag in ("generic", "default"):
+        assert (res[tag][0] - res["ref"][0]).abs().max().item() < 2e-2, tag
+        assert abs(res[tag][1] - res["ref"][1]) < 2e-3, tag
+        cos = (res[tag][2] @ res["ref"][2] / (res[tag][2].norm() * res["ref"][2].norm())).item()
+        assert cos > 0.995, (tag, cos)
+        np.testing.assert_allclose(res[tag][3].numpy(), res["ref"][3].numpy(), rtol=2e-3)

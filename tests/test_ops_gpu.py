@@ -57,6 +57,7 @@ def rnd(rng, *shape, scale=1.0):
 
 
 CONV_CASES = [  # n, h, w, ci, co   (ci includes the engine's zero padding to 8)
+    (32, 64, 64, 16, 16), (3, 40, 48, 32, 32), (2, 64, 64, 8, 16), (2, 32, 48, 16, 32), (2, 32, 32, 32, 16),
     (2, 16, 16, 8, 16), (2, 16, 32, 16, 16), (1, 24, 16, 16, 32), (2, 16, 16, 32, 32), (1, 16, 16, 32, 64),
     (2, 8, 16, 64, 64), (1, 16, 16, 64, 128), (1, 8, 16, 128, 128), (1, 8, 16, 256, 128), (1, 8, 16, 384, 128),
     (1, 16, 16, 48, 16), (1, 16, 16, 96, 32), (1, 16, 16, 192, 64), (2, 16, 16, 16, 2), (1, 16, 16, 16, 1),
@@ -73,14 +74,14 @@ def test_conv3x3_mfma_vs_ref_vs_oracle(n, h, w, ci, co):
     ldo = (co + 7) // 8 * 8
     g = geom(n, h, w, ci, ci, h, w, 1, h, w, 1, 0, 0, co, ldo, TAPS3)
     outs = []
-    for impl in (0, 1):
+    for impl in (0, 1, 2):
         out = torch.zeros(n, h, w, ldo, dtype=torch.bfloat16, device=DEV)
         run_conv(impl, g, x, wt, bias, out)
         outs.append(out[..., :co].float().cpu())
     # oracle: NCHW, weight [co][ci][ky][kx] with tap (dy,dx) -> (ky,kx) = (dy+1, dx+1)
     w_ref = wt.cpu().numpy().reshape(3, 3, ci, co).transpose(3, 2, 0, 1)
     ref = O.conv2d_fwd(x.float().cpu().numpy().transpose(0, 3, 1, 2), w_ref, bias.cpu().numpy(), 1).transpose(0, 2, 3, 1)
-    for name, o in (("ref-kernel", outs[0]), ("mfma", outs[1])):
+    for name, o in (("ref-kernel", outs[0]), ("mfma-auto", outs[1]), ("mfma-generic", outs[2])):
         np.testing.assert_allclose(o.numpy(), ref, rtol=2 ** -7, atol=2e-3, err_msg=name)
     np.testing.assert_allclose(outs[1].numpy(), outs[0].numpy(), rtol=2 ** -7, atol=2e-3)
 
@@ -120,7 +121,7 @@ def test_upconv_phases_and_stride2_dgrad(c):
     n, h, w, ldcat = 2, 8, 16, 2 * c
     x = rnd(rng, n, h, w, c).to(DEV)
     outs = []
-    for impl in (0, 1):
+    for impl in (0, 1, 2):
         cat = torch.zeros(n, 2 * h, 2 * w, ldcat, dtype=torch.bfloat16, device=DEV)
         for py in (0, 1):
             for px in (0, 1):
@@ -131,6 +132,7 @@ def test_upconv_phases_and_stride2_dgrad(c):
         assert cat[..., c:].abs().max().item() == 0.0           # the neighbouring slice is untouched
         outs.append(cat[..., :c].float().cpu().numpy())
     np.testing.assert_allclose(outs[1], outs[0], rtol=2 ** -7, atol=2e-3)
+    np.testing.assert_allclose(outs[2], outs[0], rtol=2 ** -7, atol=2e-3)
     # stride-2 3x3 conv over a [2h,2w] gradient held in a wider buffer
     dy_ = torch.zeros(n, 2 * h, 2 * w, ldcat, dtype=torch.bfloat16, device=DEV)
     dy_[..., :c] = rnd(rng, n, 2 * h, 2 * w, c).to(DEV)
