@@ -114,33 +114,40 @@ k_conv_mfma(const ConvMfmaArgs a) {
                 }
             }
         } else {
-            // ---- mode A: stream the weights tap by tap through two LDS buffers
-            uint4 wreg[WP];
-            auto load_w = [&](int t) {
-                const bf16* wsrc = a.wf + ((int64_t)(cc * ntaps + t) * a.KS) * a.NTtot * 512;
-#pragma unroll
-                for (int p = 0; p < WP; ++p) {
-                    const int i = tid + p * 256;
-                    if (i < w_pieces) {
-                        const int ks = i / (NT * 64), rem = i - ks * NT * 64;
-                        wreg[p] = *reinterpret_cast<const uint4*>(wsrc + ((int64_t)(ks * a.NTtot + cob * NT) * 64 + rem) * 8);
-                    }
-                }
-            };
-            auto store_w = [&](int buf) {
-                bf16* dst = wl + (int64_t)buf * (a.wbuf_bytes >> 1);
-#pragma unroll
-                for (int p = 0; p < WP; ++p) {
-                    const int i = tid + p * 256;
-                    if (i < w_pieces) *reinterpret_cast<uint4*>(dst + (int64_t)i * 8) = wreg[p];
-                }
-            };
-            load_w(0);
-            store_w(0);
-            __syncthreads();
+            // ---- mode A: stream the weights tap by tap through two LDS buffers.  Software pipeline with ONE barrier
+            //      per tap: regs(t) -> LDS buf[t&1]; barrier; issue global loads of tap t+1 into regs (in flight during
+            //      the MFMAs); MFMAs of tap t.  buf[(t+1)&1] is rewritten only after every wave passed the next barrier,
+            //      i.e. after all reads of tap t-1.
+            // (named registers, not an array: hipcc parks a conditionally-written uint4 array in scratch)
+            uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
+#define W_ADDR(P_, SRC_) ((SRC_) + ((int64_t)((min(tid + (P_) * 256, w_pieces - 1) / (NT * 64)) * a.NTtot + cob * NT) * 64 + \
+                                   (min(tid + (P_) * 256, w_pieces - 1) % (NT * 64))) * 8)
+#define W_LOAD(SRC_)                                                                      \
+    do {                                                                                  \
+        w0 = *reinterpret_cast<const uint4*>(W_ADDR(0, SRC_));                            \
+        if constexpr (WP > 1) w1 = *reinterpret_cast<const uint4*>(W_ADDR(1, SRC_));      \
+        if constexpr (WP > 2) w2 = *reinterpret_cast<const uint4*>(W_ADDR(2, SRC_));      \
+        if constexpr (WP > 3) w3 = *reinterpret_cast<const uint4*>(W_ADDR(3, SRC_));      \
+    } while (0)
+#define W_STORE(DST_)                                                                                         \
+    do {                                                                                                      \
+        if (tid < w_pieces) *reinterpret_cast<uint4*>((DST_) + tid * 8) = w0;                                 \
+        if constexpr (WP > 1) { if (tid + 256 < w_pieces) *reinterpret_cast<uint4*>((DST_) + (tid + 256) * 8) = w1; } \
+        if constexpr (WP > 2) { if (tid + 512 < w_pieces) *reinterpret_cast<uint4*>((DST_) + (tid + 512) * 8) = w2; } \
+        if constexpr (WP > 3) { if (tid + 768 < w_pieces) *reinterpret_cast<uint4*>((DST_) + (tid + 768) * 8) = w3; } \
+    } while (0)
+            {
+                const bf16* wsrc = a.wf + ((int64_t)(cc * ntaps) * a.KS) * a.NTtot * 512;
+                W_LOAD(wsrc);
+            }
             for (int t = 0; t < ntaps; ++t) {
-                if (t + 1 < ntaps) load_w(t + 1);
-                const bf16* wb = wl + (int64_t)(t & 1) * (a.wbuf_bytes >> 1);
+                bf16* wb = wl + (t & 1) * (a.wbuf_bytes >> 1);
+                W_STORE(wb);
+                __syncthreads();
+                if (t + 1 < ntaps) {
+                    const bf16* wsrc = a.wf + ((int64_t)(cc * ntaps + t + 1) * a.KS) * a.NTtot * 512;
+                    W_LOAD(wsrc);
+                }
                 const int tdy = a.g.dy[t] - a.dymin, tdx = a.g.dx[t] - a.dxmin;
                 for (int ks = 0; ks < a.KS; ++ks) {
                     bf16x8 af[2];
@@ -158,9 +165,11 @@ k_conv_mfma(const ConvMfmaArgs a) {
                             acc[m][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[m], acc[m][t2], 0, 0, 0);
                     }
                 }
-                if (t + 1 < ntaps) store_w((t + 1) & 1);
-                __syncthreads();
             }
+#undef W_ADDR
+#undef W_LOAD
+#undef W_STORE
+            __syncthreads();   // the last tap's buffer is free before the next chunk restages
         }
     }
 
@@ -175,9 +184,20 @@ k_conv_mfma(const ConvMfmaArgs a) {
         for (int t2 = 0; t2 < NT; ++t2) {
             const int cb = (cob * NT + t2) * 16 + 4 * q;
             if (cb >= a.g.co) continue;
+            float bvv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
+                if (cb + 3 < a.g.co) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + cb);   // flat params are 16-B aligned
+                    bvv[0] = b4.x; bvv[1] = b4.y; bvv[2] = b4.z; bvv[3] = b4.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (cb + j < a.g.co) bvv[j] = a.bias[cb + j];
+                }
+            }
             float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[m][t2][j] + ((a.bias && cb + j < a.g.co) ? a.bias[cb + j] : 0.f);
+            for (int j = 0; j < 4; ++j) v[j] = acc[m][t2][j] + bvv[j];
             if (a.out_nchw) {
                 float* o = reinterpret_cast<float*>(a.out);
 #pragma unroll
@@ -365,11 +385,12 @@ struct WgradArgs {
     int kpad, wld;
     int dymin, dxmin, HH, HWp;
     int tiles_x, tiles_y, ntiles;
-    int x_bytes;           // LDS bytes of the X halo tile
+    int xrow_bytes;        // LDS bytes of one halo row of the X tile (incl. bank padding)
+    int x_bytes, y_bytes;  // LDS bytes of one X halo tile / one dY tile
     int co_valid;          // channels of dout that exist in memory (round8(co))
 };
 
-__device__ __forceinline__ bf16x8 tr_frag(const bf16* base0, const bf16* base1) {
+__device__ __forceinline__ bf16x8 tr_frag(const char* base0, const char* base1) {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)base0);
@@ -380,18 +401,25 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* base0, const bf16* base1) 
     return f;
 }
 
+// LDS image of a [pixel][C] tile for ds_read_b64_tr_b16 (bank = (addr/4) % 64, conflicts inside a 32-lane half, whose
+// two 16-lane groups read pixels x..x+3 and x+8..x+11 of one row): pixel x of a row sits at x*R + (x>>3)*PAD with
+// R = 2*C bytes; PAD = 128 (C=16) / 32 (C=32) shifts the second group onto the banks the first one leaves free.
+template <int C>
+__device__ __forceinline__ int px_off(int x) { return x * (2 * C) + (x >> 3) * (C == 16 ? 128 : 32); }
+
 template <int WCI, int NTW>
 __global__ void __launch_bounds__(256)
 k_wgrad_mfma(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WK = 4 / WCI, CIB = WCI * 16, COB = NTW * 16;
+    constexpr int XCH = CIB / 8, YCH = COB / 8;
+    constexpr int YROW = 16 * 2 * COB + 2 * (COB == 16 ? 128 : 32);       // bytes of one 16-position dY row
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wci = wid % WCI, wk = wid / WCI;
     const int grp = lane >> 4, li = lane & 15, qrow = li >> 2, pcol = li & 3;
-    const int is = a.g.in_stride, HWp = a.HWp;
+    const int HWp = a.HWp;
     const int ci0 = blockIdx.y * CIB, co0 = blockIdx.z * COB;
-    bf16* xs = reinterpret_cast<bf16*>(smem);
-    bf16* ys = reinterpret_cast<bf16*>(smem + a.x_bytes);
+    const int buf_bytes = a.x_bytes + a.y_bytes;
 
     f32x4 acc[9][NTW];
 #pragma unroll
@@ -399,90 +427,136 @@ k_wgrad_mfma(const WgradArgs a) {
 #pragma unroll
         for (int n_ = 0; n_ < NTW; ++n_) acc[t][n_] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // per-lane position of the two half-fragments inside a k-step (32 positions = 2 tile rows of 16)
-    // half h: k = 8*grp + 4*h + qrow  ->  row (k>>4) = grp>>1, x = 8*(grp&1) + 4*h + qrow
+    // ---- staging plan, computed once: X pieces (pixel, 16-B chunk) then dY pieces; <= MAXP per thread
+    const int nx = a.HH * HWp * XCH, ny = 128 * YCH, npieces = nx + ny;
+    constexpr int MAXP = 5;
+    int goff[MAXP], loff[MAXP], pa[MAXP], pb[MAXP];   // global element offset, LDS byte offset, bound coords
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+        const int i = tid + p * 256;
+        goff[p] = 0; loff[p] = -1; pa[p] = 1 << 28; pb[p] = 0;
+        if (i < nx) {
+            const int ch = i % XCH, pix = i / XCH, hx = pix % HWp, hy = pix / HWp;
+            pa[p] = hy + a.dymin; pb[p] = hx + a.dxmin;
+            goff[p] = (pa[p] * a.g.wi + pb[p]) * a.g.ldi + ci0 + ch * 8;
+            loff[p] = hy * a.xrow_bytes + px_off<CIB>(hx) + ch * 16;
+            if (ci0 + ch * 8 >= a.g.ci) pa[p] = 1 << 28;             // channels beyond Ci: zero
+        } else if (i < npieces) {
+            const int j = i - nx, ch = j % YCH, pix = j / YCH, py = pix >> 4, pxx = pix & 15;
+            pa[p] = py; pb[p] = pxx;
+            goff[p] = ((py * a.g.out_stride) * a.g.wo + pxx * a.g.out_stride) * a.g.ldo + co0 + ch * 8;
+            loff[p] = a.x_bytes + py * YROW + px_off<COB>(pxx) + ch * 16;
+            if (co0 + ch * 8 >= a.co_valid) pa[p] = 1 << 28;
+        }
+    }
+    const bool p_is_x[MAXP] = {tid < nx, tid + 256 < nx, tid + 512 < nx, tid + 768 < nx, tid + 1024 < nx};
+
+    // tile walk (incremental)
+    const int tiles_img = a.tiles_x * a.tiles_y;
+    const int step = gridDim.x;
+    const int dn = step / tiles_img, drem = step - dn * tiles_img, dty = drem / a.tiles_x, dtx = drem - dty * a.tiles_x;
+    int tile = blockIdx.x;
+    int tn = tile / tiles_img, trem = tile - tn * tiles_img, tty = trem / a.tiles_x, ttx = trem - tty * a.tiles_x;
+
+    uint4 pre[MAXP];
+#define WG_FETCH(N_, Y_, X_)                                                                                          \
+    do {                                                                                                              \
+        const int my0_ = (Y_) * 8, mx0_ = (X_) * 16;                                                                   \
+        const bf16* xo_ = a.in + (((int64_t)(N_) * a.g.hi + my0_ * a.g.in_stride) * a.g.wi + mx0_ * a.g.in_stride) * a.g.ldi; \
+        const bf16* yo_ = a.dout + (((int64_t)(N_) * a.g.ho + my0_ * a.g.out_stride + a.g.oy0) * a.g.wo +             \
+                                    mx0_ * a.g.out_stride + a.g.ox0) * a.g.ldo;                                       \
+        _Pragma("unroll") for (int p = 0; p < MAXP; ++p) {                                                            \
+            pre[p] = make_uint4(0, 0, 0, 0);                                                                          \
+            if (p_is_x[p]) {                                                                                          \
+                const unsigned gy_ = (unsigned)(my0_ * a.g.in_stride + pa[p]), gx_ = (unsigned)(mx0_ * a.g.in_stride + pb[p]); \
+                if (gy_ < (unsigned)a.g.hi && gx_ < (unsigned)a.g.wi) pre[p] = *reinterpret_cast<const uint4*>(xo_ + goff[p]); \
+            } else if (loff[p] >= 0) {                                                                                \
+                if ((unsigned)(my0_ + pa[p]) < (unsigned)a.g.hm && mx0_ + pb[p] < a.g.wm)                             \
+                    pre[p] = *reinterpret_cast<const uint4*>(yo_ + goff[p]);                                          \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+#define WG_STASH(BUF_)                                                                                                \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int p = 0; p < MAXP; ++p)                                                              \
+            if (loff[p] >= 0) *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + loff[p]) = pre[p];                \
+    } while (0)
+
+    // per-lane fragment geometry inside a k-step (32 positions = 2 tile rows): half h -> x = 8*(grp&1) + 4*h + qrow
     const int frow = grp >> 1;
     const int fx0 = 8 * (grp & 1) + qrow, fx1 = fx0 + 4;
+    const int yb0 = px_off<COB>(fx0) + 8 * pcol, yb1 = px_off<COB>(fx1) + 8 * pcol;
+    int xoff0[9], xoff1[9];      // X fragment byte offsets per tap (relative to the k-step's halo row)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tdy = t < a.g.ntaps ? a.g.dy[t] - a.dymin : 0, tdx = t < a.g.ntaps ? a.g.dx[t] - a.dxmin : 0;
+        xoff0[t] = tdy * a.xrow_bytes + px_off<CIB>(fx0 + tdx) + wci * 32 + 8 * pcol;
+        xoff1[t] = tdy * a.xrow_bytes + px_off<CIB>(fx1 + tdx) + wci * 32 + 8 * pcol;
+    }
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        int tt = tile;
-        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
-        const int ty = tt % a.tiles_y;
-        const int n = tt / a.tiles_y;
-        const int my0 = ty * 8, mx0 = tx * 16;
-        __syncthreads();
-        // ---- X halo tile, channels [ci0, ci0+CIB)
-        constexpr int XCH = CIB / 8;
-        const int nx = a.HH * HWp * XCH;
-        for (int i = tid; i < nx; i += 256) {
-            const int ch = i % XCH, pix = i / XCH;
-            const int hx = pix % HWp, hy = pix / HWp;
-            const int gy = my0 * is + a.dymin + hy, gx = mx0 * is + a.dxmin + hx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gy >= 0 && gy < a.g.hi && gx >= 0 && gx < a.g.wi && ci0 + ch * 8 < a.g.ci)
-                v = *reinterpret_cast<const uint4*>(a.in + (((int64_t)n * a.g.hi + gy) * a.g.wi + gx) * a.g.ldi + ci0 + ch * 8);
-            *reinterpret_cast<uint4*>(xs + (int64_t)i * 8) = v;
-        }
-        // ---- dY tile, channels [co0, co0+COB)
-        constexpr int YCH = COB / 8;
-        for (int i = tid; i < 128 * YCH; i += 256) {
-            const int ch = i % YCH, pix = i / YCH;
-            const int my = my0 + (pix >> 4), mx = mx0 + (pix & 15);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (my < a.g.hm && mx < a.g.wm && co0 + ch * 8 < a.co_valid) {
-                const int oy = my * a.g.out_stride + a.g.oy0, ox = mx * a.g.out_stride + a.g.ox0;
-                v = *reinterpret_cast<const uint4*>(a.dout + (((int64_t)n * a.g.ho + oy) * a.g.wo + ox) * a.g.ldo + co0 + ch * 8);
-            }
-            *reinterpret_cast<uint4*>(ys + (int64_t)i * 8) = v;
-        }
-        __syncthreads();
+    int buf = 0;
+    if (tile < a.ntiles) { WG_FETCH(tn, tty, ttx); WG_STASH(0); }
+    __syncthreads();
+    for (; tile < a.ntiles; tile += step, buf ^= 1) {
+        int nn = tn, nyy = tty, nxx = ttx;
+        nxx += dtx; if (nxx >= a.tiles_x) { nxx -= a.tiles_x; ++nyy; }
+        nyy += dty; if (nyy >= a.tiles_y) { nyy -= a.tiles_y; ++nn; }
+        nn += dn;
+        const bool have_next = tile + step < a.ntiles;
+        if (have_next) WG_FETCH(nn, nyy, nxx);
+        const char* xs = smem + buf * buf_bytes;
+        const char* ys = xs + a.x_bytes;
         for (int ks = wk; ks < 4; ks += WK) {
             const int row = ks * 2 + frow;
             bf16x8 bfr[NTW];
 #pragma unroll
-            for (int n_ = 0; n_ < NTW; ++n_) {
-                const bf16* b0 = ys + ((row * 16 + fx0) * COB + n_ * 16 + 4 * pcol);
-                const bf16* b1 = ys + ((row * 16 + fx1) * COB + n_ * 16 + 4 * pcol);
-                bfr[n_] = tr_frag(b0, b1);
-            }
+            for (int n_ = 0; n_ < NTW; ++n_)
+                bfr[n_] = tr_frag(ys + row * YROW + yb0 + n_ * 32, ys + row * YROW + yb1 + n_ * 32);
+            const char* xr = xs + row * a.xrow_bytes;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 if (t < a.g.ntaps) {
-                    const int hy = row * is + (a.g.dy[t] - a.dymin);
-                    const int hxo = a.g.dx[t] - a.dxmin;
-                    const bf16* a0 = xs + ((hy * HWp + fx0 * is + hxo) * CIB + wci * 16 + 4 * pcol);
-                    const bf16* a1 = xs + ((hy * HWp + fx1 * is + hxo) * CIB + wci * 16 + 4 * pcol);
-                    const bf16x8 afr = tr_frag(a0, a1);
+                    const bf16x8 afr = tr_frag(xr + xoff0[t], xr + xoff1[t]);
 #pragma unroll
                     for (int n_ = 0; n_ < NTW; ++n_)
                         acc[t][n_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[n_], acc[t][n_], 0, 0, 0);
                 }
             }
         }
+        if (have_next) WG_STASH(buf ^ 1);
+        tn = nn; tty = nyy; ttx = nxx;
+        __syncthreads();
     }
+#undef WG_FETCH
+#undef WG_STASH
 
-    // ---- block result -> slab[bx][t][ci][co]; lane holds D[ci_local = 4*grp + j][co_local = li]
-    float* slab = a.slab + (int64_t)blockIdx.x * a.g.ntaps * a.kpad * a.wld;
-    if (WK > 1) {
-        float* red = reinterpret_cast<float*>(smem);
-        __syncthreads();
-        for (int i = tid; i < 9 * CIB * COB; i += 256) red[i] = 0.f;
-        __syncthreads();
+    // ---- block result -> slab[bx][t][ci][co]; lane holds D[ci_local = 4*grp + j][co_local = li].
+    //      The WK waves that split the k-steps meet through a lane-contiguous LDS exchange (no LDS float atomics: they
+    //      serialise -- 72 ds_add_f32 per lane cost ~30 us per block); wave wk == 0 of each ci tile then owns the sum.
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int PERW = 9 * NTW * 4 * 64;            // floats one wave parks
+    if (wk > 0) {
+        float* dst = red + ((wk - 1) * WCI + wci) * PERW + lane;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
-            if (t < a.g.ntaps)
+#pragma unroll
+            for (int n_ = 0; n_ < NTW; ++n_)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[((t * NTW + n_) * 4 + j) * 64] = acc[t][n_][j];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+        for (int w = 1; w < WK; ++w) {
+            const float* src = red + ((w - 1) * WCI + wci) * PERW + lane;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
                 for (int n_ = 0; n_ < NTW; ++n_)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        atomicAdd(&red[(t * CIB + wci * 16 + 4 * grp + j) * COB + n_ * 16 + li], acc[t][n_][j]);
-        __syncthreads();
-        for (int i = tid; i < a.g.ntaps * CIB * COB; i += 256) {
-            const int co = i % COB, ci = (i / COB) % CIB, t = i / (COB * CIB);
-            if (ci0 + ci < a.kpad && co0 + co < a.wld)
-                slab[((int64_t)t * a.kpad + ci0 + ci) * a.wld + co0 + co] = red[i];
+                    for (int j = 0; j < 4; ++j) acc[t][n_][j] += src[((t * NTW + n_) * 4 + j) * 64];
         }
-    } else {
+        float* slab = a.slab + (int64_t)blockIdx.x * a.g.ntaps * a.kpad * a.wld;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
             if (t < a.g.ntaps)
@@ -497,25 +571,29 @@ k_wgrad_mfma(const WgradArgs a) {
 }
 
 // sum the slabs; out[t][k][n] (engine layout, same as the slab) or, with a PackSpec, straight into the reference layout
+// PARTS threads cooperate on one output (256/PARTS outputs per block): many slabs x few outputs (16-channel layers)
+// use PARTS = 64 so the chip still sees enough blocks and each thread's chain of dependent loads stays short.
+template <int PARTS>
 __global__ void __launch_bounds__(256)
 k_reduce_dw(const float* __restrict__ slab, int gx, int64_t slab_stride, int ntaps, int K, int N, int kpad, int wld,
             PackSpec ps, int use_ps, float* __restrict__ out) {
+    constexpr int OUTS = 256 / PARTS;
     __shared__ float red[256];
-    const int o = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+    const int o = blockIdx.x * OUTS + (threadIdx.x % OUTS), part = threadIdx.x / OUTS;
     const int total = ntaps * K * N;
     float acc = 0.f;
     int n = 0, k = 0, t = 0;
     if (o < total) {
         n = o % N; k = (o / N) % K; t = o / (N * K);
         const float* p = slab + ((int64_t)t * kpad + k) * wld + n;
-        for (int b = part; b < gx; b += 16) acc += p[(int64_t)b * slab_stride];
+        for (int b = part; b < gx; b += PARTS) acc += p[(int64_t)b * slab_stride];
     }
     red[threadIdx.x] = acc;
     __syncthreads();
     if (part == 0 && o < total) {
         acc = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc += red[q * 16 + threadIdx.x];
+        for (int q = 0; q < PARTS; ++q) acc += red[q * OUTS + threadIdx.x];
         if (use_ps) {
             const int64_t a_ = ps.kn_major ? ((int64_t)k * ps.N + n) : ((int64_t)n * ps.K + k);
             out[(a_ * ps.ks + ps.ky[t]) * ps.ks + ps.kx[t]] = acc;
@@ -527,19 +605,25 @@ k_reduce_dw(const float* __restrict__ slab, int gx, int64_t slab_stride, int nta
 
 WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld) {
     WgradMfmaPlan p;
-    p.WCI = g.ci >= 64 ? 4 : g.ci >= 32 ? 2 : 1;
-    p.NTW = g.co >= 64 ? 4 : g.co >= 32 ? 2 : 1;
+    // block tile <= 32 ci x 32 co: 72 accumulator registers, >= 3 waves per SIMD, and enough (ci,co) groups that wide
+    // layers fill the chip without a deep K split (the fp32 slab per K slice is ntaps*Ci*Co*4 bytes)
+    p.WCI = g.ci >= 32 ? 2 : 1;
+    p.NTW = g.co >= 32 ? 2 : 1;
     p.gy = (g.ci + p.WCI * 16 - 1) / (p.WCI * 16);
     p.gz = (g.co + p.NTW * 16 - 1) / (p.NTW * 16);
     const int tiles_x = (g.wm + 15) / 16, tiles_y = (g.hm + 7) / 8;
     const int64_t ntiles = (int64_t)g.n * tiles_x * tiles_y;
     const int64_t slab_bytes = (int64_t)g.ntaps * kpad * wld * 4;
-    int64_t gx = std::max<int64_t>(1, std::min<int64_t>(512, 1024 / (p.gy * p.gz)));
+    int64_t gx = std::max<int64_t>(1, 1536 / (p.gy * p.gz));
     gx = std::min<int64_t>(gx, std::max<int64_t>(1, ((int64_t)24 << 20) / slab_bytes));
     gx = std::min<int64_t>(gx, ntiles);
     p.gx = (int)gx;
     p.slab_floats = (int64_t)p.gx * g.ntaps * kpad * wld;
-    p.ok = g.ci % 8 == 0 && g.ldi % 8 == 0 && g.ldo % 8 == 0;
+    int dymin, dymax, dxmin, dxmax;
+    taps_extent(g, &dymin, &dymax, &dxmin, &dxmax);
+    const int HH = 7 * g.in_stride + (dymax - dymin) + 1, HWp = 15 * g.in_stride + (dxmax - dxmin) + 1;
+    const int pieces = HH * HWp * (p.WCI * 2) + 128 * (p.NTW * 2);
+    p.ok = g.ci % 8 == 0 && g.ldi % 8 == 0 && g.ldo % 8 == 0 && g.in_stride == 1 && pieces <= 5 * 256;
     return p;
 }
 
@@ -556,33 +640,18 @@ int launch_wgrad_mfma(const stcd_conv_geom& g, const WgradMfmaPlan& p, const voi
     a.tiles_y = (g.hm + 7) / 8;
     a.ntiles = g.n * a.tiles_x * a.tiles_y;
     const int CIB = p.WCI * 16, COB = p.NTW * 16;
-    a.x_bytes = (a.HH * a.HWp * CIB * 2 + 255) & ~255;
+    const int xpad = CIB == 16 ? 128 : 32, ypad = COB == 16 ? 128 : 32;
+    a.xrow_bytes = (a.HWp * 2 * CIB + ((a.HWp + 7) / 8) * xpad + 15) & ~15;
+    a.x_bytes = (a.HH * a.xrow_bytes + 255) & ~255;
+    a.y_bytes = (8 * (16 * 2 * COB + 2 * ypad) + 255) & ~255;
     a.co_valid = (g.co + 7) & ~7;
-    size_t lds = (size_t)a.x_bytes + (size_t)128 * COB * 2;
-    if (p.WCI < 4) lds = std::max<size_t>(lds, (size_t)9 * CIB * COB * 4);
-    if (lds > 160 * 1024) return 1;
+    const int WK = 4 / p.WCI;
+    size_t lds = std::max<size_t>(2 * (size_t)(a.x_bytes + a.y_bytes), (size_t)(WK - 1) * p.WCI * 9 * p.NTW * 4 * 64 * 4);
+    if (lds > 64 * 1024 || !p.ok) return 1;
     dim3 grid((unsigned)p.gx, (unsigned)p.gy, (unsigned)p.gz);
-#define LAUNCH_WG(W_, N_)                                                                                           \
-    do {                                                                                                            \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
-            (void)hipFuncSetAttribute((const void*)k_wgrad_mfma<W_, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
-        k_wgrad_mfma<W_, N_><<<grid, 256, lds, s>>>(a);                                                             \
-    } while (0)
-    const int key = p.WCI * 10 + p.NTW;
-    switch (key) {
-        case 11: LAUNCH_WG(1, 1); break;
-        case 12: LAUNCH_WG(1, 2); break;
-        case 14: LAUNCH_WG(1, 4); break;
-        case 21: LAUNCH_WG(2, 1); break;
-        case 22: LAUNCH_WG(2, 2); break;
-        case 24: LAUNCH_WG(2, 4); break;
-        case 41: LAUNCH_WG(4, 1); break;
-        case 42: LAUNCH_WG(4, 2); break;
-        default: LAUNCH_WG(4, 4); break;
-    }
+#define LAUNCH_WG(W_, N_) k_wgrad_mfma<W_, N_><<<grid, 256, lds, s>>>(a)
+    if (p.WCI == 1) { if (p.NTW == 1) LAUNCH_WG(1, 1); else LAUNCH_WG(1, 2); }
+    else { if (p.NTW == 1) LAUNCH_WG(2, 1); else LAUNCH_WG(2, 2); }
 #undef LAUNCH_WG
     return 0;
 }
@@ -591,8 +660,12 @@ void launch_reduce_dw(const float* slab, int gx, const stcd_conv_geom& g, int K,
                       const PackSpec* ps, float* out, hipStream_t s) {
     const int total = g.ntaps * K * N;
     PackSpec dummy{};
-    k_reduce_dw<<<(total + 15) / 16, 256, 0, s>>>(slab, gx, (int64_t)g.ntaps * kpad * wld, g.ntaps, K, N, kpad, wld,
-                                                  ps ? *ps : dummy, ps ? 1 : 0, out);
+    if (gx >= 128 && total <= 16384)
+        k_reduce_dw<64><<<(total + 3) / 4, 256, 0, s>>>(slab, gx, (int64_t)g.ntaps * kpad * wld, g.ntaps, K, N, kpad, wld,
+                                                          ps ? *ps : dummy, ps ? 1 : 0, out);
+    else
+        k_reduce_dw<16><<<(total + 15) / 16, 256, 0, s>>>(slab, gx, (int64_t)g.ntaps * kpad * wld, g.ntaps, K, N, kpad, wld,
+                                                            ps ? *ps : dummy, ps ? 1 : 0, out);
 }
 
 // =====================================================================================================
@@ -627,7 +700,8 @@ k_conv_small(const ConvSmallArgs a) {
     const int q = lane >> 4, r = lane & 15;
     const int is = a.g.in_stride, HWp = a.HWp, Ci = a.Ci, nch8 = Ci >> 3;
     const int KS = a.KS;
-    bf16* halo[2] = {reinterpret_cast<bf16*>(smem), reinterpret_cast<bf16*>(smem + a.halo_bytes)};
+    bf16* const halo0 = reinterpret_cast<bf16*>(smem);     // two halo buffers, halo_elems apart (plain offset
+    const int halo_elems = a.halo_bytes >> 1;              // arithmetic keeps the LDS address space: no flat ops)
 
     // ---- filter fragments -> registers; per-lane LDS offset of each k-step's 8-channel piece
     bf16x8 wreg[KSMAX][NT];
@@ -657,52 +731,75 @@ k_conv_small(const ConvSmallArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) s1[t2][j] = s2[t2][j] = 0.f;
 
-    // ---- halo staging: piece i of the tile = pixel (i / nch8), 16-B chunk (i % nch8); <= 3 pieces per thread
+    // ---- halo staging: piece i of the tile = pixel (i / nch8), 16-B chunk (i % nch8); <= 3 pieces per thread.
+    //      Everything that does not depend on the tile is computed ONCE here (the loop below has no divisions):
+    //      per-piece element offset relative to the tile's origin pixel, and its (hy,hx) for the border test.
     const int npieces = a.HH * HWp * nch8;
     constexpr int MAXP = 3;
+    int poff[MAXP], phy[MAXP], phx[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+        const int i = tid + p * 256;
+        const int ch = i % nch8, pix = i / nch8;
+        phx[p] = pix % HWp + a.dxmin;
+        phy[p] = (i < npieces) ? pix / HWp + a.dymin : (1 << 28);     // out-of-range piece: always fails the row test
+        poff[p] = (phy[p] * a.g.wi + phx[p]) * a.g.ldi + ch * 8;
+    }
+    // bias of this lane's channels
+    float bv[NT][4];
+#pragma unroll
+    for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cb = t2 * 16 + 4 * q + j;
+            bv[t2][j] = (a.bias && cb < a.g.co) ? a.bias[cb] : 0.f;
+        }
+    // tile walk: tile -> (n, ty, tx) advanced incrementally by bpg
+    const int tiles_img = a.tiles_x * a.tiles_y;
+    const int dn = bpg / tiles_img, drem = bpg - dn * tiles_img, dty = drem / a.tiles_x, dtx = drem - dty * a.tiles_x;
+    int tile = grp * tpg + bl;
+    const int tile_end = (grp + 1) * tpg;
+    int tn = tile / tiles_img, trem = tile - tn * tiles_img, tty = trem / a.tiles_x, ttx = trem - tty * a.tiles_x;
+    auto advance = [&](int& n_, int& y_, int& x_) {
+        x_ += dtx; if (x_ >= a.tiles_x) { x_ -= a.tiles_x; ++y_; }
+        y_ += dty; if (y_ >= a.tiles_y) { y_ -= a.tiles_y; ++n_; }
+        n_ += dn;
+    };
     uint4 pre[MAXP];
-    auto fetch = [&](int tile) {
-        int tt = tile;
-        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
-        const int ty = tt % a.tiles_y;
-        const int n = tt / a.tiles_y;
+    auto fetch = [&](int n_, int y_, int x_) {
+        const int gy0 = y_ * 8 * is, gx0 = x_ * 16 * is;
+        const bf16* org = a.in + (((int64_t)n_ * a.g.hi + gy0) * a.g.wi + gx0) * a.g.ldi;
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
-            const int i = tid + p * 256;
+            const unsigned gy = (unsigned)(gy0 + phy[p]), gx = (unsigned)(gx0 + phx[p]);
             pre[p] = make_uint4(0, 0, 0, 0);
-            if (i < npieces) {
-                const int ch = i % nch8, pix = i / nch8;
-                const int hx = pix % HWp, hy = pix / HWp;
-                const int gy = ty * 8 * is + a.dymin + hy, gx = tx * 16 * is + a.dxmin + hx;
-                if (gy >= 0 && gy < a.g.hi && gx >= 0 && gx < a.g.wi)
-                    pre[p] = *reinterpret_cast<const uint4*>(a.in + (((int64_t)n * a.g.hi + gy) * a.g.wi + gx) * a.g.ldi + ch * 8);
-            }
+            if (gy < (unsigned)a.g.hi && gx < (unsigned)a.g.wi) pre[p] = *reinterpret_cast<const uint4*>(org + poff[p]);
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf_) {
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
             const int i = tid + p * 256;
-            if (i < npieces) *reinterpret_cast<uint4*>(halo[buf] + (int64_t)i * 8) = pre[p];
+            if (i < npieces) *reinterpret_cast<uint4*>(halo0 + buf_ * halo_elems + i * 8) = pre[p];
         }
     };
 
-    int tile = grp * tpg + bl;
-    const int tile_end = (grp + 1) * tpg;
     int buf = 0;
-    if (tile < tile_end) { fetch(tile); stash(0); }
+    if (tile < tile_end) { fetch(tn, tty, ttx); stash(0); }
     __syncthreads();
+    const int base0 = ((wid * 2) * is * HWp + r * is) * Ci, rowstep = is * HWp * Ci;
     for (; tile < tile_end; tile += bpg, buf ^= 1) {
-        const int next = tile + bpg;
-        if (next < tile_end) fetch(next);
+        int nn = tn, ny = tty, nx = ttx;
+        advance(nn, ny, nx);
+        const bool have_next = tile + bpg < tile_end;
+        if (have_next) fetch(nn, ny, nx);
         // ---- MFMAs of this tile
         f32x4 acc[2][NT];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int t2 = 0; t2 < NT; ++t2) acc[m][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bf16* hb = halo[buf];
-        const int base0 = ((wid * 2) * is * HWp + r * is) * Ci, rowstep = is * HWp * Ci;
+        const bf16* hb = halo0 + buf * halo_elems;
 #pragma unroll
         for (int ks = 0; ks < KSMAX; ++ks) {
             if (ks < KS) {
@@ -715,31 +812,35 @@ k_conv_small(const ConvSmallArgs a) {
                 }
             }
         }
+        // the prefetched halo goes to the other buffer BEFORE this tile's stores are issued: the wait for the loads
+        // must not also wait for fresh stores (vmcnt counts both)
+        if (have_next) stash(buf ^ 1);
         // ---- epilogue of this tile
-        int tt = tile;
-        const int tx = tt % a.tiles_x; tt /= a.tiles_x;
-        const int ty = tt % a.tiles_y;
-        const int n = tt / a.tiles_y;
-        const int mx = tx * 16 + r;
+        const int mx = ttx * 16 + r;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const int my = ty * 8 + wid * 2 + m;
+            const int my = tty * 8 + wid * 2 + m;
             if (my >= a.g.hm || mx >= a.g.wm) continue;
             const int oy = my * a.g.out_stride + a.g.oy0, ox = mx * a.g.out_stride + a.g.ox0;
+            if (a.out_nchw) {
+                float* o = reinterpret_cast<float*>(a.out) + ((int64_t)tn * a.g.co * a.g.ho + oy) * a.g.wo + ox;
 #pragma unroll
-            for (int t2 = 0; t2 < NT; ++t2) {
-                const int cb = t2 * 16 + 4 * q;
-                if (cb >= a.g.co) continue;
-                float v[4];
+                for (int t2 = 0; t2 < NT; ++t2)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[m][t2][j] + ((a.bias && cb + j < a.g.co) ? a.bias[cb + j] : 0.f);
-                if (a.out_nchw) {
-                    float* o = reinterpret_cast<float*>(a.out);
+                    for (int j = 0; j < 4; ++j) {
+                        const int cb = t2 * 16 + 4 * q + j;
+                        if (cb < a.g.co) o[(int64_t)cb * a.g.ho * a.g.wo] = acc[m][t2][j] + bv[t2][j];
+                    }
+            } else {
+                bf16* orow = reinterpret_cast<bf16*>(a.out) + (((int64_t)tn * a.g.ho + oy) * a.g.wo + ox) * a.g.ldo + 4 * q;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (cb + j < a.g.co) o[(((int64_t)n * a.g.co + cb + j) * a.g.ho + oy) * a.g.wo + ox] = v[j];
-                } else {
-                    bf16* o = reinterpret_cast<bf16*>(a.out) + (((int64_t)n * a.g.ho + oy) * a.g.wo + ox) * a.g.ldo + cb;
+                for (int t2 = 0; t2 < NT; ++t2) {
+                    const int cb = t2 * 16 + 4 * q;
+                    if (cb >= a.g.co) continue;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[m][t2][j] + bv[t2][j];
+                    bf16* o = orow + t2 * 16;
                     if (cb + 3 < a.g.co) {
                         uint2 pk;
                         pk.x = pack_bf16x2(v[0], v[1]);
@@ -759,7 +860,7 @@ k_conv_small(const ConvSmallArgs a) {
                 }
             }
         }
-        if (next < tile_end) stash(buf ^ 1);
+        tn = nn; tty = ny; ttx = nx;
         __syncthreads();
     }
 
@@ -799,7 +900,9 @@ bool conv_small_ok(const stcd_conv_geom& g, const ConvMfmaPlan& p) {
     int dymin, dymax, dxmin, dxmax;
     taps_extent(g, &dymin, &dymax, &dxmin, &dxmax);
     const int HH = 7 * g.in_stride + (dymax - dymin) + 1, HWp = 15 * g.in_stride + (dxmax - dxmin) + 1;
-    return ks <= 9 && nt <= 2 && g.ci <= 32 && HH * HWp * (g.ci / 8) <= 3 * 256;
+    // measured: the register-resident filter only pays for one n-tile and <= 5 k-steps (Ci <= 16, Co <= 16);
+    // wider cases run faster on the generic kernel (fewer registers, more waves)
+    return ks <= 5 && nt == 1 && g.ci <= 32 && HH * HWp * (g.ci / 8) <= 3 * 256;
 }
 
 // blocks the launcher will use (the BN-partial slab is sized from this)

@@ -12,6 +12,7 @@ import torch
 from stcd_amd import _lib
 
 DEV = "cuda:0"
+IMPL = 1
 TAPS3 = [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
 DEFAULT = ["c16=32,256,256,16,16", "c8=32,256,256,8,16", "c32=32,128,128,32,32", "c64=32,64,64,64,64", "c128=32,32,32,128,128",
            "d256=16,32,32,256,128", "d32=16,256,256,32,16"]
@@ -43,6 +44,8 @@ def timeit(fn, iters=20):
 def main():
     l = _lib.lib()
     which = os.environ.get("OPBENCH_KIND", "conv,wgrad").split(",")
+    global IMPL
+    IMPL = int(os.environ.get("OPBENCH_IMPL", "1"))
     for case in (sys.argv[1:] or DEFAULT):
         name, spec = case.split("=")
         n, h, w, ci, co = [int(v) for v in spec.split(",")[:5]]
@@ -59,7 +62,7 @@ def main():
         flops = 2.0 * n * h * w * 9 * ci * co
         byts = (n * h * w * (ci + co) + 9 * ci * co) * 2.0
         if "conv" in which:
-            us = timeit(lambda: _lib.check(l.stcd_op_conv(1, 1, C.byref(g), C.c_void_p(x.data_ptr()), C.c_void_p(wt.data_ptr()), None,
+            us = timeit(lambda: _lib.check(l.stcd_op_conv(1, IMPL, C.byref(g), C.c_void_p(x.data_ptr()), C.c_void_p(wt.data_ptr()), None,
                                                          C.c_void_p(out.data_ptr()), C.c_void_p(scratch.data_ptr()), nb, st)))
             print(f"{name:6s} conv  {us:8.1f} us  {flops / us / 1e6:8.1f} TFLOP/s  {byts / us / 1e3:8.1f} GB/s   (incl. filter repack launch)")
         if "wgrad" in which:
