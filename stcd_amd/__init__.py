@@ -5,7 +5,7 @@ host-side mirror of the reference's Python interface for the path (model classes
 ``CDTrainer``).  Importing the package does not touch the GPU or load the library; the first model
 construction does, and raises if the library has not been built.
 """
-__all__ = ["SiamUnet_diff", "SiamUnet_conc", "SiamUnet_sub"]
+__all__ = ["SiamUnet_diff", "SiamUnet_conc", "SiamUnet_sub", "SNUNet_ECAM"]
 
 
 def __getattr__(name):

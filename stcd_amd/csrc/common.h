@@ -174,6 +174,7 @@ struct BnActArgs {
     const float* mask;                      // nullable, [groups*npg][C]
     int C, groups, npg, H, W;
     int relu;                               // 0: affine only
+    const void* res = nullptr; int ldres = 0; // optional residual added before the ReLU (plain [N,HW,ldres] tensor)
 };
 void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s);
 void launch_maxpool(int dt, const void* A, int lda, void* P, int ldp, int N, int H, int W, int C, hipStream_t s);
@@ -193,14 +194,27 @@ void launch_rep_pad_bwd(int dt, void* dD, int ld, int N, int H, int W, int h0, i
 // backward of bn_act (train): dz = dA*mask*(z>0); sums of dz and dz*xhat per (group, channel)
 void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, const void* Y, int ldy, const float* stat,
                           const float* mask, int C, int groups, int npg, int64_t HW, int relu, float* partial,
-                          hipStream_t s);
+                          hipStream_t s, const void* res = nullptr, int ldres = 0);
 // coef fp32 [groups][5][C] = (scale, shift, b, mean, c) with dY = scale*dz + b*(y-mean) + c ; dgamma/dbeta summed over groups
 void launch_bn_bwd_finalize(const float* partial, int nchunk, int C, int groups, int64_t pixels_per_group,
                             const float* stat, float* coef, float* dgamma, float* dbeta, hipStream_t s);
 // dY = scale*(dz - k1 - xhat*k2); dY is a plain tensor and may alias dA when dA is plain too
+// optional: res (residual inside the ReLU gate), dZout (the gated dz is also written: the residual branch's gradient),
+// extra (added to dY: gradient arriving through a residual branch)
 void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
                          const float* stat, const float* coef, const float* mask, int C, int groups, int npg, int64_t HW,
-                         int relu, hipStream_t s);
+                         int relu, hipStream_t s, const void* res = nullptr, int ldres = 0, void* dZout = nullptr,
+                         int lddz = 0, const void* extra = nullptr, int ldex = 0);
+// dst[.., 0:C] (ld ldd) = or += src[.., 0:C] (ld lds): dense concatenation by copy, and its gradient scatter
+void launch_slice(int dt, void* dst, int ldd, const void* src, int lds, int64_t pixels, int C, int accumulate, hipStream_t s);
+// ECAM head of SNUNet (SNUNet.py:46-59,144-149); scratch layouts documented at the kernels (kernels_ew.hip)
+void launch_ecam_forward(int dt, const void* X, int ld, void* Z, int ldz, int N, int64_t HW, int C4, const float* w1a,
+                         const float* w2a, const float* w1b, const float* w2b, float* pool, int64_t* argm, float* att,
+                         float* hid, hipStream_t s);
+void launch_ecam_backward(int dt, const void* X, int ld, const void* dZ, int lddz, void* dX, int lddx, int N, int64_t HW, int C4,
+                          const float* w1a, const float* w2a, const float* w1b, const float* w2b, float* gw1a, float* gw2a,
+                          float* gw1b, float* gw2b, const float* pool, const int64_t* argm, const float* att, const float* hid,
+                          float* sums, float* dpool, hipStream_t s);
 // dA (+)= route(dP) to the first maximum of each 2x2 window of A
 void launch_pool_bwd(int dt, const void* A, int lda, int64_t a_goff, const void* dP, int ldp, void* dA, int ldda,
                      int64_t da_goff, int groups, int npg, int H, int W, int C, int accumulate, hipStream_t s);

@@ -22,7 +22,7 @@ namespace stcd {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
-enum ConvKind { K_CONV3 = 0, K_CONVT3_S1 = 1, K_UPCONV = 2 };
+enum ConvKind { K_CONV3 = 0, K_CONVT3_S1 = 1, K_UPCONV = 2, K_CONV1 = 3, K_CONVT2 = 4 };
 
 struct TRef { int64_t off = -1; int ld = 0; };                 // byte offset in workspace, pixel stride (elements)
 struct GRef { int64_t off = -1; int ld = 0; int64_t goff = 0; }; // grouped view (see common.h)
@@ -94,8 +94,37 @@ struct Prof {
     ~Prof() { for (auto ev : pool) (void)hipEventDestroy(ev); }
 };
 
+// ---- SNUNet-ECAM plan (SNUNet.py:63-152)
+struct SrcSlice { TRef src; TRef dsrc; int C = 0; };        // a producer tensor copied into / scattered from a concat slice
+struct NBlock {                                              // conv_block_nested (SNUNet.py:8-26)
+    std::string name;
+    int c1 = -1, bn1 = -1, c2 = -1, bn2 = -1;
+    int N = 0, H = 0, W = 0, groups = 1, npg = 0, Cin = 0, C = 0;
+    TRef in, dIn;                                            // (concat) input and its gradient; dIn.off < 0: no data gradient
+    std::vector<SrcSlice> srcs;                              // prefix slices copied in; the up-sampled tail is written in place
+    int up = -1;
+    TRef Y1, A1, Y2, Out, P, dOut, dP, dZ2, dA1;
+    bool pool = false;
+    int64_t stat1 = -1, coef1 = -1, stat2 = -1, coef2 = -1;
+    ConvOp f1, f2, d1, d2; WgradOp w1, w2;
+};
+struct SnUp {                                                // up: ConvTranspose2d(C, C, 2, stride=2) (SNUNet.py:29-43)
+    int conv = -1, N = 0, h = 0, w = 0, C = 0;
+    TRef src, dsrc, out, dOut, tmp;                          // out/dOut: tail slice of the consumer's concat buffers
+    ConvOp fwd[4], dgr; WgradOp wg[4];
+};
+
 struct stcd_engine_impl {
     Prof prof;
+    std::vector<NBlock> sn_blocks;
+    std::vector<SnUp> sn_ups;
+    std::vector<int> sn_order;                               // forward order of blocks (index into sn_blocks)
+    int sn_final = -1;
+    int64_t sn_w[4] = {0, 0, 0, 0};                          // ca.fc1, ca.fc2, ca1.fc1, ca1.fc2 offsets in the flat params
+    TRef snE, sndE, snZ, sndZ;
+    int64_t sn_pool = -1, sn_argm = -1, sn_att = -1, sn_hid = -1, sn_sums = -1, sn_dpool = -1;
+    int64_t sn_dout_begin = -1, sn_dout_end = -1;
+    ConvOp sn_final_fwd, sn_final_dgr; WgradOp sn_final_wg;
     int arch = 0, in_ch = 3, label = 2, dt = F32;
     float drop_p = 0.2f;
     std::vector<stcd_tensor_info> params;
@@ -154,6 +183,20 @@ static void add_param(stcd_engine& e, const std::string& name, std::initializer_
 }
 
 static void make_specs(ConvW& c, bool need_dgrad) {
+    if (c.kind == K_CONV1 || c.kind == K_CONVT2) {
+        const int ks = c.kind == K_CONV1 ? 1 : 2;
+        PackSpec& f = c.fwd;
+        f.ks = ks; f.K = c.cin; f.N = c.cout; f.kpad = c.kin_p; f.wld = c.nout_p;
+        f.ntaps = ks * ks;
+        f.kn_major = c.kind == K_CONVT2;              // ConvTranspose2d weights are [Cin][Cout][k][k]
+        for (int t = 0; t < f.ntaps; ++t) { f.ky[t] = t / ks; f.kx[t] = t % ks; }   // K_CONVT2: tap = output phase (py,px)
+        PackSpec& d = c.dgrad;
+        d.ks = ks; d.K = c.cout; d.N = c.cin; d.kpad = c.nout_p; d.wld = round8(c.cin);
+        d.ntaps = need_dgrad ? ks * ks : 0;
+        d.kn_major = c.kind == K_CONV1;
+        for (int t = 0; t < ks * ks; ++t) { d.ky[t] = t / ks; d.kx[t] = t % ks; }   // K_CONVT2: tap (dy,dx) of the stride-2 gather
+        return;
+    }
     PackSpec& f = c.fwd;
     f.ks = 3;
     f.K = c.cin; f.N = c.cout; f.kpad = c.kin_p; f.wld = c.nout_p;
@@ -203,6 +246,8 @@ static int add_conv(stcd_engine& e, const std::string& name, int kind, int cin, 
     c.name = name; c.kind = kind; c.cin = cin; c.cout = cout;
     c.kin_p = round8(cin); c.nout_p = round8(cout);
     if (kind == K_CONV3) add_param(e, name + ".weight", {cout, cin, 3, 3}, &c.w_off);
+    else if (kind == K_CONV1) add_param(e, name + ".weight", {cout, cin, 1, 1}, &c.w_off);
+    else if (kind == K_CONVT2) add_param(e, name + ".weight", {cin, cout, 2, 2}, &c.w_off);
     else add_param(e, name + ".weight", {cin, cout, 3, 3}, &c.w_off);
     add_param(e, name + ".bias", {cout}, &c.b_off);
     make_specs(c, need_dgrad);
@@ -300,6 +345,51 @@ static stcd_conv_geom geom_up_phase(const UpConv& U, int py, int px, int ldi, in
     static const int start[4] = {0, 1, 3, 5};
     *tap0 = start[py * 2 + px];
     return g;
+}
+
+static void build_pack_jobs(stcd_engine& e, Bump& ws) {
+    // ---- one repack launch per forward: job tables (uploaded to the workspace on first use)
+    for (int with_dgrad = 0; with_dgrad < 2; ++with_dgrad) {
+        std::vector<PackJob>& jobs = e.jobs[with_dgrad];
+        jobs.clear();
+        int64_t cur = 0;
+        auto push = [&](PackJob j) { j.start = cur; cur += j.count; jobs.push_back(j); };
+        const bool mfma = e.dt == BF16 && e.use_mfma;
+        if (!mfma) {
+            for (auto& cv : e.convs)
+                for (int d = 0; d <= with_dgrad; ++d) {
+                    const PackSpec& ps = d ? cv.dgrad : cv.fwd;
+                    if (!ps.ntaps) continue;
+                    PackJob j{};
+                    j.kind = 0; j.ps = ps; j.src_off = cv.w_off; j.dst_off = d ? cv.wpk_dgrad : cv.wpk_fwd;
+                    j.count = (int64_t)ps.ntaps * ps.kpad * ps.wld;
+                    push(j);
+                }
+        } else {
+            for (const ConvOp* op : e.conv_ops) {
+                if (op->dgrad && !with_dgrad) continue;
+                const ConvW& cv = e.convs[op->conv];
+                const PackSpec& full = op->dgrad ? cv.dgrad : cv.fwd;
+                PackJob j{};
+                j.ps = full;
+                j.ps.ntaps = op->g.ntaps;
+                for (int t = 0; t < op->g.ntaps; ++t) { j.ps.ky[t] = full.ky[op->tap0 + t]; j.ps.kx[t] = full.kx[op->tap0 + t]; }
+                j.src_off = cv.w_off;
+                if (op->plan.ok && op->wf >= 0) {
+                    j.kind = 1; j.dst_off = op->wf; j.count = op->plan.wf_elems;
+                    j.Ci = op->g.ci; j.Co = op->g.co; j.CiB = op->plan.CiB; j.nchunks = op->plan.nchunks; j.KS = op->plan.KS;
+                    j.NTtot = op->plan.NTtot; j.modeB = op->plan.modeB;
+                } else {   // no MFMA plan for this launch: it runs on the reference kernel and needs the fp32 image
+                    j.kind = 0;
+                    j.dst_off = (op->dgrad ? cv.wpk_dgrad : cv.wpk_fwd) + (int64_t)op->tap0 * full.kpad * full.wld * 4;
+                    j.count = (int64_t)j.ps.ntaps * full.kpad * full.wld;
+                }
+                push(j);
+            }
+        }
+        e.jobs_total[with_dgrad] = cur;
+        e.jobs_off[with_dgrad] = ws.take((int64_t)jobs.size() * sizeof(PackJob) + 16);
+    }
 }
 
 static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
@@ -485,48 +575,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     }
     e.slab = ws.take(e.slab_floats * 4);
 
-    // ---- one repack launch per forward: job tables (uploaded to the workspace on first use)
-    for (int with_dgrad = 0; with_dgrad < 2; ++with_dgrad) {
-        std::vector<PackJob>& jobs = e.jobs[with_dgrad];
-        jobs.clear();
-        int64_t cur = 0;
-        auto push = [&](PackJob j) { j.start = cur; cur += j.count; jobs.push_back(j); };
-        const bool mfma = e.dt == BF16 && e.use_mfma;
-        if (!mfma) {
-            for (auto& cv : e.convs)
-                for (int d = 0; d <= with_dgrad; ++d) {
-                    const PackSpec& ps = d ? cv.dgrad : cv.fwd;
-                    if (!ps.ntaps) continue;
-                    PackJob j{};
-                    j.kind = 0; j.ps = ps; j.src_off = cv.w_off; j.dst_off = d ? cv.wpk_dgrad : cv.wpk_fwd;
-                    j.count = (int64_t)ps.ntaps * ps.kpad * ps.wld;
-                    push(j);
-                }
-        } else {
-            for (const ConvOp* op : e.conv_ops) {
-                if (op->dgrad && !with_dgrad) continue;
-                const ConvW& cv = e.convs[op->conv];
-                const PackSpec& full = op->dgrad ? cv.dgrad : cv.fwd;
-                PackJob j{};
-                j.ps = full;
-                j.ps.ntaps = op->g.ntaps;
-                for (int t = 0; t < op->g.ntaps; ++t) { j.ps.ky[t] = full.ky[op->tap0 + t]; j.ps.kx[t] = full.kx[op->tap0 + t]; }
-                j.src_off = cv.w_off;
-                if (op->plan.ok && op->wf >= 0) {
-                    j.kind = 1; j.dst_off = op->wf; j.count = op->plan.wf_elems;
-                    j.Ci = op->g.ci; j.Co = op->g.co; j.CiB = op->plan.CiB; j.nchunks = op->plan.nchunks; j.KS = op->plan.KS;
-                    j.NTtot = op->plan.NTtot; j.modeB = op->plan.modeB;
-                } else {   // no MFMA plan for this launch: it runs on the reference kernel and needs the fp32 image
-                    j.kind = 0;
-                    j.dst_off = (op->dgrad ? cv.wpk_dgrad : cv.wpk_fwd) + (int64_t)op->tap0 * full.kpad * full.wld * 4;
-                    j.count = (int64_t)j.ps.ntaps * full.kpad * full.wld;
-                }
-                push(j);
-            }
-        }
-        e.jobs_total[with_dgrad] = cur;
-        e.jobs_off[with_dgrad] = ws.take((int64_t)jobs.size() * sizeof(PackJob) + 16);
-    }
+    build_pack_jobs(e, ws);
     e.jobs_uploaded_ws = nullptr;
     e.ws_bytes = ws.cur;
     return 0;
@@ -806,6 +855,421 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
     return 0;
 }
 
+// ================================================================================================ SNUNet-ECAM
+static const int SN_F[5] = {32, 64, 128, 256, 512};
+
+static int add_block_params(stcd_engine& e, const std::string& name, int cin, int c, int calls, bool need_dgrad1, NBlock* b) {
+    b->name = name; b->Cin = cin; b->C = c;
+    b->c1 = add_conv(e, name + ".conv1", K_CONV3, cin, c, need_dgrad1);
+    b->bn1 = add_bn(e, name + ".bn1", c, calls);
+    b->c2 = add_conv(e, name + ".conv2", K_CONV3, c, c, true);
+    b->bn2 = add_bn(e, name + ".bn2", c, calls);
+    return 0;
+}
+
+// registration order of SNUNet_ECAM.__init__ (SNUNet.py:73-106)
+static void build_snunet_tables(stcd_engine& e) {
+    const int* f = SN_F;
+    e.sn_blocks.clear(); e.sn_ups.clear();
+    auto blk = [&](const std::string& n, int cin, int c, int calls, bool dg) {
+        NBlock b; add_block_params(e, n, cin, c, calls, dg, &b); e.sn_blocks.push_back(b);
+    };
+    auto up = [&](const std::string& n, int c) {
+        SnUp u; u.C = c; u.conv = add_conv(e, n + ".up", K_CONVT2, c, c, true); e.sn_ups.push_back(u);
+    };
+    blk("conv0_0", e.in_ch, f[0], 2, false);
+    blk("conv1_0", f[0], f[1], 2, true); up("Up1_0", f[1]);
+    blk("conv2_0", f[1], f[2], 2, true); up("Up2_0", f[2]);
+    blk("conv3_0", f[2], f[3], 2, true); up("Up3_0", f[3]);
+    blk("conv4_0", f[3], f[4], 1, true); up("Up4_0", f[4]);
+    blk("conv0_1", f[0] * 2 + f[1], f[0], 1, true);
+    blk("conv1_1", f[1] * 2 + f[2], f[1], 1, true); up("Up1_1", f[1]);
+    blk("conv2_1", f[2] * 2 + f[3], f[2], 1, true); up("Up2_1", f[2]);
+    blk("conv3_1", f[3] * 2 + f[4], f[3], 1, true); up("Up3_1", f[3]);
+    blk("conv0_2", f[0] * 3 + f[1], f[0], 1, true);
+    blk("conv1_2", f[1] * 3 + f[2], f[1], 1, true); up("Up1_2", f[1]);
+    blk("conv2_2", f[2] * 3 + f[3], f[2], 1, true); up("Up2_2", f[2]);
+    blk("conv0_3", f[0] * 4 + f[1], f[0], 1, true);
+    blk("conv1_3", f[1] * 4 + f[2], f[1], 1, true); up("Up1_3", f[1]);
+    blk("conv0_4", f[0] * 5 + f[1], f[0], 1, true);
+    const int c4 = f[0] * 4, c1 = f[0];
+    add_param(e, "ca.fc1.weight", {c4 / 16, c4, 1, 1}, &e.sn_w[0]);
+    add_param(e, "ca.fc2.weight", {c4, c4 / 16, 1, 1}, &e.sn_w[1]);
+    add_param(e, "ca1.fc1.weight", {c1 / 4, c1, 1, 1}, &e.sn_w[2]);
+    add_param(e, "ca1.fc2.weight", {c1, c1 / 4, 1, 1}, &e.sn_w[3]);
+    e.sn_final = add_conv(e, "conv_final", K_CONV1, c4, e.label, true);
+    e.enc_param_end = 0;      // one backward stage: every gradient is final when stage 0 returns
+}
+
+static int sn_block_index(const stcd_engine& e, const std::string& name) {
+    for (size_t i = 0; i < e.sn_blocks.size(); ++i)
+        if (e.sn_blocks[i].name == name) return (int)i;
+    return -1;
+}
+static int sn_up_index(const stcd_engine& e, const std::string& name) {
+    for (size_t i = 0; i < e.sn_ups.size(); ++i)
+        if (e.convs[e.sn_ups[i].conv].name == name + ".up") return (int)i;
+    return -1;
+}
+
+static stcd_conv_geom geom1(int N, int H, int W, int K, int ldi, int co, int ldo) {   // 1x1
+    stcd_conv_geom g = geom3(N, H, W, K, ldi, co, ldo);
+    g.ntaps = 1; g.dy[0] = 0; g.dx[0] = 0;
+    return g;
+}
+
+static int configure_snunet(stcd_engine& e, int B, int H, int W) {
+    const int64_t T = (int64_t)dsize(e.dt);
+    const int* f = SN_F;
+    e.drops.clear(); e.drop_floats = 0;
+    e.conv_ops.clear(); e.slab_floats = 0;
+    Bump ws;
+    int64_t max_partial = 0;
+    int hs[5], wsz[5];
+    hs[0] = H; wsz[0] = W;
+    for (int l = 0; l < 4; ++l) { hs[l + 1] = hs[l] / 2; wsz[l + 1] = wsz[l] / 2; }
+    auto plain = [&](int N, int h, int w, int C) { TRef t; t.off = ws.take((int64_t)N * h * w * C * T); t.ld = C; return t; };
+    auto B_ = [&](const char* n) -> NBlock& { return e.sn_blocks[sn_block_index(e, n)]; };
+
+    e.X0 = plain(2 * B, H, W, 8);
+    e.G = plain(B, H, W, 8);
+    const int c4 = f[0] * 4;
+    e.snE = plain(B, H, W, c4); e.snZ = plain(B, H, W, c4); e.sndZ = plain(B, H, W, c4);
+
+    // ---- activation buffers of every block.  dOut buffers are allocated back to back: one memset per backward.
+    e.sn_dout_begin = ws.cur;
+    e.sndE = plain(B, H, W, c4);
+    for (auto& b : e.sn_blocks) {
+        const int lvl = b.name[4] - '0', j = b.name[6] - '0';
+        const bool enc = j == 0;
+        b.H = hs[lvl]; b.W = wsz[lvl];
+        b.N = (enc && lvl < 4) ? 2 * B : B;
+        b.groups = (enc && lvl < 4) ? 2 : 1;
+        b.npg = B;
+        if (lvl == 0 && j >= 1) {            // x0_1..x0_4 live directly in the ECAM input (one copy less)
+            b.dOut.off = e.sndE.off + (int64_t)(j - 1) * f[0] * T; b.dOut.ld = c4;
+        } else {
+            b.dOut = plain(b.N, b.H, b.W, b.C);
+        }
+    }
+    e.sn_dout_end = ws.cur;
+    for (auto& b : e.sn_blocks) {
+        const int lvl = b.name[4] - '0', j = b.name[6] - '0';
+        const bool enc = j == 0;
+        if (lvl == 0 && j >= 1) { b.Out.off = e.snE.off + (int64_t)(j - 1) * f[0] * T; b.Out.ld = c4; }
+        else b.Out = plain(b.N, b.H, b.W, b.C);
+        b.Y1 = plain(b.N, b.H, b.W, b.C); b.A1 = plain(b.N, b.H, b.W, b.C); b.Y2 = plain(b.N, b.H, b.W, b.C);
+        b.dZ2 = plain(b.N, b.H, b.W, b.C); b.dA1 = plain(b.N, b.H, b.W, b.C);
+        b.pool = enc && lvl < 4;
+        if (b.pool) { b.P = plain(b.N, b.H / 2, b.W / 2, b.C); b.dP = plain(b.N, b.H / 2, b.W / 2, b.C); }
+        b.stat1 = ws.take((int64_t)b.groups * 4 * b.C * 4); b.coef1 = ws.take((int64_t)b.groups * 5 * b.C * 4);
+        b.stat2 = ws.take((int64_t)b.groups * 4 * b.C * 4); b.coef2 = ws.take((int64_t)b.groups * 5 * b.C * 4);
+        max_partial = std::max<int64_t>(max_partial, (int64_t)b.groups * bn_stats_chunks((int64_t)b.npg * b.H * b.W, b.C) * 2 * b.C);
+    }
+    // ---- inputs
+    for (auto& b : e.sn_blocks) {
+        const int lvl = b.name[4] - '0', j = b.name[6] - '0';
+        b.srcs.clear(); b.up = -1;
+        if (j == 0) {
+            if (lvl == 0) { b.in = e.X0; b.Cin = 8; b.dIn.off = -1; }
+            else {
+                NBlock& prev = e.sn_blocks[sn_block_index(e, std::string("conv") + char('0' + lvl - 1) + "_0")];
+                b.in = prev.P; b.dIn = prev.dP; b.Cin = prev.C;
+                if (lvl == 4) {             // only the B date goes one level deeper (SNUNet.py:123 is commented out)
+                    const int64_t half = (int64_t)B * (prev.H / 2) * (prev.W / 2) * prev.C * T;
+                    b.in.off += half; b.dIn.off += half;
+                }
+            }
+            continue;
+        }
+        b.in = plain(b.N, b.H, b.W, b.Cin); b.dIn = plain(b.N, b.H, b.W, b.Cin);
+        NBlock& enc = e.sn_blocks[sn_block_index(e, std::string("conv") + char('0' + lvl) + "_0")];
+        const int64_t half = (int64_t)B * enc.H * enc.W * enc.C * T;
+        int coff = 0;
+        auto add_src = [&](TRef src, TRef dsrc, int C) {
+            SrcSlice s_; s_.src = src; s_.dsrc = dsrc; s_.C = C; b.srcs.push_back(s_); coff += C;
+        };
+        add_src(enc.Out, enc.dOut, enc.C);                                                 // x{lvl}_0A
+        add_src(TRef{enc.Out.off + half, enc.Out.ld}, TRef{enc.dOut.off + half, enc.dOut.ld}, enc.C);   // x{lvl}_0B
+        for (int k = 1; k < j; ++k) {
+            NBlock& d = e.sn_blocks[sn_block_index(e, std::string("conv") + char('0' + lvl) + "_" + char('0' + k))];
+            add_src(d.Out, d.dOut, d.C);
+        }
+        // up-sampled tail: Up{lvl+1}_{j-1}( x{lvl+1}_{j-1} ), the B date for j == 1
+        const std::string upname = std::string("Up") + char('0' + lvl + 1) + "_" + char('0' + j - 1);
+        b.up = sn_up_index(e, upname);
+        SnUp& u = e.sn_ups[b.up];
+        NBlock& lower = e.sn_blocks[sn_block_index(e, std::string("conv") + char('0' + lvl + 1) + "_" + char('0' + j - 1))];
+        u.N = B; u.h = lower.H; u.w = lower.W;
+        u.src = lower.Out; u.dsrc = lower.dOut;
+        if (j == 1 && lvl + 1 < 4) {        // encoder output of both dates: take the B half
+            const int64_t lh = (int64_t)B * lower.H * lower.W * lower.C * T;
+            u.src.off += lh; u.dsrc.off += lh;
+        }
+        u.out = TRef{b.in.off + (int64_t)coff * T, b.Cin};
+        u.dOut = TRef{b.dIn.off + (int64_t)coff * T, b.Cin};
+        u.tmp = plain(B, u.h, u.w, u.C);
+    }
+    // ---- forward order (SNUNet.py:119-142)
+    static const char* ORDER[] = {"conv0_0", "conv1_0", "conv2_0", "conv3_0", "conv4_0", "conv0_1", "conv1_1", "conv0_2", "conv2_1",
+                                  "conv1_2", "conv0_3", "conv3_1", "conv2_2", "conv1_3", "conv0_4"};
+    e.sn_order.clear();
+    for (auto n : ORDER) e.sn_order.push_back(sn_block_index(e, n));
+
+    e.bn_partial = ws.take(max_partial * 4);
+    e.scratch8 = ws.take(256);
+    e.masks = ws.take(256);
+    e.sn_pool = ws.take((int64_t)B * 4 * c4 * 4); e.sn_argm = ws.take((int64_t)B * 2 * c4 * 8);
+    e.sn_att = ws.take((int64_t)B * 2 * c4 * 4); e.sn_hid = ws.take((int64_t)B * 2 * 2 * 16 * 4);
+    e.sn_sums = ws.take((int64_t)B * 2 * c4 * 4); e.sn_dpool = ws.take((int64_t)B * 4 * c4 * 4);
+    for (auto& c : e.convs) {
+        c.wpk_fwd = ws.take((int64_t)c.fwd.ntaps * c.fwd.kpad * c.fwd.wld * 4);
+        if (c.dgrad.ntaps) c.wpk_dgrad = ws.take((int64_t)c.dgrad.ntaps * c.dgrad.kpad * c.dgrad.wld * 4);
+    }
+    e.dwe_begin = ws.cur;
+    for (auto& c : e.convs) {
+        c.dwe_floats = (int64_t)c.fwd.ntaps * c.fwd.kpad * c.fwd.wld;
+        c.dwe = ws.take(c.dwe_floats * 4);
+    }
+    e.dwe_end = ws.cur;
+
+    auto bind_conv = [&](ConvOp& op, const stcd_conv_geom& g, int conv, bool dgrad, int tap0, int kreal, int nreal) {
+        op.g = g; op.conv = conv; op.dgrad = dgrad; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
+        op.plan = ConvMfmaPlan(); op.wf = -1; op.small = false;
+        if (e.dt == BF16) {
+            op.plan = conv_mfma_plan(g);
+            if (op.plan.ok) op.wf = ws.take(op.plan.wf_elems * 2);
+            op.small = conv_small_ok(g, op.plan);
+        }
+        e.conv_ops.push_back(&op);
+    };
+    auto bind_wgrad = [&](WgradOp& op, const stcd_conv_geom& g, int conv, int tap0, int kreal, int nreal) {
+        op.g = g; op.conv = conv; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
+        op.plan = WgradMfmaPlan();
+        if (e.dt == BF16) {
+            op.plan = wgrad_mfma_plan(g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
+            e.slab_floats = std::max(e.slab_floats, op.plan.slab_floats);
+        }
+    };
+    for (auto& b : e.sn_blocks) {
+        const ConvW& c1 = e.convs[b.c1];
+        const ConvW& c2 = e.convs[b.c2];
+        bind_conv(b.f1, geom3(b.N, b.H, b.W, b.Cin, b.in.ld, b.C, b.Y1.ld), b.c1, false, 0, c1.cin, b.C);
+        bind_wgrad(b.w1, geom3(b.N, b.H, b.W, b.Cin, b.in.ld, b.C, b.dA1.ld), b.c1, 0, c1.cin, b.C);
+        if (b.dIn.off >= 0) bind_conv(b.d1, geom3(b.N, b.H, b.W, c1.dgrad.kpad, b.dA1.ld, c1.cin, b.dIn.ld), b.c1, true, 0, b.C, c1.cin);
+        bind_conv(b.f2, geom3(b.N, b.H, b.W, b.C, b.A1.ld, b.C, b.Y2.ld), b.c2, false, 0, b.C, b.C);
+        bind_wgrad(b.w2, geom3(b.N, b.H, b.W, b.C, b.A1.ld, b.C, b.dOut.ld), b.c2, 0, b.C, b.C);
+        bind_conv(b.d2, geom3(b.N, b.H, b.W, c2.dgrad.kpad, b.dOut.ld, b.C, b.dA1.ld), b.c2, true, 0, b.C, b.C);
+    }
+    for (auto& u : e.sn_ups) {
+        if (u.N == 0) continue;
+        const ConvW& cv = e.convs[u.conv];
+        for (int ph = 0; ph < 4; ++ph) {
+            stcd_conv_geom g;
+            memset(&g, 0, sizeof(g));
+            g.n = u.N; g.hi = u.h; g.wi = u.w; g.ci = u.C; g.ldi = u.src.ld;
+            g.hm = u.h; g.wm = u.w; g.in_stride = 1;
+            g.ho = 2 * u.h; g.wo = 2 * u.w; g.out_stride = 2; g.oy0 = ph >> 1; g.ox0 = ph & 1;
+            g.co = u.C; g.ldo = u.out.ld;
+            g.ntaps = 1; g.dy[0] = 0; g.dx[0] = 0;
+            bind_conv(u.fwd[ph], g, u.conv, false, ph, u.C, u.C);
+            bind_wgrad(u.wg[ph], g, u.conv, ph, u.C, u.C);
+        }
+        stcd_conv_geom gd;
+        memset(&gd, 0, sizeof(gd));
+        gd.n = u.N; gd.hi = 2 * u.h; gd.wi = 2 * u.w; gd.ci = cv.dgrad.kpad; gd.ldi = u.dOut.ld;
+        gd.hm = u.h; gd.wm = u.w; gd.in_stride = 2;
+        gd.ho = u.h; gd.wo = u.w; gd.out_stride = 1;
+        gd.co = u.C; gd.ldo = u.tmp.ld;
+        gd.ntaps = 4;
+        for (int t = 0; t < 4; ++t) { gd.dy[t] = (int8_t)(t >> 1); gd.dx[t] = (int8_t)(t & 1); }
+        bind_conv(u.dgr, gd, u.conv, true, 0, u.C, u.C);
+    }
+    {
+        const ConvW& cv = e.convs[e.sn_final];
+        bind_conv(e.sn_final_fwd, geom1(B, H, W, c4, e.snZ.ld, e.label, e.label), e.sn_final, false, 0, c4, e.label);
+        bind_wgrad(e.sn_final_wg, geom1(B, H, W, c4, e.snZ.ld, e.label, 8), e.sn_final, 0, c4, e.label);
+        bind_conv(e.sn_final_dgr, geom1(B, H, W, cv.dgrad.kpad, 8, c4, e.sndZ.ld), e.sn_final, true, 0, e.label, c4);
+    }
+    e.slab = ws.take(e.slab_floats * 4);
+    build_pack_jobs(e, ws);
+    e.jobs_uploaded_ws = nullptr;
+    e.ws_bytes = ws.cur;
+    return 0;
+}
+
+static void sn_block_forward(const Ctx& c, const NBlock& b, float* bn_running, bool training) {
+    stcd_engine& e = c.e;
+    const int64_t T = (int64_t)dsize(e.dt), px = (int64_t)b.N * b.H * b.W, ppg = (int64_t)b.npg * b.H * b.W;
+    const double act_bytes = (double)px * b.C * (double)T;
+    int coff = 0;
+    for (auto& s_ : b.srcs) {
+        ProfScope ps(c, PC_POOL_FUSE, 0.0, 2.0 * px * s_.C * (double)T);
+        launch_slice(e.dt, c.at<char>(b.in.off) + (int64_t)coff * T, b.in.ld, c.at(s_.src.off), s_.src.ld, px, s_.C, 0, c.s);
+        coff += s_.C;
+    }
+    auto bn_stage = [&](const ConvOp& f, const void* in, int conv, int bni, const TRef& Y, int64_t stat_off) {
+        const ConvW& cv = e.convs[conv];
+        const BnP& bn = e.bns[bni];
+        int fused = 0;
+        exec_conv(c, f, in, c.params + cv.b_off, c.at(Y.off), false, training ? b.groups : 0, &fused);
+        float* stat = c.at<float>(stat_off);
+        if (training) {
+            if (!fused) {
+                ProfScope ps(c, PC_BN_STATS, 0.0, act_bytes);
+                launch_bn_stats(e.dt, c.at(Y.off), Y.ld, b.C, b.groups, ppg, c.at<float>(e.bn_partial), c.s);
+            }
+            launch_bn_finalize(c.at<float>(e.bn_partial), fused ? fused : bn_stats_chunks(ppg, b.C), b.C, b.groups, ppg,
+                               c.params + bn.g_off, c.params + bn.b_off, bn_running + bn.run_off, bn_running + bn.run_off + b.C,
+                               stat, 0.1f, 1e-5f, c.s);
+        } else {
+            launch_bn_eval_prepare(b.C, b.groups, c.params + bn.g_off, c.params + bn.b_off, bn_running + bn.run_off,
+                                   bn_running + bn.run_off + b.C, stat, 1e-5f, c.s);
+        }
+    };
+    bn_stage(b.f1, c.at(b.in.off), b.c1, b.bn1, b.Y1, b.stat1);
+    BnActArgs a;
+    a.Y = c.at(b.Y1.off); a.ldy = b.Y1.ld; a.A = c.at(b.A1.off); a.lda = b.A1.ld; a.a_group_off = ppg * b.A1.ld;
+    a.P = nullptr; a.ldp = 0; a.stat = c.at<float>(b.stat1); a.mask = nullptr;
+    a.C = b.C; a.groups = b.groups; a.npg = b.npg; a.H = b.H; a.W = b.W; a.relu = 1;
+    {
+        ProfScope ps(c, PC_BN_ACT, 0.0, 2.0 * act_bytes);
+        launch_bn_act(e.dt, a, c.s);
+    }
+    bn_stage(b.f2, c.at(b.A1.off), b.c2, b.bn2, b.Y2, b.stat2);
+    a.Y = c.at(b.Y2.off); a.ldy = b.Y2.ld; a.A = c.at(b.Out.off); a.lda = b.Out.ld; a.a_group_off = ppg * b.Out.ld;
+    a.P = b.pool ? c.at(b.P.off) : nullptr; a.ldp = b.P.ld; a.stat = c.at<float>(b.stat2);
+    a.res = c.at(b.Y1.off); a.ldres = b.Y1.ld;        // identity = conv1's raw output (SNUNet.py:19,25)
+    {
+        ProfScope ps(c, PC_BN_ACT, 0.0, (b.pool ? 3.25 : 3.0) * act_bytes);
+        launch_bn_act(e.dt, a, c.s);
+    }
+}
+
+static void sn_block_backward(const Ctx& c, const NBlock& b) {
+    stcd_engine& e = c.e;
+    const int64_t T = (int64_t)dsize(e.dt), HW = (int64_t)b.H * b.W, px = (int64_t)b.N * HW, ppg = (int64_t)b.npg * HW;
+    const double act_bytes = (double)px * b.C * (double)T;
+    float* partial = c.at<float>(e.bn_partial);
+    const BnP& bn1 = e.bns[b.bn1];
+    const BnP& bn2 = e.bns[b.bn2];
+    const int64_t goff_out = ppg * b.dOut.ld, goff_a1 = ppg * b.dA1.ld;
+    // out = relu(bn2(y2) + y1): gate on z2 + y1; dZ2 (gated) is also the gradient of the identity branch
+    {
+        ProfScope ps(c, PC_BN_BWD_REDUCE, 0.0, 3.0 * act_bytes);
+        launch_bn_bwd_reduce(e.dt, c.at(b.dOut.off), b.dOut.ld, goff_out, c.at(b.Y2.off), b.Y2.ld, c.at<float>(b.stat2), nullptr, b.C,
+                             b.groups, b.npg, HW, 1, partial, c.s, c.at(b.Y1.off), b.Y1.ld);
+    }
+    launch_bn_bwd_finalize(partial, bn_stats_chunks(ppg, b.C), b.C, b.groups, ppg, c.at<float>(b.stat2), c.at<float>(b.coef2),
+                           c.grads + bn2.g_off, c.grads + bn2.b_off, c.s);
+    {
+        ProfScope ps(c, PC_BN_BWD_APPLY, 0.0, 5.0 * act_bytes);
+        launch_bn_bwd_apply(e.dt, c.at(b.dOut.off), b.dOut.ld, goff_out, c.at(b.dOut.off), b.dOut.ld, c.at(b.Y2.off), b.Y2.ld,
+                            c.at<float>(b.stat2), c.at<float>(b.coef2), nullptr, b.C, b.groups, b.npg, HW, 1, c.s, c.at(b.Y1.off), b.Y1.ld,
+                            c.at(b.dZ2.off), b.dZ2.ld, nullptr, 0);
+    }
+    exec_wgrad(c, b.w2, c.at(b.A1.off), c.at(b.dOut.off));                   // dOut now holds dY2
+    exec_conv(c, b.d2, c.at(b.dOut.off), nullptr, c.at(b.dA1.off), false);
+    {
+        ProfScope ps(c, PC_BN_BWD_REDUCE, 0.0, 2.0 * act_bytes);
+        launch_bn_bwd_reduce(e.dt, c.at(b.dA1.off), b.dA1.ld, goff_a1, c.at(b.Y1.off), b.Y1.ld, c.at<float>(b.stat1), nullptr, b.C,
+                             b.groups, b.npg, HW, 1, partial, c.s);
+    }
+    launch_bn_bwd_finalize(partial, bn_stats_chunks(ppg, b.C), b.C, b.groups, ppg, c.at<float>(b.stat1), c.at<float>(b.coef1),
+                           c.grads + bn1.g_off, c.grads + bn1.b_off, c.s);
+    {
+        ProfScope ps(c, PC_BN_BWD_APPLY, 0.0, 4.0 * act_bytes);
+        launch_bn_bwd_apply(e.dt, c.at(b.dA1.off), b.dA1.ld, goff_a1, c.at(b.dA1.off), b.dA1.ld, c.at(b.Y1.off), b.Y1.ld,
+                            c.at<float>(b.stat1), c.at<float>(b.coef1), nullptr, b.C, b.groups, b.npg, HW, 1, c.s, nullptr, 0, nullptr, 0,
+                            c.at(b.dZ2.off), b.dZ2.ld);
+    }
+    // conv1's bias reaches the loss only through the identity branch (its BN path has zero gradient): db1 = sum dZ2
+    launch_bias_grad(e.dt, c.at(b.dZ2.off), b.dZ2.ld, px, b.C, c.grads + e.convs[b.c1].b_off, c.s);
+    exec_wgrad(c, b.w1, c.at(b.in.off), c.at(b.dA1.off));                   // dA1 now holds dY1
+    if (b.dIn.off >= 0) exec_conv(c, b.d1, c.at(b.dA1.off), nullptr, c.at(b.dIn.off), false);
+}
+
+static void sn_up_forward(const Ctx& c, const SnUp& u) {
+    const ConvW& cv = c.e.convs[u.conv];
+    for (int ph = 0; ph < 4; ++ph) exec_conv(c, u.fwd[ph], c.at(u.src.off), c.params + cv.b_off, c.at(u.out.off), false);
+}
+static void sn_up_backward(const Ctx& c, const SnUp& u) {
+    stcd_engine& e = c.e;
+    const ConvW& cv = e.convs[u.conv];
+    const int64_t T = (int64_t)dsize(e.dt);
+    launch_bias_grad(e.dt, c.at(u.dOut.off), u.dOut.ld, (int64_t)u.N * 4 * u.h * u.w, u.C, c.grads + cv.b_off, c.s);
+    for (int ph = 0; ph < 4; ++ph) exec_wgrad(c, u.wg[ph], c.at(u.src.off), c.at(u.dOut.off));
+    exec_conv(c, u.dgr, c.at(u.dOut.off), nullptr, c.at(u.tmp.off), false);
+    ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.0 * u.N * u.h * u.w * u.C * (double)T);
+    launch_slice(e.dt, c.at(u.dsrc.off), u.dsrc.ld, c.at(u.tmp.off), u.tmp.ld, (int64_t)u.N * u.h * u.w, u.C, 1, c.s);
+}
+
+static int forward_snunet(stcd_engine& e, const float* x1, const float* x2, const float* params, float* bn_running, int training,
+                          float* logits, void* workspace, hipStream_t s) {
+    Ctx c{e, (char*)workspace, params, nullptr, s};
+    if (pack_all_weights(c, training != 0)) return 1;
+    launch_in_pack(e.dt, x1, x2, c.at(e.X0.off), e.B, e.in_ch, e.H, e.W, s);
+    for (int bi : e.sn_order) {
+        const NBlock& b = e.sn_blocks[bi];
+        if (b.up >= 0) sn_up_forward(c, e.sn_ups[b.up]);
+        sn_block_forward(c, b, bn_running, training != 0);
+    }
+    const int c4 = SN_F[0] * 4;
+    launch_ecam_forward(e.dt, c.at(e.snE.off), e.snE.ld, c.at(e.snZ.off), e.snZ.ld, e.B, (int64_t)e.H * e.W, c4, params + e.sn_w[0],
+                        params + e.sn_w[1], params + e.sn_w[2], params + e.sn_w[3], c.at<float>(e.sn_pool), c.at<int64_t>(e.sn_argm),
+                        c.at<float>(e.sn_att), c.at<float>(e.sn_hid), s);
+    exec_conv(c, e.sn_final_fwd, c.at(e.snZ.off), params + e.convs[e.sn_final].b_off, logits, true);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
+static int backward_snunet(stcd_engine& e, const float* grad_logits, const float* params, float* grads, void* workspace, int stage,
+                           hipStream_t s) {
+    if (stage == 1) return 0;            // single-stage plan: everything is final after stage 0 / -1
+    Ctx c{e, (char*)workspace, params, grads, s};
+    const int dt = e.dt, B = e.B;
+    const int64_t T = (int64_t)dsize(dt);
+    const int c4 = SN_F[0] * 4;
+    STCD_HIP(hipMemsetAsync(grads, 0, e.param_floats * 4, s));
+    if (!mfma_on(e)) STCD_HIP(hipMemsetAsync(c.at(e.dwe_begin), 0, e.dwe_end - e.dwe_begin, s));
+    STCD_HIP(hipMemsetAsync(c.at(e.sn_dout_begin), 0, e.sn_dout_end - e.sn_dout_begin, s));
+    for (auto& b : e.sn_blocks)          // pooled gradients of the A half of conv3_0 never get written (x4_0A does not exist)
+        if (b.pool && b.name == "conv3_0") STCD_HIP(hipMemsetAsync(c.at(b.dP.off), 0, (int64_t)B * (b.H / 2) * (b.W / 2) * b.C * T, s));
+    launch_gout_pack(dt, grad_logits, c.at(e.G.off), B, e.label, e.H, e.W, s);
+    const ConvW& cf = e.convs[e.sn_final];
+    STCD_HIP(hipMemsetAsync(c.at(e.scratch8), 0, 32, s));
+    launch_bias_grad(dt, c.at(e.G.off), 8, (int64_t)B * e.H * e.W, 8, c.at<float>(e.scratch8), s);
+    STCD_HIP(hipMemcpyAsync(grads + cf.b_off, c.at(e.scratch8), (size_t)e.label * 4, hipMemcpyDeviceToDevice, s));
+    exec_wgrad(c, e.sn_final_wg, c.at(e.snZ.off), c.at(e.G.off));
+    exec_conv(c, e.sn_final_dgr, c.at(e.G.off), nullptr, c.at(e.sndZ.off), false);
+    launch_ecam_backward(dt, c.at(e.snE.off), e.snE.ld, c.at(e.sndZ.off), e.sndZ.ld, c.at(e.sndE.off), e.sndE.ld, B, (int64_t)e.H * e.W, c4,
+                         params + e.sn_w[0], params + e.sn_w[1], params + e.sn_w[2], params + e.sn_w[3], grads + e.sn_w[0],
+                         grads + e.sn_w[1], grads + e.sn_w[2], grads + e.sn_w[3], c.at<float>(e.sn_pool), c.at<int64_t>(e.sn_argm),
+                         c.at<float>(e.sn_att), c.at<float>(e.sn_hid), c.at<float>(e.sn_sums), c.at<float>(e.sn_dpool), s);
+    for (int oi = (int)e.sn_order.size() - 1; oi >= 0; --oi) {
+        const NBlock& b = e.sn_blocks[e.sn_order[oi]];
+        if (b.pool) {    // gradient coming back through the 2x2 max-pool of this encoder output
+            ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.25 * b.N * b.H * b.W * b.C * (double)T);
+            const int64_t goff = (int64_t)b.npg * b.H * b.W;
+            launch_pool_bwd(dt, c.at(b.Out.off), b.Out.ld, goff * b.Out.ld, c.at(b.dP.off), b.dP.ld, c.at(b.dOut.off), b.dOut.ld,
+                            goff * b.dOut.ld, b.groups, b.npg, b.H, b.W, b.C, 1, s);
+        }
+        sn_block_backward(c, b);
+        if (b.dIn.off >= 0 && !b.srcs.empty()) {
+            const int64_t px = (int64_t)b.N * b.H * b.W;
+            int coff = 0;
+            for (auto& s_ : b.srcs) {
+                ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.0 * px * s_.C * (double)T);
+                launch_slice(dt, c.at(s_.dsrc.off), s_.dsrc.ld, c.at<char>(b.dIn.off) + (int64_t)coff * T, b.dIn.ld, px, s_.C, 1, s);
+                coff += s_.C;
+            }
+        }
+        if (b.up >= 0) sn_up_backward(c, e.sn_ups[b.up]);
+    }
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace stcd
 
 // ================================================================================================ C ABI
@@ -817,7 +1281,6 @@ int stcd_abi_version(void) { return STCD_ABI_VERSION; }
 int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out) {
     STCD_CHECK(out != nullptr, "out is null");
     STCD_CHECK(arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SNUNET, "unknown arch");
-    STCD_CHECK(arch != STCD_ARCH_SNUNET, "SNUNet plan is built by engine_snunet (not linked in this build)");
     STCD_CHECK(in_ch >= 1 && in_ch <= 8, "in_ch must be in [1,8]");
     STCD_CHECK(label_ch >= 1 && label_ch <= 8, "label_ch must be in [1,8]");
     STCD_CHECK(dtype == STCD_DTYPE_F32 || dtype == STCD_DTYPE_BF16, "unknown dtype");
@@ -827,7 +1290,8 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
     e->use_mfma = !(env && env[0] == '1');
     env = getenv("STCD_NO_SMALL_KERNEL");
     e->use_small = !(env && env[0] == '1');
-    build_fcsiam_tables(*e);
+    if (arch == STCD_ARCH_SNUNET) build_snunet_tables(*e);
+    else build_fcsiam_tables(*e);
     *out = e.release();
     return 0;
 }
@@ -859,7 +1323,10 @@ int stcd_configure(stcd_engine* e, int batch, int height, int width) {
     STCD_CHECK((int64_t)2 * batch * height * width * 16 < ((int64_t)1 << 31), "tensor too large for 32-bit pixel indexing");
     e->configured = false;
     e->B = batch; e->H = height; e->W = width;
-    if (configure_fcsiam(*e, batch, height, width)) return 1;
+    if (e->arch == STCD_ARCH_SNUNET) {
+        STCD_CHECK(height % 16 == 0 && width % 16 == 0, "SNUNet needs height and width divisible by 16 (the reference's cat of up-sampled maps fails otherwise)");
+        if (configure_snunet(*e, batch, height, width)) return 1;
+    } else if (configure_fcsiam(*e, batch, height, width)) return 1;
     e->configured = true;
     e->fwd_training = false;
     return 0;
@@ -889,8 +1356,10 @@ int stcd_forward(stcd_engine* e, const float* x1, const float* x2, const float* 
     STCD_CHECK(e && e->configured, "engine not configured");
     STCD_CHECK(x1 && x2 && params && bn_running && logits && workspace, "null pointer argument");
     e->fwd_training = false;
-    int rc = forward_fcsiam(*e, x1, x2, params, bn_running, dropout_masks, dropout_seed, training, logits, workspace,
-                            (hipStream_t)hip_stream);
+    int rc = e->arch == STCD_ARCH_SNUNET
+                 ? forward_snunet(*e, x1, x2, params, bn_running, training, logits, workspace, (hipStream_t)hip_stream)
+                 : forward_fcsiam(*e, x1, x2, params, bn_running, dropout_masks, dropout_seed, training, logits, workspace,
+                                  (hipStream_t)hip_stream);
     if (rc == 0) e->fwd_training = training != 0;
     return rc;
 }
@@ -901,6 +1370,7 @@ int stcd_backward(stcd_engine* e, const float* grad_logits, const float* params,
     STCD_CHECK(e->fwd_training, "backward requires a preceding training-mode forward on this engine");
     STCD_CHECK(grad_logits && params && grads && workspace, "null pointer argument");
     STCD_CHECK(stage >= -1 && stage <= 1, "stage must be -1, 0 or 1");
+    if (e->arch == STCD_ARCH_SNUNET) return backward_snunet(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
     return backward_fcsiam(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
 }
 

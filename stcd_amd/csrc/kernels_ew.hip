@@ -107,8 +107,8 @@ int bn_stats_chunks(int64_t ppg, int C) {
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256)
 k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, const float* __restrict__ stat,
-            const float* __restrict__ mask, int C, int npg, int64_t HW, int relu, int64_t ppg, int nchunk,
-            float* __restrict__ partial) {
+            const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg, int64_t HW, int relu,
+            int64_t ppg, int nchunk, float* __restrict__ partial) {
     __shared__ float red[256 * 16];
     const int g = blockIdx.y, chunk = blockIdx.x;
     const int cb = C >> 3;                   // channel blocks (power of two, <= 256)
@@ -143,9 +143,12 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
             float d[8];
             load8<T>(dA + g * dav.goff + p * dav.ld + mycb * 8, d);
             const float* mk = mask ? mask + ((int64_t)(g * npg + nig)) * C + mycb * 8 : nullptr;
+            float rs[8];
+            if (res) load8<T>(res + ((int64_t)g * ppg + p) * ldres + mycb * 8, rs);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float z = y[j] * scale[j] + shift[j];
+                if (res) z += rs[j];
                 float dz = d[j] * (mk ? mk[j] : 1.f);
                 if (relu && !(z > 0.f)) dz = 0.f;
                 s1[j] += dz;
@@ -172,14 +175,11 @@ void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t p
     dim3 grid(nchunk, groups);
     GV z{0, 0};
     if (dt == BF16)
-        k_bn_reduce<bf16, 0><<<grid, 256, 0, s>>>((const bf16*)Y, ld, nullptr, z, nullptr, nullptr, C, 0, 1, 0, ppg, nchunk, partial);
+        k_bn_reduce<bf16, 0><<<grid, 256, 0, s>>>((const bf16*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, partial);
     else
-        k_bn_reduce<float, 0><<<grid, 256, 0, s>>>((const float*)Y, ld, nullptr, z, nullptr, nullptr, C, 0, 1, 0, ppg, nchunk, partial);
+        k_bn_reduce<float, 0><<<grid, 256, 0, s>>>((const float*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, partial);
 }
 
-void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, const void* Y, int ldy, const float* stat,
-                          const float* mask, int C, int groups, int npg, int64_t HW, int relu, float* partial,
-                          hipStream_t s);
 
 // sum the per-chunk partials of 16 channels with 16 threads each; result for (group g, which) in sm[..] of part 0
 __device__ __forceinline__ void chunk_sums(const float* __restrict__ partial, int nchunk, int C, int g, int c, int part,
@@ -260,8 +260,8 @@ void launch_bn_eval_prepare(int C, int groups, const float* gamma, const float* 
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restrict__ P, int ldp,
-         const float* __restrict__ stat, const float* __restrict__ mask, int C, int npg, int H, int W, int relu,
-         int64_t total) {
+         const float* __restrict__ stat, const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg,
+         int H, int W, int relu, int64_t total) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
@@ -284,11 +284,13 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
     for (int k = 0; k < 4; ++k) {
         int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
         if (y >= H || x >= W) continue;
-        float v[8];
+        float v[8], rs[8];
         load8<T>(Y + (((int64_t)n * H + y) * W + x) * ldy + c0, v);
+        if (res) load8<T>(res + (((int64_t)n * H + y) * W + x) * ldres + c0, rs);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float z = v[j] * sc[j] + sh[j];
+            if (res) z += rs[j];                 // residual add before the ReLU (SNUNet conv_block_nested, SNUNet.py:25)
             if (relu) z = fmaxf(z, 0.f);
             v[j] = round_as<T>(z * mk[j]);
             best[j] = k == 0 ? v[j] : fmaxf(best[j], v[j]);
@@ -303,10 +305,10 @@ void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s) {
     GV av{a.lda, a.a_group_off};
     if (dt == BF16)
         k_bn_act<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)a.Y, a.ldy, (bf16*)a.A, av, (bf16*)a.P, a.ldp, a.stat,
-                                                        a.mask, a.C, a.npg, a.H, a.W, a.relu, total);
+                                                        a.mask, (const bf16*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total);
     else
         k_bn_act<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)a.Y, a.ldy, (float*)a.A, av, (float*)a.P, a.ldp,
-                                                         a.stat, a.mask, a.C, a.npg, a.H, a.W, a.relu, total);
+                                                         a.stat, a.mask, (const float*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total);
 }
 
 template <typename T>
@@ -480,7 +482,8 @@ __device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
 template <typename T, int PX>
 __global__ void __launch_bounds__(256)
 k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, const T* __restrict__ Y, int ldy,
-               const float* __restrict__ bw, const float* __restrict__ mask, int C, int npg, int64_t HW, int relu,
+               const float* __restrict__ bw, const float* __restrict__ mask, const T* __restrict__ res, int ldres,
+               T* __restrict__ dZout, int lddz, const T* __restrict__ extra, int ldex, int C, int npg, int64_t HW, int relu,
                int64_t total) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -497,15 +500,22 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
     if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
 #pragma unroll
     for (int k = 0; k < PX; ++k) {
-        float y[8], d[8], o[8];
+        float y[8], d[8], o[8], rs[8], dzv[8], ex[8];
         load8<T>(Y + (p0 + k) * ldy + c0, y);
         load8<T>(dA + g * dav.goff + (pig0 + k) * dav.ld + c0, d);
+        if (res) load8<T>(res + (p0 + k) * ldres + c0, rs);
+        if (extra) load8<T>(extra + (p0 + k) * ldex + c0, ex);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float dz = mask ? d[j] * mk[j] : d[j];
-            if (relu && !(y[j] * sc[j] + sh[j] > 0.f)) dz = 0.f;
+            float z = y[j] * sc[j] + sh[j];
+            if (res) z += rs[j];
+            if (relu && !(z > 0.f)) dz = 0.f;
+            dzv[j] = dz;
             o[j] = sc[j] * dz + kb[j] * (y[j] - mu[j]) + kc[j];
+            if (extra) o[j] += ex[j];
         }
+        if (dZout) store8<T>(dZout + (p0 + k) * lddz + c0, dzv);
         store8<T>(dY + (p0 + k) * lddy + c0, o);
     }
 }
@@ -600,6 +610,248 @@ void launch_fill(float* p, int64_t n, float v, hipStream_t s) {
     if (n > 0) k_fill<<<cdiv(n, 256), 256, 0, s>>>(p, n, v);
 }
 
+// ------------------------------------------------------------------ channel-slice copy / accumulate (dense concatenation)
+template <typename T>
+__global__ void k_slice(T* __restrict__ dst, int ldd, const T* __restrict__ src, int lds, int C, int accumulate, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3;
+    const uint32_t iu = (uint32_t)i;
+    const int c0 = (int)(iu % (uint32_t)cb) * 8;
+    const int64_t p = iu / (uint32_t)cb;
+    float v[8];
+    load8<T>(src + p * lds + c0, v);
+    if (accumulate) {
+        float w[8];
+        load8<T>(dst + p * ldd + c0, w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += w[j];
+    }
+    store8<T>(dst + p * ldd + c0, v);
+}
+void launch_slice(int dt, void* dst, int ldd, const void* src, int lds, int64_t pixels, int C, int accumulate, hipStream_t s) {
+    int64_t total = pixels * (C / 8);
+    if (total == 0) return;
+    if (dt == BF16) k_slice<bf16><<<cdiv(total, 256), 256, 0, s>>>((bf16*)dst, ldd, (const bf16*)src, lds, C, accumulate, total);
+    else k_slice<float><<<cdiv(total, 256), 256, 0, s>>>((float*)dst, ldd, (const float*)src, lds, C, accumulate, total);
+}
+
+// ------------------------------------------------------------------ ECAM (SNUNet.py:46-59, :144-149)
+// out = cat(x0_1..x0_4) lives in one [N,HW,4*C1] buffer X (C1 = 32); intra = sum of its four C1-slices.
+// pool[n][0][c] = mean_hw X[n,.,c], pool[n][1][c] = max_hw X[n,.,c]   (c < 4*C1)
+// pool[n][2][c'] = mean_hw intra, pool[n][3][c'] = max_hw intra        (c' < C1)  -- stored at c' of rows 2,3
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_ecam_pool(const T* __restrict__ X, int ld, int64_t HW, int C4, float* __restrict__ pool, int64_t* __restrict__ argm) {
+    // block = (image n, channel c); 256 threads over pixels.  c < C4: plain channel; c >= C4: intra channel c-C4.
+    __shared__ float ssum[256], smax[256];
+    __shared__ int sarg[256];
+    const int n = blockIdx.y, c = blockIdx.x, C1 = C4 / 4;
+    const bool intra = c >= C4;
+    const int cc = intra ? c - C4 : c;
+    float sm = 0.f, mx = -INFINITY;
+    int am = 0;
+    for (int64_t p = threadIdx.x; p < HW; p += 256) {
+        const T* px = X + ((int64_t)n * HW + p) * ld;
+        float v = intra ? ((float)px[cc] + (float)px[cc + C1]) + ((float)px[cc + 2 * C1] + (float)px[cc + 3 * C1]) : (float)px[cc];
+        if (intra) v = round_as<T>(v);        // the oracle materialises `intra` as a tensor of the activation dtype
+        sm += v;
+        if (v > mx) { mx = v; am = (int)p; }
+    }
+    ssum[threadIdx.x] = sm; smax[threadIdx.x] = mx; sarg[threadIdx.x] = am;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            ssum[threadIdx.x] += ssum[threadIdx.x + o];
+            const float m2 = smax[threadIdx.x + o];
+            const int a2 = sarg[threadIdx.x + o];
+            if (m2 > smax[threadIdx.x] || (m2 == smax[threadIdx.x] && a2 < sarg[threadIdx.x])) { smax[threadIdx.x] = m2; sarg[threadIdx.x] = a2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float* pr = pool + (int64_t)n * 4 * C4;
+        pr[(intra ? 2 : 0) * C4 + cc] = ssum[0] / (float)HW;
+        pr[(intra ? 3 : 1) * C4 + cc] = smax[0];
+        argm[(int64_t)n * 2 * C4 + (intra ? C4 : 0) + cc] = sarg[0];
+    }
+}
+
+// att[n][c] = sigmoid(W2 relu(W1 avg) + W2 relu(W1 max)); also keeps the hidden pre-activations for backward.
+// one block per (n, which): which 0 -> ca over C4 channels (hidden C4/16), 1 -> ca1 over C1 channels (hidden C1/4)
+__global__ void k_ecam_mlp(const float* __restrict__ pool, int C4, const float* __restrict__ w1a, const float* __restrict__ w2a,
+                           const float* __restrict__ w1b, const float* __restrict__ w2b, float* __restrict__ att,
+                           float* __restrict__ hid) {
+    const int n = blockIdx.x, which = blockIdx.y, C1 = C4 / 4;
+    const int C = which ? C1 : C4, Hd = which ? C1 / 4 : C4 / 16;
+    const float* w1 = which ? w1b : w1a;     // [Hd][C]
+    const float* w2 = which ? w2b : w2a;     // [C][Hd]
+    const float* avg = pool + (int64_t)n * 4 * C4 + (which ? 2 : 0) * C4;
+    const float* mx = avg + C4;
+    __shared__ float h[2][16];
+    float* hrow = hid + ((int64_t)n * 2 + which) * 2 * 16;
+    if ((int)threadIdx.x < 2 * Hd) {
+        const int k = threadIdx.x % Hd, src = threadIdx.x / Hd;
+        const float* v = src ? mx : avg;
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a += w1[k * C + c] * v[c];
+        hrow[src * 16 + k] = a;             // pre-ReLU
+        h[src][k] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float o = 0.f;
+        for (int k = 0; k < Hd; ++k) o += w2[c * Hd + k] * (h[0][k] + h[1][k]);
+        att[((int64_t)n * 2 + which) * C4 + c] = 1.f / (1.f + expf(-o));
+    }
+}
+
+// Z[n,p,c] = ca[n,c] * (X[n,p,c] + ca1[n, c % C1])
+template <typename T>
+__global__ void k_ecam_apply(const T* __restrict__ X, int ld, T* __restrict__ Z, int ldz, const float* __restrict__ att, int64_t HW,
+                             int C4, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C4 >> 3, C1 = C4 / 4;
+    const uint32_t iu = (uint32_t)i;
+    const int c0 = (int)(iu % (uint32_t)cb) * 8;
+    const int64_t p = iu / (uint32_t)cb;
+    const int n = (int)((uint32_t)p / (uint32_t)HW);
+    const float* ca = att + (int64_t)n * 2 * C4, *ca1 = ca + C4;
+    float x[8], z[8];
+    load8<T>(X + p * ld + c0, x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = ca[c0 + j] * (x[j] + ca1[(c0 + j) % C1]);
+    store8<T>(Z + p * ldz + c0, z);
+}
+
+// backward, pass 1: dX = ca * dZ (written), and per-(n,c) sums  S1[c] = sum_p dZ*(X + ca1)  (-> d ca),
+// S2[c] = sum_p dZ*ca (-> d ca1 after folding the 4 slices).  block = (n, channel block of 8), threads over pixels.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_ecam_bwd1(const T* __restrict__ X, int ld, const T* __restrict__ dZ, int lddz, T* __restrict__ dX, int lddx,
+            const float* __restrict__ att, int64_t HW, int C4, float* __restrict__ sums) {
+    __shared__ float red[256 * 16];
+    const int n = blockIdx.y, c0 = blockIdx.x * 8, C1 = C4 / 4;
+    const float* ca = att + (int64_t)n * 2 * C4, *ca1 = ca + C4;
+    float s1[8], s2[8], cav[8], c1v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = s2[j] = 0.f; cav[j] = ca[c0 + j]; c1v[j] = ca1[(c0 + j) % C1]; }
+    for (int64_t p = threadIdx.x; p < HW; p += 256) {
+        const int64_t q = (int64_t)n * HW + p;
+        float x[8], g[8], o[8];
+        load8<T>(X + q * ld + c0, x);
+        load8<T>(dZ + q * lddz + c0, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[j] = cav[j] * g[j]; s1[j] += g[j] * (x[j] + c1v[j]); s2[j] += o[j]; }
+        store8<T>(dX + q * lddx + c0, o);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s1[j]; red[threadIdx.x * 16 + 8 + j] = s2[j]; }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float a = 0.f;
+        for (int l = 0; l < 256; ++l) a += red[l * 16 + threadIdx.x];
+        sums[((int64_t)n * 2 + (threadIdx.x >> 3)) * C4 + c0 + (threadIdx.x & 7)] = a;
+    }
+}
+
+// backward of the two channel-attention MLPs: from d att (= S1 for ca; folded S2 for ca1) to d avg / d max per channel
+// and the fc weight gradients (accumulated over n with atomics: tiny).  One block per (n, which).
+__global__ void k_ecam_mlp_bwd(const float* __restrict__ pool, const float* __restrict__ att, const float* __restrict__ hid,
+                               const float* __restrict__ sums, int C4, const float* __restrict__ w1a, const float* __restrict__ w2a,
+                               const float* __restrict__ w1b, const float* __restrict__ w2b, float* __restrict__ gw1a,
+                               float* __restrict__ gw2a, float* __restrict__ gw1b, float* __restrict__ gw2b,
+                               float* __restrict__ dpool) {
+    const int n = blockIdx.x, which = blockIdx.y, C1 = C4 / 4;
+    const int C = which ? C1 : C4, Hd = which ? C1 / 4 : C4 / 16;
+    const float* w1 = which ? w1b : w1a; const float* w2 = which ? w2b : w2a;
+    float* gw1 = which ? gw1b : gw1a; float* gw2 = which ? gw2b : gw2a;
+    const float* avg = pool + (int64_t)n * 4 * C4 + (which ? 2 : 0) * C4;
+    const float* mx = avg + C4;
+    const float* a = att + ((int64_t)n * 2 + which) * C4;
+    const float* hrow = hid + ((int64_t)n * 2 + which) * 2 * 16;
+    __shared__ float dpre[512];      // d(pre-sigmoid) per channel
+    __shared__ float dh[2][16];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float datt;
+        if (!which) datt = sums[((int64_t)n * 2 + 0) * C4 + c];
+        else datt = sums[((int64_t)n * 2 + 1) * C4 + c] + sums[((int64_t)n * 2 + 1) * C4 + c + C1] +
+                    sums[((int64_t)n * 2 + 1) * C4 + c + 2 * C1] + sums[((int64_t)n * 2 + 1) * C4 + c + 3 * C1];
+        dpre[c] = datt * a[c] * (1.f - a[c]);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * Hd) {
+        const int k = threadIdx.x % Hd, src = threadIdx.x / Hd;
+        float g = 0.f;
+        for (int c = 0; c < C; ++c) g += dpre[c] * w2[c * Hd + k];
+        dh[src][k] = hrow[src * 16 + k] > 0.f ? g : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float da = 0.f, dm = 0.f;
+        for (int k = 0; k < Hd; ++k) {
+            da += dh[0][k] * w1[k * C + c];
+            dm += dh[1][k] * w1[k * C + c];
+            atomicAdd(&gw2[c * Hd + k], dpre[c] * (fmaxf(hrow[k], 0.f) + fmaxf(hrow[16 + k], 0.f)));
+            atomicAdd(&gw1[k * C + c], dh[0][k] * avg[c] + dh[1][k] * mx[c]);
+        }
+        dpool[((int64_t)n * 4 + (which ? 2 : 0)) * C4 + c] = da;
+        dpool[((int64_t)n * 4 + (which ? 3 : 1)) * C4 + c] = dm;
+    }
+}
+
+// backward, pass 2: dX[n,p,c] += davg[c]/HW + [p == argmax_c] dmax[c]  + (same through intra: channel c % C1)
+template <typename T>
+__global__ void k_ecam_bwd2(T* __restrict__ dX, int lddx, const float* __restrict__ dpool, const int64_t* __restrict__ argm, int64_t HW,
+                            int C4, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C4 >> 3, C1 = C4 / 4;
+    const uint32_t iu = (uint32_t)i;
+    const int c0 = (int)(iu % (uint32_t)cb) * 8;
+    const int64_t q = iu / (uint32_t)cb;
+    const int n = (int)((uint32_t)q / (uint32_t)HW);
+    const int64_t p = q - (int64_t)n * HW;
+    const float* dp = dpool + (int64_t)n * 4 * C4;
+    const int64_t* am = argm + (int64_t)n * 2 * C4;
+    const float inv = 1.f / (float)HW;
+    float v[8];
+    load8<T>(dX + q * lddx + c0, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j, c1 = c % C1;
+        float add = dp[c] * inv + (am[c] == p ? dp[C4 + c] : 0.f);
+        add += dp[2 * C4 + c1] * inv + (am[C4 + c1] == p ? dp[3 * C4 + c1] : 0.f);
+        v[j] += add;
+    }
+    store8<T>(dX + q * lddx + c0, v);
+}
+
+void launch_ecam_forward(int dt, const void* X, int ld, void* Z, int ldz, int N, int64_t HW, int C4, const float* w1a,
+                         const float* w2a, const float* w1b, const float* w2b, float* pool, int64_t* argm, float* att,
+                         float* hid, hipStream_t s) {
+    dim3 g1(C4 + C4 / 4, N);
+    if (dt == BF16) k_ecam_pool<bf16><<<g1, 256, 0, s>>>((const bf16*)X, ld, HW, C4, pool, argm);
+    else k_ecam_pool<float><<<g1, 256, 0, s>>>((const float*)X, ld, HW, C4, pool, argm);
+    k_ecam_mlp<<<dim3(N, 2), 128, 0, s>>>(pool, C4, w1a, w2a, w1b, w2b, att, hid);
+    int64_t total = (int64_t)N * HW * (C4 / 8);
+    if (dt == BF16) k_ecam_apply<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)X, ld, (bf16*)Z, ldz, att, HW, C4, total);
+    else k_ecam_apply<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)X, ld, (float*)Z, ldz, att, HW, C4, total);
+}
+void launch_ecam_backward(int dt, const void* X, int ld, const void* dZ, int lddz, void* dX, int lddx, int N, int64_t HW, int C4,
+                          const float* w1a, const float* w2a, const float* w1b, const float* w2b, float* gw1a, float* gw2a,
+                          float* gw1b, float* gw2b, const float* pool, const int64_t* argm, const float* att, const float* hid,
+                          float* sums, float* dpool, hipStream_t s) {
+    dim3 g1(C4 / 8, N);
+    if (dt == BF16) k_ecam_bwd1<bf16><<<g1, 256, 0, s>>>((const bf16*)X, ld, (const bf16*)dZ, lddz, (bf16*)dX, lddx, att, HW, C4, sums);
+    else k_ecam_bwd1<float><<<g1, 256, 0, s>>>((const float*)X, ld, (const float*)dZ, lddz, (float*)dX, lddx, att, HW, C4, sums);
+    k_ecam_mlp_bwd<<<dim3(N, 2), 128, 0, s>>>(pool, att, hid, sums, C4, w1a, w2a, w1b, w2b, gw1a, gw2a, gw1b, gw2b, dpool);
+    int64_t total = (int64_t)N * HW * (C4 / 8);
+    if (dt == BF16) k_ecam_bwd2<bf16><<<cdiv(total, 256), 256, 0, s>>>((bf16*)dX, lddx, dpool, argm, HW, C4, total);
+    else k_ecam_bwd2<float><<<cdiv(total, 256), 256, 0, s>>>((float*)dX, lddx, dpool, argm, HW, C4, total);
+}
+
 // ------------------------------------------------------------------ typed launch wrappers using grouped views
 #define DISPATCH(dt, KERNEL, ...)                          \
     do {                                                   \
@@ -609,25 +861,26 @@ void launch_fill(float* p, int64_t n, float v, hipStream_t s) {
 
 void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, const void* Y, int ldy, const float* stat,
                           const float* mask, int C, int groups, int npg, int64_t HW, int relu, float* partial,
-                          hipStream_t s) {
+                          hipStream_t s, const void* res, int ldres) {
     int64_t ppg = (int64_t)npg * HW;
     int nchunk = bn_stats_chunks(ppg, C);
     dim3 grid(nchunk, groups);
     GV dav{ldda, da_goff};
     if (dt == BF16)
-        k_bn_reduce<bf16, 1><<<grid, 256, 0, s>>>((const bf16*)Y, ldy, (const bf16*)dA, dav, stat, mask, C, npg, HW, relu, ppg, nchunk, partial);
+        k_bn_reduce<bf16, 1><<<grid, 256, 0, s>>>((const bf16*)Y, ldy, (const bf16*)dA, dav, stat, mask, (const bf16*)res, ldres, C, npg, HW, relu, ppg, nchunk, partial);
     else
-        k_bn_reduce<float, 1><<<grid, 256, 0, s>>>((const float*)Y, ldy, (const float*)dA, dav, stat, mask, C, npg, HW, relu, ppg, nchunk, partial);
+        k_bn_reduce<float, 1><<<grid, 256, 0, s>>>((const float*)Y, ldy, (const float*)dA, dav, stat, mask, (const float*)res, ldres, C, npg, HW, relu, ppg, nchunk, partial);
 }
 
 void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
                          const float* stat, const float* coef, const float* mask, int C, int groups, int npg, int64_t HW,
-                         int relu, hipStream_t s) {
+                         int relu, hipStream_t s, const void* res, int ldres, void* dZout, int lddz, const void* extra,
+                         int ldex) {
     GV dav{ldda, da_goff};
     (void)stat;
     const int px = (HW % 4 == 0) ? 4 : 1;        // odd-sized maps (ReplicationPad2d branch): one pixel per thread
     int64_t total = (int64_t)groups * npg * HW / px * (C / 8);
-#define BWD_APPLY(T_, PX_) k_bn_bwd_apply<T_, PX_><<<cdiv(total, 256), 256, 0, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, coef, mask, C, npg, HW, relu, total)
+#define BWD_APPLY(T_, PX_) k_bn_bwd_apply<T_, PX_><<<cdiv(total, 256), 256, 0, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, coef, mask, (const T_*)res, ldres, (T_*)dZout, lddz, (const T_*)extra, ldex, C, npg, HW, relu, total)
     if (dt == BF16) { if (px == 4) BWD_APPLY(bf16, 4); else BWD_APPLY(bf16, 1); }
     else { if (px == 4) BWD_APPLY(float, 4); else BWD_APPLY(float, 1); }
 #undef BWD_APPLY

@@ -261,3 +261,89 @@ class SiamUnet_sub(_FCSiam):
     """Signed skips f2 - f1; returns a one-element list like the reference (SiamUnet_sub.py:150,177-180)."""
     ARCH = "sub"
     RETURNS_LIST = True
+
+
+class _NestedBlockHolder(nn.Module):
+    """Parameter holder with the reference's names: conv_block_nested (SNUNet.py:8-16)."""
+
+    def __init__(self, in_ch, mid_ch, out_ch):
+        super().__init__()
+        self.activation = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(in_ch, mid_ch, kernel_size=3, padding=1, bias=True)
+        self.bn1 = nn.BatchNorm2d(mid_ch)
+        self.conv2 = nn.Conv2d(mid_ch, out_ch, kernel_size=3, padding=1, bias=True)
+        self.bn2 = nn.BatchNorm2d(out_ch)
+
+
+class _UpHolder(nn.Module):
+    """up (SNUNet.py:29-38): ConvTranspose2d(C, C, 2, stride=2)."""
+
+    def __init__(self, in_ch):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(in_ch, in_ch, 2, stride=2)
+
+
+class _ChannelAttentionHolder(nn.Module):
+    """ChannelAttention (SNUNet.py:46-54): two bias-free 1x1 convs."""
+
+    def __init__(self, in_channels, ratio=16):
+        super().__init__()
+        self.fc1 = nn.Conv2d(in_channels, in_channels // ratio, 1, bias=False)
+        self.fc2 = nn.Conv2d(in_channels // ratio, in_channels, 1, bias=False)
+
+
+class SNUNet_ECAM(HipChangeDetector):
+    """SNUNet-CD with ECAM (SNUNet.py:63-152): SNUNet_ECAM(in_ch=3, out_ch=1).forward(xA, xB) -> logits tensor.
+    Same parameter names / registration order / default initialisation (kaiming fan_out for Conv2d, BN 1/0,
+    SNUNet.py:108-113) as the reference."""
+
+    ARCH = "snunet"
+
+    def __init__(self, in_ch=3, out_ch=1, dtype: Optional[str] = None):
+        super().__init__(in_ch, out_ch, dtype)
+        n1 = 32
+        f = [n1, n1 * 2, n1 * 4, n1 * 8, n1 * 16]
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.conv0_0 = _NestedBlockHolder(in_ch, f[0], f[0])
+        self.conv1_0 = _NestedBlockHolder(f[0], f[1], f[1])
+        self.Up1_0 = _UpHolder(f[1])
+        self.conv2_0 = _NestedBlockHolder(f[1], f[2], f[2])
+        self.Up2_0 = _UpHolder(f[2])
+        self.conv3_0 = _NestedBlockHolder(f[2], f[3], f[3])
+        self.Up3_0 = _UpHolder(f[3])
+        self.conv4_0 = _NestedBlockHolder(f[3], f[4], f[4])
+        self.Up4_0 = _UpHolder(f[4])
+        self.conv0_1 = _NestedBlockHolder(f[0] * 2 + f[1], f[0], f[0])
+        self.conv1_1 = _NestedBlockHolder(f[1] * 2 + f[2], f[1], f[1])
+        self.Up1_1 = _UpHolder(f[1])
+        self.conv2_1 = _NestedBlockHolder(f[2] * 2 + f[3], f[2], f[2])
+        self.Up2_1 = _UpHolder(f[2])
+        self.conv3_1 = _NestedBlockHolder(f[3] * 2 + f[4], f[3], f[3])
+        self.Up3_1 = _UpHolder(f[3])
+        self.conv0_2 = _NestedBlockHolder(f[0] * 3 + f[1], f[0], f[0])
+        self.conv1_2 = _NestedBlockHolder(f[1] * 3 + f[2], f[1], f[1])
+        self.Up1_2 = _UpHolder(f[1])
+        self.conv2_2 = _NestedBlockHolder(f[2] * 3 + f[3], f[2], f[2])
+        self.Up2_2 = _UpHolder(f[2])
+        self.conv0_3 = _NestedBlockHolder(f[0] * 4 + f[1], f[0], f[0])
+        self.conv1_3 = _NestedBlockHolder(f[1] * 4 + f[2], f[1], f[1])
+        self.Up1_3 = _UpHolder(f[1])
+        self.conv0_4 = _NestedBlockHolder(f[0] * 5 + f[1], f[0], f[0])
+        self.ca = _ChannelAttentionHolder(f[0] * 4, ratio=16)
+        self.ca1 = _ChannelAttentionHolder(f[0], ratio=16 // 4)
+        self.conv_final = nn.Conv2d(f[0] * 4, out_ch, kernel_size=1)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self._check_layout()
+
+    def __deepcopy__(self, memo):
+        new = type(self)(self._engine.in_ch, self._engine.label_ch, self._engine.dtype)
+        new.load_state_dict({k: v.detach().clone() for k, v in self.state_dict().items()})
+        new.train(self.training)
+        if self._flat_params is not None:
+            new.to(self._flat_params.device)
+        return new

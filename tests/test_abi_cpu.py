@@ -72,3 +72,19 @@ def test_error_reporting_through_the_abi():
     assert l.stcd_configure(h, 1, 8, 8) != 0 and b">= 16" in l.stcd_last_error()
     assert l.stcd_configure(h, 2, 100, 100) == 0 and l.stcd_workspace_bytes(h) > 0
     l.stcd_destroy(h)
+
+
+def test_snunet_state_dict_layout_is_the_reference_layout():
+    from oracle import snunet_ref as S
+    from stcd_amd.modules import SNUNet_ECAM
+
+    for label in (1, 2):
+        m = SNUNet_ECAM(3, label)
+        sd = m.state_dict()
+        specs = S.param_specs(3, label)           # pinned against the reference by tests/golden (oracle tests)
+        assert list(sd.keys()) == [n for n, _, _ in specs] and len(sd) == 236
+        for (n, shape, _), v in zip(specs, sd.values()):
+            assert tuple(v.shape) == tuple(shape), n
+        st = S.synth_state(3, label, seed=3, perturb_running=True)
+        m.load_state_dict(st, strict=True)
+        assert all(torch.equal(v, st[k]) for k, v in m.state_dict().items())
