@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub"])
+    ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub", "snunet"])
     ap.add_argument("--batch", type=int, default=16, help="image pairs per GPU per step")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -51,28 +51,30 @@ def parse():
 def cpu_baseline(arch, label, size, pairs, steps):
     """The oracle timed on the host: same step (fwd + CE + bwd + AdamW), fp32, all host threads."""
     from oracle import fcsiam_ref as R
+    from oracle import snunet_ref as SN
     from stcd_amd import synth
 
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(ncpu, int(os.environ.get("STCD_CPU_THREADS", "16")))))
     a, b, lab = synth.make_batch(pairs, size, size, seed=1337)
     A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab)
-    st = R.synth_state(arch, 3, label, seed=1)
+    st = SN.synth_state(3, label, seed=1) if arch == "snunet" else R.synth_state(arch, 3, label, seed=1)
     params = [v.requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
     opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
-    masks = R.synth_masks(arch, pairs, seed=2)
+    masks = None if arch == "snunet" else R.synth_masks(arch, pairs, seed=2)
     times = []
     for i in range(steps + 1):
         t0 = time.perf_counter()
         opt.zero_grad()
-        loss = R.cross_entropy(R.forward(arch, st, A, B, training=True, masks=masks), L)
+        out = SN.forward(st, A, B, training=True) if arch == "snunet" else R.forward(arch, st, A, B, training=True, masks=masks)
+        loss = R.cross_entropy(out, L)
         loss.backward()
         opt.step()
         if i > 0:
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     return {"value": round(pairs / med, 3), "unit": "image-pairs/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/fcsiam_ref.py SiamUnet_{arch}(3,{label}) fp32, {pairs} pairs {size}x{size}, "
+            "sample": f"oracle/{'snunet_ref.py SNUNet_ECAM' if arch == 'snunet' else 'fcsiam_ref.py SiamUnet_' + arch}(3,{label}) fp32, {pairs} pairs {size}x{size}, "
                       f"median of {steps} full steps after 1 warm-up ({med * 1e3:.0f} ms/step)"}
 
 
@@ -81,13 +83,13 @@ def main():
     from stcd_amd import synth
     from stcd_amd.ddp import FlatGradReducer, broadcast_parameters, init_distributed
     from stcd_amd.losses import bce_dice_with_logits, cross_entropy
-    from stcd_amd.modules import SiamUnet_conc, SiamUnet_diff, SiamUnet_sub
+    from stcd_amd.modules import SiamUnet_conc, SiamUnet_diff, SiamUnet_sub, SNUNet_ECAM
 
     rank, local_rank, world = init_distributed()
     assert world == args.gpus or world == 1 and args.gpus == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU fallback"
     dev = torch.device("cuda", local_rank)
-    cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub}[args.model]
+    cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub, "snunet": SNUNet_ECAM}[args.model]
 
     torch.manual_seed(1337)
     model = cls(3, args.label, dtype=args.dtype).to(dev).train()
@@ -130,14 +132,14 @@ def main():
 
     result = {
         "metric": "image-pairs/sec (256x256 bf16 SiamUnet_diff train)" if (args.model, args.size, args.dtype) == ("diff", 256, "bf16")
-        else f"image-pairs/sec ({args.size}x{args.size} {args.dtype} SiamUnet_{args.model} train)",
+        else f"image-pairs/sec ({args.size}x{args.size} {args.dtype} {'SNUNet_ECAM' if args.model == 'snunet' else 'SiamUnet_' + args.model} train)",
         "value": round(world * args.batch * args.steps / elapsed, 2),
         "unit": "image-pairs/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"SiamUnet_{args.model}(3,{args.label}) {args.size}x{args.size} full training step "
+        "config": {"workload": f"{'SNUNet_ECAM' if args.model == 'snunet' else 'SiamUnet_' + args.model}(3,{args.label}) {args.size}x{args.size} full training step "
                                f"(fwd + {'cross_entropy' if args.label == 2 else 'sigmoid+cd_loss'} + bwd + AdamW), "
                                f"{args.batch} pairs/GPU, synthetic LEVIR-CD-shaped pairs resident in HBM",
                    "global_batch": world * args.batch, "image": args.size, "parallelism": f"dp{world}",
