@@ -121,6 +121,10 @@ int stcd_grad_stage_range(const stcd_engine* e, int stage, int64_t* begin, int64
 #define STCD_PROFILE_CLASSES 8
 int stcd_profile_enable(stcd_engine* e, int on);
 int stcd_profile_read(stcd_engine* e, int klass, double* total_ms, int64_t* launches, double* flops, double* bytes);
+/* the same records grouped by kernel NAME (a substring of the name rocprofv3 prints, e.g. "k_conv_mfma<4>") */
+int stcd_profile_num_kernels(const stcd_engine* e);
+int stcd_profile_kernel(stcd_engine* e, int i, char* name, int name_cap, double* total_ms, int64_t* launches, double* flops,
+                        double* bytes);
 
 /* ---- losses, fused forward+backward: replace cross_entropy (losses.py:6-21) and
  *      cd_loss(sigmoid(x),y) == BCE_DICE (losses.py:24-34; train_pse_cd.py:227-228,436-462) ----

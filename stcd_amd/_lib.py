@@ -66,6 +66,8 @@ _PROTOS = {
     "stcd_grad_stage_range": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "stcd_profile_enable": (_i, [_vp, _i]),
     "stcd_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "stcd_profile_num_kernels": (_i, [_vp]),
+    "stcd_profile_kernel": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "stcd_loss_scratch_bytes": (_i64, []),
     "stcd_loss_ce": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "stcd_loss_bce_dice": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),

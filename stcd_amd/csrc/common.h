@@ -125,6 +125,18 @@ WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld);
 int launch_wgrad_mfma(const stcd_conv_geom& g, const WgradMfmaPlan& p, const void* in, const void* dout, float* slab,
                       int kpad, int wld, hipStream_t s);
 struct PackSpec;
+// Batched slab reduction: ONE launch per backward stage sums every weight-gradient launch's K-split slabs straight
+// into the reference-layout gradient tensors (device job table built at configure time).
+struct ReduceJob {
+    int64_t start, count;      // range in the launch's global index space (count = outputs * 16 lanes)
+    int64_t slab_off;          // byte offset of this launch's slabs in the workspace
+    int64_t out_off;           // float offset of the filter in the flat gradient buffer
+    int64_t slab_stride;       // floats between consecutive slabs
+    int gx, ntaps, K, N, kpad, wld;
+    int ks, kn_major;          // reference index map of the launch's taps (as PackSpec)
+    int8_t ky[9], kx[9];
+};
+void launch_reduce_jobs(const ReduceJob* jobs_dev, int njobs, int64_t total, const char* ws, float* grads, hipStream_t s);
 // out = sum of the gx slabs; ps == nullptr: engine layout [tap][kpad][wld], else scattered into the reference layout
 void launch_reduce_dw(const float* slab, int gx, const stcd_conv_geom& g, int K, int N, int kpad, int wld,
                       const PackSpec* ps, float* out, hipStream_t s);

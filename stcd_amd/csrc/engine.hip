@@ -59,6 +59,8 @@ struct WgradOp {
     stcd_conv_geom g{};
     int conv = -1, tap0 = 0, kreal = 0, nreal = 0;
     WgradMfmaPlan plan;
+    int64_t slab = -1;                   // this launch's own K-split slabs (reduced in one batched launch per stage)
+    int stage = 0;
 };
 
 struct Cbrd {                         // conv -> BN -> ReLU -> Dropout2d [-> pool]
@@ -81,12 +83,19 @@ struct UpConv {
 //      roofline measurement; off by default, adds nothing to the normal path)
 enum ProfClass { PC_CONV = 0, PC_WGRAD = 1, PC_BN_STATS = 2, PC_BN_ACT = 3, PC_BN_BWD_REDUCE = 4, PC_BN_BWD_APPLY = 5,
                  PC_POOL_FUSE = 6, PC_PACK = 7, PC_COUNT = 8 };
-struct ProfRec { hipEvent_t a, b; int klass; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int klass; int name_id; double flops, bytes; };
 struct Prof {
     bool on = false;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
+    std::vector<std::string> names;      // kernel names as rocprofv3 prints them (substring), interned
     size_t used = 0;
+    int intern(const std::string& n) {
+        for (size_t i = 0; i < names.size(); ++i)
+            if (names[i] == n) return (int)i;
+        names.push_back(n);
+        return (int)names.size() - 1;
+    }
     hipEvent_t get() {
         if (used == pool.size()) { hipEvent_t ev; (void)hipEventCreate(&ev); pool.push_back(ev); }
         return pool[used++];
@@ -144,6 +153,9 @@ struct stcd_engine_impl {
     ConvOp final_fwd, final_dgr; WgradOp final_wg;
     std::vector<ConvOp*> conv_ops;      // every ConvOp of the plan (weight-image packing walks this)
     int64_t slab = -1, slab_floats = 0;
+    std::vector<WgradOp*> wgrad_ops;                    // every WgradOp of the plan
+    std::vector<ReduceJob> rjobs[2];                    // per backward stage
+    int64_t rjobs_total[2] = {0, 0}, rjobs_off[2] = {-1, -1};
     // batched filter repacking: [0] = forward-only job list (eval), [1] = forward + data-gradient filters (training)
     std::vector<PackJob> jobs[2];
     int64_t jobs_total[2] = {0, 0}, jobs_off[2] = {-1, -1};
@@ -348,6 +360,30 @@ static stcd_conv_geom geom_up_phase(const UpConv& U, int py, int px, int ldi, in
 }
 
 static void build_pack_jobs(stcd_engine& e, Bump& ws) {
+    // ---- per-launch slab regions + the batched reduce job tables (MFMA path only)
+    for (int st = 0; st < 2; ++st) { e.rjobs[st].clear(); e.rjobs_total[st] = 0; }
+    if (e.dt == BF16 && e.use_mfma) {
+        int64_t cur[2] = {0, 0};
+        for (WgradOp* op : e.wgrad_ops) {
+            if (!op->plan.ok) continue;
+            const ConvW& cv = e.convs[op->conv];
+            op->slab = ws.take(op->plan.slab_floats * 4);
+            ReduceJob j{};
+            j.slab_off = op->slab; j.out_off = cv.w_off;
+            j.slab_stride = (int64_t)op->g.ntaps * cv.fwd.kpad * cv.fwd.wld;
+            j.gx = op->plan.gx; j.ntaps = op->g.ntaps; j.K = cv.cin; j.N = cv.cout; j.kpad = cv.fwd.kpad; j.wld = cv.fwd.wld;
+            j.ks = cv.fwd.ks; j.kn_major = cv.fwd.kn_major;
+            for (int t = 0; t < op->g.ntaps; ++t) { j.ky[t] = cv.fwd.ky[op->tap0 + t]; j.kx[t] = cv.fwd.kx[op->tap0 + t]; }
+            j.count = (int64_t)j.ntaps * j.K * j.N * 16;
+            j.start = cur[op->stage];
+            cur[op->stage] += j.count;
+            e.rjobs[op->stage].push_back(j);
+        }
+        for (int st = 0; st < 2; ++st) {
+            e.rjobs_total[st] = cur[st];
+            e.rjobs_off[st] = ws.take((int64_t)e.rjobs[st].size() * sizeof(ReduceJob) + 16);
+        }
+    }
     // ---- one repack launch per forward: job tables (uploaded to the workspace on first use)
     for (int with_dgrad = 0; with_dgrad < 2; ++with_dgrad) {
         std::vector<PackJob>& jobs = e.jobs[with_dgrad];
@@ -509,6 +545,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
 
     // ---- bind every conv-shaped launch (geometry, filter, MFMA plan); the layer vectors are final from here on
     e.conv_ops.clear();
+    e.wgrad_ops.clear();
     e.slab_floats = 0;
     auto bind_conv = [&](ConvOp& op, const stcd_conv_geom& g, int conv, bool dgrad, int tap0, int kreal, int nreal) {
         op.g = g; op.conv = conv; op.dgrad = dgrad; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
@@ -522,11 +559,10 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     };
     auto bind_wgrad = [&](WgradOp& op, const stcd_conv_geom& g, int conv, int tap0, int kreal, int nreal) {
         op.g = g; op.conv = conv; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
-        op.plan = WgradMfmaPlan();
-        if (e.dt == BF16) {
-            op.plan = wgrad_mfma_plan(g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
-            e.slab_floats = std::max(e.slab_floats, op.plan.slab_floats);
-        }
+        op.plan = WgradMfmaPlan(); op.slab = -1;
+        op.stage = e.convs[conv].w_off < e.enc_param_end ? 1 : 0;     // encoder filters are finalised by stage 1
+        if (e.dt == BF16) op.plan = wgrad_mfma_plan(g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
+        e.wgrad_ops.push_back(&op);
     };
     auto bind_cbrd = [&](Cbrd& L) {
         const ConvW& cv = e.convs[L.conv];
@@ -593,14 +629,18 @@ struct Ctx {
 
 struct ProfScope {
     Prof& p; hipStream_t s; bool on; hipEvent_t b;
-    ProfScope(const Ctx& c, int klass, double flops, double bytes);
+    ProfScope(const Ctx& c, int klass, double flops, double bytes, const char* kernel = nullptr);
     ~ProfScope() { if (on) (void)hipEventRecord(b, s); }
 };
 
-ProfScope::ProfScope(const Ctx& c, int klass, double flops, double bytes) : p(c.e.prof), s(c.s), on(c.e.prof.on), b(nullptr) {
+ProfScope::ProfScope(const Ctx& c, int klass, double flops, double bytes, const char* kernel)
+    : p(c.e.prof), s(c.s), on(c.e.prof.on), b(nullptr) {
     if (!on) return;
+    static const char* DEF[PC_COUNT] = {"k_conv", "k_wgrad", "k_bn_reduce<T, 0>", "k_bn_act", "k_bn_reduce<T, 1>", "k_bn_bwd_apply",
+                                        "k_pool_bwd|k_fuse|k_slice", "k_pack_jobs|k_reduce_dw"};
     ProfRec r;
     r.a = p.get(); r.b = p.get(); r.klass = klass; r.flops = flops; r.bytes = bytes;
+    r.name_id = p.intern(kernel ? kernel : DEF[klass]);
     b = r.b;
     p.recs.push_back(r);
     (void)hipEventRecord(r.a, s);
@@ -625,7 +665,13 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     const PackSpec& ps = op.dgrad ? cv.dgrad : cv.fwd;
     double fl, by;
     conv_work(c.e, op.g, op.kreal, op.nreal, &fl, &by);
-    ProfScope prof(c, PC_CONV, fl, by);
+    char kname[64];
+    const bool small_path = mfma_on(c.e) && op.small && op.wf >= 0 && c.e.use_small;
+    const bool mfma_path = !small_path && mfma_on(c.e) && op.plan.ok && op.wf >= 0;
+    if (small_path) snprintf(kname, sizeof(kname), "k_conv_small<1, %d>", (op.g.ntaps * op.g.ci + 31) / 32 <= 5 ? 5 : 9);
+    else if (mfma_path) snprintf(kname, sizeof(kname), "k_conv_mfma<%d>", op.plan.NT);
+    else snprintf(kname, sizeof(kname), "k_conv_ref");
+    ProfScope prof(c, PC_CONV, fl, by, kname);
     if (stat_chunks) *stat_chunks = 0;
     if (mfma_on(c.e) && op.small && op.wf >= 0 && c.e.use_small) {
         const int groups = stat_groups > 0 ? stat_groups : 1;
@@ -653,18 +699,18 @@ static void exec_wgrad(const Ctx& c, const WgradOp& op, const void* in, const vo
     if (mfma_on(c.e) && op.plan.ok) {
         int rc;
         {
-            ProfScope prof(c, PC_WGRAD, fl, by);
-            rc = launch_wgrad_mfma(op.g, op.plan, in, dout, c.at<float>(c.e.slab), sub.kpad, sub.wld, c.s);
+            char kname[64];
+            snprintf(kname, sizeof(kname), "k_wgrad_mfma<%d, %d>", op.plan.WCI, op.plan.NTW);
+            ProfScope prof(c, PC_WGRAD, fl, by, kname);
+            rc = launch_wgrad_mfma(op.g, op.plan, in, dout, c.at<float>(op.slab), sub.kpad, sub.wld, c.s);
         }
-        if (rc == 0) {
-            ProfScope prof(c, PC_PACK, 0.0, 0.0);
-            launch_reduce_dw(c.at<float>(c.e.slab), op.plan.gx, op.g, cv.cin, cv.cout, sub.kpad, sub.wld, &sub, c.grads + cv.w_off, c.s);
-            return;
-        }
+        if (rc == 0) return;       // the slabs are summed by the stage's batched reduce launch (reduce_stage)
     }
     float* dwe = c.at<float>(cv.dwe) + (int64_t)op.tap0 * sub.kpad * sub.wld;
+    if (mfma_on(c.e))   // the bulk memset of the reference path's accumulators is skipped in MFMA mode
+        (void)hipMemsetAsync(dwe, 0, (size_t)sub.ntaps * sub.kpad * sub.wld * 4, c.s);
     {
-        ProfScope prof(c, PC_WGRAD, fl, by);
+        ProfScope prof(c, PC_WGRAD, fl, by, "k_wgrad_ref");
         launch_wgrad_ref(c.e.dt, op.g, in, dout, dwe, sub.kpad, sub.wld, c.s);
     }
     launch_unpack_dw(sub, dwe, c.grads + cv.w_off, c.s);
@@ -673,16 +719,27 @@ static void exec_wgrad(const Ctx& c, const WgradOp& op, const void* in, const vo
 static int pack_all_weights(const Ctx& c, bool with_dgrad) {
     stcd_engine& e = c.e;
     if (e.jobs_uploaded_ws != (const void*)c.ws) {      // first use of this workspace: upload both job tables
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k) {
             if (!e.jobs[k].empty())
                 STCD_HIP(hipMemcpyAsync(c.at(e.jobs_off[k]), e.jobs[k].data(), e.jobs[k].size() * sizeof(PackJob),
                                         hipMemcpyHostToDevice, c.s));
+            if (!e.rjobs[k].empty())
+                STCD_HIP(hipMemcpyAsync(c.at(e.rjobs_off[k]), e.rjobs[k].data(), e.rjobs[k].size() * sizeof(ReduceJob),
+                                        hipMemcpyHostToDevice, c.s));
+        }
         e.jobs_uploaded_ws = c.ws;
     }
     const int k = with_dgrad ? 1 : 0;
     ProfScope prof(c, PC_PACK, 0.0, 0.0);
     launch_pack_jobs(c.at<PackJob>(e.jobs_off[k]), (int)e.jobs[k].size(), e.jobs_total[k], c.params, c.ws, c.s);
     return 0;
+}
+
+static void reduce_stage(const Ctx& c, int stage) {
+    stcd_engine& e = c.e;
+    if (e.rjobs[stage].empty()) return;
+    ProfScope prof(c, PC_PACK, 0.0, 0.0, "k_reduce_jobs");
+    launch_reduce_jobs(c.at<ReduceJob>(e.rjobs_off[stage]), (int)e.rjobs[stage].size(), e.rjobs_total[stage], c.ws, c.grads, c.s);
 }
 
 static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool training) {
@@ -838,6 +895,7 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
                                 (int64_t)e.Hs[s_] * e.Ws[s_], C, s);
             }
         }
+        reduce_stage(c, 0);
     }
     if (stage < 0 || stage == 1) {
         for (int li = (int)e.enc.size() - 1; li >= 0; --li) {
@@ -850,6 +908,7 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
             }
             cbrd_backward(c, L);
         }
+        reduce_stage(c, 1);
     }
     STCD_HIP(hipGetLastError());
     return 0;
@@ -922,7 +981,7 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
     const int64_t T = (int64_t)dsize(e.dt);
     const int* f = SN_F;
     e.drops.clear(); e.drop_floats = 0;
-    e.conv_ops.clear(); e.slab_floats = 0;
+    e.conv_ops.clear(); e.wgrad_ops.clear(); e.slab_floats = 0;
     Bump ws;
     int64_t max_partial = 0;
     int hs[5], wsz[5];
@@ -1045,11 +1104,9 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
     };
     auto bind_wgrad = [&](WgradOp& op, const stcd_conv_geom& g, int conv, int tap0, int kreal, int nreal) {
         op.g = g; op.conv = conv; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
-        op.plan = WgradMfmaPlan();
-        if (e.dt == BF16) {
-            op.plan = wgrad_mfma_plan(g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
-            e.slab_floats = std::max(e.slab_floats, op.plan.slab_floats);
-        }
+        op.plan = WgradMfmaPlan(); op.slab = -1; op.stage = 0;
+        if (e.dt == BF16) op.plan = wgrad_mfma_plan(g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
+        e.wgrad_ops.push_back(&op);
     };
     for (auto& b : e.sn_blocks) {
         const ConvW& c1 = e.convs[b.c1];
@@ -1266,6 +1323,7 @@ static int backward_snunet(stcd_engine& e, const float* grad_logits, const float
         }
         if (b.up >= 0) sn_up_backward(c, e.sn_ups[b.up]);
     }
+    reduce_stage(c, 0);
     STCD_HIP(hipGetLastError());
     return 0;
 }
@@ -1386,6 +1444,7 @@ int stcd_profile_enable(stcd_engine* e, int on) {
     STCD_CHECK(e != nullptr, "engine is null");
     e->prof.on = on != 0;
     e->prof.recs.clear();
+    e->prof.names.clear();
     e->prof.used = 0;
     return 0;
 }
@@ -1395,6 +1454,23 @@ int stcd_profile_read(stcd_engine* e, int klass, double* total_ms, int64_t* laun
     *total_ms = 0.0; *launches = 0; *flops = 0.0; *bytes = 0.0;
     for (auto& r : e->prof.recs) {
         if (r.klass != klass) continue;
+        STCD_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        STCD_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        *total_ms += ms; *launches += 1; *flops += r.flops; *bytes += r.bytes;
+    }
+    return 0;
+}
+
+int stcd_profile_num_kernels(const stcd_engine* e) { return e ? (int)e->prof.names.size() : 0; }
+int stcd_profile_kernel(stcd_engine* e, int i, char* name, int name_cap, double* total_ms, int64_t* launches, double* flops,
+                        double* bytes) {
+    STCD_CHECK(e && name && total_ms && launches && flops && bytes && name_cap > 0, "bad argument");
+    STCD_CHECK(i >= 0 && i < (int)e->prof.names.size(), "kernel index out of range");
+    snprintf(name, (size_t)name_cap, "%s", e->prof.names[i].c_str());
+    *total_ms = 0.0; *launches = 0; *flops = 0.0; *bytes = 0.0;
+    for (auto& r : e->prof.recs) {
+        if (r.name_id != i) continue;
         STCD_HIP(hipEventSynchronize(r.b));
         float ms = 0.f;
         STCD_HIP(hipEventElapsedTime(&ms, r.a, r.b));

@@ -603,6 +603,35 @@ k_reduce_dw(const float* __restrict__ slab, int gx, int64_t slab_stride, int nta
     }
 }
 
+// 16 consecutive lanes cooperate on one output element: lane l sums slabs l, l+16, ... and a 4-step xor-shuffle
+// finishes it.  Thread index space = concatenation of all jobs' (outputs x 16).
+__global__ void __launch_bounds__(256)
+k_reduce_jobs(const ReduceJob* __restrict__ jobs, int njobs, int64_t total, const char* __restrict__ ws, float* __restrict__ grads) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;                      // totals are multiples of 16: a 16-lane group is never split
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const ReduceJob& jb = jobs[lo];
+    const int64_t e = i - jb.start;
+    const int o = (int)(e >> 4), part = (int)(e & 15);
+    const int n = o % jb.N, k = (o / jb.N) % jb.K, t = o / (jb.N * jb.K);
+    const float* p = reinterpret_cast<const float*>(ws + jb.slab_off) + ((int64_t)t * jb.kpad + k) * jb.wld + n;
+    float acc = 0.f;
+    for (int b = part; b < jb.gx; b += 16) acc += p[(int64_t)b * jb.slab_stride];
+#pragma unroll
+    for (int sft = 1; sft < 16; sft <<= 1) acc += __shfl_xor(acc, sft, 64);
+    if (part == 0) {
+        const int64_t a_ = jb.kn_major ? ((int64_t)k * jb.N + n) : ((int64_t)n * jb.K + k);
+        grads[jb.out_off + (a_ * jb.ks + jb.ky[t]) * jb.ks + jb.kx[t]] = acc;
+    }
+}
+void launch_reduce_jobs(const ReduceJob* jobs_dev, int njobs, int64_t total, const char* ws, float* grads, hipStream_t s) {
+    if (njobs > 0 && total > 0) k_reduce_jobs<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(jobs_dev, njobs, total, ws, grads);
+}
+
 WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld) {
     WgradMfmaPlan p;
     // block tile <= 32 ci x 32 co: 72 accumulator registers, >= 3 waves per SIMD, and enough (ci,co) groups that wide

@@ -143,3 +143,13 @@ class Engine:
             _lib.check(self._l.stcd_profile_read(self._h, k, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
             out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
         return out
+
+    def profile_kernels(self):
+        """-> {kernel name (as rocprofv3 prints it, substring): dict(ms, launches, flops, bytes)}."""
+        out = {}
+        buf = C.create_string_buffer(96)
+        for i in range(self._l.stcd_profile_num_kernels(self._h)):
+            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            _lib.check(self._l.stcd_profile_kernel(self._h, i, buf, 96, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+            out[buf.value.decode()] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        return out
