@@ -374,7 +374,11 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
             j.gx = op->plan.gx; j.ntaps = op->g.ntaps; j.K = cv.cin; j.N = cv.cout; j.kpad = cv.fwd.kpad; j.wld = cv.fwd.wld;
             j.ks = cv.fwd.ks; j.kn_major = cv.fwd.kn_major;
             for (int t = 0; t < op->g.ntaps; ++t) { j.ky[t] = cv.fwd.ky[op->tap0 + t]; j.kx[t] = cv.fwd.kx[op->tap0 + t]; }
-            j.count = (int64_t)j.ntaps * j.K * j.N * 16;
+            {   // index space: parts x outputs (padded to whole waves); <= 32 slabs per part
+                const int64_t outs_pad = ((int64_t)j.ntaps * j.K * j.N + 63) & ~(int64_t)63;
+                const int parts = (j.gx + 31) / 32;
+                j.count = outs_pad * parts;
+            }
             j.start = cur[op->stage];
             cur[op->stage] += j.count;
             e.rjobs[op->stage].push_back(j);

@@ -603,12 +603,13 @@ k_reduce_dw(const float* __restrict__ slab, int gx, int64_t slab_stride, int nta
     }
 }
 
-// 16 consecutive lanes cooperate on one output element: lane l sums slabs l, l+16, ... and a 4-step xor-shuffle
-// finishes it.  Thread index space = concatenation of all jobs' (outputs x 16).
+// Thread = (output element, slab range "part"): consecutive lanes take consecutive outputs, so every slab read is a
+// coalesced row; a job with many slabs is cut into parts of <= 32 slabs that finish with one float atomicAdd each
+// (the gradient buffer is zeroed at the start of backward; <= 48 adders per address, spread over the whole tensor).
 __global__ void __launch_bounds__(256)
 k_reduce_jobs(const ReduceJob* __restrict__ jobs, int njobs, int64_t total, const char* __restrict__ ws, float* __restrict__ grads) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;                      // totals are multiples of 16: a 16-lane group is never split
+    if (i >= total) return;
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -616,17 +617,28 @@ k_reduce_jobs(const ReduceJob* __restrict__ jobs, int njobs, int64_t total, cons
     }
     const ReduceJob& jb = jobs[lo];
     const int64_t e = i - jb.start;
-    const int o = (int)(e >> 4), part = (int)(e & 15);
+    const int outs = jb.ntaps * jb.K * jb.N, outs_pad = (outs + 63) & ~63;
+    const int part = (int)(e / outs_pad), o = (int)(e - (int64_t)part * outs_pad);
+    if (o >= outs) return;
+    const int parts = (int)(jb.count / outs_pad);
+    const int chunk = (jb.gx + parts - 1) / parts;
+    const int b0 = part * chunk, b1 = min(jb.gx, b0 + chunk);
     const int n = o % jb.N, k = (o / jb.N) % jb.K, t = o / (jb.N * jb.K);
     const float* p = reinterpret_cast<const float*>(ws + jb.slab_off) + ((int64_t)t * jb.kpad + k) * jb.wld + n;
-    float acc = 0.f;
-    for (int b = part; b < jb.gx; b += 16) acc += p[(int64_t)b * jb.slab_stride];
-#pragma unroll
-    for (int sft = 1; sft < 16; sft <<= 1) acc += __shfl_xor(acc, sft, 64);
-    if (part == 0) {
-        const int64_t a_ = jb.kn_major ? ((int64_t)k * jb.N + n) : ((int64_t)n * jb.K + k);
-        grads[jb.out_off + (a_ * jb.ks + jb.ky[t]) * jb.ks + jb.kx[t]] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+        a0 += p[(int64_t)b * jb.slab_stride];
+        a1 += p[(int64_t)(b + 1) * jb.slab_stride];
+        a2 += p[(int64_t)(b + 2) * jb.slab_stride];
+        a3 += p[(int64_t)(b + 3) * jb.slab_stride];
     }
+    for (; b < b1; ++b) a0 += p[(int64_t)b * jb.slab_stride];
+    const float acc = (a0 + a1) + (a2 + a3);
+    const int64_t a_ = jb.kn_major ? ((int64_t)k * jb.N + n) : ((int64_t)n * jb.K + k);
+    float* dst = grads + jb.out_off + (a_ * jb.ks + jb.ky[t]) * jb.ks + jb.kx[t];
+    if (parts == 1) *dst = acc;
+    else atomicAdd(dst, acc);
 }
 void launch_reduce_jobs(const ReduceJob* jobs_dev, int njobs, int64_t total, const char* ws, float* grads, hipStream_t s) {
     if (njobs > 0 && total > 0) k_reduce_jobs<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(jobs_dev, njobs, total, ws, grads);
