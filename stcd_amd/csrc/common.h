@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <string.h>
 
 #include "../../include/stcd_hip.h"
 
@@ -124,6 +125,27 @@ struct WgradMfmaPlan {
 WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld);
 int launch_wgrad_mfma(const stcd_conv_geom& g, const WgradMfmaPlan& p, const void* in, const void* dout, float* slab,
                       int kpad, int wld, hipStream_t s);
+// One weight-gradient launch as the kernel sees it.  A backward stage runs ALL its launches of one kernel variant as a
+// single grouped grid (device job table, blockIdx -> job by binary search): parallelism then comes from the layers
+// side by side, so each block can own many tiles (few K-split slabs) and no layer pays its own launch / tail.
+struct WgradJob {
+    stcd_conv_geom g;
+    int64_t in_off, dout_off, slab_off;    // bytes from the base pointer handed to the kernel (absolute when base == 0)
+    int kpad, wld;
+    int dymin, dxmin, HH, HWp;
+    int tiles_x, tiles_y, ntiles;
+    int xrow_bytes;                        // LDS bytes of one halo row of the X tile (incl. bank padding)
+    int x_bytes, y_bytes;                  // LDS bytes of one X halo tile / one dY tile
+    int co_valid;                          // channels of dout that exist in memory (round8(co))
+    int gx, gy, gz;                        // block grid of this job
+    int start;                             // first block of the job inside a grouped launch
+    int lds_bytes;
+};
+WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t in_off, int64_t dout_off, int64_t slab_off,
+                        int kpad, int wld);
+int wgrad_variant_slots(int WCI, int NTW, bool t9, int lds_bytes);   // resident blocks of that kernel variant on the chip
+int launch_wgrad_group(int WCI, int NTW, bool t9, const WgradJob* jobs_dev, int njobs, int total_blocks, int lds_bytes,
+                       const char* base, hipStream_t s);
 struct PackSpec;
 // Batched slab reduction: ONE launch per backward stage sums every weight-gradient launch's K-split slabs straight
 // into the reference-layout gradient tensors (device job table built at configure time).

@@ -61,6 +61,15 @@ struct WgradOp {
     WgradMfmaPlan plan;
     int64_t slab = -1;                   // this launch's own K-split slabs (reduced in one batched launch per stage)
     int stage = 0;
+    int64_t in_off = -1, dout_off = -1;  // workspace offsets of X and dY (grouped launch at the end of the stage)
+    bool grouped = false;
+};
+struct WgradGroup {                      // all launches of one kernel variant in one backward stage
+    int WCI = 1, NTW = 1; bool t9 = false;
+    std::vector<WgradJob> jobs;
+    int total_blocks = 0, lds_bytes = 0;
+    int64_t table_off = -1;
+    double flops = 0.0, bytes = 0.0;
 };
 
 struct Cbrd {                         // conv -> BN -> ReLU -> Dropout2d [-> pool]
@@ -154,6 +163,7 @@ struct stcd_engine_impl {
     std::vector<ConvOp*> conv_ops;      // every ConvOp of the plan (weight-image packing walks this)
     int64_t slab = -1, slab_floats = 0;
     std::vector<WgradOp*> wgrad_ops;                    // every WgradOp of the plan
+    std::vector<WgradGroup> wgroups[2];                 // per backward stage: grouped weight-gradient launches
     std::vector<ReduceJob> rjobs[2];                    // per backward stage
     int64_t rjobs_total[2] = {0, 0}, rjobs_off[2] = {-1, -1};
     // batched filter repacking: [0] = forward-only job list (eval), [1] = forward + data-gradient filters (training)
@@ -165,7 +175,7 @@ struct stcd_engine_impl {
     TRef D[4], dD[4], P[4], dP[4];
     int64_t bn_partial2 = -1;
     int64_t bn_partial = -1, masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
-    int use_mfma = 1, use_small = 1;
+    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8;
 };
 
 }  // namespace stcd
@@ -359,15 +369,73 @@ static stcd_conv_geom geom_up_phase(const UpConv& U, int py, int px, int ldi, in
     return g;
 }
 
+static void conv_work(const stcd_engine& e, const stcd_conv_geom& g, int kreal, int nreal, double* flops, double* bytes);
+
 static void build_pack_jobs(stcd_engine& e, Bump& ws) {
     // ---- per-launch slab regions + the batched reduce job tables (MFMA path only)
     for (int st = 0; st < 2; ++st) { e.rjobs[st].clear(); e.rjobs_total[st] = 0; }
+    for (int st = 0; st < 2; ++st) e.wgroups[st].clear();
     if (e.dt == BF16 && e.use_mfma) {
+        // ---- grouped weight-gradient launches: one grid per (stage, kernel variant).  The K split (gx) of every layer is
+        //      chosen for the GROUP: about two resident rounds of blocks over all its layers, each block owning at least
+        //      8 tiles, so deep layers get few slabs and the prologue / slab epilogue is amortised.
+        if (e.use_wgroup) {
+            for (WgradOp* op : e.wgrad_ops) {
+                if (!op->plan.ok) continue;
+                const bool t9 = op->g.ntaps == 9;
+                std::vector<WgradGroup>& gs = e.wgroups[op->stage];
+                size_t gi = 0;
+                for (; gi < gs.size(); ++gi)
+                    if (gs[gi].WCI == op->plan.WCI && gs[gi].NTW == op->plan.NTW && gs[gi].t9 == t9) break;
+                if (gi == gs.size()) { WgradGroup g; g.WCI = op->plan.WCI; g.NTW = op->plan.NTW; g.t9 = t9; gs.push_back(g); }
+                op->grouped = true;
+            }
+            for (int st = 0; st < 2; ++st)
+                for (WgradGroup& G : e.wgroups[st]) {
+                    std::vector<WgradOp*> ops;
+                    int64_t W = 0;
+                    for (WgradOp* op : e.wgrad_ops)
+                        if (op->grouped && op->stage == st && op->plan.WCI == G.WCI && op->plan.NTW == G.NTW && (op->g.ntaps == 9) == G.t9) {
+                            ops.push_back(op);
+                            const int64_t ntiles = (int64_t)op->g.n * ((op->g.wm + 15) / 16) * ((op->g.hm + 7) / 8);
+                            W += ntiles * op->plan.gy * op->plan.gz;
+                        }
+                    for (WgradOp* op : ops) {   // LDS need of the group = max over its jobs
+                        const ConvW& cv = e.convs[op->conv];
+                        WgradJob j = wgrad_make_job(op->g, op->plan, 0, 0, 0, cv.fwd.kpad, cv.fwd.wld);
+                        G.lds_bytes = std::max(G.lds_bytes, j.lds_bytes);
+                    }
+                    const int slots = wgrad_variant_slots(G.WCI, G.NTW, G.t9, G.lds_bytes);
+                    const int64_t tpb = std::max<int64_t>(e.wgroup_min_tiles, (W + 2 * slots - 1) / (2 * slots));
+                    for (WgradOp* op : ops) {
+                        const ConvW& cv = e.convs[op->conv];
+                        const int64_t ntiles = (int64_t)op->g.n * ((op->g.wm + 15) / 16) * ((op->g.hm + 7) / 8);
+                        const int64_t slab_bytes = (int64_t)op->g.ntaps * cv.fwd.kpad * cv.fwd.wld * 4;
+                        int64_t gx = std::max<int64_t>(1, (ntiles + tpb - 1) / tpb);
+                        gx = std::min<int64_t>(gx, std::max<int64_t>(1, ((int64_t)32 << 20) / slab_bytes));
+                        op->plan.gx = (int)gx;
+                        op->plan.slab_floats = gx * op->g.ntaps * cv.fwd.kpad * cv.fwd.wld;
+                    }
+                }
+        }
         int64_t cur[2] = {0, 0};
         for (WgradOp* op : e.wgrad_ops) {
             if (!op->plan.ok) continue;
             const ConvW& cv = e.convs[op->conv];
             op->slab = ws.take(op->plan.slab_floats * 4);
+            if (op->grouped) {
+                const bool t9 = op->g.ntaps == 9;
+                for (WgradGroup& G : e.wgroups[op->stage])
+                    if (G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9) {
+                        WgradJob j = wgrad_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld);
+                        j.start = G.total_blocks;
+                        G.total_blocks += j.gx * j.gy * j.gz;
+                        G.jobs.push_back(j);
+                        double fl, by;
+                        conv_work(e, op->g, op->kreal, op->nreal, &fl, &by);
+                        G.flops += fl; G.bytes += by;
+                    }
+            }
             ReduceJob j{};
             j.slab_off = op->slab; j.out_off = cv.w_off;
             j.slab_stride = (int64_t)op->g.ntaps * cv.fwd.kpad * cv.fwd.wld;
@@ -386,6 +454,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
         for (int st = 0; st < 2; ++st) {
             e.rjobs_total[st] = cur[st];
             e.rjobs_off[st] = ws.take((int64_t)e.rjobs[st].size() * sizeof(ReduceJob) + 16);
+            for (WgradGroup& G : e.wgroups[st]) G.table_off = ws.take((int64_t)G.jobs.size() * sizeof(WgradJob) + 16);
         }
     }
     // ---- one repack launch per forward: job tables (uploaded to the workspace on first use)
@@ -561,8 +630,10 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         }
         e.conv_ops.push_back(&op);
     };
-    auto bind_wgrad = [&](WgradOp& op, const stcd_conv_geom& g, int conv, int tap0, int kreal, int nreal) {
+    auto bind_wgrad = [&](WgradOp& op, const stcd_conv_geom& g, int conv, int tap0, int kreal, int nreal, int64_t in_off,
+                          int64_t dout_off) {
         op.g = g; op.conv = conv; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
+        op.in_off = in_off; op.dout_off = dout_off; op.grouped = false;
         op.plan = WgradMfmaPlan(); op.slab = -1;
         op.stage = e.convs[conv].w_off < e.enc_param_end ? 1 : 0;     // encoder filters are finalised by stage 1
         if (e.dt == BF16) op.plan = wgrad_mfma_plan(g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
@@ -571,7 +642,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     auto bind_cbrd = [&](Cbrd& L) {
         const ConvW& cv = e.convs[L.conv];
         bind_conv(L.fwd, geom3(L.N, L.H, L.W, L.K, L.in.ld, cv.cout, L.Y.ld), L.conv, false, 0, cv.cin, cv.cout);
-        bind_wgrad(L.wg, geom3(L.N, L.H, L.W, L.K, L.in.ld, cv.cout, L.dY.ld), L.conv, 0, cv.cin, cv.cout);
+        bind_wgrad(L.wg, geom3(L.N, L.H, L.W, L.K, L.in.ld, cv.cout, L.dY.ld), L.conv, 0, cv.cin, cv.cout, L.in.off, L.dY.off);
         if (L.has_dIn)
             bind_conv(L.dgr, geom3(L.N, L.H, L.W, cv.dgrad.kpad, L.dY.ld, cv.cin, L.dIn.ld), L.conv, true, 0, cv.cout, cv.cin);
     };
@@ -583,7 +654,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             int tap0;
             stcd_conv_geom g = geom_up_phase(U, ph >> 1, ph & 1, U.in.ld, U.out.ld, &tap0);
             bind_conv(U.fwd[ph], g, U.conv, false, tap0, U.C, U.C);
-            bind_wgrad(U.wg[ph], g, U.conv, tap0, U.C, U.C);
+            bind_wgrad(U.wg[ph], g, U.conv, tap0, U.C, U.C, U.in.off, U.dOut.off);
         }
         // data gradient: 3x3 stride-2 conv over dOut.  (hi,wi) are the BUFFER dims (row pitch); taps reach at most
         // row 2h-1 / col 2w-1, so replication-padded rows/cols are never read.
@@ -600,7 +671,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     {
         const ConvW& cv = e.convs[e.final_conv];
         bind_conv(e.final_fwd, geom3(B, H, W, cv.kin_p, e.finalIn.ld, e.label, e.label), e.final_conv, false, 0, cv.cin, e.label);
-        bind_wgrad(e.final_wg, geom3(B, H, W, cv.kin_p, e.finalIn.ld, e.label, 8), e.final_conv, 0, cv.cin, e.label);
+        bind_wgrad(e.final_wg, geom3(B, H, W, cv.kin_p, e.finalIn.ld, e.label, 8), e.final_conv, 0, cv.cin, e.label, e.finalIn.off, e.G.off);
         bind_conv(e.final_dgr, geom3(B, H, W, cv.dgrad.kpad, 8, cv.cin, e.dFinalIn.ld), e.final_conv, true, 0, e.label, cv.cin);
     }
     {   // the fused-statistics conv kernels write one partial row per block: make sure the shared slab holds them
@@ -700,6 +771,7 @@ static void exec_wgrad(const Ctx& c, const WgradOp& op, const void* in, const vo
     for (int t = 0; t < op.g.ntaps; ++t) { sub.ky[t] = cv.fwd.ky[op.tap0 + t]; sub.kx[t] = cv.fwd.kx[op.tap0 + t]; }
     double fl, by;
     conv_work(c.e, op.g, op.kreal, op.nreal, &fl, &by);
+    if (mfma_on(c.e) && op.plan.ok && op.grouped) return;    // runs in the stage's grouped launch (wgrad_stage)
     if (mfma_on(c.e) && op.plan.ok) {
         int rc;
         {
@@ -730,6 +802,8 @@ static int pack_all_weights(const Ctx& c, bool with_dgrad) {
             if (!e.rjobs[k].empty())
                 STCD_HIP(hipMemcpyAsync(c.at(e.rjobs_off[k]), e.rjobs[k].data(), e.rjobs[k].size() * sizeof(ReduceJob),
                                         hipMemcpyHostToDevice, c.s));
+            for (WgradGroup& G : e.wgroups[k])
+                STCD_HIP(hipMemcpyAsync(c.at(G.table_off), G.jobs.data(), G.jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, c.s));
         }
         e.jobs_uploaded_ws = c.ws;
     }
@@ -741,6 +815,14 @@ static int pack_all_weights(const Ctx& c, bool with_dgrad) {
 
 static void reduce_stage(const Ctx& c, int stage) {
     stcd_engine& e = c.e;
+    for (const WgradGroup& G : e.wgroups[stage]) {
+        char kname[64];
+        snprintf(kname, sizeof(kname), "k_wgrad_group<%d, %d, %s>", G.WCI, G.NTW, G.t9 ? "true" : "false");
+        ProfScope prof(c, PC_WGRAD, G.flops, G.bytes, kname);
+        if (launch_wgrad_group(G.WCI, G.NTW, G.t9, c.at<WgradJob>(G.table_off), (int)G.jobs.size(), G.total_blocks, G.lds_bytes,
+                               c.ws, c.s) != 0)
+            set_error("grouped weight-gradient launch exceeds the LDS budget");
+    }
     if (e.rjobs[stage].empty()) return;
     ProfScope prof(c, PC_PACK, 0.0, 0.0, "k_reduce_jobs");
     launch_reduce_jobs(c.at<ReduceJob>(e.rjobs_off[stage]), (int)e.rjobs[stage].size(), e.rjobs_total[stage], c.ws, c.grads, c.s);
@@ -1106,8 +1188,10 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
         }
         e.conv_ops.push_back(&op);
     };
-    auto bind_wgrad = [&](WgradOp& op, const stcd_conv_geom& g, int conv, int tap0, int kreal, int nreal) {
+    auto bind_wgrad = [&](WgradOp& op, const stcd_conv_geom& g, int conv, int tap0, int kreal, int nreal, int64_t in_off,
+                          int64_t dout_off) {
         op.g = g; op.conv = conv; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
+        op.in_off = in_off; op.dout_off = dout_off; op.grouped = false;
         op.plan = WgradMfmaPlan(); op.slab = -1; op.stage = 0;
         if (e.dt == BF16) op.plan = wgrad_mfma_plan(g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
         e.wgrad_ops.push_back(&op);
@@ -1116,10 +1200,10 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
         const ConvW& c1 = e.convs[b.c1];
         const ConvW& c2 = e.convs[b.c2];
         bind_conv(b.f1, geom3(b.N, b.H, b.W, b.Cin, b.in.ld, b.C, b.Y1.ld), b.c1, false, 0, c1.cin, b.C);
-        bind_wgrad(b.w1, geom3(b.N, b.H, b.W, b.Cin, b.in.ld, b.C, b.dA1.ld), b.c1, 0, c1.cin, b.C);
+        bind_wgrad(b.w1, geom3(b.N, b.H, b.W, b.Cin, b.in.ld, b.C, b.dA1.ld), b.c1, 0, c1.cin, b.C, b.in.off, b.dA1.off);
         if (b.dIn.off >= 0) bind_conv(b.d1, geom3(b.N, b.H, b.W, c1.dgrad.kpad, b.dA1.ld, c1.cin, b.dIn.ld), b.c1, true, 0, b.C, c1.cin);
         bind_conv(b.f2, geom3(b.N, b.H, b.W, b.C, b.A1.ld, b.C, b.Y2.ld), b.c2, false, 0, b.C, b.C);
-        bind_wgrad(b.w2, geom3(b.N, b.H, b.W, b.C, b.A1.ld, b.C, b.dOut.ld), b.c2, 0, b.C, b.C);
+        bind_wgrad(b.w2, geom3(b.N, b.H, b.W, b.C, b.A1.ld, b.C, b.dOut.ld), b.c2, 0, b.C, b.C, b.A1.off, b.dOut.off);
         bind_conv(b.d2, geom3(b.N, b.H, b.W, c2.dgrad.kpad, b.dOut.ld, b.C, b.dA1.ld), b.c2, true, 0, b.C, b.C);
     }
     for (auto& u : e.sn_ups) {
@@ -1134,7 +1218,7 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
             g.co = u.C; g.ldo = u.out.ld;
             g.ntaps = 1; g.dy[0] = 0; g.dx[0] = 0;
             bind_conv(u.fwd[ph], g, u.conv, false, ph, u.C, u.C);
-            bind_wgrad(u.wg[ph], g, u.conv, ph, u.C, u.C);
+            bind_wgrad(u.wg[ph], g, u.conv, ph, u.C, u.C, u.src.off, u.dOut.off);
         }
         stcd_conv_geom gd;
         memset(&gd, 0, sizeof(gd));
@@ -1149,7 +1233,7 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
     {
         const ConvW& cv = e.convs[e.sn_final];
         bind_conv(e.sn_final_fwd, geom1(B, H, W, c4, e.snZ.ld, e.label, e.label), e.sn_final, false, 0, c4, e.label);
-        bind_wgrad(e.sn_final_wg, geom1(B, H, W, c4, e.snZ.ld, e.label, 8), e.sn_final, 0, c4, e.label);
+        bind_wgrad(e.sn_final_wg, geom1(B, H, W, c4, e.snZ.ld, e.label, 8), e.sn_final, 0, c4, e.label, e.snZ.off, e.G.off);
         bind_conv(e.sn_final_dgr, geom1(B, H, W, cv.dgrad.kpad, 8, c4, e.sndZ.ld), e.sn_final, true, 0, e.label, c4);
     }
     e.slab = ws.take(e.slab_floats * 4);
@@ -1352,6 +1436,10 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
     e->use_mfma = !(env && env[0] == '1');
     env = getenv("STCD_NO_SMALL_KERNEL");
     e->use_small = !(env && env[0] == '1');
+    env = getenv("STCD_NO_WGRAD_GROUPS");
+    e->use_wgroup = !(env && env[0] == '1');
+    env = getenv("STCD_WGRAD_MIN_TILES");
+    if (env && atoi(env) > 0) e->wgroup_min_tiles = atoi(env);
     if (arch == STCD_ARCH_SNUNET) build_snunet_tables(*e);
     else build_fcsiam_tables(*e);
     *out = e.release();

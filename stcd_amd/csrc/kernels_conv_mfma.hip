@@ -377,18 +377,6 @@ int launch_conv_mfma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const void*
 //   grid.x = position blocks, each walks tiles t = bx, bx+gx, ... and finally writes ONE fp32 slab
 //            [tap][ci][co] (plain coalesced stores, no global atomics: deterministic, and far cheaper than 1.3 TB/s
 //            atomics); k_reduce_dw sums the slabs straight into the reference-layout gradient.
-struct WgradArgs {
-    stcd_conv_geom g;
-    const bf16* in;
-    const bf16* dout;
-    float* slab;           // [gx][ntaps][kpad][wld]
-    int kpad, wld;
-    int dymin, dxmin, HH, HWp;
-    int tiles_x, tiles_y, ntiles;
-    int xrow_bytes;        // LDS bytes of one halo row of the X tile (incl. bank padding)
-    int x_bytes, y_bytes;  // LDS bytes of one X halo tile / one dY tile
-    int co_valid;          // channels of dout that exist in memory (round8(co))
-};
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* base0, const char* base1) {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -407,10 +395,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base0, const char* base1) 
 template <int C>
 __device__ __forceinline__ int px_off(int x) { return x * (2 * C) + (x >> 3) * (C == 16 ? 128 : 32); }
 
-template <int WCI, int NTW>
-__global__ void __launch_bounds__(256)
-k_wgrad_mfma(const WgradArgs a) {
+template <int WCI, int NTW, bool T9>
+__device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bf16* a_in = reinterpret_cast<const bf16*>(base + a.in_off);
+    const bf16* a_dout = reinterpret_cast<const bf16*>(base + a.dout_off);
+    float* a_slab = reinterpret_cast<float*>(const_cast<char*>(base) + a.slab_off);
     constexpr int WK = 4 / WCI, CIB = WCI * 16, COB = NTW * 16;
     constexpr int XCH = CIB / 8, YCH = COB / 8;
     constexpr int YROW = 16 * 2 * COB + 2 * (COB == 16 ? 128 : 32);       // bytes of one 16-position dY row
@@ -418,8 +408,9 @@ k_wgrad_mfma(const WgradArgs a) {
     const int wci = wid % WCI, wk = wid / WCI;
     const int grp = lane >> 4, li = lane & 15, qrow = li >> 2, pcol = li & 3;
     const int HWp = a.HWp;
-    const int ci0 = blockIdx.y * CIB, co0 = blockIdx.z * COB;
+    const int ci0 = by * CIB, co0 = bz * COB;
     const int buf_bytes = a.x_bytes + a.y_bytes;
+    const int ntaps = T9 ? 9 : a.g.ntaps;
 
     f32x4 acc[9][NTW];
 #pragma unroll
@@ -427,71 +418,78 @@ k_wgrad_mfma(const WgradArgs a) {
 #pragma unroll
         for (int n_ = 0; n_ < NTW; ++n_) acc[t][n_] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- staging plan, computed once: X pieces (pixel, 16-B chunk) then dY pieces; <= MAXP per thread
-    const int nx = a.HH * HWp * XCH, ny = 128 * YCH, npieces = nx + ny;
-    constexpr int MAXP = 5;
-    int goff[MAXP], loff[MAXP], pa[MAXP], pb[MAXP];   // global element offset, LDS byte offset, bound coords
+    // ---- staging plan, computed once.  X halo: pieces i = tid + p*256 < nx (<= MAXX per thread); dY: exactly NTW
+    //      pieces per thread (128 positions x YCH chunks = 256*NTW).  Every load below is unconditional (an
+    //      out-of-range piece reads the tile origin and is zeroed by a select), so the loop body has no divergent
+    //      branches and all loads of a tile are in flight together.
+    const int nx = a.HH * HWp * XCH;
+    constexpr int MAXX = 3;
+    int xg[MAXX], xl[MAXX], xa[MAXX], xb[MAXX];       // global element offset, LDS byte offset, bound coords
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
-        const int i = tid + p * 256;
-        goff[p] = 0; loff[p] = -1; pa[p] = 1 << 28; pb[p] = 0;
-        if (i < nx) {
-            const int ch = i % XCH, pix = i / XCH, hx = pix % HWp, hy = pix / HWp;
-            pa[p] = hy + a.dymin; pb[p] = hx + a.dxmin;
-            goff[p] = (pa[p] * a.g.wi + pb[p]) * a.g.ldi + ci0 + ch * 8;
-            loff[p] = hy * a.xrow_bytes + px_off<CIB>(hx) + ch * 16;
-            if (ci0 + ch * 8 >= a.g.ci) pa[p] = 1 << 28;             // channels beyond Ci: zero
-        } else if (i < npieces) {
-            const int j = i - nx, ch = j % YCH, pix = j / YCH, py = pix >> 4, pxx = pix & 15;
-            pa[p] = py; pb[p] = pxx;
-            goff[p] = ((py * a.g.out_stride) * a.g.wo + pxx * a.g.out_stride) * a.g.ldo + co0 + ch * 8;
-            loff[p] = a.x_bytes + py * YROW + px_off<COB>(pxx) + ch * 16;
-            if (co0 + ch * 8 >= a.co_valid) pa[p] = 1 << 28;
-        }
+    for (int p = 0; p < MAXX; ++p) {
+        const int i = min(tid + p * 256, nx - 1);
+        const int ch = i % XCH, pix = i / XCH, hx = pix % HWp, hy = pix / HWp;
+        xa[p] = hy + a.dymin; xb[p] = hx + a.dxmin;
+        xg[p] = (xa[p] * a.g.wi + xb[p]) * a.g.ldi + ci0 + ch * 8;
+        xl[p] = hy * a.xrow_bytes + px_off<CIB>(hx) + ch * 16;
+        if (ci0 + ch * 8 >= a.g.ci) xa[p] = 1 << 28;                 // channels beyond Ci: zero
     }
-    const bool p_is_x[MAXP] = {tid < nx, tid + 256 < nx, tid + 512 < nx, tid + 768 < nx, tid + 1024 < nx};
+    int yg[NTW], yl[NTW], ya[NTW], yb[NTW];
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) {
+        const int j = tid + q * 256, ch = j % YCH, pix = j / YCH, py = pix >> 4, pxx = pix & 15;
+        ya[q] = py; yb[q] = pxx;
+        yg[q] = ((py * a.g.out_stride) * a.g.wo + pxx * a.g.out_stride) * a.g.ldo + co0 + ch * 8;
+        yl[q] = a.x_bytes + py * YROW + px_off<COB>(pxx) + ch * 16;
+        if (co0 + ch * 8 >= a.co_valid) ya[q] = 1 << 28;
+    }
+    const int npx = (nx + 255) >> 8;                  // X pieces in use (uniform)
 
     // tile walk (incremental)
     const int tiles_img = a.tiles_x * a.tiles_y;
-    const int step = gridDim.x;
+    const int step = a.gx;
     const int dn = step / tiles_img, drem = step - dn * tiles_img, dty = drem / a.tiles_x, dtx = drem - dty * a.tiles_x;
-    int tile = blockIdx.x;
+    int tile = bx;
     int tn = tile / tiles_img, trem = tile - tn * tiles_img, tty = trem / a.tiles_x, ttx = trem - tty * a.tiles_x;
 
-    uint4 pre[MAXP];
+    uint4 prex[MAXX], prey[NTW];
 #define WG_FETCH(N_, Y_, X_)                                                                                          \
     do {                                                                                                              \
         const int my0_ = (Y_) * 8, mx0_ = (X_) * 16;                                                                   \
-        const bf16* xo_ = a.in + (((int64_t)(N_) * a.g.hi + my0_ * a.g.in_stride) * a.g.wi + mx0_ * a.g.in_stride) * a.g.ldi; \
-        const bf16* yo_ = a.dout + (((int64_t)(N_) * a.g.ho + my0_ * a.g.out_stride + a.g.oy0) * a.g.wo +             \
+        const bf16* xo_ = a_in + (((int64_t)(N_) * a.g.hi + my0_) * a.g.wi + mx0_) * a.g.ldi;                         \
+        const bf16* yo_ = a_dout + (((int64_t)(N_) * a.g.ho + my0_ * a.g.out_stride + a.g.oy0) * a.g.wo +             \
                                     mx0_ * a.g.out_stride + a.g.ox0) * a.g.ldo;                                       \
-        _Pragma("unroll") for (int p = 0; p < MAXP; ++p) {                                                            \
-            pre[p] = make_uint4(0, 0, 0, 0);                                                                          \
-            if (p_is_x[p]) {                                                                                          \
-                const unsigned gy_ = (unsigned)(my0_ * a.g.in_stride + pa[p]), gx_ = (unsigned)(mx0_ * a.g.in_stride + pb[p]); \
-                if (gy_ < (unsigned)a.g.hi && gx_ < (unsigned)a.g.wi) pre[p] = *reinterpret_cast<const uint4*>(xo_ + goff[p]); \
-            } else if (loff[p] >= 0) {                                                                                \
-                if ((unsigned)(my0_ + pa[p]) < (unsigned)a.g.hm && mx0_ + pb[p] < a.g.wm)                             \
-                    pre[p] = *reinterpret_cast<const uint4*>(yo_ + goff[p]);                                          \
+        _Pragma("unroll") for (int p = 0; p < MAXX; ++p) {                                                            \
+            if (p < npx) {                                                                                            \
+                const bool ok_ = (unsigned)(my0_ + xa[p]) < (unsigned)a.g.hi && (unsigned)(mx0_ + xb[p]) < (unsigned)a.g.wi; \
+                const uint4 v_ = *reinterpret_cast<const uint4*>(xo_ + (ok_ ? xg[p] : 0));                            \
+                prex[p] = ok_ ? v_ : make_uint4(0, 0, 0, 0);                                                          \
             }                                                                                                         \
+        }                                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < NTW; ++q) {                                                             \
+            const bool ok_ = (unsigned)(my0_ + ya[q]) < (unsigned)a.g.hm && mx0_ + yb[q] < a.g.wm;                     \
+            const uint4 v_ = *reinterpret_cast<const uint4*>(yo_ + (ok_ ? yg[q] : 0));                                \
+            prey[q] = ok_ ? v_ : make_uint4(0, 0, 0, 0);                                                              \
         }                                                                                                             \
     } while (0)
 #define WG_STASH(BUF_)                                                                                                \
     do {                                                                                                              \
-        _Pragma("unroll") for (int p = 0; p < MAXP; ++p)                                                              \
-            if (loff[p] >= 0) *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + loff[p]) = pre[p];                \
+        _Pragma("unroll") for (int p = 0; p < MAXX; ++p)                                                              \
+            if (p < npx && tid + p * 256 < nx) *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + xl[p]) = prex[p]; \
+        _Pragma("unroll") for (int q = 0; q < NTW; ++q)                                                               \
+            *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + yl[q]) = prey[q];                                   \
     } while (0)
 
     // per-lane fragment geometry inside a k-step (32 positions = 2 tile rows): half h -> x = 8*(grp&1) + 4*h + qrow
     const int frow = grp >> 1;
     const int fx0 = 8 * (grp & 1) + qrow, fx1 = fx0 + 4;
-    const int yb0 = px_off<COB>(fx0) + 8 * pcol, yb1 = px_off<COB>(fx1) + 8 * pcol;
-    int xoff0[9], xoff1[9];      // X fragment byte offsets per tap (relative to the k-step's halo row)
+    const int yb0 = frow * YROW + px_off<COB>(fx0) + 8 * pcol, yb1 = frow * YROW + px_off<COB>(fx1) + 8 * pcol;
+    int xoff0[9], xoff1[9];      // X fragment byte offsets per tap (relative to the k-step's first halo row)
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const int tdy = t < a.g.ntaps ? a.g.dy[t] - a.dymin : 0, tdx = t < a.g.ntaps ? a.g.dx[t] - a.dxmin : 0;
-        xoff0[t] = tdy * a.xrow_bytes + px_off<CIB>(fx0 + tdx) + wci * 32 + 8 * pcol;
-        xoff1[t] = tdy * a.xrow_bytes + px_off<CIB>(fx1 + tdx) + wci * 32 + 8 * pcol;
+        const int tdy = t < ntaps ? a.g.dy[t] - a.dymin : 0, tdx = t < ntaps ? a.g.dx[t] - a.dxmin : 0;
+        xoff0[t] = (tdy + frow) * a.xrow_bytes + px_off<CIB>(fx0 + tdx) + wci * 32 + 8 * pcol;
+        xoff1[t] = (tdy + frow) * a.xrow_bytes + px_off<CIB>(fx1 + tdx) + wci * 32 + 8 * pcol;
     }
 
     int buf = 0;
@@ -506,20 +504,31 @@ k_wgrad_mfma(const WgradArgs a) {
         if (have_next) WG_FETCH(nn, nyy, nxx);
         const char* xs = smem + buf * buf_bytes;
         const char* ys = xs + a.x_bytes;
+#pragma unroll
         for (int ks = wk; ks < 4; ks += WK) {
-            const int row = ks * 2 + frow;
             bf16x8 bfr[NTW];
 #pragma unroll
             for (int n_ = 0; n_ < NTW; ++n_)
-                bfr[n_] = tr_frag(ys + row * YROW + yb0 + n_ * 32, ys + row * YROW + yb1 + n_ * 32);
-            const char* xr = xs + row * a.xrow_bytes;
+                bfr[n_] = tr_frag(ys + ks * 2 * YROW + yb0 + n_ * 32, ys + ks * 2 * YROW + yb1 + n_ * 32);
+            const char* xr = xs + ks * 2 * a.xrow_bytes;
+            if constexpr (T9) {
+                bf16x8 afr[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                if (t < a.g.ntaps) {
-                    const bf16x8 afr = tr_frag(xr + xoff0[t], xr + xoff1[t]);
+                for (int t = 0; t < 9; ++t) afr[t] = tr_frag(xr + xoff0[t], xr + xoff1[t]);
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
 #pragma unroll
                     for (int n_ = 0; n_ < NTW; ++n_)
-                        acc[t][n_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[n_], acc[t][n_], 0, 0, 0);
+                        acc[t][n_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[t], bfr[n_], acc[t][n_], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (t < ntaps) {
+                        const bf16x8 afr = tr_frag(xr + xoff0[t], xr + xoff1[t]);
+#pragma unroll
+                        for (int n_ = 0; n_ < NTW; ++n_)
+                            acc[t][n_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[n_], acc[t][n_], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -546,7 +555,7 @@ k_wgrad_mfma(const WgradArgs a) {
     }
     __syncthreads();
     if (wk == 0) {
-#pragma unroll
+#pragma unroll 1
         for (int w = 1; w < WK; ++w) {
             const float* src = red + ((w - 1) * WCI + wci) * PERW + lane;
 #pragma unroll
@@ -556,10 +565,10 @@ k_wgrad_mfma(const WgradArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[t][n_][j] += src[((t * NTW + n_) * 4 + j) * 64];
         }
-        float* slab = a.slab + (int64_t)blockIdx.x * a.g.ntaps * a.kpad * a.wld;
+        float* slab = a_slab + (int64_t)bx * ntaps * a.kpad * a.wld;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
-            if (t < a.g.ntaps)
+            if (t < ntaps)
 #pragma unroll
                 for (int n_ = 0; n_ < NTW; ++n_)
 #pragma unroll
@@ -568,6 +577,26 @@ k_wgrad_mfma(const WgradArgs a) {
                         if (ci < a.kpad && co < a.wld) slab[((int64_t)t * a.kpad + ci) * a.wld + co] = acc[t][n_][j];
                     }
     }
+}
+
+template <int WCI, int NTW, bool T9>
+__global__ void __launch_bounds__(256, 2)
+k_wgrad_mfma(const WgradJob a) {
+    wgrad_body<WCI, NTW, T9>(a, nullptr, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+template <int WCI, int NTW, bool T9>
+__global__ void __launch_bounds__(256, 2)
+k_wgrad_group(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
+    int lo = 0, hi = njobs - 1;            // last job with start <= blockIdx.x (uniform: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WgradJob& a = jobs[lo];
+    const int lb = blockIdx.x - a.start;
+    const int bx = lb % a.gx, r = lb / a.gx;
+    wgrad_body<WCI, NTW, T9>(a, base, bx, r % a.gy, r / a.gy);
 }
 
 // sum the slabs; out[t][k][n] (engine layout, same as the slab) or, with a PackSpec, straight into the reference layout
@@ -655,7 +684,8 @@ WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld) {
     const int tiles_x = (g.wm + 15) / 16, tiles_y = (g.hm + 7) / 8;
     const int64_t ntiles = (int64_t)g.n * tiles_x * tiles_y;
     const int64_t slab_bytes = (int64_t)g.ntaps * kpad * wld * 4;
-    int64_t gx = std::max<int64_t>(1, 1536 / (p.gy * p.gz));
+    static const int target_blocks = [] { const char* e = getenv("STCD_WGRAD_BLOCKS"); return e ? atoi(e) : 1536; }();
+    int64_t gx = std::max<int64_t>(1, target_blocks / (p.gy * p.gz));
     gx = std::min<int64_t>(gx, std::max<int64_t>(1, ((int64_t)24 << 20) / slab_bytes));
     gx = std::min<int64_t>(gx, ntiles);
     p.gx = (int)gx;
@@ -663,16 +693,17 @@ WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld) {
     int dymin, dymax, dxmin, dxmax;
     taps_extent(g, &dymin, &dymax, &dxmin, &dxmax);
     const int HH = 7 * g.in_stride + (dymax - dymin) + 1, HWp = 15 * g.in_stride + (dxmax - dxmin) + 1;
-    const int pieces = HH * HWp * (p.WCI * 2) + 128 * (p.NTW * 2);
-    p.ok = g.ci % 8 == 0 && g.ldi % 8 == 0 && g.ldo % 8 == 0 && g.in_stride == 1 && pieces <= 5 * 256;
+    const int xpieces = HH * HWp * (p.WCI * 2);
+    p.ok = g.ci % 8 == 0 && g.ldi % 8 == 0 && g.ldo % 8 == 0 && g.in_stride == 1 && xpieces <= 3 * 256 && g.hm <= g.hi && g.wm <= g.wi;
     return p;
 }
 
-int launch_wgrad_mfma(const stcd_conv_geom& g, const WgradMfmaPlan& p, const void* in, const void* dout, float* slab,
-                      int kpad, int wld, hipStream_t s) {
-    WgradArgs a;
+WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t in_off, int64_t dout_off, int64_t slab_off,
+                        int kpad, int wld) {
+    WgradJob a;
+    memset(&a, 0, sizeof(a));
     a.g = g;
-    a.in = (const bf16*)in; a.dout = (const bf16*)dout; a.slab = slab; a.kpad = kpad; a.wld = wld;
+    a.in_off = in_off; a.dout_off = dout_off; a.slab_off = slab_off; a.kpad = kpad; a.wld = wld;
     int dymax, dxmax;
     taps_extent(g, &a.dymin, &dymax, &a.dxmin, &dxmax);
     a.HH = 7 * g.in_stride + (dymax - a.dymin) + 1;
@@ -686,14 +717,53 @@ int launch_wgrad_mfma(const stcd_conv_geom& g, const WgradMfmaPlan& p, const voi
     a.x_bytes = (a.HH * a.xrow_bytes + 255) & ~255;
     a.y_bytes = (8 * (16 * 2 * COB + 2 * ypad) + 255) & ~255;
     a.co_valid = (g.co + 7) & ~7;
+    a.gx = p.gx; a.gy = p.gy; a.gz = p.gz; a.start = 0;
     const int WK = 4 / p.WCI;
-    size_t lds = std::max<size_t>(2 * (size_t)(a.x_bytes + a.y_bytes), (size_t)(WK - 1) * p.WCI * 9 * p.NTW * 4 * 64 * 4);
-    if (lds > 64 * 1024 || !p.ok) return 1;
+    a.lds_bytes = (int)std::max<size_t>(2 * (size_t)(a.x_bytes + a.y_bytes), (size_t)(WK - 1) * p.WCI * 9 * p.NTW * 4 * 64 * 4);
+    return a;
+}
+
+#define WG_DISPATCH(W_, N_, T_, WHAT)                                       \
+    do {                                                                    \
+        if ((W_) == 1 && (N_) == 1) { if (T_) { WHAT(1, 1, true); } else { WHAT(1, 1, false); } }   \
+        else if ((W_) == 1) { if (T_) { WHAT(1, 2, true); } else { WHAT(1, 2, false); } }           \
+        else if ((N_) == 1) { if (T_) { WHAT(2, 1, true); } else { WHAT(2, 1, false); } }           \
+        else { if (T_) { WHAT(2, 2, true); } else { WHAT(2, 2, false); } }                          \
+    } while (0)
+
+int wgrad_variant_slots(int WCI, int NTW, bool t9, int lds_bytes) {
+    int dev = 0, cus = 256, per_cu = 2;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 512; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+#define WG_OCC(W_, N_, T_) \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wgrad_group<W_, N_, T_>, 256, (size_t)lds_bytes) != hipSuccess) per_cu = 2
+    WG_DISPATCH(WCI, NTW, t9, WG_OCC);
+#undef WG_OCC
+    (void)hipGetLastError();
+    return std::max(1, per_cu) * cus;
+}
+
+int launch_wgrad_group(int WCI, int NTW, bool t9, const WgradJob* jobs_dev, int njobs, int total_blocks, int lds_bytes,
+                       const char* base, hipStream_t s) {
+    if (njobs <= 0 || total_blocks <= 0) return 0;
+    if (lds_bytes > 64 * 1024) return 1;
+#define WG_GROUP(W_, N_, T_) k_wgrad_group<W_, N_, T_><<<(unsigned)total_blocks, 256, (size_t)lds_bytes, s>>>(jobs_dev, njobs, base)
+    WG_DISPATCH(WCI, NTW, t9, WG_GROUP);
+#undef WG_GROUP
+    return 0;
+}
+
+int launch_wgrad_mfma(const stcd_conv_geom& g, const WgradMfmaPlan& p, const void* in, const void* dout, float* slab,
+                      int kpad, int wld, hipStream_t s) {
+    if (!p.ok) return 1;
+    const WgradJob a = wgrad_make_job(g, p, (int64_t)(intptr_t)in, (int64_t)(intptr_t)dout, (int64_t)(intptr_t)slab, kpad, wld);
+    if (a.lds_bytes > 64 * 1024) return 1;
     dim3 grid((unsigned)p.gx, (unsigned)p.gy, (unsigned)p.gz);
-#define LAUNCH_WG(W_, N_) k_wgrad_mfma<W_, N_><<<grid, 256, lds, s>>>(a)
-    if (p.WCI == 1) { if (p.NTW == 1) LAUNCH_WG(1, 1); else LAUNCH_WG(1, 2); }
-    else { if (p.NTW == 1) LAUNCH_WG(2, 1); else LAUNCH_WG(2, 2); }
-#undef LAUNCH_WG
+    const bool t9 = g.ntaps == 9;
+#define WG_ONE(W_, N_, T_) k_wgrad_mfma<W_, N_, T_><<<grid, 256, (size_t)a.lds_bytes, s>>>(a)
+    WG_DISPATCH(p.WCI, p.NTW, t9, WG_ONE);
+#undef WG_ONE
     return 0;
 }
 
