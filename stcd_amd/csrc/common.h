@@ -111,6 +111,15 @@ void launch_pack_frag(const stcd_conv_geom& g, const ConvMfmaPlan& p, const floa
                       hipStream_t s);
 int launch_conv_mfma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const void* in, const void* wf, const float* bias,
                      void* out, bool out_nchw_f32, hipStream_t s);
+// resident-filter persistent kernel for 3x3 stride-1 convs with Ci % 32 == 0 (uses the mode-A fragment image)
+struct ConvResPlan {
+    int NT = 0, nslices = 0, P = 0, blocks = 0;
+    int filt_bytes = 0, lds_bytes = 0;
+    bool ok = false;
+};
+ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups);
+int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvResPlan& rp, const void* in, const void* wf,
+                    const float* bias, void* out, int groups, float* stat_partial, int cpad, hipStream_t s);
 // small-channel persistent kernel (filter in registers, double-buffered halo, optional fused BN statistics);
 // uses the mode-B fragment image of conv_mfma_plan.
 bool conv_small_ok(const stcd_conv_geom& g, const ConvMfmaPlan& p);

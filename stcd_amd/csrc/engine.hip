@@ -54,6 +54,7 @@ struct ConvOp {
     int kreal = 0, nreal = 0;            // un-padded channels (algorithmic work accounting)
     ConvMfmaPlan plan; int64_t wf = -1;  // MFMA path: plan + fragment-order weight image (workspace offset)
     bool small = false;                  // eligible for the small-channel persistent kernel
+    ConvResPlan res; int res_groups = 1; // resident-filter persistent kernel (3x3 stride 1, Ci % 32 == 0)
 };
 struct WgradOp {
     stcd_conv_geom g{};
@@ -175,7 +176,7 @@ struct stcd_engine_impl {
     TRef D[4], dD[4], P[4], dP[4];
     int64_t bn_partial2 = -1;
     int64_t bn_partial = -1, masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
-    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8;
+    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, use_res = 1;
 };
 
 }  // namespace stcd
@@ -620,13 +621,14 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     e.conv_ops.clear();
     e.wgrad_ops.clear();
     e.slab_floats = 0;
-    auto bind_conv = [&](ConvOp& op, const stcd_conv_geom& g, int conv, bool dgrad, int tap0, int kreal, int nreal) {
+    auto bind_conv = [&](ConvOp& op, const stcd_conv_geom& g, int conv, bool dgrad, int tap0, int kreal, int nreal, int groups = 1) {
         op.g = g; op.conv = conv; op.dgrad = dgrad; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
-        op.plan = ConvMfmaPlan(); op.wf = -1;
+        op.plan = ConvMfmaPlan(); op.wf = -1; op.res = ConvResPlan(); op.res_groups = groups;
         if (e.dt == BF16) {
             op.plan = conv_mfma_plan(g);
             if (op.plan.ok) op.wf = ws.take(op.plan.wf_elems * 2);
             op.small = conv_small_ok(g, op.plan);
+            if (e.use_res && !op.small) op.res = conv_res_plan(g, op.plan, groups);
         }
         e.conv_ops.push_back(&op);
     };
@@ -641,7 +643,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     };
     auto bind_cbrd = [&](Cbrd& L) {
         const ConvW& cv = e.convs[L.conv];
-        bind_conv(L.fwd, geom3(L.N, L.H, L.W, L.K, L.in.ld, cv.cout, L.Y.ld), L.conv, false, 0, cv.cin, cv.cout);
+        bind_conv(L.fwd, geom3(L.N, L.H, L.W, L.K, L.in.ld, cv.cout, L.Y.ld), L.conv, false, 0, cv.cin, cv.cout, L.groups);
         bind_wgrad(L.wg, geom3(L.N, L.H, L.W, L.K, L.in.ld, cv.cout, L.dY.ld), L.conv, 0, cv.cin, cv.cout, L.in.off, L.dY.off);
         if (L.has_dIn)
             bind_conv(L.dgr, geom3(L.N, L.H, L.W, cv.dgrad.kpad, L.dY.ld, cv.cin, L.dIn.ld), L.conv, true, 0, cv.cout, cv.cin);
@@ -678,6 +680,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         int64_t need = 0;
         auto rows = [&](const Cbrd& L) {
             if (L.fwd.small) need = std::max<int64_t>(need, (int64_t)conv_small_blocks(L.fwd.g, L.groups) * 2 * L.fwd.g.co);
+            if (L.fwd.res.ok) need = std::max<int64_t>(need, (int64_t)L.fwd.res.P * L.groups * 2 * L.fwd.g.co);
         };
         for (auto& L : e.enc) rows(L);
         for (auto& L : e.dec) rows(L);
@@ -742,8 +745,10 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     conv_work(c.e, op.g, op.kreal, op.nreal, &fl, &by);
     char kname[64];
     const bool small_path = mfma_on(c.e) && op.small && op.wf >= 0 && c.e.use_small;
-    const bool mfma_path = !small_path && mfma_on(c.e) && op.plan.ok && op.wf >= 0;
-    if (small_path) snprintf(kname, sizeof(kname), "k_conv_small<1, %d>", (op.g.ntaps * op.g.ci + 31) / 32 <= 5 ? 5 : 9);
+    const bool res_path = !small_path && mfma_on(c.e) && op.res.ok && op.wf >= 0 && !nchw;
+    const bool mfma_path = !small_path && !res_path && mfma_on(c.e) && op.plan.ok && op.wf >= 0;
+    if (res_path) snprintf(kname, sizeof(kname), "k_conv_res<%d>", op.res.NT);
+    else if (small_path) snprintf(kname, sizeof(kname), "k_conv_small<1, %d>", (op.g.ntaps * op.g.ci + 31) / 32 <= 5 ? 5 : 9);
     else if (mfma_path) snprintf(kname, sizeof(kname), "k_conv_mfma<%d>", op.plan.NT);
     else snprintf(kname, sizeof(kname), "k_conv_ref");
     ProfScope prof(c, PC_CONV, fl, by, kname);
@@ -753,6 +758,14 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
         float* sp = stat_groups > 0 ? c.at<float>(c.e.bn_partial) : nullptr;
         if (launch_conv_small(op.g, in, c.at(op.wf), bias, out, nchw, groups, sp, op.g.co, c.s) == 0) {
             if (stat_chunks && stat_groups > 0) *stat_chunks = conv_small_blocks(op.g, groups) / groups;
+            return;
+        }
+    }
+    if (res_path) {
+        const bool want = stat_groups > 0 && stat_groups == op.res_groups;
+        float* sp = want ? c.at<float>(c.e.bn_partial) : nullptr;
+        if (launch_conv_res(op.g, op.plan, op.res, in, c.at(op.wf), bias, out, op.res_groups, sp, op.g.co, c.s) == 0) {
+            if (stat_chunks && want) *stat_chunks = op.res.P;
             return;
         }
     }
@@ -1110,6 +1123,7 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
         b.stat1 = ws.take((int64_t)b.groups * 4 * b.C * 4); b.coef1 = ws.take((int64_t)b.groups * 5 * b.C * 4);
         b.stat2 = ws.take((int64_t)b.groups * 4 * b.C * 4); b.coef2 = ws.take((int64_t)b.groups * 5 * b.C * 4);
         max_partial = std::max<int64_t>(max_partial, (int64_t)b.groups * bn_stats_chunks((int64_t)b.npg * b.H * b.W, b.C) * 2 * b.C);
+        max_partial = std::max<int64_t>(max_partial, (int64_t)1024 * 2 * b.C);   // fused-statistics rows of k_conv_res (<= 1024 blocks)
     }
     // ---- inputs
     for (auto& b : e.sn_blocks) {
@@ -1178,13 +1192,14 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
     }
     e.dwe_end = ws.cur;
 
-    auto bind_conv = [&](ConvOp& op, const stcd_conv_geom& g, int conv, bool dgrad, int tap0, int kreal, int nreal) {
+    auto bind_conv = [&](ConvOp& op, const stcd_conv_geom& g, int conv, bool dgrad, int tap0, int kreal, int nreal, int groups = 1) {
         op.g = g; op.conv = conv; op.dgrad = dgrad; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
-        op.plan = ConvMfmaPlan(); op.wf = -1; op.small = false;
+        op.plan = ConvMfmaPlan(); op.wf = -1; op.small = false; op.res = ConvResPlan(); op.res_groups = groups;
         if (e.dt == BF16) {
             op.plan = conv_mfma_plan(g);
             if (op.plan.ok) op.wf = ws.take(op.plan.wf_elems * 2);
             op.small = conv_small_ok(g, op.plan);
+            if (e.use_res && !op.small) op.res = conv_res_plan(g, op.plan, groups);
         }
         e.conv_ops.push_back(&op);
     };
@@ -1199,10 +1214,10 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
     for (auto& b : e.sn_blocks) {
         const ConvW& c1 = e.convs[b.c1];
         const ConvW& c2 = e.convs[b.c2];
-        bind_conv(b.f1, geom3(b.N, b.H, b.W, b.Cin, b.in.ld, b.C, b.Y1.ld), b.c1, false, 0, c1.cin, b.C);
+        bind_conv(b.f1, geom3(b.N, b.H, b.W, b.Cin, b.in.ld, b.C, b.Y1.ld), b.c1, false, 0, c1.cin, b.C, b.groups);
         bind_wgrad(b.w1, geom3(b.N, b.H, b.W, b.Cin, b.in.ld, b.C, b.dA1.ld), b.c1, 0, c1.cin, b.C, b.in.off, b.dA1.off);
         if (b.dIn.off >= 0) bind_conv(b.d1, geom3(b.N, b.H, b.W, c1.dgrad.kpad, b.dA1.ld, c1.cin, b.dIn.ld), b.c1, true, 0, b.C, c1.cin);
-        bind_conv(b.f2, geom3(b.N, b.H, b.W, b.C, b.A1.ld, b.C, b.Y2.ld), b.c2, false, 0, b.C, b.C);
+        bind_conv(b.f2, geom3(b.N, b.H, b.W, b.C, b.A1.ld, b.C, b.Y2.ld), b.c2, false, 0, b.C, b.C, b.groups);
         bind_wgrad(b.w2, geom3(b.N, b.H, b.W, b.C, b.A1.ld, b.C, b.dOut.ld), b.c2, 0, b.C, b.C, b.A1.off, b.dOut.off);
         bind_conv(b.d2, geom3(b.N, b.H, b.W, c2.dgrad.kpad, b.dOut.ld, b.C, b.dA1.ld), b.c2, true, 0, b.C, b.C);
     }
@@ -1436,6 +1451,8 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
     e->use_mfma = !(env && env[0] == '1');
     env = getenv("STCD_NO_SMALL_KERNEL");
     e->use_small = !(env && env[0] == '1');
+    env = getenv("STCD_NO_RES_KERNEL");
+    e->use_res = !(env && env[0] == '1');
     env = getenv("STCD_NO_WGRAD_GROUPS");
     e->use_wgroup = !(env && env[0] == '1');
     env = getenv("STCD_WGRAD_MIN_TILES");
@@ -1628,6 +1645,13 @@ int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, c
                        "small-channel kernel rejected the geometry");
             STCD_HIP(hipGetLastError());
             return 0;
+        }
+        if (impl == 1 && !(getenv("STCD_NO_RES_KERNEL") && getenv("STCD_NO_RES_KERNEL")[0] == '1')) {
+            const ConvResPlan rp = conv_res_plan(*g, p, 1);
+            if (rp.ok && launch_conv_res(*g, p, rp, in, scratch, bias, out, 1, nullptr, g->co, (hipStream_t)hip_stream) == 0) {
+                STCD_HIP(hipGetLastError());
+                return 0;
+            }
         }
         STCD_CHECK(launch_conv_mfma(*g, p, in, scratch, bias, out, false, (hipStream_t)hip_stream) == 0, "LDS budget exceeded");
         STCD_HIP(hipGetLastError());

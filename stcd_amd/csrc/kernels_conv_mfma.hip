@@ -1055,4 +1055,304 @@ int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_mo
     return 0;
 }
 
+// =====================================================================================================
+// 3x3 stride-1 convolutions with Ci % 32 == 0 (forward, data gradient, stride-1 transposed): resident-filter kernel.
+//   * block = 4 waves, output tile 16 rows x 16 columns; wave w owns rows 4w..4w+3.  A wave reads the 6 halo rows it
+//     touches ONCE per column shift and reuses them for the three row taps (18 activation-fragment reads feed
+//     36*NT MFMAs per 32-channel step), so the LDS pipe stays well under the MFMA rate.
+//   * the block's filter slice (NT n-tiles x all Ci x 9 taps, fragment order) is loaded into LDS once; the block is
+//     persistent over tiles of its BN group, walking (tile, 32-channel chunk) steps with the next step's halo chunk
+//     in flight in registers and two LDS halo buffers: one barrier per step, none inside it.
+//   * epilogue: bias, bf16 NHWC store, optional fused BN statistics (per-lane running sums over all the block's
+//     tiles, reduced once at the end into one partial row per block).
+struct ConvResArgs {
+    stcd_conv_geom g;
+    const bf16* in;
+    const bf16* wf;        // mode-A fragment image of conv_mfma_plan: [Ci/CiB][tap][CiB/32][NTtot][64][8]
+    const float* bias;     // nullable
+    bf16* out;
+    int NTtot, KSp;        // n-tiles of the image, k-steps per image chunk (CiB / 32)
+    int nchunks;           // Ci / 32
+    int nslices, P, groups;
+    int tiles_x, tiles_y, ntiles;
+    int filt_bytes;        // LDS bytes of the filter slice
+    float* stat_partial;   // nullable: [groups][P][2][cpad]
+    int cpad;
+};
+
+constexpr int RES_HW = 18, RES_HALO_BYTES = RES_HW * RES_HW * 64;   // 18 x 18 pixels x 32 channels bf16
+
+template <int NT>
+__global__ void __launch_bounds__(256, 2)
+k_conv_res(const ConvResArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int q = lane >> 4, r = lane & 15;
+    const int P = a.P;
+    const int bl = blockIdx.x % P, rest = blockIdx.x / P, slice = rest % a.nslices, grp = rest / a.nslices;
+    char* const filt = smem;                                  // [chunk][tap][NT][64 lanes][16 B]
+    char* const halo0 = smem + a.filt_bytes;                  // two halo buffers, RES_HALO_BYTES apart
+    const int ntaps = 9;
+
+    // tap index of every (row shift, column shift)
+    int tix[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                if (a.g.dy[t] + 1 == dy && a.g.dx[t] + 1 == dx) tix[dy][dx] = t;
+    }
+
+    // ---- halo staging plan: piece i = pixel (i >> 2), 16-B chunk (i & 3); 1296 pieces, <= 6 per thread
+    constexpr int NPIECE = RES_HW * RES_HW * 4, MAXP = (NPIECE + 255) / 256;
+    int poff[MAXP], pyx[MAXP], plds[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+        const int i = min(tid + p * 256, NPIECE - 1);
+        const int ch = i & 3, pix = i >> 2, hx = pix % RES_HW, hy = pix / RES_HW;
+        pyx[p] = ((hy - 1) << 16) | ((hx - 1) & 0xffff);
+        poff[p] = ((hy - 1) * a.g.wi + (hx - 1)) * a.g.ldi + ch * 8;
+        plds[p] = (pix * 4 + (ch ^ ((hx >> 1) & 3))) * 16;
+    }
+    float bv[NT][4];
+#pragma unroll
+    for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cb = (slice * NT + t2) * 16 + 4 * q + j;
+            bv[t2][j] = (a.bias && cb < a.g.co) ? a.bias[cb] : 0.f;
+        }
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s1[t2][j] = s2[t2][j] = 0.f;
+
+    // tile walk inside the group: tiles bl, bl + P, ...
+    const int tpg = a.ntiles / a.groups;
+    const int tiles_img = a.tiles_x * a.tiles_y;
+    const int dn = P / tiles_img, drem = P - dn * tiles_img, dty = drem / a.tiles_x, dtx = drem - dty * a.tiles_x;
+    int tile = grp * tpg + bl;
+    const int tile_end = (grp + 1) * tpg;
+    int tn = tile / tiles_img, trem = tile - tn * tiles_img, tty = trem / a.tiles_x, ttx = trem - tty * a.tiles_x;
+
+    uint4 pre[MAXP];
+#define RES_FETCH(N_, Y_, X_, C_)                                                                                      \
+    do {                                                                                                               \
+        const int gy0_ = (Y_) * 16, gx0_ = (X_) * 16;                                                                   \
+        const bf16* org_ = a.in + (((int64_t)(N_) * a.g.hi + gy0_) * a.g.wi + gx0_) * a.g.ldi + (C_) * 32;             \
+        _Pragma("unroll") for (int p = 0; p < MAXP; ++p) {                                                             \
+            const int hy_ = pyx[p] >> 16, hx_ = (int)(short)(pyx[p] & 0xffff);                                         \
+            const bool ok_ = (unsigned)(gy0_ + hy_) < (unsigned)a.g.hi && (unsigned)(gx0_ + hx_) < (unsigned)a.g.wi;   \
+            const uint4 v_ = *reinterpret_cast<const uint4*>(org_ + (ok_ ? poff[p] : 0));                              \
+            pre[p] = ok_ ? v_ : make_uint4(0, 0, 0, 0);                                                                \
+        }                                                                                                              \
+    } while (0)
+#define RES_STASH(BUF_)                                                                                                \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int p = 0; p < MAXP; ++p)                                                               \
+            if (tid + p * 256 < NPIECE) *reinterpret_cast<uint4*>(halo0 + (BUF_) * RES_HALO_BYTES + plds[p]) = pre[p]; \
+    } while (0)
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int t2 = 0; t2 < NT; ++t2) acc[m][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane halo read offsets: row (4*wid + hr), column r + dx, 16-B chunk q (swizzled by the column)
+    int aoff[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) aoff[dx] = (((4 * wid) * RES_HW + r + dx) * 4 + (q ^ (((r + dx) >> 1) & 3))) * 16;
+
+    int buf = 0, cc = 0;
+    if (tile < tile_end) RES_FETCH(tn, tty, ttx, 0);       // first halo chunk in flight while the filter is staged
+    // ---- filter slice -> LDS (once per block): wave w takes fragments w, w+4, ...; 8 loads in flight per lane
+    {
+        const int nfrag = a.nchunks * ntaps * NT;
+        for (int f0 = wid; f0 < nfrag; f0 += 32) {
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = min(f0 + 4 * k, nfrag - 1);
+                const int ntl = f % NT, ft = f / NT, t = ft % ntaps, c32 = ft / ntaps;
+                const int64_t src = ((int64_t)((c32 / a.KSp) * ntaps + t) * a.KSp + (c32 % a.KSp)) * a.NTtot + slice * NT + ntl;
+                v[k] = *reinterpret_cast<const uint4*>(a.wf + (src * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (f0 + 4 * k < nfrag) *reinterpret_cast<uint4*>(filt + ((int64_t)(f0 + 4 * k) * 64 + lane) * 16) = v[k];
+        }
+    }
+    if (tile < tile_end) RES_STASH(0);
+    __syncthreads();
+    while (tile < tile_end) {
+        // next step: next chunk of this tile, or chunk 0 of the next tile
+        int nn = tn, ny = tty, nx = ttx, nc = cc + 1, ntile = tile;
+        if (nc == a.nchunks) {
+            nc = 0; ntile = tile + P;
+            nx += dtx; if (nx >= a.tiles_x) { nx -= a.tiles_x; ++ny; }
+            ny += dty; if (ny >= a.tiles_y) { ny -= a.tiles_y; ++nn; }
+            nn += dn;
+        }
+        const bool have_next = ntile < tile_end;
+        if (have_next) RES_FETCH(nn, ny, nx, nc);
+        const char* hb = halo0 + buf * RES_HALO_BYTES;
+        const char* fb = filt + (int64_t)cc * (ntaps * NT * 1024) + lane * 16;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            bf16x8 afr[6];
+#pragma unroll
+            for (int hr = 0; hr < 6; ++hr) afr[hr] = *reinterpret_cast<const bf16x8*>(hb + aoff[dx] + hr * (RES_HW * 64));
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const char* ft = fb + tix[dy][dx] * (NT * 1024);
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) {
+                    const bf16x8 wfr = *reinterpret_cast<const bf16x8*>(ft + t2 * 1024);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        acc[m][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, afr[m + dy], acc[m][t2], 0, 0, 0);
+                }
+            }
+        }
+        if (have_next) RES_STASH(buf ^ 1);
+        if (nc == 0) {
+            // ---- epilogue of this tile: lane (q, r) holds channels 4q..4q+3 of n-tile t2 at row 4*wid + m, column r
+            const int mx = ttx * 16 + r;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int my = tty * 16 + wid * 4 + m;
+                const bool inside = my < a.g.hm && mx < a.g.wm;
+                bf16* orow = a.out + (((int64_t)tn * a.g.ho + my) * a.g.wo + mx) * a.g.ldo + slice * NT * 16 + 4 * q;
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) {
+                    const int cb = (slice * NT + t2) * 16 + 4 * q;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[m][t2][j] + bv[t2][j];
+                    acc[m][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (!inside || cb >= a.g.co) continue;
+                    bf16* o = orow + t2 * 16;
+                    if (cb + 3 < a.g.co) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(v[0], v[1]);
+                        pk.y = pack_bf16x2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(o) = pk;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (cb + j < a.g.co) o[j] = (bf16)v[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float rv = round_as<bf16>(v[j]);
+                        s1[t2][j] += rv;
+                        s2[t2][j] += rv * rv;
+                    }
+                }
+            }
+        }
+        tn = nn; tty = ny; ttx = nx; cc = nc; tile = ntile; buf ^= 1;
+        __syncthreads();
+    }
+#undef RES_FETCH
+#undef RES_STASH
+
+    // ---- fused BN statistics: one partial row per block; slices fill disjoint channel ranges of row (grp, bl)
+    if (a.stat_partial) {
+        float* red = reinterpret_cast<float*>(smem);     // [4 waves][NT][4 q][4 j][2]  (the filter is dead by now)
+        __syncthreads();
+#pragma unroll
+        for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = s1[t2][j], y = s2[t2][j];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); }
+                if (r == 0) {
+                    red[(((wid * NT + t2) * 4 + q) * 4 + j) * 2] = x;
+                    red[(((wid * NT + t2) * 4 + q) * 4 + j) * 2 + 1] = y;
+                }
+            }
+        __syncthreads();
+        float* outp = a.stat_partial + ((int64_t)grp * P + bl) * 2 * a.cpad;
+        for (int i = tid; i < NT * 16 * 2; i += 256) {
+            const int which = i / (NT * 16), c = i - which * NT * 16;
+            const int t2 = c >> 4, qq = (c >> 2) & 3, j = c & 3;
+            float acc_ = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) acc_ += red[(((w * NT + t2) * 4 + qq) * 4 + j) * 2 + which];
+            const int ch = slice * NT * 16 + c;
+            if (ch < a.cpad) outp[which * a.cpad + ch] = acc_;
+        }
+    }
+}
+
+static int conv_res_filter_budget() {
+    static const int kb = [] { const char* e = getenv("STCD_CONV_RES_KB"); return e ? atoi(e) : 38; }();
+    return kb;
+}
+
+ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups) {
+    ConvResPlan rp;
+    if (!p.ok || p.modeB || g.ntaps != 9 || g.in_stride != 1 || g.out_stride != 1 || g.oy0 != 0 || g.ox0 != 0) return rp;
+    if (g.ci % 32 != 0 || g.ldi % 8 != 0 || g.ldo % 4 != 0 || g.hm > g.hi || g.wm > g.wi) return rp;
+    if (groups < 1 || g.n % groups != 0) return rp;
+    bool seen[9] = {false};
+    for (int t = 0; t < 9; ++t) {
+        if (g.dy[t] < -1 || g.dy[t] > 1 || g.dx[t] < -1 || g.dx[t] > 1) return rp;
+        seen[(g.dy[t] + 1) * 3 + g.dx[t] + 1] = true;
+    }
+    for (int t = 0; t < 9; ++t) if (!seen[t]) return rp;
+    const int nchunks = g.ci / 32;
+    int NT = std::min(4, p.NT);
+    while (NT > 1 && nchunks * 9 * NT > conv_res_filter_budget()) NT >>= 1;
+    if (nchunks * 9 * NT * 1024 + 2 * RES_HALO_BYTES > 160 * 1024 - 512) return rp;
+    if (p.NTtot % NT != 0) return rp;
+    rp.NT = NT; rp.nslices = p.NTtot / NT;
+    rp.filt_bytes = nchunks * 9 * NT * 1024;
+    rp.lds_bytes = rp.filt_bytes + 2 * RES_HALO_BYTES;
+    const int64_t tiles_x = (g.wm + 15) / 16, tiles_y = (g.hm + 15) / 16, ntiles = (int64_t)g.n * tiles_x * tiles_y;
+    const int64_t tpg = ntiles / groups;
+    const int per_cu = std::max(1, std::min(4, (160 * 1024) / (rp.lds_bytes + 256)));
+    const int64_t slots = (int64_t)per_cu * 256;
+    int64_t P = std::max<int64_t>(1, slots / ((int64_t)groups * rp.nslices));
+    rp.P = (int)std::min<int64_t>(P, tpg);
+    rp.blocks = rp.P * rp.nslices * groups;
+    rp.ok = true;
+    return rp;
+}
+
+int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvResPlan& rp, const void* in, const void* wf,
+                    const float* bias, void* out, int groups, float* stat_partial, int cpad, hipStream_t s) {
+    if (!rp.ok) return 1;
+    ConvResArgs a;
+    a.g = g;
+    a.in = (const bf16*)in; a.wf = (const bf16*)wf; a.bias = bias; a.out = (bf16*)out;
+    a.NTtot = p.NTtot; a.KSp = p.CiB / 32; a.nchunks = g.ci / 32;
+    a.nslices = rp.nslices; a.P = rp.P; a.groups = groups;
+    a.tiles_x = (g.wm + 15) / 16; a.tiles_y = (g.hm + 15) / 16; a.ntiles = g.n * a.tiles_x * a.tiles_y;
+    a.filt_bytes = rp.filt_bytes;
+    a.stat_partial = stat_partial; a.cpad = cpad;
+#define LAUNCH_RES(N_)                                                                                            \
+    do {                                                                                                          \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute((const void*)k_conv_res<N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        k_conv_res<N_><<<(unsigned)rp.blocks, 256, (size_t)rp.lds_bytes, s>>>(a);                                 \
+    } while (0)
+    switch (rp.NT) {
+        case 1: LAUNCH_RES(1); break;
+        case 2: LAUNCH_RES(2); break;
+        default: LAUNCH_RES(4); break;
+    }
+#undef LAUNCH_RES
+    return 0;
+}
+
 }  // namespace stcd

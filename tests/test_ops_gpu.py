@@ -62,6 +62,7 @@ CONV_CASES = [  # n, h, w, ci, co   (ci includes the engine's zero padding to 8)
     (2, 8, 16, 64, 64), (1, 16, 16, 64, 128), (1, 8, 16, 128, 128), (1, 8, 16, 256, 128), (1, 8, 16, 384, 128),
     (1, 16, 16, 48, 16), (1, 16, 16, 96, 32), (1, 16, 16, 192, 64), (2, 16, 16, 16, 2), (1, 16, 16, 16, 1),
     (1, 20, 18, 16, 16), (1, 9, 11, 64, 64), (1, 25, 7, 32, 32),
+    (16, 64, 64, 32, 32), (6, 48, 80, 64, 32), (40, 32, 32, 128, 64),     # persistent multi-tile walks of k_conv_res
 ]
 
 
