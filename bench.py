@@ -84,6 +84,7 @@ def main():
     from stcd_amd.ddp import FlatGradReducer, broadcast_parameters, init_distributed
     from stcd_amd.losses import bce_dice_with_logits, cross_entropy
     from stcd_amd.modules import SiamUnet_conc, SiamUnet_diff, SiamUnet_sub, SNUNet_ECAM
+    from stcd_amd.optim import FlatAdamW
 
     rank, local_rank, world = init_distributed()
     assert world == args.gpus or world == 1 and args.gpus == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
@@ -94,7 +95,7 @@ def main():
     torch.manual_seed(1337)
     model = cls(3, args.label, dtype=args.dtype).to(dev).train()
     broadcast_parameters(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, fused=True)
+    opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)     # torch.optim.AdamW semantics, one launch
     reducer = FlatGradReducer(model)  # noqa: F841  (installs the gradient hook when world > 1)
 
     a, b, lab = synth.make_batch(args.batch, args.size, args.size, seed=1337 + rank)

@@ -143,6 +143,13 @@ int stcd_loss_bce_dice(const float* x, const float* target, int64_t numel, int f
 int stcd_confusion_update(const float* logits, const int64_t* target, int batch, int classes, int64_t hw,
                           int64_t* cm, void* hip_stream);
 
+/* ---- optimizer: one launch of torch.optim.Adam (decoupled == 0: weight decay added to the gradient) or
+ *      torch.optim.AdamW (decoupled != 0) over the flat parameter / gradient buffers, amsgrad off
+ *      (replaces optimizer_G.step(): models/trainer.py:46-50,312-314; train_pse_cd.py:431,239).
+ *      step = 1-based update count (bias correction); exp_avg / exp_avg_sq: fp32 state, zero-initialised. */
+int stcd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel, int64_t step,
+                   double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled, void* hip_stream);
+
 /* ---- per-op entry points (NHWC, activation dtype per `dtype`); used by the parity tests.
  *      Geometry is the engine's generic "tap list" convolution: see DESIGN.md section 3. ---- */
 typedef struct stcd_conv_geom {

@@ -43,7 +43,7 @@ class ConvGeom(C.Structure):
                 ("dy", C.c_int8 * 9), ("dx", C.c_int8 * 9), ("pad_", C.c_int8 * 2)]
 
 
-_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 _PROTOS = {
     "stcd_last_error": (C.c_char_p, []),
     "stcd_abi_version": (_i, []),
@@ -72,6 +72,7 @@ _PROTOS = {
     "stcd_loss_ce": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "stcd_loss_bce_dice": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "stcd_confusion_update": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp]),
+    "stcd_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _d, _i, _vp]),
     "stcd_op_conv": (_i, [_i, _i, C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "stcd_op_wgrad": (_i, [_i, _i, C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _i64, _vp]),
     "stcd_op_scratch_bytes": (_i64, [C.POINTER(ConvGeom)]),

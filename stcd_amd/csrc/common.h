@@ -273,6 +273,8 @@ void launch_loss_ce(const float* logits, const int64_t* target, int B, int Cn, i
                     float* dlogits, void* scratch, hipStream_t s);
 void launch_loss_bce_dice(const float* logits, const float* target, int64_t n, int from_logits, float* loss,
                           float* dlogits, void* scratch, hipStream_t s);
+void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float omb1, float beta2, float omb2, float eps,
+                 float wd, int decoupled, float step_size, float inv_bc2_sqrt, hipStream_t s);
 void launch_confusion(const float* logits, const int64_t* target, int B, int Cn, int64_t HW, int64_t* cm,
                       hipStream_t s);
 

@@ -1614,6 +1614,21 @@ int stcd_confusion_update(const float* logits, const int64_t* target, int batch,
     return 0;
 }
 
+int stcd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel, int64_t step, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, int decoupled, void* hip_stream) {
+    STCD_CHECK(params && grads && exp_avg && exp_avg_sq, "null pointer argument");
+    STCD_CHECK(numel >= 1 && step >= 1, "numel and step must be >= 1");
+    STCD_CHECK(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
+               "buffers must be 16-byte aligned");
+    // scalars are formed in double like torch's Python floats, then rounded once to fp32
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    launch_adam(params, grads, exp_avg, exp_avg_sq, numel, (float)lr, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                (float)eps, (float)weight_decay, decoupled ? 1 : 0, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)),
+                (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
 static int check_geom(const stcd_conv_geom* g) {
     STCD_CHECK(g != nullptr, "geometry is null");
     STCD_CHECK(g->ntaps >= 1 && g->ntaps <= 9, "ntaps must be in [1,9]");

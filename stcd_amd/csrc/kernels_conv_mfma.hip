@@ -586,7 +586,7 @@ k_wgrad_mfma(const WgradJob a) {
 }
 
 template <int WCI, int NTW, bool T9>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (WCI == 2 && NTW == 2) ? 3 : 2)
 k_wgrad_group(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
     int lo = 0, hi = njobs - 1;            // last job with start <= blockIdx.x (uniform: scalar loads)
     while (lo < hi) {

@@ -181,31 +181,43 @@ void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t p
 }
 
 
-// sum the per-chunk partials of 16 channels with 16 threads each; result for (group g, which) in sm[..] of part 0
+// sum the per-chunk partials of 16 channels with 64 threads each (1024-thread block); 4 independent row loads in
+// flight per thread (the fused-statistics convs deliver up to ~1000 rows per group).  Result in part 0's registers.
+constexpr int FIN_PARTS = 64, FIN_THREADS = 16 * FIN_PARTS;
 __device__ __forceinline__ void chunk_sums(const float* __restrict__ partial, int nchunk, int C, int g, int c, int part,
                                            double* sm, double* s1, double* s2) {
     double a1 = 0.0, a2 = 0.0;
-    if (c < C)
-        for (int k = part; k < nchunk; k += 16) {
-            const float* p = partial + ((int64_t)g * nchunk + k) * 2 * C;
-            a1 += p[c];
-            a2 += p[C + c];
+    if (c < C) {
+        const float* base = partial + (int64_t)g * nchunk * 2 * C + c;
+        for (int k = part; k < nchunk; k += 4 * FIN_PARTS) {
+            float v1[4], v2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k + u * FIN_PARTS;
+                const bool ok = kk < nchunk;
+                const float* p = base + (int64_t)(ok ? kk : part) * 2 * C;
+                const float x = p[0], y = p[C];
+                v1[u] = ok ? x : 0.f; v2[u] = ok ? y : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a1 += v1[u]; a2 += v2[u]; }
         }
+    }
     __syncthreads();
     sm[threadIdx.x] = a1;
-    sm[256 + threadIdx.x] = a2;
+    sm[FIN_THREADS + threadIdx.x] = a2;
     __syncthreads();
     a1 = 0.0; a2 = 0.0;
     if (part == 0)
-        for (int q = 0; q < 16; ++q) { a1 += sm[q * 16 + (threadIdx.x & 15)]; a2 += sm[256 + q * 16 + (threadIdx.x & 15)]; }
+        for (int q = 0; q < FIN_PARTS; ++q) { a1 += sm[q * 16 + (threadIdx.x & 15)]; a2 += sm[FIN_THREADS + q * 16 + (threadIdx.x & 15)]; }
     *s1 = a1; *s2 = a2;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(FIN_THREADS)
 k_bn_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg,
               const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
               float* __restrict__ rvar, float* __restrict__ stat, float momentum, float eps) {
-    __shared__ double sm[512];
+    __shared__ double sm[2 * FIN_THREADS];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
     const bool owner = part == 0 && c < C;
     float rm = (owner && rmean) ? rmean[c] : 0.f, rv = (owner && rvar) ? rvar[c] : 0.f;
@@ -232,7 +244,7 @@ k_bn_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, 
 void launch_bn_finalize(const float* partial, int nchunk, int C, int groups, int64_t ppg, const float* gamma,
                         const float* beta, float* rmean, float* rvar, float* stat, float momentum, float eps,
                         hipStream_t s) {
-    k_bn_finalize<<<cdiv(C, 16), 256, 0, s>>>(partial, nchunk, C, groups, ppg, gamma, beta, rmean, rvar, stat, momentum, eps);
+    k_bn_finalize<<<cdiv(C, 16), FIN_THREADS, 0, s>>>(partial, nchunk, C, groups, ppg, gamma, beta, rmean, rvar, stat, momentum, eps);
 }
 
 __global__ void k_bn_eval_prepare(int C, int groups, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -520,10 +532,10 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(FIN_THREADS)
 k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg, const float* __restrict__ stat,
                   float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double sm[512];
+    __shared__ double sm[2 * FIN_THREADS];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
     const bool owner = part == 0 && c < C;
     double tg = 0.0, tb = 0.0;
@@ -552,7 +564,7 @@ k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int grou
 }
 void launch_bn_bwd_finalize(const float* partial, int nchunk, int C, int groups, int64_t ppg, const float* stat, float* coef,
                             float* dgamma, float* dbeta, hipStream_t s) {
-    k_bn_bwd_finalize<<<cdiv(C, 16), 256, 0, s>>>(partial, nchunk, C, groups, ppg, stat, coef, dgamma, dbeta);
+    k_bn_bwd_finalize<<<cdiv(C, 16), FIN_THREADS, 0, s>>>(partial, nchunk, C, groups, ppg, stat, coef, dgamma, dbeta);
 }
 
 // ------------------------------------------------------------------ bias gradient (layers without a following BN)

@@ -188,4 +188,50 @@ void launch_confusion(const float* logits, const int64_t* target, int B, int Cn,
     k_confusion<<<nb, 256, 0, s>>>(logits, target, Cn, HW, npix, (unsigned long long*)cm);
 }
 
+// ------------------------------------------------------------------ fused Adam / AdamW over the flat buffers
+// One launch updates every parameter (torch.optim.Adam / AdamW, amsgrad=False, maximize=False; trainer.py:46-50,
+// train_pse_cd.py:431): 4 floats per thread, fp32 arithmetic in torch's operation order.
+__global__ void __launch_bounds__(256)
+k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+       float lr, float omb1, float beta2, float omb2, float eps, float wd, int decoupled, float step_size, float inv_bc2_sqrt) {
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    float pv[4], gv[4], mv[4], vv[4];
+    const bool full = i0 + 3 < n;
+    if (full) {
+        *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p + i0);
+        *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g + i0);
+        *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m + i0);
+        *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v + i0);
+    } else {
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = i0 + j < n;
+            pv[j] = ok ? p[i0 + j] : 0.f; gv[j] = ok ? g[i0 + j] : 0.f; mv[j] = ok ? m[i0 + j] : 0.f; vv[j] = ok ? v[i0 + j] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float gr = gv[j];
+        if (decoupled) pv[j] *= 1.f - lr * wd;          // AdamW: param.mul_(1 - lr * weight_decay)
+        else gr = gr + wd * pv[j];                      // Adam: grad.add(param, alpha=weight_decay)
+        mv[j] = mv[j] + (gr - mv[j]) * omb1;            // exp_avg.lerp_(grad, 1 - beta1)
+        vv[j] = vv[j] * beta2 + omb2 * gr * gr;          // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        const float denom = sqrtf(vv[j]) * inv_bc2_sqrt + eps;
+        pv[j] = pv[j] - step_size * (mv[j] / denom);
+    }
+    if (full) {
+        *reinterpret_cast<float4*>(p + i0) = *reinterpret_cast<const float4*>(pv);
+        *reinterpret_cast<float4*>(m + i0) = *reinterpret_cast<const float4*>(mv);
+        *reinterpret_cast<float4*>(v + i0) = *reinterpret_cast<const float4*>(vv);
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < n) { p[i0 + j] = pv[j]; m[i0 + j] = mv[j]; v[i0 + j] = vv[j]; }
+    }
+}
+void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float omb1, float beta2, float omb2, float eps,
+                 float wd, int decoupled, float step_size, float inv_bc2_sqrt, hipStream_t s) {
+    const int64_t threads = (n + 3) / 4;
+    k_adam<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(p, g, m, v, n, lr, omb1, beta2, omb2, eps, wd, decoupled, step_size, inv_bc2_sqrt);
+}
+
 }  // namespace stcd

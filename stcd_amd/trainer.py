@@ -19,6 +19,8 @@ import torch
 import torch.nn.functional as F
 import torch.optim as optim
 
+from .optim import FlatAdam, FlatAdamW
+
 from . import losses
 from .metrics import ConfuseMatrixMeter, SegmentationMetric
 from .networks import define_G, get_scheduler
@@ -54,6 +56,11 @@ class Timer:
         return self.get_stage_elapsed() * (1 - self.progress) / self.progress / 3600.0
 
 
+def _is_engine(net):
+    from .modules import HipChangeDetector
+    return isinstance(getattr(net, "module", net), HipChangeDetector)
+
+
 def _as_list(pred):
     return list(pred) if isinstance(pred, (list, tuple)) else [pred]
 
@@ -70,10 +77,12 @@ class CDTrainer:
         params = self.net_G.parameters()
         if args.optimizer == "sgd":          # trainer.py:41-50
             self.optimizer_G = optim.SGD(params, lr=self.lr, momentum=0.99, weight_decay=5e-4)
-        elif args.optimizer == "adam":
-            self.optimizer_G = optim.Adam(params, lr=self.lr, weight_decay=0)
+        elif args.optimizer == "adam":       # one fused launch over the flat buffers (stcd_amd.optim) on the engine modules
+            self.optimizer_G = (FlatAdam(self.net_G, lr=self.lr, weight_decay=0) if _is_engine(self.net_G)
+                                else optim.Adam(params, lr=self.lr, weight_decay=0))
         elif args.optimizer == "adamw":
-            self.optimizer_G = optim.AdamW(params, lr=self.lr, betas=(0.9, 0.999), weight_decay=0.01)
+            self.optimizer_G = (FlatAdamW(self.net_G, lr=self.lr, betas=(0.9, 0.999), weight_decay=0.01) if _is_engine(self.net_G)
+                                else optim.AdamW(params, lr=self.lr, betas=(0.9, 0.999), weight_decay=0.01))
         else:
             raise NotImplementedError(args.optimizer)
         self.exp_lr_scheduler_G = get_scheduler(self.optimizer_G, args)
