@@ -111,9 +111,11 @@ void launch_pack_frag(const stcd_conv_geom& g, const ConvMfmaPlan& p, const floa
                       hipStream_t s);
 int launch_conv_mfma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const void* in, const void* wf, const float* bias,
                      void* out, bool out_nchw_f32, hipStream_t s);
+int launch_conv_mfma_x4(const stcd_conv_geom g[4], const ConvMfmaPlan p[4], const void* in, const void* const wf[4],
+                        const float* bias, void* out, hipStream_t s);
 // resident-filter persistent kernel for 3x3 stride-1 convs with Ci % 32 == 0 (uses the mode-A fragment image)
 struct ConvResPlan {
-    int NT = 0, nslices = 0, P = 0, blocks = 0;
+    int NT = 0, CW = 32, nslices = 0, P = 0, blocks = 0;
     int filt_bytes = 0, lds_bytes = 0;
     bool ok = false;
 };

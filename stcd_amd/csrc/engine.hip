@@ -747,7 +747,7 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     const bool small_path = mfma_on(c.e) && op.small && op.wf >= 0 && c.e.use_small;
     const bool res_path = !small_path && mfma_on(c.e) && op.res.ok && op.wf >= 0 && !nchw;
     const bool mfma_path = !small_path && !res_path && mfma_on(c.e) && op.plan.ok && op.wf >= 0;
-    if (res_path) snprintf(kname, sizeof(kname), "k_conv_res<%d>", op.res.NT);
+    if (res_path) snprintf(kname, sizeof(kname), "k_conv_res<%d, %d>", op.res.NT, op.res.CW);
     else if (small_path) snprintf(kname, sizeof(kname), "k_conv_small<1, %d>", (op.g.ntaps * op.g.ci + 31) / 32 <= 5 ? 5 : 9);
     else if (mfma_path) snprintf(kname, sizeof(kname), "k_conv_mfma<%d>", op.plan.NT);
     else snprintf(kname, sizeof(kname), "k_conv_ref");
@@ -774,6 +774,24 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
         return;
     const float* w = c.at<float>(op.dgrad ? cv.wpk_dgrad : cv.wpk_fwd) + (int64_t)op.tap0 * ps.kpad * ps.wld;
     launch_conv_ref(c.e.dt, op.g, in, w, ps.kpad, ps.wld, bias, out, nchw, c.s);
+}
+
+// the four sub-pixel phases of a stride-2 transposed convolution as one launch; false: not applicable (caller loops)
+static bool exec_conv_x4(const Ctx& c, const ConvOp ops[4], const void* in, const float* bias, void* out) {
+    if (!mfma_on(c.e)) return false;
+    stcd_conv_geom g[4]; ConvMfmaPlan p[4]; const void* wf[4];
+    double fl = 0.0, by = 0.0;
+    for (int k = 0; k < 4; ++k) {
+        if (!ops[k].plan.ok || ops[k].wf < 0) return false;
+        g[k] = ops[k].g; p[k] = ops[k].plan; wf[k] = c.at(ops[k].wf);
+        double f1, b1;
+        conv_work(c.e, ops[k].g, ops[k].kreal, ops[k].nreal, &f1, &b1);
+        fl += f1; by += b1;
+    }
+    char kname[64];
+    snprintf(kname, sizeof(kname), "k_conv_mfma_x4<%d>", p[0].NT);
+    ProfScope prof(c, PC_CONV, fl, by, kname);
+    return launch_conv_mfma_x4(g, p, in, wf, bias, out, c.s) == 0;
 }
 
 // weight gradient of one launch, delivered straight into the reference-layout gradient tensor
@@ -903,7 +921,8 @@ static void cbrd_backward(const Ctx& c, const Cbrd& L) {
 static void upconv_forward(const Ctx& c, const UpConv& U) {
     stcd_engine& e = c.e;
     const ConvW& cv = e.convs[U.conv];
-    for (int ph = 0; ph < 4; ++ph) exec_conv(c, U.fwd[ph], c.at(U.in.off), c.params + cv.b_off, c.at(U.out.off), false);
+    if (!exec_conv_x4(c, U.fwd, c.at(U.in.off), c.params + cv.b_off, c.at(U.out.off)))
+        for (int ph = 0; ph < 4; ++ph) exec_conv(c, U.fwd[ph], c.at(U.in.off), c.params + cv.b_off, c.at(U.out.off), false);
     launch_rep_pad(e.dt, c.at(U.out.off), U.out.ld, U.N, U.Ho, U.Wo, 2 * U.h, 2 * U.w, U.C, c.s);
 }
 
@@ -1351,6 +1370,7 @@ static void sn_block_backward(const Ctx& c, const NBlock& b) {
 
 static void sn_up_forward(const Ctx& c, const SnUp& u) {
     const ConvW& cv = c.e.convs[u.conv];
+    if (exec_conv_x4(c, u.fwd, c.at(u.src.off), c.params + cv.b_off, c.at(u.out.off))) return;
     for (int ph = 0; ph < 4; ++ph) exec_conv(c, u.fwd[ph], c.at(u.src.off), c.params + cv.b_off, c.at(u.out.off), false);
 }
 static void sn_up_backward(const Ctx& c, const SnUp& u) {

@@ -40,17 +40,15 @@ struct ConvMfmaArgs {
 };
 
 template <int NT>
-__global__ void __launch_bounds__(256)
-k_conv_mfma(const ConvMfmaArgs a) {
+__device__ __forceinline__ void conv_mfma_body(const ConvMfmaArgs& a, const int bx, const int cob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int q = lane >> 4, r = lane & 15;
-    int bid = blockIdx.x;
+    int bid = bx;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int n = bid / a.tiles_y;
     const int my0 = ty * 8, mx0 = tx * 16;
-    const int cob = blockIdx.y;
     const int is = a.g.in_stride;
     const int CiB = a.CiB, nch8 = CiB >> 3, swmask = a.swmask, HWp = a.HWp;
     bf16* halo = reinterpret_cast<bf16*>(smem);
@@ -220,6 +218,21 @@ k_conv_mfma(const ConvMfmaArgs a) {
     }
 }
 
+template <int NT>
+__global__ void __launch_bounds__(256)
+k_conv_mfma(const ConvMfmaArgs a) {
+    conv_mfma_body<NT>(a, blockIdx.x, blockIdx.y);
+}
+
+// the 4 sub-pixel phases of a stride-2 transposed convolution in ONE launch (same input, disjoint outputs, same
+// grid shape): blockIdx.z picks the phase's argument block from the kernarg segment
+struct ConvMfmaArgs4 { ConvMfmaArgs a[4]; };
+template <int NT>
+__global__ void __launch_bounds__(256)
+k_conv_mfma_x4(const ConvMfmaArgs4 j) {
+    conv_mfma_body<NT>(j.a[blockIdx.z], blockIdx.x, blockIdx.y);
+}
+
 // ------------------------------------------------------------------ host side
 static void taps_extent(const stcd_conv_geom& g, int* dymin, int* dymax, int* dxmin, int* dxmax) {
     *dymin = *dxmin = 127; *dymax = *dxmax = -127;
@@ -326,9 +339,8 @@ void launch_pack_frag(const stcd_conv_geom& g, const ConvMfmaPlan& p, const floa
                                                                       p.NTtot, p.modeB, (bf16*)dst, p.wf_elems);
 }
 
-int launch_conv_mfma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const void* in, const void* wf, const float* bias,
-                     void* out, bool out_nchw, hipStream_t s) {
-    ConvMfmaArgs a;
+static size_t conv_mfma_args(const stcd_conv_geom& g, const ConvMfmaPlan& p, const void* in, const void* wf, const float* bias,
+                             void* out, bool out_nchw, ConvMfmaArgs& a) {
     a.g = g;
     a.in = (const bf16*)in; a.wf = (const bf16*)wf; a.bias = bias; a.out = out; a.out_nchw = out_nchw ? 1 : 0;
     a.CiB = p.CiB; a.nchunks = p.nchunks; a.KS = p.KS; a.modeB = p.modeB; a.NTtot = p.NTtot;
@@ -342,7 +354,13 @@ int launch_conv_mfma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const void*
     a.tiles_y = (g.hm + 7) / 8;
     a.halo_bytes = (a.HH * a.HWp * p.CiB * 2 + 255) & ~255;
     a.wbuf_bytes = p.modeB ? ((p.KS * p.NT * 1024 + 1) / 2 + 255) & ~255 : (p.KS * p.NT * 1024 + 255) & ~255;
-    const size_t lds = (size_t)a.halo_bytes + 2 * (size_t)a.wbuf_bytes + 128;
+    return (size_t)a.halo_bytes + 2 * (size_t)a.wbuf_bytes + 128;
+}
+
+int launch_conv_mfma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const void* in, const void* wf, const float* bias,
+                     void* out, bool out_nchw, hipStream_t s) {
+    ConvMfmaArgs a;
+    const size_t lds = conv_mfma_args(g, p, in, wf, bias, out, out_nchw, a);
     if (lds > 160 * 1024) return 1;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * g.n), (unsigned)(p.NTtot / p.NT));
 #define LAUNCH_NT(N_)                                                                                             \
@@ -361,6 +379,37 @@ int launch_conv_mfma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const void*
         default: LAUNCH_NT(8); break;
     }
 #undef LAUNCH_NT
+    return 0;
+}
+
+// 0 = launched; 1 = the four phases do not share a launch shape (caller falls back to four launches)
+int launch_conv_mfma_x4(const stcd_conv_geom g[4], const ConvMfmaPlan p[4], const void* in, const void* const wf[4],
+                        const float* bias, void* out, hipStream_t s) {
+    ConvMfmaArgs4 j;
+    size_t lds = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (!p[k].ok || p[k].NT != p[0].NT || p[k].NTtot != p[0].NTtot || g[k].n != g[0].n || g[k].hm != g[0].hm || g[k].wm != g[0].wm)
+            return 1;
+        lds = std::max(lds, conv_mfma_args(g[k], p[k], in, wf[k], bias, out, false, j.a[k]));
+    }
+    if (lds > 160 * 1024) return 1;
+    dim3 grid((unsigned)(j.a[0].tiles_x * j.a[0].tiles_y * g[0].n), (unsigned)(p[0].NTtot / p[0].NT), 4);
+#define LAUNCH_X4(N_)                                                                                             \
+    do {                                                                                                          \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute((const void*)k_conv_mfma_x4<N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        k_conv_mfma_x4<N_><<<grid, 256, lds, s>>>(j);                                                             \
+    } while (0)
+    switch (p[0].NT) {
+        case 1: LAUNCH_X4(1); break;
+        case 2: LAUNCH_X4(2); break;
+        case 4: LAUNCH_X4(4); break;
+        default: LAUNCH_X4(8); break;
+    }
+#undef LAUNCH_X4
     return 0;
 }
 
@@ -1080,19 +1129,25 @@ struct ConvResArgs {
     int cpad;
 };
 
-constexpr int RES_HW = 18, RES_HALO_BYTES = RES_HW * RES_HW * 64;   // 18 x 18 pixels x 32 channels bf16
+constexpr int RES_HW = 18;     // halo edge of the 16 x 16 output tile
 
-template <int NT>
-__global__ void __launch_bounds__(256, 2)
+// CW = channels per pipeline step (32: 64-B pixel rows; 64: full 128-B lines and half as many steps -- used whenever
+// Ci % 64 == 0, where the wider co slice it leaves room for also halves the re-reads of X through L2).
+template <int NT, int CW>
+__global__ void __launch_bounds__(256, (CW == 64 && NT == 4) ? 1 : 2)
 k_conv_res(const ConvResArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KSC = CW / 32, CH8 = CW / 8, LG8 = CW == 64 ? 3 : 2, SW = CH8 - 1;
+    constexpr int HALO_BYTES = RES_HW * RES_HW * CW * 2;
+    constexpr int NPIECE = RES_HW * RES_HW * CH8, MAXP = (NPIECE + 255) / 256, PIXSTEP = 256 >> LG8;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int q = lane >> 4, r = lane & 15;
     const int P = a.P;
     const int bl = blockIdx.x % P, rest = blockIdx.x / P, slice = rest % a.nslices, grp = rest / a.nslices;
-    char* const filt = smem;                                  // [chunk][tap][NT][64 lanes][16 B]
-    char* const halo0 = smem + a.filt_bytes;                  // two halo buffers, RES_HALO_BYTES apart
+    char* const filt = smem;                                  // [32-ch chunk][tap][NT][64 lanes][16 B]
+    char* const halo0 = smem + a.filt_bytes;                  // two halo buffers, HALO_BYTES apart
     const int ntaps = 9;
+    const int nsteps = a.nchunks / KSC;                       // pipeline steps per tile (nchunks = Ci / 32)
 
     // tap index of every (row shift, column shift)
     int tix[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -1105,16 +1160,17 @@ k_conv_res(const ConvResArgs a) {
                 if (a.g.dy[t] + 1 == dy && a.g.dx[t] + 1 == dx) tix[dy][dx] = t;
     }
 
-    // ---- halo staging plan: piece i = pixel (i >> 2), 16-B chunk (i & 3); 1296 pieces, <= 6 per thread
-    constexpr int NPIECE = RES_HW * RES_HW * 4, MAXP = (NPIECE + 255) / 256;
-    int poff[MAXP], pyx[MAXP], plds[MAXP];
+    // ---- halo staging plan: piece i = tid + p*256 = pixel (i >> LG8), 16-B chunk ch = tid & SW (the same for every p);
+    //      only the halo coordinates are kept per piece, offsets are rebuilt from them (2 FMAs) at use.
+    const int ch = tid & SW;
+    int pyx[MAXP], poff[MAXP], plds[MAXP];
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
-        const int i = min(tid + p * 256, NPIECE - 1);
-        const int ch = i & 3, pix = i >> 2, hx = pix % RES_HW, hy = pix / RES_HW;
+        const int pix = min((tid >> LG8) + p * PIXSTEP, RES_HW * RES_HW - 1);
+        const int hx = pix % RES_HW, hy = pix / RES_HW;
         pyx[p] = ((hy - 1) << 16) | ((hx - 1) & 0xffff);
-        poff[p] = ((hy - 1) * a.g.wi + (hx - 1)) * a.g.ldi + ch * 8;
-        plds[p] = (pix * 4 + (ch ^ ((hx >> 1) & 3))) * 16;
+        poff[p] = ((hy - 1) * a.g.wi + (hx - 1)) * a.g.ldi;
+        plds[p] = (pix * CH8 + (ch ^ ((hx >> 1) & SW))) * 16;
     }
     float bv[NT][4];
 #pragma unroll
@@ -1134,15 +1190,26 @@ k_conv_res(const ConvResArgs a) {
     const int tpg = a.ntiles / a.groups;
     const int tiles_img = a.tiles_x * a.tiles_y;
     const int dn = P / tiles_img, drem = P - dn * tiles_img, dty = drem / a.tiles_x, dtx = drem - dty * a.tiles_x;
-    int tile = grp * tpg + bl;
+    const int tile0 = grp * tpg + bl;
     const int tile_end = (grp + 1) * tpg;
-    int tn = tile / tiles_img, trem = tile - tn * tiles_img, tty = trem / a.tiles_x, ttx = trem - tty * a.tiles_x;
 
+    // ---- software pipeline: the halo chunk of step s+1 is requested into registers before the MFMAs of step s and
+    //      parked in the other LDS buffer after them; one barrier per step.  A step = (tile, CW-channel chunk).
+    struct Pos { int tile, n, y, x, c; };
     uint4 pre[MAXP];
-#define RES_FETCH(N_, Y_, X_, C_)                                                                                      \
+#define RES_ADV(P_)                                                                                                    \
     do {                                                                                                               \
-        const int gy0_ = (Y_) * 16, gx0_ = (X_) * 16;                                                                   \
-        const bf16* org_ = a.in + (((int64_t)(N_) * a.g.hi + gy0_) * a.g.wi + gx0_) * a.g.ldi + (C_) * 32;             \
+        if (++(P_).c == nsteps) {                                                                                      \
+            (P_).c = 0; (P_).tile += P;                                                                                \
+            (P_).x += dtx; if ((P_).x >= a.tiles_x) { (P_).x -= a.tiles_x; ++(P_).y; }                                 \
+            (P_).y += dty; if ((P_).y >= a.tiles_y) { (P_).y -= a.tiles_y; ++(P_).n; }                                 \
+            (P_).n += dn;                                                                                              \
+        }                                                                                                              \
+    } while (0)
+#define RES_FETCH(P_)                                                                                                  \
+    do {                                                                                                               \
+        const int gy0_ = (P_).y * 16, gx0_ = (P_).x * 16;                                                               \
+        const bf16* org_ = a.in + (((int64_t)(P_).n * a.g.hi + gy0_) * a.g.wi + gx0_) * a.g.ldi + (P_).c * CW + ch * 8; \
         _Pragma("unroll") for (int p = 0; p < MAXP; ++p) {                                                             \
             const int hy_ = pyx[p] >> 16, hx_ = (int)(short)(pyx[p] & 0xffff);                                         \
             const bool ok_ = (unsigned)(gy0_ + hy_) < (unsigned)a.g.hi && (unsigned)(gx0_ + hx_) < (unsigned)a.g.wi;   \
@@ -1153,7 +1220,8 @@ k_conv_res(const ConvResArgs a) {
 #define RES_STASH(BUF_)                                                                                                \
     do {                                                                                                               \
         _Pragma("unroll") for (int p = 0; p < MAXP; ++p)                                                               \
-            if (tid + p * 256 < NPIECE) *reinterpret_cast<uint4*>(halo0 + (BUF_) * RES_HALO_BYTES + plds[p]) = pre[p]; \
+            if ((tid >> LG8) + p * PIXSTEP < RES_HW * RES_HW)                                                          \
+                *reinterpret_cast<uint4*>(halo0 + (BUF_) * HALO_BYTES + plds[p]) = pre[p];                             \
     } while (0)
 
     f32x4 acc[4][NT];
@@ -1162,13 +1230,20 @@ k_conv_res(const ConvResArgs a) {
 #pragma unroll
         for (int t2 = 0; t2 < NT; ++t2) acc[m][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // per-lane halo read offsets: row (4*wid + hr), column r + dx, 16-B chunk q (swizzled by the column)
-    int aoff[3];
+    // per-lane halo read offsets: row (4*wid + hr), column r + dx, 16-B chunk ks*4 + q (swizzled by the column)
+    int aoff[KSC][3];
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) aoff[dx] = (((4 * wid) * RES_HW + r + dx) * 4 + (q ^ (((r + dx) >> 1) & 3))) * 16;
+    for (int ks = 0; ks < KSC; ++ks)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+            aoff[ks][dx] = (((4 * wid) * RES_HW + r + dx) * CH8 + ((ks * 4 + q) ^ (((r + dx) >> 1) & SW))) * 16;
 
-    int buf = 0, cc = 0;
-    if (tile < tile_end) RES_FETCH(tn, tty, ttx, 0);       // first halo chunk in flight while the filter is staged
+    Pos cur{tile0, 0, 0, 0, 0};
+    cur.n = tile0 / tiles_img;
+    { const int trem = tile0 - cur.n * tiles_img; cur.y = trem / a.tiles_x; cur.x = trem - cur.y * a.tiles_x; }
+    Pos nxt = cur; RES_ADV(nxt);
+    int buf = 0;
+    if (cur.tile < tile_end) RES_FETCH(cur);               // first halo chunk in flight while the filter is staged
     // ---- filter slice -> LDS (once per block): wave w takes fragments w, w+4, ...; 8 loads in flight per lane
     {
         const int nfrag = a.nchunks * ntaps * NT;
@@ -1186,47 +1261,43 @@ k_conv_res(const ConvResArgs a) {
                 if (f0 + 4 * k < nfrag) *reinterpret_cast<uint4*>(filt + ((int64_t)(f0 + 4 * k) * 64 + lane) * 16) = v[k];
         }
     }
-    if (tile < tile_end) RES_STASH(0);
+    if (cur.tile < tile_end) RES_STASH(0);
     __syncthreads();
-    while (tile < tile_end) {
-        // next step: next chunk of this tile, or chunk 0 of the next tile
-        int nn = tn, ny = tty, nx = ttx, nc = cc + 1, ntile = tile;
-        if (nc == a.nchunks) {
-            nc = 0; ntile = tile + P;
-            nx += dtx; if (nx >= a.tiles_x) { nx -= a.tiles_x; ++ny; }
-            ny += dty; if (ny >= a.tiles_y) { ny -= a.tiles_y; ++nn; }
-            nn += dn;
-        }
-        const bool have_next = ntile < tile_end;
-        if (have_next) RES_FETCH(nn, ny, nx, nc);
-        const char* hb = halo0 + buf * RES_HALO_BYTES;
-        const char* fb = filt + (int64_t)cc * (ntaps * NT * 1024) + lane * 16;
+    while (cur.tile < tile_end) {
+        const bool have_next = nxt.tile < tile_end;
+        if (have_next) RES_FETCH(nxt);
+        const char* hb = halo0 + buf * HALO_BYTES;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            bf16x8 afr[6];
+        for (int ks = 0; ks < KSC; ++ks) {
+            const char* fb = filt + (int64_t)(cur.c * KSC + ks) * (ntaps * NT * 1024) + lane * 16;
 #pragma unroll
-            for (int hr = 0; hr < 6; ++hr) afr[hr] = *reinterpret_cast<const bf16x8*>(hb + aoff[dx] + hr * (RES_HW * 64));
+            for (int dx = 0; dx < 3; ++dx) {
+                bf16x8 afr[6];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const char* ft = fb + tix[dy][dx] * (NT * 1024);
+                for (int hr = 0; hr < 6; ++hr)
+                    afr[hr] = *reinterpret_cast<const bf16x8*>(hb + aoff[ks][dx] + hr * (RES_HW * CW * 2));
 #pragma unroll
-                for (int t2 = 0; t2 < NT; ++t2) {
-                    const bf16x8 wfr = *reinterpret_cast<const bf16x8*>(ft + t2 * 1024);
+                for (int dy = 0; dy < 3; ++dy) {
+                    const char* ft = fb + tix[dy][dx] * (NT * 1024);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        acc[m][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, afr[m + dy], acc[m][t2], 0, 0, 0);
+                    for (int t2 = 0; t2 < NT; ++t2) {
+                        const bf16x8 wfr = *reinterpret_cast<const bf16x8*>(ft + t2 * 1024);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            acc[m][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, afr[m + dy], acc[m][t2], 0, 0, 0);
+                    }
                 }
             }
         }
         if (have_next) RES_STASH(buf ^ 1);
-        if (nc == 0) {
+        if (cur.c == nsteps - 1) {
             // ---- epilogue of this tile: lane (q, r) holds channels 4q..4q+3 of n-tile t2 at row 4*wid + m, column r
-            const int mx = ttx * 16 + r;
+            const int mx = cur.x * 16 + r;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int my = tty * 16 + wid * 4 + m;
+                const int my = cur.y * 16 + wid * 4 + m;
                 const bool inside = my < a.g.hm && mx < a.g.wm;
-                bf16* orow = a.out + (((int64_t)tn * a.g.ho + my) * a.g.wo + mx) * a.g.ldo + slice * NT * 16 + 4 * q;
+                bf16* orow = a.out + (((int64_t)cur.n * a.g.ho + my) * a.g.wo + mx) * a.g.ldo + slice * NT * 16 + 4 * q;
 #pragma unroll
                 for (int t2 = 0; t2 < NT; ++t2) {
                     const int cb = (slice * NT + t2) * 16 + 4 * q;
@@ -1255,9 +1326,10 @@ k_conv_res(const ConvResArgs a) {
                 }
             }
         }
-        tn = nn; tty = ny; ttx = nx; cc = nc; tile = ntile; buf ^= 1;
+        cur = nxt; RES_ADV(nxt); buf ^= 1;
         __syncthreads();
     }
+#undef RES_ADV
 #undef RES_FETCH
 #undef RES_STASH
 
@@ -1285,8 +1357,8 @@ k_conv_res(const ConvResArgs a) {
             float acc_ = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) acc_ += red[(((w * NT + t2) * 4 + qq) * 4 + j) * 2 + which];
-            const int ch = slice * NT * 16 + c;
-            if (ch < a.cpad) outp[which * a.cpad + ch] = acc_;
+            const int chn = slice * NT * 16 + c;
+            if (chn < a.cpad) outp[which * a.cpad + chn] = acc_;
         }
     }
 }
@@ -1308,13 +1380,25 @@ ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int gr
     }
     for (int t = 0; t < 9; ++t) if (!seen[t]) return rp;
     const int nchunks = g.ci / 32;
-    int NT = std::min(4, p.NT);
-    while (NT > 1 && nchunks * 9 * NT > conv_res_filter_budget()) NT >>= 1;
-    if (nchunks * 9 * NT * 1024 + 2 * RES_HALO_BYTES > 160 * 1024 - 512) return rp;
+    static const bool wide_ok = [] { const char* e = getenv("STCD_CONV_RES_NO_CW64"); return !(e && e[0] == '1'); }();
+    int CW = 32, NT = 1;
+    if (wide_ok && g.ci % 64 == 0 && g.ci >= 256) {
+        // 64-channel steps, one block per CU (measured: only pays for the deepest layers, whose 32-channel form has
+        // twice the steps; below that two resident blocks per CU win): widest co slice that fits beside the halos
+        const int halo2 = 2 * RES_HW * RES_HW * 64 * 2;
+        int nt = std::min(4, p.NT);
+        while (nt > 1 && (nchunks * 9 * nt * 1024 + halo2 > 160 * 1024 - 1024 || p.NTtot % nt != 0)) nt >>= 1;
+        if (nchunks * 9 * nt * 1024 + halo2 <= 160 * 1024 - 1024) { CW = 64; NT = nt; }
+    }
+    if (CW == 32) {
+        NT = std::min(4, p.NT);
+        while (NT > 1 && nchunks * 9 * NT > conv_res_filter_budget()) NT >>= 1;
+        if (nchunks * 9 * NT * 1024 + 2 * RES_HW * RES_HW * 64 > 160 * 1024 - 1024) return rp;
+    }
     if (p.NTtot % NT != 0) return rp;
-    rp.NT = NT; rp.nslices = p.NTtot / NT;
+    rp.NT = NT; rp.CW = CW; rp.nslices = p.NTtot / NT;
     rp.filt_bytes = nchunks * 9 * NT * 1024;
-    rp.lds_bytes = rp.filt_bytes + 2 * RES_HALO_BYTES;
+    rp.lds_bytes = rp.filt_bytes + 2 * RES_HW * RES_HW * CW * 2;
     const int64_t tiles_x = (g.wm + 15) / 16, tiles_y = (g.hm + 15) / 16, ntiles = (int64_t)g.n * tiles_x * tiles_y;
     const int64_t tpg = ntiles / groups;
     const int per_cu = std::max(1, std::min(4, (160 * 1024) / (rp.lds_bytes + 256)));
@@ -1337,19 +1421,27 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
     a.tiles_x = (g.wm + 15) / 16; a.tiles_y = (g.hm + 15) / 16; a.ntiles = g.n * a.tiles_x * a.tiles_y;
     a.filt_bytes = rp.filt_bytes;
     a.stat_partial = stat_partial; a.cpad = cpad;
-#define LAUNCH_RES(N_)                                                                                            \
+#define LAUNCH_RES(N_, W_)                                                                                        \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
-            (void)hipFuncSetAttribute((const void*)k_conv_res<N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void*)k_conv_res<N_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        k_conv_res<N_><<<(unsigned)rp.blocks, 256, (size_t)rp.lds_bytes, s>>>(a);                                 \
+        k_conv_res<N_, W_><<<(unsigned)rp.blocks, 256, (size_t)rp.lds_bytes, s>>>(a);                             \
     } while (0)
-    switch (rp.NT) {
-        case 1: LAUNCH_RES(1); break;
-        case 2: LAUNCH_RES(2); break;
-        default: LAUNCH_RES(4); break;
+    if (rp.CW == 64) {
+        switch (rp.NT) {
+            case 1: LAUNCH_RES(1, 64); break;
+            case 2: LAUNCH_RES(2, 64); break;
+            default: LAUNCH_RES(4, 64); break;
+        }
+    } else {
+        switch (rp.NT) {
+            case 1: LAUNCH_RES(1, 32); break;
+            case 2: LAUNCH_RES(2, 32); break;
+            default: LAUNCH_RES(4, 32); break;
+        }
     }
 #undef LAUNCH_RES
     return 0;

@@ -577,7 +577,18 @@ k_bias_grad(const T* __restrict__ dY, int ld, int64_t pixels, int C, float* __re
     float s[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = 0.f;
-    for (int64_t p = (int64_t)blockIdx.x * lanes + lane; p < pixels; p += (int64_t)gridDim.x * lanes) {
+    const int64_t stride = (int64_t)gridDim.x * lanes;
+    int64_t p = (int64_t)blockIdx.x * lanes + lane;
+    for (; p + 3 * stride < pixels; p += 4 * stride) {      // 4 independent loads in flight per thread
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load8<T>(dY + (p + u * stride) * ld + mycb * 8, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += v[u][j];
+    }
+    for (; p < pixels; p += stride) {
         float v[8];
         load8<T>(dY + p * ld + mycb * 8, v);
 #pragma unroll
@@ -594,7 +605,7 @@ k_bias_grad(const T* __restrict__ dY, int ld, int64_t pixels, int C, float* __re
 }
 void launch_bias_grad(int dt, const void* dY, int ld, int64_t pixels, int C, float* db, hipStream_t s) {
     int lanes = 256 / (C / 8);
-    int grid = (int)std::min<int64_t>(512, (pixels + lanes - 1) / lanes);
+    int grid = (int)std::min<int64_t>(1024, (pixels + 4 * lanes - 1) / (4 * lanes));
     if (grid < 1) grid = 1;
     if (dt == BF16) k_bias_grad<bf16><<<grid, 256, 0, s>>>((const bf16*)dY, ld, pixels, C, db);
     else k_bias_grad<float><<<grid, 256, 0, s>>>((const float*)dY, ld, pixels, C, db);
