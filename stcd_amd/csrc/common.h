@@ -98,6 +98,8 @@ void launch_conv_ref(int dt, const stcd_conv_geom& g, const void* in, const floa
 // dw fp32 [ntaps][kpad][wld] += sum_pixels in(tap) * dout ; caller zeroes dw.
 void launch_wgrad_ref(int dt, const stcd_conv_geom& g, const void* in, const void* dout, float* dw, int kpad, int wld,
                       hipStream_t s);
+void launch_wgrad_ref_f64(int dt, const stcd_conv_geom& g, const void* in, const void* dout, double* dw, int kpad, int wld,
+                          hipStream_t s);
 
 // ---- MFMA (bf16) implementations, kernels_conv_mfma.hip
 struct ConvMfmaPlan {
@@ -184,7 +186,7 @@ struct PackSpec {
     int8_t ky[9], kx[9];
 };
 void launch_pack_w(const PackSpec& ps, const float* src, float* dst, hipStream_t s);          // dst[t][k][n]
-void launch_unpack_dw(const PackSpec& ps, const float* dwe, float* gsrc, hipStream_t s);      // gsrc[src idx] = dwe[t][k][n]
+void launch_unpack_dw(const PackSpec& ps, const double* dwe, float* gsrc, hipStream_t s);      // gsrc[src idx] = dwe[t][k][n]
 
 // One launch repacks every filter of the network straight from the reference-layout parameters:
 // job kind 0 -> fp32 [tap][kpad][wld] (reference kernels), kind 1 -> bf16 MFMA-fragment image.

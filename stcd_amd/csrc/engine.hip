@@ -613,7 +613,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     e.dwe_begin = ws.cur;
     for (auto& c : e.convs) {
         c.dwe_floats = (int64_t)c.fwd.ntaps * c.fwd.kpad * c.fwd.wld;
-        c.dwe = ws.take(c.dwe_floats * 4);
+        c.dwe = ws.take(c.dwe_floats * 8);     // fp64 accumulators of the reference weight-gradient path
     }
     e.dwe_end = ws.cur;
 
@@ -813,12 +813,12 @@ static void exec_wgrad(const Ctx& c, const WgradOp& op, const void* in, const vo
         }
         if (rc == 0) return;       // the slabs are summed by the stage's batched reduce launch (reduce_stage)
     }
-    float* dwe = c.at<float>(cv.dwe) + (int64_t)op.tap0 * sub.kpad * sub.wld;
+    double* dwe = c.at<double>(cv.dwe) + (int64_t)op.tap0 * sub.kpad * sub.wld;
     if (mfma_on(c.e))   // the bulk memset of the reference path's accumulators is skipped in MFMA mode
-        (void)hipMemsetAsync(dwe, 0, (size_t)sub.ntaps * sub.kpad * sub.wld * 4, c.s);
+        (void)hipMemsetAsync(dwe, 0, (size_t)sub.ntaps * sub.kpad * sub.wld * 8, c.s);
     {
         ProfScope prof(c, PC_WGRAD, fl, by, "k_wgrad_ref");
-        launch_wgrad_ref(c.e.dt, op.g, in, dout, dwe, sub.kpad, sub.wld, c.s);
+        launch_wgrad_ref_f64(c.e.dt, op.g, in, dout, dwe, sub.kpad, sub.wld, c.s);
     }
     launch_unpack_dw(sub, dwe, c.grads + cv.w_off, c.s);
 }
@@ -1207,7 +1207,7 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
     e.dwe_begin = ws.cur;
     for (auto& c : e.convs) {
         c.dwe_floats = (int64_t)c.fwd.ntaps * c.fwd.kpad * c.fwd.wld;
-        c.dwe = ws.take(c.dwe_floats * 4);
+        c.dwe = ws.take(c.dwe_floats * 8);     // fp64 accumulators of the reference weight-gradient path
     }
     e.dwe_end = ws.cur;
 

@@ -58,9 +58,11 @@ void launch_conv_ref(int dt, const stcd_conv_geom& g, const void* in, const floa
 
 // dw[t][ci][co] += sum over a chunk of output positions of in(m, tap t)[ci] * dout(m)[co]
 #define WG_CHUNK 2048
-template <typename T>
+// ACC = double for the engine's parity path: the chunks meet through atomics, and in double the summation order no
+// longer shows in the fp32 result (reproducible gradients run to run); float for the per-op entry point.
+template <typename T, typename ACC>
 __global__ void __launch_bounds__(256)
-k_wgrad_ref(stcd_conv_geom g, const T* __restrict__ in, const T* __restrict__ dout, float* __restrict__ dw, int kpad,
+k_wgrad_ref(stcd_conv_geom g, const T* __restrict__ in, const T* __restrict__ dout, ACC* __restrict__ dw, int kpad,
             int wld, int64_t positions) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)g.ntaps * g.ci * g.co) return;
@@ -68,7 +70,7 @@ k_wgrad_ref(stcd_conv_geom g, const T* __restrict__ in, const T* __restrict__ do
     int ci = (int)((idx / g.co) % g.ci);
     int t = (int)(idx / ((int64_t)g.co * g.ci));
     int64_t m0 = (int64_t)blockIdx.y * WG_CHUNK, m1 = min(positions, m0 + WG_CHUNK);
-    float acc = 0.f;
+    ACC acc = 0;
     for (int64_t m = m0; m < m1; ++m) {
         int mx = (int)(m % g.wm);
         int64_t r = m / g.wm;
@@ -79,7 +81,7 @@ k_wgrad_ref(stcd_conv_geom g, const T* __restrict__ in, const T* __restrict__ do
         int oy = my * g.out_stride + g.oy0, ox = mx * g.out_stride + g.ox0;
         float a = (float)in[(((int64_t)n * g.hi + iy) * g.wi + ix) * g.ldi + ci];
         float b = (float)dout[(((int64_t)n * g.ho + oy) * g.wo + ox) * g.ldo + co];
-        acc += a * b;
+        acc += (ACC)a * (ACC)b;
     }
     atomicAdd(dw + ((int64_t)t * kpad + ci) * wld + co, acc);
 }
@@ -90,8 +92,17 @@ void launch_wgrad_ref(int dt, const stcd_conv_geom& g, const void* in, const voi
     int64_t outs = (int64_t)g.ntaps * g.ci * g.co;
     if (positions == 0 || outs == 0) return;
     dim3 grid((unsigned)((outs + 255) / 256), (unsigned)((positions + WG_CHUNK - 1) / WG_CHUNK));
-    if (dt == BF16) k_wgrad_ref<bf16><<<grid, 256, 0, s>>>(g, (const bf16*)in, (const bf16*)dout, dw, kpad, wld, positions);
-    else k_wgrad_ref<float><<<grid, 256, 0, s>>>(g, (const float*)in, (const float*)dout, dw, kpad, wld, positions);
+    if (dt == BF16) k_wgrad_ref<bf16, float><<<grid, 256, 0, s>>>(g, (const bf16*)in, (const bf16*)dout, dw, kpad, wld, positions);
+    else k_wgrad_ref<float, float><<<grid, 256, 0, s>>>(g, (const float*)in, (const float*)dout, dw, kpad, wld, positions);
+}
+void launch_wgrad_ref_f64(int dt, const stcd_conv_geom& g, const void* in, const void* dout, double* dw, int kpad, int wld,
+                          hipStream_t s) {
+    int64_t positions = (int64_t)g.n * g.hm * g.wm;
+    int64_t outs = (int64_t)g.ntaps * g.ci * g.co;
+    if (positions == 0 || outs == 0) return;
+    dim3 grid((unsigned)((outs + 255) / 256), (unsigned)((positions + WG_CHUNK - 1) / WG_CHUNK));
+    if (dt == BF16) k_wgrad_ref<bf16, double><<<grid, 256, 0, s>>>(g, (const bf16*)in, (const bf16*)dout, dw, kpad, wld, positions);
+    else k_wgrad_ref<float, double><<<grid, 256, 0, s>>>(g, (const float*)in, (const float*)dout, dw, kpad, wld, positions);
 }
 
 }  // namespace stcd

@@ -77,7 +77,7 @@ void launch_pack_w(const PackSpec& ps, const float* src, float* dst, hipStream_t
     int64_t total = (int64_t)ps.ntaps * ps.kpad * ps.wld;
     k_pack_w<<<cdiv(total, 256), 256, 0, s>>>(ps, src, dst);
 }
-__global__ void k_unpack_dw(PackSpec ps, const float* __restrict__ dwe, float* __restrict__ gsrc) {
+__global__ void k_unpack_dw(PackSpec ps, const double* __restrict__ dwe, float* __restrict__ gsrc) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)ps.ntaps * ps.K * ps.N;
     if (i >= total) return;
@@ -85,9 +85,9 @@ __global__ void k_unpack_dw(PackSpec ps, const float* __restrict__ dwe, float* _
     int k = (int)((i / ps.N) % ps.K);
     int t = (int)(i / ((int64_t)ps.N * ps.K));
     int64_t a = ps.kn_major ? ((int64_t)k * ps.N + n) : ((int64_t)n * ps.K + k);
-    gsrc[(a * ps.ks + ps.ky[t]) * ps.ks + ps.kx[t]] = dwe[((int64_t)t * ps.kpad + k) * ps.wld + n];
+    gsrc[(a * ps.ks + ps.ky[t]) * ps.ks + ps.kx[t]] = (float)dwe[((int64_t)t * ps.kpad + k) * ps.wld + n];
 }
-void launch_unpack_dw(const PackSpec& ps, const float* dwe, float* gsrc, hipStream_t s) {
+void launch_unpack_dw(const PackSpec& ps, const double* dwe, float* gsrc, hipStream_t s) {
     int64_t total = (int64_t)ps.ntaps * ps.K * ps.N;
     k_unpack_dw<<<cdiv(total, 256), 256, 0, s>>>(ps, dwe, gsrc);
 }
@@ -128,34 +128,47 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
         }
     }
     const T* yb = Y + ((int64_t)g * ppg) * ldy + mycb * 8;
-    int nig = 0, pin = 0;                       // image-in-group and pixel-in-image of the current pixel (MODE 1)
-    if (MODE == 1) {
-        nig = (int)((uint32_t)(p0 + lane) / (uint32_t)HW);
-        pin = (int)((p0 + lane) - (int64_t)nig * HW);
-    }
-    for (int64_t p = p0 + lane; p < p1; p += lanes) {
-        float y[8];
-        load8<T>(yb + p * ldy, y);
-        if (MODE == 0) {
+    // 4 pixels per trip, every load of the trip issued before the arithmetic (a block owns only ~8 pixels per thread:
+    // one load in flight at a time made the small maps pure latency)
+    constexpr int U = 4;
+    for (int64_t p = p0 + lane; p < p1; p += U * lanes) {
+        float y[U][8], d[U][8], rs[U][8], mk[U][8];
+        bool ok[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s1[j] += y[j]; s2[j] += y[j] * y[j]; }
-        } else {
-            float d[8];
-            load8<T>(dA + g * dav.goff + p * dav.ld + mycb * 8, d);
-            const float* mk = mask ? mask + ((int64_t)(g * npg + nig)) * C + mycb * 8 : nullptr;
-            float rs[8];
-            if (res) load8<T>(res + ((int64_t)g * ppg + p) * ldres + mycb * 8, rs);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float z = y[j] * scale[j] + shift[j];
-                if (res) z += rs[j];
-                float dz = d[j] * (mk ? mk[j] : 1.f);
-                if (relu && !(z > 0.f)) dz = 0.f;
-                s1[j] += dz;
-                s2[j] += dz * (y[j] - mean[j]) * invstd[j];
+        for (int u = 0; u < U; ++u) {
+            const int64_t pu = p + (int64_t)u * lanes;
+            ok[u] = pu < p1;
+            const int64_t pc = ok[u] ? pu : p;
+            load8<T>(yb + pc * ldy, y[u]);
+            if (MODE == 1) {
+                load8<T>(dA + g * dav.goff + pc * dav.ld + mycb * 8, d[u]);
+                if (res) load8<T>(res + ((int64_t)g * ppg + pc) * ldres + mycb * 8, rs[u]);
+                if (mask) {
+                    const int nig = (int)((uint32_t)pc / (uint32_t)HW);
+                    const float4* mp = reinterpret_cast<const float4*>(mask + ((int64_t)(g * npg + nig)) * C + mycb * 8);
+                    const float4 m0 = mp[0], m1 = mp[1];
+                    mk[u][0] = m0.x; mk[u][1] = m0.y; mk[u][2] = m0.z; mk[u][3] = m0.w;
+                    mk[u][4] = m1.x; mk[u][5] = m1.y; mk[u][6] = m1.z; mk[u][7] = m1.w;
+                }
             }
-            pin += lanes;
-            while (pin >= HW) { pin -= (int)HW; ++nig; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s1[j] += y[u][j]; s2[j] += y[u][j] * y[u][j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float z = y[u][j] * scale[j] + shift[j];
+                    if (res) z += rs[u][j];
+                    float dz = d[u][j] * (mask ? mk[u][j] : 1.f);
+                    if (relu && !(z > 0.f)) dz = 0.f;
+                    s1[j] += dz;
+                    s2[j] += dz * (y[u][j] - mean[j]) * invstd[j];
+                }
+            }
         }
     }
 #pragma unroll
@@ -183,16 +196,16 @@ void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t p
 
 // sum the per-chunk partials of 16 channels with 64 threads each (1024-thread block); 4 independent row loads in
 // flight per thread (the fused-statistics convs deliver up to ~1000 rows per group).  Result in part 0's registers.
-constexpr int FIN_PARTS = 64, FIN_THREADS = 16 * FIN_PARTS;
+constexpr int FIN_PARTS = 64, FIN_THREADS = 16 * FIN_PARTS, FIN_U = 16;   // 1024 rows = one batch of loads
 __device__ __forceinline__ void chunk_sums(const float* __restrict__ partial, int nchunk, int C, int g, int c, int part,
                                            double* sm, double* s1, double* s2) {
     double a1 = 0.0, a2 = 0.0;
     if (c < C) {
         const float* base = partial + (int64_t)g * nchunk * 2 * C + c;
-        for (int k = part; k < nchunk; k += 4 * FIN_PARTS) {
-            float v1[4], v2[4];
+        for (int k = part; k < nchunk; k += FIN_U * FIN_PARTS) {
+            float v1[FIN_U], v2[FIN_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < FIN_U; ++u) {
                 const int kk = k + u * FIN_PARTS;
                 const bool ok = kk < nchunk;
                 const float* p = base + (int64_t)(ok ? kk : part) * 2 * C;
@@ -200,7 +213,7 @@ __device__ __forceinline__ void chunk_sums(const float* __restrict__ partial, in
                 v1[u] = ok ? x : 0.f; v2[u] = ok ? y : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { a1 += v1[u]; a2 += v2[u]; }
+            for (int u = 0; u < FIN_U; ++u) { a1 += v1[u]; a2 += v2[u]; }
         }
     }
     __syncthreads();
@@ -274,40 +287,59 @@ __global__ void __launch_bounds__(256)
 k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restrict__ P, int ldp,
          const float* __restrict__ stat, const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg,
          int H, int W, int relu, int64_t total) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+    const int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i64 >= total) return;
     const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
-    int c0 = (int)(i % cb) * 8;
-    int64_t r = i / cb;
-    int xc = (int)(r % Wc); r /= Wc;
-    int yc = (int)(r % Hc);
-    int n = (int)(r / Hc);
-    int g = n / npg, nig = n - g * npg;
+    // 32-bit index arithmetic (the launcher guarantees total < 2^31)
+    uint32_t r = (uint32_t)i64;
+    const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
+    const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
+    const int yc = (int)(r % (uint32_t)Hc);
+    const int n = (int)(r / (uint32_t)Hc);
+    const int g = n / npg, nig = n - g * npg;
     const float* st = stat + (int64_t)g * 4 * C + c0;
     float sc[8], sh[8], mk[8];
+    {
+        const float4 a0 = *reinterpret_cast<const float4*>(st + 2 * C), a1 = *reinterpret_cast<const float4*>(st + 2 * C + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(st + 3 * C), b1 = *reinterpret_cast<const float4*>(st + 3 * C + 4);
+        sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+        sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+        if (mask) {
+            const float4* mp = reinterpret_cast<const float4*>(mask + (int64_t)n * C + c0);
+            const float4 m0 = mp[0], m1 = mp[1];
+            mk[0] = m0.x; mk[1] = m0.y; mk[2] = m0.z; mk[3] = m0.w; mk[4] = m1.x; mk[5] = m1.y; mk[6] = m1.z; mk[7] = m1.w;
+        } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        sc[j] = st[2 * C + j];
-        sh[j] = st[3 * C + j];
-        mk[j] = mask ? mask[(int64_t)n * C + c0 + j] : 1.f;
+            for (int j = 0; j < 8; ++j) mk[j] = 1.f;
+        }
+    }
+    // the 2x2 quad: all loads first (clamped inside the map), then the arithmetic and the stores
+    float v[4][8], rs[4][8];
+    bool ok[4];
+    int64_t pix[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+        ok[k] = y < H && x < W;
+        pix[k] = ((int64_t)n * H + (ok[k] ? y : 2 * yc)) * W + (ok[k] ? x : 2 * xc);
+        load8<T>(Y + pix[k] * ldy + c0, v[k]);
+        if (res) load8<T>(res + pix[k] * ldres + c0, rs[k]);
     }
     float best[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
-        if (y >= H || x >= W) continue;
-        float v[8], rs[8];
-        load8<T>(Y + (((int64_t)n * H + y) * W + x) * ldy + c0, v);
-        if (res) load8<T>(res + (((int64_t)n * H + y) * W + x) * ldres + c0, rs);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float z = v[j] * sc[j] + sh[j];
-            if (res) z += rs[j];                 // residual add before the ReLU (SNUNet conv_block_nested, SNUNet.py:25)
+            float z = v[k][j] * sc[j] + sh[j];
+            if (res) z += rs[k][j];              // residual add before the ReLU (SNUNet conv_block_nested, SNUNet.py:25)
             if (relu) z = fmaxf(z, 0.f);
-            v[j] = round_as<T>(z * mk[j]);
-            best[j] = k == 0 ? v[j] : fmaxf(best[j], v[j]);
+            v[k][j] = round_as<T>(z * mk[j]);
+            best[j] = k == 0 ? v[k][j] : fmaxf(best[j], v[k][j]);   // pooled cells are complete quads: every k is inside
         }
-        store8<T>(A + g * av.goff + (((int64_t)nig * H + y) * W + x) * av.ld + c0, v);
+        if (ok[k]) {
+            const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+            store8<T>(A + g * av.goff + (((int64_t)nig * H + y) * W + x) * av.ld + c0, v[k]);
+        }
     }
     if (P && yc < Hp && xc < Wp) store8<T>(P + (((int64_t)n * Hp + yc) * Wp + xc) * ldp + c0, best);
 }
@@ -510,28 +542,32 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
     const float* w = bw + (int64_t)g * 5 * C + c0;
     ld8f(w, sc); ld8f(w + C, sh); ld8f(w + 2 * C, kb); ld8f(w + 3 * C, mu); ld8f(w + 4 * C, kc);
     if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
+    // all loads of the PX pixels first (dY may alias dA: every thread reads its own elements before it writes them)
+    float y[PX][8], d[PX][8], rs[PX][8], ex[PX][8];
 #pragma unroll
     for (int k = 0; k < PX; ++k) {
-        float y[8], d[8], o[8], rs[8], dzv[8], ex[8];
-        load8<T>(Y + (p0 + k) * ldy + c0, y);
-        load8<T>(dA + g * dav.goff + (pig0 + k) * dav.ld + c0, d);
-        if (res) load8<T>(res + (p0 + k) * ldres + c0, rs);
-        if (extra) load8<T>(extra + (p0 + k) * ldex + c0, ex);
+        load8<T>(Y + (p0 + k) * ldy + c0, y[k]);
+        load8<T>(dA + g * dav.goff + (pig0 + k) * dav.ld + c0, d[k]);
+        if (res) load8<T>(res + (p0 + k) * ldres + c0, rs[k]);
+        if (extra) load8<T>(extra + (p0 + k) * ldex + c0, ex[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        float o[8], dzv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float dz = mask ? d[j] * mk[j] : d[j];
-            float z = y[j] * sc[j] + sh[j];
-            if (res) z += rs[j];
+            float dz = mask ? d[k][j] * mk[j] : d[k][j];
+            float z = y[k][j] * sc[j] + sh[j];
+            if (res) z += rs[k][j];
             if (relu && !(z > 0.f)) dz = 0.f;
             dzv[j] = dz;
-            o[j] = sc[j] * dz + kb[j] * (y[j] - mu[j]) + kc[j];
-            if (extra) o[j] += ex[j];
+            o[j] = sc[j] * dz + kb[j] * (y[k][j] - mu[j]) + kc[j];
+            if (extra) o[j] += ex[k][j];
         }
         if (dZout) store8<T>(dZout + (p0 + k) * lddz + c0, dzv);
         store8<T>(dY + (p0 + k) * lddy + c0, o);
     }
 }
-
 __global__ void __launch_bounds__(FIN_THREADS)
 k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg, const float* __restrict__ stat,
                   float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -603,9 +639,29 @@ k_bias_grad(const T* __restrict__ dY, int ld, int64_t pixels, int C, float* __re
         atomicAdd(db + c, acc);
     }
 }
+// parity (fp32) mode: one block per 8-channel group walks every pixel in a fixed order and tree-reduces in LDS, so the
+// result does not depend on scheduling (the production kernel above meets through float atomics)
+__global__ void __launch_bounds__(256)
+k_bias_grad_det(const float* __restrict__ dY, int ld, int64_t pixels, int C, float* __restrict__ db) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t p = threadIdx.x; p < pixels; p += 256) acc += (double)dY[p * ld + c];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[c] += (float)red[0];
+}
 void launch_bias_grad(int dt, const void* dY, int ld, int64_t pixels, int C, float* db, hipStream_t s) {
+    if (dt != BF16) {
+        k_bias_grad_det<<<C, 256, 0, s>>>((const float*)dY, ld, pixels, C, db);
+        return;
+    }
     int lanes = 256 / (C / 8);
-    int grid = (int)std::min<int64_t>(1024, (pixels + 4 * lanes - 1) / (4 * lanes));
+    int grid = (int)std::min<int64_t>(256, (pixels + 4 * lanes - 1) / (4 * lanes));   // <= 256 atomic adders per channel
     if (grid < 1) grid = 1;
     if (dt == BF16) k_bias_grad<bf16><<<grid, 256, 0, s>>>((const bf16*)dY, ld, pixels, C, db);
     else k_bias_grad<float><<<grid, 256, 0, s>>>((const float*)dY, ld, pixels, C, db);
