@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Copy the judged artefacts of tools/profile_round.sh from gpurun_out/<tag>/ into profiles/ (tracked):
+  <tag>_bench.json          the bench.py line (roofline + cpu_baseline)
+  <tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary of `bench.py --no-cpu-baseline`
+  <tag>_pmc_traffic.txt     per-kernel HBM-side bytes per launch from the separate FETCH_SIZE / WRITE_SIZE passes
+                            (FETCH_SIZE, WRITE_SIZE are KiB; FETCH_SIZE doubled per the gfx950 correction of
+                            /opt/skills/guides/MI355X_MICROARCH.md, section HBM)
+usage: python tools/collect_profiles.py r01
+"""
+import collections, csv, glob, json, os, re, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = f"gpurun_out/{tag}", "profiles"
+os.makedirs(dst, exist_ok=True)
+line = [l for l in open(f"{src}/bench.json") if l.startswith("{")][-1]
+json.loads(line)
+open(f"{dst}/{tag}_bench.json", "w").write(line)
+stats = glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True)[0]
+shutil.copy(stats, f"{dst}/{tag}_kernel_stats.csv")
+
+
+def short(n):
+    n = n.split("(")[0].replace("void ", "")
+    m = re.match(r"_ZN4stcd\d+(k_[a-z_0-9]+)", n)
+    return "stcd::" + m.group(1) if m else n
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(f"{path}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+fetch, write = per_kernel(f"{src}/pmc_fetch", "FETCH_SIZE"), per_kernel(f"{src}/pmc_write", "WRITE_SIZE")
+rows = []
+for k in sorted(set(fetch) | set(write)):
+    if "stcd" not in k:
+        continue
+    f = fetch.get(k, [0.0]); w = write.get(k, [0.0])
+    fb = 2.0 * 1024.0 * sum(f) / len(f)          # KiB -> bytes, x2 (gfx950: 128-B requests tallied at 64 B)
+    wb = 1024.0 * sum(w) / len(w)
+    rows.append((fb + wb, k, len(f), fb, wb))
+rows.sort(reverse=True)
+with open(f"{dst}/{tag}_pmc_traffic.txt", "w") as o:
+    o.write("# HBM-side traffic per launch (bytes), averaged over the launches of 4 bench steps; separate --pmc passes\n")
+    o.write("# read = 2 * 1024 * FETCH_SIZE (gfx950 correction), write = 1024 * WRITE_SIZE\n")
+    o.write(f"{'kernel':48s} {'launches':>8s} {'read_B':>14s} {'write_B':>14s} {'total_B':>14s}\n")
+    for tot, k, n, fb, wb in rows:
+        o.write(f"{k[:48]:48s} {n:8d} {fb:14.0f} {wb:14.0f} {tot:14.0f}\n")
+print(open(f"{dst}/{tag}_pmc_traffic.txt").read()[:3000])
