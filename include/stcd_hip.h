@@ -150,6 +150,19 @@ int stcd_confusion_update(const float* logits, const int64_t* target, int batch,
 int stcd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel, int64_t step,
                    double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled, void* hip_stream);
 
+/* ---- pseudo-change pair synthesis on the device (replaces the file-based assembly of data/dataset.py:468-482 plus
+ *      ToTensor/Normalize :499-500 and the paired cutout :24-57; the reference holds NO generator arithmetic, so the
+ *      blend below is this library's own specification -- oracle/pseudo_ref.py restates it, parity is unpinned).
+ *      img_a, donor: uint8 [B,H,W,3] (HWC, device); mask: uint8 [B,H,W] (>= 1 means building); change: uint8 [B]
+ *      (tile is in the change list); alpha: nullable fp32 [B] blend strength (NULL = 1: donor replaces A inside the
+ *      mask, as the reference's in-painted file does); erase_xywh: nullable int32 [B,4] cutout rectangle (w == 0: none),
+ *      filled with per-pixel uniform values from `seed`, identical in A and B, label 255 there (host mean3/std3).
+ *      x1, x2: fp32 [B,3,H,W] normalised; c_label / s_label_a / s_label_b: int64 [B,H,W] (the last two nullable). */
+int stcd_pseudo_pair(const uint8_t* img_a, const uint8_t* donor, const uint8_t* mask, const uint8_t* change, const float* alpha,
+                     const int32_t* erase_xywh, uint64_t seed, int batch, int height, int width, const float* mean3,
+                     const float* std3, float* x1, float* x2, int64_t* c_label, int64_t* s_label_a, int64_t* s_label_b,
+                     void* hip_stream);
+
 /* ---- per-op entry points (NHWC, activation dtype per `dtype`); used by the parity tests.
  *      Geometry is the engine's generic "tap list" convolution: see DESIGN.md section 3. ---- */
 typedef struct stcd_conv_geom {

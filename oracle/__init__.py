@@ -11,4 +11,8 @@ captured from the reference's own leaf modules (``tests/golden/*.npz``, produced
 by ``tests/golden/make_golden.py`` in the authoring container, where
 ``/root/reference`` is importable).  The reference has no tests of its own
 (SURVEY.md section 4), so those captured vectors are the only pin.
+
+Exception: ``pseudo_ref.py`` (pseudo-change pair synthesis) is PARITY UNPINNED --
+the reference assembles those pairs from files and holds no generator arithmetic
+(see the module header for what is and is not taken from the reference).
 """

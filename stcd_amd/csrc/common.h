@@ -279,6 +279,9 @@ void launch_loss_bce_dice(const float* logits, const float* target, int64_t n, i
                           float* dlogits, void* scratch, hipStream_t s);
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float omb1, float beta2, float omb2, float eps,
                  float wd, int decoupled, float step_size, float inv_bc2_sqrt, hipStream_t s);
+void launch_pseudo_pair(const uint8_t* A, const uint8_t* donor, const uint8_t* mask, const uint8_t* change, const float* alpha,
+                        const int32_t* erase, uint64_t seed, int B, int H, int W, const float* mean, const float* std_,
+                        float* x1, float* x2, int64_t* c_label, int64_t* s_label_a, int64_t* s_label_b, hipStream_t s);
 void launch_confusion(const float* logits, const int64_t* target, int B, int Cn, int64_t HW, int64_t* cm,
                       hipStream_t s);
 

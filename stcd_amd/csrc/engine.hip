@@ -1649,6 +1649,19 @@ int stcd_adam_step(float* params, const float* grads, float* exp_avg, float* exp
     return 0;
 }
 
+int stcd_pseudo_pair(const uint8_t* img_a, const uint8_t* donor, const uint8_t* mask, const uint8_t* change, const float* alpha,
+                     const int32_t* erase_xywh, uint64_t seed, int batch, int height, int width, const float* mean3,
+                     const float* std3, float* x1, float* x2, int64_t* c_label, int64_t* s_label_a, int64_t* s_label_b,
+                     void* hip_stream) {
+    STCD_CHECK(img_a && donor && mask && change && x1 && x2 && c_label && mean3 && std3, "null pointer argument");
+    STCD_CHECK(batch >= 1 && height >= 1 && width >= 1, "bad shape");
+    STCD_CHECK(std3[0] > 0.f && std3[1] > 0.f && std3[2] > 0.f, "std must be positive");
+    launch_pseudo_pair(img_a, donor, mask, change, alpha, erase_xywh, seed, batch, height, width, mean3, std3, x1, x2, c_label,
+                       s_label_a, s_label_b, (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
 static int check_geom(const stcd_conv_geom* g) {
     STCD_CHECK(g != nullptr, "geometry is null");
     STCD_CHECK(g->ntaps >= 1 && g->ntaps <= 9, "ntaps must be in [1,9]");

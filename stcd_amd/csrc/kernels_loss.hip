@@ -234,4 +234,63 @@ void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float 
     k_adam<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(p, g, m, v, n, lr, omb1, beta2, omb2, eps, wd, decoupled, step_size, inv_bc2_sqrt);
 }
 
+// ------------------------------------------------------------------ pseudo-change pair synthesis (own specification)
+// The reference assembles a pseudo-change pair from files (data/dataset.py:468-482): B := an in-painted copy of A and
+// change-label := A's building mask when the tile is in the change list, else B := A and label := 0; then
+// ToTensor + Normalize (dataset.py:499-500) and, optionally, the paired cutout erase (dataset.py:24-57).  No generator
+// arithmetic exists there, so this kernel defines it: B = A outside the mask, round(alpha*donor + (1-alpha)*A) inside.
+// One thread per pixel: 3 uint8 channels in, 2 x 3 normalised fp32 NCHW values + 3 int64 labels out.
+__device__ __forceinline__ uint32_t pc_hash(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + 1);   // splitmix64 (same generator as the dropout masks)
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 40);               // 24 random bits
+}
+__global__ void __launch_bounds__(256)
+k_pseudo_pair(const uint8_t* __restrict__ A, const uint8_t* __restrict__ donor, const uint8_t* __restrict__ mask,
+              const uint8_t* __restrict__ change, const float* __restrict__ alpha, const int32_t* __restrict__ erase,
+              uint64_t seed, int B, int H, int W, float m0, float m1, float m2, float is0, float is1, float is2,
+              float* __restrict__ x1, float* __restrict__ x2, int64_t* __restrict__ c_label, int64_t* __restrict__ s_label_a,
+              int64_t* __restrict__ s_label_b) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t HW = (int64_t)H * W;
+    if (i >= (int64_t)B * HW) return;
+    const int n = (int)(i / HW);
+    const int64_t pix = i - (int64_t)n * HW;
+    const int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
+    const bool ch = change[n] != 0;
+    const bool m = mask[i] >= 1;                                      // label[label >= 1] = 1   (dataset.py:461)
+    const float al = alpha ? alpha[n] : 1.f;
+    bool er = false;
+    if (erase) {                                                      // (x, y, w, h) per sample; w == 0: no erase
+        const int ex = erase[4 * n], ey = erase[4 * n + 1], ew = erase[4 * n + 2], eh = erase[4 * n + 3];
+        er = ew > 0 && eh > 0 && x >= ex && x < ex + ew && y >= ey && y < ey + eh;
+    }
+    const float mean[3] = {m0, m1, m2}, istd[3] = {is0, is1, is2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float a = (float)A[i * 3 + c];
+        float b = a;
+        if (ch && m) b = rintf(al * (float)donor[i * 3 + c] + (1.f - al) * a);
+        if (er) {                                                     // pixel-level erase, the SAME value in A and B
+            a = (float)(pc_hash(seed, (uint64_t)i * 3 + c) & 255u);
+            b = a;
+        }
+        x1[((int64_t)n * 3 + c) * HW + pix] = (a * (1.f / 255.f) - mean[c]) * istd[c];
+        x2[((int64_t)n * 3 + c) * HW + pix] = (b * (1.f / 255.f) - mean[c]) * istd[c];
+    }
+    const int64_t lab = m ? 1 : 0;
+    c_label[i] = er ? 255 : (ch ? lab : 0);                           // cutout marks its rectangle 255 (dataset.py:52)
+    if (s_label_a) s_label_a[i] = lab;
+    if (s_label_b) s_label_b[i] = ch ? 0 : lab;
+}
+void launch_pseudo_pair(const uint8_t* A, const uint8_t* donor, const uint8_t* mask, const uint8_t* change, const float* alpha,
+                        const int32_t* erase, uint64_t seed, int B, int H, int W, const float* mean, const float* std_,
+                        float* x1, float* x2, int64_t* c_label, int64_t* s_label_a, int64_t* s_label_b, hipStream_t s) {
+    const int64_t total = (int64_t)B * H * W;
+    k_pseudo_pair<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(A, donor, mask, change, alpha, erase, seed, B, H, W, mean[0], mean[1],
+                                                                  mean[2], 1.f / std_[0], 1.f / std_[1], 1.f / std_[2], x1, x2,
+                                                                  c_label, s_label_a, s_label_b);
+}
+
 }  // namespace stcd
