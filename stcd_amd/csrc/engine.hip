@@ -176,7 +176,7 @@ struct stcd_engine_impl {
     TRef D[4], dD[4], P[4], dP[4];
     int64_t bn_partial2 = -1;
     int64_t bn_partial = -1, masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
-    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, use_res = 1;
+    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1;
 };
 
 }  // namespace stcd
@@ -407,7 +407,8 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                         G.lds_bytes = std::max(G.lds_bytes, j.lds_bytes);
                     }
                     const int slots = wgrad_variant_slots(G.WCI, G.NTW, G.t9, G.lds_bytes);
-                    const int64_t tpb = std::max<int64_t>(e.wgroup_min_tiles, (W + 2 * slots - 1) / (2 * slots));
+                    const int64_t rounds = e.wgroup_rounds;
+                    const int64_t tpb = std::max<int64_t>(e.wgroup_min_tiles, (W + rounds * slots - 1) / (rounds * slots));
                     for (WgradOp* op : ops) {
                         const ConvW& cv = e.convs[op->conv];
                         const int64_t ntiles = (int64_t)op->g.n * ((op->g.wm + 15) / 16) * ((op->g.hm + 7) / 8);
@@ -1475,6 +1476,8 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
     e->use_res = !(env && env[0] == '1');
     env = getenv("STCD_NO_WGRAD_GROUPS");
     e->use_wgroup = !(env && env[0] == '1');
+    env = getenv("STCD_WGRAD_ROUNDS");
+    if (env && atoi(env) > 0) e->wgroup_rounds = atoi(env);
     env = getenv("STCD_WGRAD_MIN_TILES");
     if (env && atoi(env) > 0) e->wgroup_min_tiles = atoi(env);
     if (arch == STCD_ARCH_SNUNET) build_snunet_tables(*e);

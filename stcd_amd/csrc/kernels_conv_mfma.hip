@@ -1391,9 +1391,19 @@ ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int gr
         if (nchunks * 9 * nt * 1024 + halo2 <= 160 * 1024 - 1024) { CW = 64; NT = nt; }
     }
     if (CW == 32) {
-        NT = std::min(4, p.NT);
-        while (NT > 1 && nchunks * 9 * NT > conv_res_filter_budget()) NT >>= 1;
-        if (nchunks * 9 * NT * 1024 + 2 * RES_HW * RES_HW * 64 > 160 * 1024 - 1024) return rp;
+        // widest co slice that still leaves two blocks per CU; if even one n-tile cannot (deep layers), the widest that
+        // fits at all -- a single resident block should at least not re-read X once per slice
+        const int halo2 = 2 * RES_HW * RES_HW * 64, cap = 160 * 1024 - 1024;
+        auto fits = [&](int nt, int blocks_per_cu) {
+            return p.NTtot % nt == 0 && (nchunks * 9 * nt * 1024 + halo2) * blocks_per_cu <= cap;
+        };
+        const int ntmax = std::min(4, p.NT);
+        NT = 0;
+        for (int nt = ntmax; nt >= 1 && !NT; nt >>= 1)
+            if (fits(nt, 2) && nchunks * 9 * nt <= conv_res_filter_budget()) NT = nt;
+        for (int nt = ntmax; nt >= 1 && !NT; nt >>= 1)
+            if (fits(nt, 1)) NT = nt;
+        if (!NT) return rp;
     }
     if (p.NTtot % NT != 0) return rp;
     rp.NT = NT; rp.CW = CW; rp.nslices = p.NTtot / NT;
