@@ -257,11 +257,12 @@ void launch_slice(int dt, void* dst, int ldd, const void* src, int lds, int64_t 
 // ECAM head of SNUNet (SNUNet.py:46-59,144-149); scratch layouts documented at the kernels (kernels_ew.hip)
 void launch_ecam_forward(int dt, const void* X, int ld, void* Z, int ldz, int N, int64_t HW, int C4, const float* w1a,
                          const float* w2a, const float* w1b, const float* w2b, float* pool, int64_t* argm, float* att,
-                         float* hid, hipStream_t s);
+                         float* hid, float* part, hipStream_t s);
+int64_t ecam_part_floats(int N, int C4);       // scratch of the chunked ECAM reductions (`part`)
 void launch_ecam_backward(int dt, const void* X, int ld, const void* dZ, int lddz, void* dX, int lddx, int N, int64_t HW, int C4,
                           const float* w1a, const float* w2a, const float* w1b, const float* w2b, float* gw1a, float* gw2a,
                           float* gw1b, float* gw2b, const float* pool, const int64_t* argm, const float* att, const float* hid,
-                          float* sums, float* dpool, hipStream_t s);
+                          float* sums, float* dpool, float* part, hipStream_t s);
 // dA (+)= route(dP) to the first maximum of each 2x2 window of A
 void launch_pool_bwd(int dt, const void* A, int lda, int64_t a_goff, const void* dP, int ldp, void* dA, int ldda,
                      int64_t da_goff, int groups, int npg, int H, int W, int C, int accumulate, hipStream_t s);

@@ -141,7 +141,7 @@ struct stcd_engine_impl {
     int sn_final = -1;
     int64_t sn_w[4] = {0, 0, 0, 0};                          // ca.fc1, ca.fc2, ca1.fc1, ca1.fc2 offsets in the flat params
     TRef snE, sndE, snZ, sndZ;
-    int64_t sn_pool = -1, sn_argm = -1, sn_att = -1, sn_hid = -1, sn_sums = -1, sn_dpool = -1;
+    int64_t sn_pool = -1, sn_argm = -1, sn_att = -1, sn_hid = -1, sn_sums = -1, sn_dpool = -1, sn_part = -1;
     int64_t sn_dout_begin = -1, sn_dout_end = -1;
     ConvOp sn_final_fwd, sn_final_dgr; WgradOp sn_final_wg;
     int arch = 0, in_ch = 3, label = 2, dt = F32;
@@ -1201,6 +1201,7 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
     e.sn_pool = ws.take((int64_t)B * 4 * c4 * 4); e.sn_argm = ws.take((int64_t)B * 2 * c4 * 8);
     e.sn_att = ws.take((int64_t)B * 2 * c4 * 4); e.sn_hid = ws.take((int64_t)B * 2 * 2 * 16 * 4);
     e.sn_sums = ws.take((int64_t)B * 2 * c4 * 4); e.sn_dpool = ws.take((int64_t)B * 4 * c4 * 4);
+    e.sn_part = ws.take(ecam_part_floats(B, c4) * 4);
     for (auto& c : e.convs) {
         c.wpk_fwd = ws.take((int64_t)c.fwd.ntaps * c.fwd.kpad * c.fwd.wld * 4);
         if (c.dgrad.ntaps) c.wpk_dgrad = ws.take((int64_t)c.dgrad.ntaps * c.dgrad.kpad * c.dgrad.wld * 4);
@@ -1398,7 +1399,7 @@ static int forward_snunet(stcd_engine& e, const float* x1, const float* x2, cons
     const int c4 = SN_F[0] * 4;
     launch_ecam_forward(e.dt, c.at(e.snE.off), e.snE.ld, c.at(e.snZ.off), e.snZ.ld, e.B, (int64_t)e.H * e.W, c4, params + e.sn_w[0],
                         params + e.sn_w[1], params + e.sn_w[2], params + e.sn_w[3], c.at<float>(e.sn_pool), c.at<int64_t>(e.sn_argm),
-                        c.at<float>(e.sn_att), c.at<float>(e.sn_hid), s);
+                        c.at<float>(e.sn_att), c.at<float>(e.sn_hid), c.at<float>(e.sn_part), s);
     exec_conv(c, e.sn_final_fwd, c.at(e.snZ.off), params + e.convs[e.sn_final].b_off, logits, true);
     STCD_HIP(hipGetLastError());
     return 0;
@@ -1426,7 +1427,7 @@ static int backward_snunet(stcd_engine& e, const float* grad_logits, const float
     launch_ecam_backward(dt, c.at(e.snE.off), e.snE.ld, c.at(e.sndZ.off), e.sndZ.ld, c.at(e.sndE.off), e.sndE.ld, B, (int64_t)e.H * e.W, c4,
                          params + e.sn_w[0], params + e.sn_w[1], params + e.sn_w[2], params + e.sn_w[3], grads + e.sn_w[0],
                          grads + e.sn_w[1], grads + e.sn_w[2], grads + e.sn_w[3], c.at<float>(e.sn_pool), c.at<int64_t>(e.sn_argm),
-                         c.at<float>(e.sn_att), c.at<float>(e.sn_hid), c.at<float>(e.sn_sums), c.at<float>(e.sn_dpool), s);
+                         c.at<float>(e.sn_att), c.at<float>(e.sn_hid), c.at<float>(e.sn_sums), c.at<float>(e.sn_dpool), c.at<float>(e.sn_part), s);
     for (int oi = (int)e.sn_order.size() - 1; oi >= 0; --oi) {
         const NBlock& b = e.sn_blocks[e.sn_order[oi]];
         if (b.pool) {    // gradient coming back through the 2x2 max-pool of this encoder output

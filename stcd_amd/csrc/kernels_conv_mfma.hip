@@ -1174,12 +1174,16 @@ k_conv_res(const ConvResArgs a) {
     }
     float bv[NT][4];
 #pragma unroll
-    for (int t2 = 0; t2 < NT; ++t2)
+    for (int t2 = 0; t2 < NT; ++t2) {
+        const int cb = (slice * NT + t2) * 16 + 4 * q;
+        if (a.bias && cb + 3 < a.g.co) {                      // flat parameter tensors are 16-B aligned
+            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + cb);
+            bv[t2][0] = b4.x; bv[t2][1] = b4.y; bv[t2][2] = b4.z; bv[t2][3] = b4.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cb = (slice * NT + t2) * 16 + 4 * q + j;
-            bv[t2][j] = (a.bias && cb < a.g.co) ? a.bias[cb] : 0.f;
+            for (int j = 0; j < 4; ++j) bv[t2][j] = (a.bias && cb + j < a.g.co) ? a.bias[cb + j] : 0.f;
         }
+    }
     float s1[NT][4], s2[NT][4];
 #pragma unroll
     for (int t2 = 0; t2 < NT; ++t2)
@@ -1244,20 +1248,22 @@ k_conv_res(const ConvResArgs a) {
     Pos nxt = cur; RES_ADV(nxt);
     int buf = 0;
     if (cur.tile < tile_end) RES_FETCH(cur);               // first halo chunk in flight while the filter is staged
-    // ---- filter slice -> LDS (once per block): wave w takes fragments w, w+4, ...; 8 loads in flight per lane
+    // ---- filter slice -> LDS (once per block): wave w takes fragments w, w+4, ...; 9 loads in flight per lane (the
+    //      common 36-fragment slices arrive in ONE round trip)
     {
         const int nfrag = a.nchunks * ntaps * NT;
-        for (int f0 = wid; f0 < nfrag; f0 += 32) {
-            uint4 v[8];
+        constexpr int FB = 9;
+        for (int f0 = wid; f0 < nfrag; f0 += 4 * FB) {
+            uint4 v[FB];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < FB; ++k) {
                 const int f = min(f0 + 4 * k, nfrag - 1);
                 const int ntl = f % NT, ft = f / NT, t = ft % ntaps, c32 = ft / ntaps;
                 const int64_t src = ((int64_t)((c32 / a.KSp) * ntaps + t) * a.KSp + (c32 % a.KSp)) * a.NTtot + slice * NT + ntl;
                 v[k] = *reinterpret_cast<const uint4*>(a.wf + (src * 64 + lane) * 8);
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
+            for (int k = 0; k < FB; ++k)
                 if (f0 + 4 * k < nfrag) *reinterpret_cast<uint4*>(filt + ((int64_t)(f0 + 4 * k) * 64 + lane) * 16) = v[k];
         }
     }

@@ -196,7 +196,7 @@ void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t p
 
 // sum the per-chunk partials of 16 channels with 64 threads each (1024-thread block); 4 independent row loads in
 // flight per thread (the fused-statistics convs deliver up to ~1000 rows per group).  Result in part 0's registers.
-constexpr int FIN_PARTS = 64, FIN_THREADS = 16 * FIN_PARTS, FIN_U = 16;   // 1024 rows = one batch of loads
+constexpr int FIN_PARTS = 64, FIN_THREADS = 16 * FIN_PARTS, FIN_U = 4;
 __device__ __forceinline__ void chunk_sums(const float* __restrict__ partial, int nchunk, int C, int g, int c, int part,
                                            double* sm, double* s1, double* s2) {
     double a1 = 0.0, a2 = 0.0;
@@ -234,6 +234,7 @@ k_bn_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, 
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
     const bool owner = part == 0 && c < C;
     float rm = (owner && rmean) ? rmean[c] : 0.f, rv = (owner && rvar) ? rvar[c] : 0.f;
+    const float gam = owner ? gamma[c] : 0.f, bet = owner ? beta[c] : 0.f;   // in flight together with the partial rows
     for (int g = 0; g < groups; ++g) {   // sequential: the shared encoder BN sees T1 then T2 (SiamUnet_diff.py:99,123)
         double s1, s2;
         chunk_sums(partial, nchunk, C, g, c, part, sm, &s1, &s2);
@@ -241,12 +242,12 @@ k_bn_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, 
         double mean = s1 / ppg, var = s2 / ppg - mean * mean;
         if (var < 0.0) var = 0.0;
         double invstd = 1.0 / sqrt(var + (double)eps);
-        float sc = (float)(gamma[c] * invstd);
+        float sc = (float)(gam * invstd);
         float* st = stat + (int64_t)g * 4 * C;
         st[c] = (float)mean;
         st[C + c] = (float)invstd;
         st[2 * C + c] = sc;
-        st[3 * C + c] = (float)(beta[c] - mean * gamma[c] * invstd);
+        st[3 * C + c] = (float)(bet - mean * gam * invstd);
         double unb = ppg > 1 ? var * ((double)ppg / (double)(ppg - 1)) : var;
         rm = (float)((1.0 - momentum) * rm + momentum * mean);
         rv = (float)((1.0 - momentum) * rv + momentum * unb);
@@ -575,17 +576,21 @@ k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int grou
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
     const bool owner = part == 0 && c < C;
     double tg = 0.0, tb = 0.0;
+    float stv[2][4];                     // this channel's (mean, invstd, scale, shift) per group: loaded up front so the
+#pragma unroll                           // misses overlap the partial-row loads (groups <= 2)
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) stv[g][k] = (owner && g < groups) ? stat[(int64_t)g * 4 * C + k * C + c] : 0.f;
     for (int g = 0; g < groups; ++g) {
         double s1, s2;
         chunk_sums(partial, nchunk, C, g, c, part, sm, &s1, &s2);
         if (!owner) continue;
         {   // coefficients of dY = a*dz + b*y + c  (see k_bn_bwd_apply)
-            const float* st = stat + (int64_t)g * 4 * C;
-            const double mean = st[c], invstd = st[C + c], scale = st[2 * C + c];
+            const double mean = stv[g & 1][0], invstd = stv[g & 1][1], scale = stv[g & 1][2];
             const double k1 = s1 / ppg, k2 = s2 / ppg;
             float* bw = coef + (int64_t)g * 5 * C;
             bw[c] = (float)scale;
-            bw[C + c] = st[3 * C + c];
+            bw[C + c] = stv[g & 1][3];
             bw[2 * C + c] = (float)(-scale * k2 * invstd);
             bw[3 * C + c] = (float)mean;
             bw[4 * C + c] = (float)(-scale * k1);
@@ -719,40 +724,87 @@ void launch_slice(int dt, void* dst, int ldd, const void* src, int lds, int64_t 
 // out = cat(x0_1..x0_4) lives in one [N,HW,4*C1] buffer X (C1 = 32); intra = sum of its four C1-slices.
 // pool[n][0][c] = mean_hw X[n,.,c], pool[n][1][c] = max_hw X[n,.,c]   (c < 4*C1)
 // pool[n][2][c'] = mean_hw intra, pool[n][3][c'] = max_hw intra        (c' < C1)  -- stored at c' of rows 2,3
+// Two phases.  Phase 1: block = (pixel chunk, image); thread = (pixel lane, 8-channel block): every pixel row is read
+// once, as whole 16-B pieces (a block per channel re-read the tensor 160 times at a 256-B stride); the threads of the
+// first C1/8 channel blocks also form the intra sum.  Per-block partials (sum, max, arg max) go to `part`
+// [n][chunk][3][C4 + C1]; phase 2 folds the chunks in order (ties -> lowest pixel index, as torch.max over a flat map).
+constexpr int ECAM_CHUNKS = 128;
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_ecam_pool(const T* __restrict__ X, int ld, int64_t HW, int C4, float* __restrict__ pool, int64_t* __restrict__ argm) {
-    // block = (image n, channel c); 256 threads over pixels.  c < C4: plain channel; c >= C4: intra channel c-C4.
-    __shared__ float ssum[256], smax[256];
-    __shared__ int sarg[256];
-    const int n = blockIdx.y, c = blockIdx.x, C1 = C4 / 4;
-    const bool intra = c >= C4;
-    const int cc = intra ? c - C4 : c;
-    float sm = 0.f, mx = -INFINITY;
-    int am = 0;
-    for (int64_t p = threadIdx.x; p < HW; p += 256) {
-        const T* px = X + ((int64_t)n * HW + p) * ld;
-        float v = intra ? ((float)px[cc] + (float)px[cc + C1]) + ((float)px[cc + 2 * C1] + (float)px[cc + 3 * C1]) : (float)px[cc];
-        if (intra) v = round_as<T>(v);        // the oracle materialises `intra` as a tensor of the activation dtype
-        sm += v;
-        if (v > mx) { mx = v; am = (int)p; }
-    }
-    ssum[threadIdx.x] = sm; smax[threadIdx.x] = mx; sarg[threadIdx.x] = am;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
-            ssum[threadIdx.x] += ssum[threadIdx.x + o];
-            const float m2 = smax[threadIdx.x + o];
-            const int a2 = sarg[threadIdx.x + o];
-            if (m2 > smax[threadIdx.x] || (m2 == smax[threadIdx.x] && a2 < sarg[threadIdx.x])) { smax[threadIdx.x] = m2; sarg[threadIdx.x] = a2; }
+k_ecam_pool_part(const T* __restrict__ X, int ld, int64_t HW, int C4, float* __restrict__ part) {
+    extern __shared__ float esm[];                 // [3][lanes][C4 + C1]
+    const int n = blockIdx.y, chunk = blockIdx.x, C1 = C4 / 4, CT = C4 + C1;
+    const int cb = C4 >> 3, lanes = 256 / cb;
+    const int mycb = threadIdx.x % cb, lane = threadIdx.x / cb;
+    const bool do_intra = mycb < (C1 >> 3);
+    const int64_t per = (HW + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)chunk * per, p1 = min(HW, p0 + per);
+    float sm[8], mx[8], smi[8], mxi[8];
+    int am[8], ami[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sm[j] = smi[j] = 0.f; mx[j] = mxi[j] = -INFINITY; am[j] = ami[j] = 0; }
+    for (int64_t p = p0 + lane; p < p1; p += lanes) {
+        const T* px = X + ((int64_t)n * HW + p) * ld + mycb * 8;
+        float x0[8], x1[8], x2[8], x3[8];
+        load8<T>(px, x0);
+        if (do_intra) { load8<T>(px + C1, x1); load8<T>(px + 2 * C1, x2); load8<T>(px + 3 * C1, x3); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sm[j] += x0[j];
+            if (x0[j] > mx[j]) { mx[j] = x0[j]; am[j] = (int)p; }
         }
-        __syncthreads();
+        if (do_intra) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // the oracle materialises `intra` as a tensor of the activation dtype
+                const float v = round_as<T>((x0[j] + x1[j]) + (x2[j] + x3[j]));
+                smi[j] += v;
+                if (v > mxi[j]) { mxi[j] = v; ami[j] = (int)p; }
+            }
+        }
     }
-    if (threadIdx.x == 0) {
+    float* ssum = esm; float* smax = esm + lanes * CT; int* sarg = reinterpret_cast<int*>(esm + 2 * lanes * CT);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = mycb * 8 + j;
+        ssum[lane * CT + c] = sm[j]; smax[lane * CT + c] = mx[j]; sarg[lane * CT + c] = am[j];
+        if (do_intra) { ssum[lane * CT + C4 + c] = smi[j]; smax[lane * CT + C4 + c] = mxi[j]; sarg[lane * CT + C4 + c] = ami[j]; }
+    }
+    __syncthreads();
+    float* out = part + ((int64_t)n * gridDim.x + chunk) * 3 * CT;
+    for (int c = threadIdx.x; c < CT; c += 256) {
+        float s_ = 0.f, m_ = -INFINITY;
+        int a_ = 0x7fffffff;
+        for (int l = 0; l < lanes; ++l) {
+            s_ += ssum[l * CT + c];
+            const float m2 = smax[l * CT + c];
+            const int a2 = sarg[l * CT + c];
+            if (m2 > m_ || (m2 == m_ && a2 < a_)) { m_ = m2; a_ = a2; }
+        }
+        out[c] = s_; out[CT + c] = m_; reinterpret_cast<int*>(out)[2 * CT + c] = a_;
+    }
+}
+// pool[n][0][c] = mean_hw X[n,:,c], pool[n][1][c] = max_hw (with arg max in argm[n][0][c])   (c < C4)
+// pool[n][2][c'] = mean_hw intra, pool[n][3][c'] = max_hw intra        (c' < C1)  -- stored at c' of rows 2,3
+__global__ void k_ecam_pool_fin(const float* __restrict__ part, int nchunk, int64_t HW, int C4, float* __restrict__ pool,
+                                int64_t* __restrict__ argm) {
+    const int n = blockIdx.x, C1 = C4 / 4, CT = C4 + C1;
+    for (int c = threadIdx.x; c < CT; c += blockDim.x) {
+        float s_ = 0.f, m_ = -INFINITY;
+        int a_ = 0x7fffffff;
+        for (int k = 0; k < nchunk; ++k) {
+            const float* r = part + ((int64_t)n * nchunk + k) * 3 * CT;
+            s_ += r[c];
+            const float m2 = r[CT + c];
+            const int a2 = reinterpret_cast<const int*>(r)[2 * CT + c];
+            if (m2 > m_ || (m2 == m_ && a2 < a_)) { m_ = m2; a_ = a2; }
+        }
+        const bool intra = c >= C4;
+        const int cc = intra ? c - C4 : c;
         float* pr = pool + (int64_t)n * 4 * C4;
-        pr[(intra ? 2 : 0) * C4 + cc] = ssum[0] / (float)HW;
-        pr[(intra ? 3 : 1) * C4 + cc] = smax[0];
-        argm[(int64_t)n * 2 * C4 + (intra ? C4 : 0) + cc] = sarg[0];
+        pr[(intra ? 2 : 0) * C4 + cc] = s_ / (float)HW;
+        pr[(intra ? 3 : 1) * C4 + cc] = m_;
+        argm[(int64_t)n * 2 * C4 + (intra ? C4 : 0) + cc] = a_;
     }
 }
 
@@ -809,29 +861,52 @@ __global__ void k_ecam_apply(const T* __restrict__ X, int ld, T* __restrict__ Z,
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_ecam_bwd1(const T* __restrict__ X, int ld, const T* __restrict__ dZ, int lddz, T* __restrict__ dX, int lddx,
-            const float* __restrict__ att, int64_t HW, int C4, float* __restrict__ sums) {
-    __shared__ float red[256 * 16];
-    const int n = blockIdx.y, c0 = blockIdx.x * 8, C1 = C4 / 4;
+            const float* __restrict__ att, int64_t HW, int C4, float* __restrict__ part) {
+    // block = (pixel chunk, image); thread = (pixel lane, 8-channel block): whole pixel rows, once.  Partial sums per
+    // block -> part[n][chunk][2][C4]; k_ecam_sums_fin folds the chunks in order.
+    extern __shared__ float esm[];                 // [lanes][2 * C4]
+    const int n = blockIdx.y, chunk = blockIdx.x, C1 = C4 / 4;
+    const int cb = C4 >> 3, lanes = 256 / cb;
+    const int mycb = threadIdx.x % cb, lane = threadIdx.x / cb, c0 = mycb * 8;
     const float* ca = att + (int64_t)n * 2 * C4, *ca1 = ca + C4;
+    const int64_t per = (HW + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)chunk * per, p1 = min(HW, p0 + per);
     float s1[8], s2[8], cav[8], c1v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = s2[j] = 0.f; cav[j] = ca[c0 + j]; c1v[j] = ca1[(c0 + j) % C1]; }
-    for (int64_t p = threadIdx.x; p < HW; p += 256) {
-        const int64_t q = (int64_t)n * HW + p;
-        float x[8], g[8], o[8];
-        load8<T>(X + q * ld + c0, x);
-        load8<T>(dZ + q * lddz + c0, g);
+    for (int64_t p = p0 + lane; p < p1; p += 2 * lanes) {
+        const int64_t q0 = (int64_t)n * HW + p, q1 = q0 + lanes;
+        const bool two = p + lanes < p1;
+        float x[2][8], g[2][8], o[8];
+        load8<T>(X + q0 * ld + c0, x[0]);
+        load8<T>(dZ + q0 * lddz + c0, g[0]);
+        load8<T>(X + (two ? q1 : q0) * ld + c0, x[1]);
+        load8<T>(dZ + (two ? q1 : q0) * lddz + c0, g[1]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { o[j] = cav[j] * g[j]; s1[j] += g[j] * (x[j] + c1v[j]); s2[j] += o[j]; }
-        store8<T>(dX + q * lddx + c0, o);
+        for (int j = 0; j < 8; ++j) { o[j] = cav[j] * g[0][j]; s1[j] += g[0][j] * (x[0][j] + c1v[j]); s2[j] += o[j]; }
+        store8<T>(dX + q0 * lddx + c0, o);
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o[j] = cav[j] * g[1][j]; s1[j] += g[1][j] * (x[1][j] + c1v[j]); s2[j] += o[j]; }
+            store8<T>(dX + q1 * lddx + c0, o);
+        }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s1[j]; red[threadIdx.x * 16 + 8 + j] = s2[j]; }
+    for (int j = 0; j < 8; ++j) { esm[lane * 2 * C4 + c0 + j] = s1[j]; esm[lane * 2 * C4 + C4 + c0 + j] = s2[j]; }
     __syncthreads();
-    if (threadIdx.x < 16) {
-        float a = 0.f;
-        for (int l = 0; l < 256; ++l) a += red[l * 16 + threadIdx.x];
-        sums[((int64_t)n * 2 + (threadIdx.x >> 3)) * C4 + c0 + (threadIdx.x & 7)] = a;
+    float* out = part + ((int64_t)n * gridDim.x + chunk) * 2 * C4;
+    for (int c = threadIdx.x; c < 2 * C4; c += 256) {
+        float a_ = 0.f;
+        for (int l = 0; l < lanes; ++l) a_ += esm[l * 2 * C4 + c];
+        out[c] = a_;
+    }
+}
+__global__ void k_ecam_sums_fin(const float* __restrict__ part, int nchunk, int C4, float* __restrict__ sums) {
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < 2 * C4; c += blockDim.x) {
+        float a_ = 0.f;
+        for (int k = 0; k < nchunk; ++k) a_ += part[((int64_t)n * nchunk + k) * 2 * C4 + c];
+        sums[(int64_t)n * 2 * C4 + c] = a_;
     }
 }
 
@@ -895,24 +970,37 @@ __global__ void k_ecam_bwd2(T* __restrict__ dX, int lddx, const float* __restric
     const float* dp = dpool + (int64_t)n * 4 * C4;
     const int64_t* am = argm + (int64_t)n * 2 * C4;
     const float inv = 1.f / (float)HW;
-    float v[8];
+    const int ci = c0 % C1;                         // 8 consecutive channels stay inside one C1 slice (C1 % 8 == 0)
+    float davg[8], dmax[8], diavg[8], dimax[8], v[8];
+    ld8f(dp + c0, davg); ld8f(dp + C4 + c0, dmax); ld8f(dp + 2 * C4 + ci, diavg); ld8f(dp + 3 * C4 + ci, dimax);
+    longlong2 a0[4], a1[4];                         // arg-max pixel of the 8 plain / 8 intra channels (16-B loads)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a0[k] = *reinterpret_cast<const longlong2*>(am + c0 + 2 * k);
+        a1[k] = *reinterpret_cast<const longlong2*>(am + C4 + ci + 2 * k);
+    }
     load8<T>(dX + q * lddx + c0, v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int c = c0 + j, c1 = c % C1;
-        float add = dp[c] * inv + (am[c] == p ? dp[C4 + c] : 0.f);
-        add += dp[2 * C4 + c1] * inv + (am[C4 + c1] == p ? dp[3 * C4 + c1] : 0.f);
+        const int64_t ap = (j & 1) ? a0[j >> 1].y : a0[j >> 1].x, ai = (j & 1) ? a1[j >> 1].y : a1[j >> 1].x;
+        float add = davg[j] * inv + (ap == p ? dmax[j] : 0.f);
+        add += diavg[j] * inv + (ai == p ? dimax[j] : 0.f);
         v[j] += add;
     }
     store8<T>(dX + q * lddx + c0, v);
 }
 
+int64_t ecam_part_floats(int N, int C4) { return (int64_t)N * ECAM_CHUNKS * 3 * (C4 + C4 / 4); }
 void launch_ecam_forward(int dt, const void* X, int ld, void* Z, int ldz, int N, int64_t HW, int C4, const float* w1a,
                          const float* w2a, const float* w1b, const float* w2b, float* pool, int64_t* argm, float* att,
-                         float* hid, hipStream_t s) {
-    dim3 g1(C4 + C4 / 4, N);
-    if (dt == BF16) k_ecam_pool<bf16><<<g1, 256, 0, s>>>((const bf16*)X, ld, HW, C4, pool, argm);
-    else k_ecam_pool<float><<<g1, 256, 0, s>>>((const float*)X, ld, HW, C4, pool, argm);
+                         float* hid, float* part, hipStream_t s) {
+    const int CT = C4 + C4 / 4, lanes = 256 / (C4 / 8);
+    const int nchunk = (int)std::min<int64_t>(ECAM_CHUNKS, (HW + lanes - 1) / lanes);
+    dim3 g1(nchunk, N);
+    const size_t sm1 = (size_t)3 * lanes * CT * 4;
+    if (dt == BF16) k_ecam_pool_part<bf16><<<g1, 256, sm1, s>>>((const bf16*)X, ld, HW, C4, part);
+    else k_ecam_pool_part<float><<<g1, 256, sm1, s>>>((const float*)X, ld, HW, C4, part);
+    k_ecam_pool_fin<<<N, 256, 0, s>>>(part, nchunk, HW, C4, pool, argm);
     k_ecam_mlp<<<dim3(N, 2), 128, 0, s>>>(pool, C4, w1a, w2a, w1b, w2b, att, hid);
     int64_t total = (int64_t)N * HW * (C4 / 8);
     if (dt == BF16) k_ecam_apply<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)X, ld, (bf16*)Z, ldz, att, HW, C4, total);
@@ -921,10 +1009,14 @@ void launch_ecam_forward(int dt, const void* X, int ld, void* Z, int ldz, int N,
 void launch_ecam_backward(int dt, const void* X, int ld, const void* dZ, int lddz, void* dX, int lddx, int N, int64_t HW, int C4,
                           const float* w1a, const float* w2a, const float* w1b, const float* w2b, float* gw1a, float* gw2a,
                           float* gw1b, float* gw2b, const float* pool, const int64_t* argm, const float* att, const float* hid,
-                          float* sums, float* dpool, hipStream_t s) {
-    dim3 g1(C4 / 8, N);
-    if (dt == BF16) k_ecam_bwd1<bf16><<<g1, 256, 0, s>>>((const bf16*)X, ld, (const bf16*)dZ, lddz, (bf16*)dX, lddx, att, HW, C4, sums);
-    else k_ecam_bwd1<float><<<g1, 256, 0, s>>>((const float*)X, ld, (const float*)dZ, lddz, (float*)dX, lddx, att, HW, C4, sums);
+                          float* sums, float* dpool, float* part, hipStream_t s) {
+    const int lanes = 256 / (C4 / 8);
+    const int nchunk = (int)std::min<int64_t>(ECAM_CHUNKS, (HW + lanes - 1) / lanes);
+    dim3 g1(nchunk, N);
+    const size_t sm1 = (size_t)lanes * 2 * C4 * 4;
+    if (dt == BF16) k_ecam_bwd1<bf16><<<g1, 256, sm1, s>>>((const bf16*)X, ld, (const bf16*)dZ, lddz, (bf16*)dX, lddx, att, HW, C4, part);
+    else k_ecam_bwd1<float><<<g1, 256, sm1, s>>>((const float*)X, ld, (const float*)dZ, lddz, (float*)dX, lddx, att, HW, C4, part);
+    k_ecam_sums_fin<<<N, 256, 0, s>>>(part, nchunk, C4, sums);
     k_ecam_mlp_bwd<<<dim3(N, 2), 128, 0, s>>>(pool, att, hid, sums, C4, w1a, w2a, w1b, w2b, gw1a, gw2a, gw1b, gw2b, dpool);
     int64_t total = (int64_t)N * HW * (C4 / 8);
     if (dt == BF16) k_ecam_bwd2<bf16><<<cdiv(total, 256), 256, 0, s>>>((bf16*)dX, lddx, dpool, argm, HW, C4, total);
