@@ -266,6 +266,12 @@ void launch_ecam_backward(int dt, const void* X, int ld, const void* dZ, int ldd
 // dA (+)= route(dP) to the first maximum of each 2x2 window of A
 void launch_pool_bwd(int dt, const void* A, int lda, int64_t a_goff, const void* dP, int ldp, void* dA, int ldda,
                      int64_t da_goff, int groups, int npg, int H, int W, int C, int accumulate, hipStream_t s);
+// encoder skip layer: dA = pool gradient + skip-fusion gradient and the BN-backward partial sums of it, in one pass
+// (mode 0: |a1-a2| skips, 1: a2-a1); partial rows as launch_bn_bwd_reduce, skip_bwd_chunks() rows per date
+int skip_bwd_chunks(int B, int H, int W, int C);
+void launch_skip_bwd(int dt, int mode, const void* A, int lda, int64_t a_goff, const void* Y, int ldy, const void* dD, int ldd,
+                     const void* dP, int ldp, void* dA, int ldda, int64_t da_goff, const float* stat, const float* mask, int B,
+                     int H, int W, int C, float* partial, hipStream_t s);
 // db[c] = sum over pixels of dY[.., c]  (db zeroed by caller; atomics)
 void launch_bias_grad(int dt, const void* dY, int ld, int64_t pixels, int C, float* db, hipStream_t s);
 // masks from a counter hash: mask[i] = (u(seed, i) >= p) / (1-p)

@@ -176,7 +176,7 @@ struct stcd_engine_impl {
     TRef D[4], dD[4], P[4], dP[4];
     int64_t bn_partial2 = -1;
     int64_t bn_partial = -1, masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
-    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1;
+    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1;
 };
 
 }  // namespace stcd
@@ -560,6 +560,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             L.stat = ws.take((int64_t)2 * 4 * C * 4);
             L.coef = ws.take((int64_t)2 * 5 * C * 4);
             max_partial = std::max<int64_t>(max_partial, (int64_t)2 * bn_stats_chunks((int64_t)B * h * w, C) * 2 * C);
+            if (last) max_partial = std::max<int64_t>(max_partial, (int64_t)2 * skip_bwd_chunks(B, h, w, C) * 2 * C);
             e.enc.push_back(L);
         }
     }
@@ -892,7 +893,8 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     launch_bn_act(e.dt, a, c.s);
 }
 
-static void cbrd_backward(const Ctx& c, const Cbrd& L) {
+// skip_chunks > 0: dA and the BN partial sums were already produced by launch_skip_bwd (that many rows per date)
+static void cbrd_backward(const Ctx& c, const Cbrd& L, int skip_chunks = 0) {
     stcd_engine& e = c.e;
     const ConvW& cv = e.convs[L.conv];
     const BnP& bn = e.bns[L.bn];
@@ -902,13 +904,13 @@ static void cbrd_backward(const Ctx& c, const Cbrd& L) {
     const float* mask = e.drop_p > 0.f ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
     float* partial = c.at<float>(e.bn_partial);
     const double act_bytes = (double)L.N * HW * C * (double)dsize(e.dt);
-    {
+    if (!skip_chunks) {
         ProfScope ps(c, PC_BN_BWD_REDUCE, 0.0, 2.0 * act_bytes);
         launch_bn_bwd_reduce(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.Y.off), L.Y.ld, stat, mask, C, L.groups, L.npg, HW, 1,
                              partial, c.s);
     }
-    launch_bn_bwd_finalize(partial, bn_stats_chunks(ppg, C), C, L.groups, ppg, stat, c.at<float>(L.coef), c.grads + bn.g_off,
-                           c.grads + bn.b_off, c.s);
+    launch_bn_bwd_finalize(partial, skip_chunks ? skip_chunks : bn_stats_chunks(ppg, C), C, L.groups, ppg, stat, c.at<float>(L.coef),
+                           c.grads + bn.g_off, c.grads + bn.b_off, c.s);
     {
         ProfScope ps(c, PC_BN_BWD_APPLY, 0.0, 3.0 * act_bytes);
         launch_bn_bwd_apply(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.dY.off), L.dY.ld, c.at(L.Y.off), L.Y.ld, stat,
@@ -1007,7 +1009,7 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
             const int s_ = U.level, C = ENC_C[s_];
             upconv_backward(c, U);
             const Cbrd& skip = e.enc[SKIP_IDX[s_]];
-            if (e.arch != STCD_ARCH_CONC) {
+            if (e.arch != STCD_ARCH_CONC && !e.use_skip_fused) {
                 ProfScope ps(c, PC_POOL_FUSE, 0.0, (e.arch == STCD_ARCH_DIFF ? 5.0 : 3.0) * B * e.Hs[s_] * e.Ws[s_] * C * (double)T);
                 launch_fuse_bwd(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(skip.A.off), skip.A.ld, skip.A.goff,
                                 c.at<char>(e.dD[s_].off) + C * T, e.dD[s_].ld, c.at(skip.dA.off), skip.dA.ld, skip.dA.goff, B,
@@ -1019,13 +1021,25 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
     if (stage < 0 || stage == 1) {
         for (int li = (int)e.enc.size() - 1; li >= 0; --li) {
             const Cbrd& L = e.enc[li];
-            if (L.pool) {  // dA_skip += gradient routed back through the 2x2 max-pool
+            int skip_chunks = 0;
+            if (L.pool && e.arch != STCD_ARCH_CONC && e.use_skip_fused) {
+                // pool gradient + skip-fusion gradient + BN partial sums of the level's last conv in one pass
+                const int C = e.convs[L.conv].cout;
+                int lvl = 0;
+                while (lvl < 4 && SKIP_IDX[lvl] != li) ++lvl;
+                ProfScope ps(c, PC_POOL_FUSE, 0.0, 4.75 * L.N * L.H * L.W * C * (double)T, "k_skip_bwd");
+                launch_skip_bwd(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(L.A.off), L.A.ld, L.A.goff, c.at(L.Y.off), L.Y.ld,
+                                c.at<char>(e.dD[lvl].off) + C * T, e.dD[lvl].ld, c.at(L.dPool.off), L.dPool.ld, c.at(L.dA.off), L.dA.ld,
+                                L.dA.goff, c.at<float>(L.stat), e.drop_p > 0.f ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr,
+                                L.npg, L.H, L.W, C, c.at<float>(e.bn_partial), s);
+                skip_chunks = skip_bwd_chunks(L.npg, L.H, L.W, C);
+            } else if (L.pool) {  // dA_skip += gradient routed back through the 2x2 max-pool
                 const int C = e.convs[L.conv].cout;
                 ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.25 * L.N * L.H * L.W * C * (double)T);
                 launch_pool_bwd(dt, c.at(L.A.off), L.A.ld, L.A.goff, c.at(L.dPool.off), L.dPool.ld, c.at(L.dA.off), L.dA.ld,
                                 L.dA.goff, L.groups, L.npg, L.H, L.W, C, 1, s);
             }
-            cbrd_backward(c, L);
+            cbrd_backward(c, L, skip_chunks);
         }
         reduce_stage(c, 1);
     }
@@ -1477,6 +1491,8 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
     e->use_res = !(env && env[0] == '1');
     env = getenv("STCD_NO_WGRAD_GROUPS");
     e->use_wgroup = !(env && env[0] == '1');
+    env = getenv("STCD_NO_SKIP_FUSED");
+    e->use_skip_fused = !(env && env[0] == '1');
     env = getenv("STCD_WGRAD_ROUNDS");
     if (env && atoi(env) > 0) e->wgroup_rounds = atoi(env);
     env = getenv("STCD_WGRAD_MIN_TILES");

@@ -473,6 +473,100 @@ __global__ void k_fuse_bwd(int mode, const T* __restrict__ A, GV av, const T* __
     store8<T>(dA + dav.goff + p * dav.ld + c0, db);
 }
 
+__device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// ------------------------------------------------------------------ backward of an encoder skip layer, one pass
+// The last conv of an encoder level feeds the 2x2 max-pool AND the bi-temporal skip.  Its dA is the sum of the pool
+// gradient (routed to the first maximum of each window, as k_pool_bwd) and the skip-fusion gradient (sign(a1-a2)*g for
+// |a1-a2|, -/+g for a2-a1, as k_fuse_bwd); the BatchNorm backward then needs sum(dz) and sum(dz*xhat) of it.  Doing the
+// three in one pass saves three tensor round trips per level.  grid = (chunks, 2 dates); thread = one 2x2 quad x 8
+// channels of one image; partial rows as k_bn_reduce<T,1> writes them (chunks = gridDim.x rows per date).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_skip_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int ldd,
+           const T* __restrict__ dP, int ldp, T* __restrict__ dA, GV dav, const float* __restrict__ stat,
+           const float* __restrict__ mask, int B, int H, int W, int C, int64_t total, float* __restrict__ partial) {
+    __shared__ float red[256 * 16];
+    const int g = blockIdx.y;
+    const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
+    const int lanes = 256 / cb, mycb = threadIdx.x % cb, lane = threadIdx.x / cb;
+    const int64_t i64 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    if (i64 < total) {
+        uint32_t r = (uint32_t)i64;
+        const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
+        const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
+        const int yc = (int)(r % (uint32_t)Hc);
+        const int nb = (int)(r / (uint32_t)Hc);             // image inside the date
+        const bool pooled = yc < Hp && xc < Wp;
+        float mean[8], invstd[8], scale[8], shift[8], mk[8];
+        const float* st = stat + (int64_t)g * 4 * C + c0;
+        ld8f(st, mean); ld8f(st + C, invstd); ld8f(st + 2 * C, scale); ld8f(st + 3 * C, shift);
+        if (mask) ld8f(mask + ((int64_t)g * B + nb) * C + c0, mk);
+        // this date's and the other date's activations of the quad (clamped inside the map), pooled gradient
+        float as[4][8], ao[4][8], gp[8];
+        bool ok[4];
+        int64_t pix[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+            ok[k] = y < H && x < W;
+            pix[k] = ((int64_t)nb * H + (ok[k] ? y : 2 * yc)) * W + (ok[k] ? x : 2 * xc);
+            load8<T>(A + g * av.goff + pix[k] * av.ld + c0, as[k]);
+            if (mode == 0) load8<T>(A + (1 - g) * av.goff + pix[k] * av.ld + c0, ao[k]);
+        }
+        if (pooled) load8<T>(dP + ((((int64_t)g * B + nb) * Hp + yc) * Wp + xc) * ldp + c0, gp);
+        int arg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int b = 0;
+            float bvv = as[0][j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (as[k][j] > bvv) { bvv = as[k][j]; b = k; }
+            arg[j] = pooled ? b : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gk[8], y[8], v[8];
+            load8<T>(dD + pix[k] * ldd + c0, gk);
+            load8<T>(Y + ((int64_t)g * B * H * W + pix[k]) * ldy + c0, y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // date 0 receives +sign(a0-a1)*g, date 1 the negative; "sub" (f2 - f1): date 0 gets -g, date 1 +g
+                float sgn;
+                if (mode == 0) { const float d = g == 0 ? as[k][j] - ao[k][j] : ao[k][j] - as[k][j]; sgn = (float)((d > 0.f) - (d < 0.f)); }
+                else sgn = -1.f;
+                if (g == 1) sgn = -sgn;
+                float da = sgn * gk[j];
+                if (arg[j] == k) da += gp[j];
+                da = round_as<T>(da);
+                v[j] = da;
+                const float z = y[j] * scale[j] + shift[j];
+                float dz = mask ? da * mk[j] : da;
+                if (!(z > 0.f)) dz = 0.f;
+                if (ok[k]) { s1[j] += dz; s2[j] += dz * (y[j] - mean[j]) * invstd[j]; }
+            }
+            if (ok[k]) store8<T>(dA + g * dav.goff + pix[k] * dav.ld + c0, v);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s1[j]; red[threadIdx.x * 16 + 8 + j] = s2[j]; }
+    __syncthreads();
+    float* out = partial + ((int64_t)g * gridDim.x + blockIdx.x) * 2 * C;
+    for (int o = threadIdx.x; o < 2 * C; o += 256) {
+        const int which = o / C, c = o - which * C;
+        float acc = 0.f;
+        for (int l = 0; l < lanes; ++l) acc += red[(l * cb + (c >> 3)) * 16 + which * 8 + (c & 7)];
+        out[o] = acc;
+    }
+}
+
 // ------------------------------------------------------------------ replication pad of trailing rows / cols
 template <typename T>
 __global__ void k_rep_pad(T* __restrict__ D, int ld, int H, int W, int h0, int w0, int C, int64_t total) {
@@ -520,10 +614,6 @@ __global__ void k_rep_pad_bwd(T* __restrict__ dD, int ld, int H, int W, int h0, 
 // k_bn_bwd_finalize: bw[g][0..4][C] = (scale, shift, b = -scale*k2*invstd, mean, c = -scale*k1).
 // (y - mean) is formed explicitly: folding mean into c cancels catastrophically in fp32.
 // thread -> (4 consecutive pixels, 8 channels): the 4x8 constants are loaded once as float4s.
-__device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
-    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
 template <typename T, int PX>
 __global__ void __launch_bounds__(256)
 k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, const T* __restrict__ Y, int ldy,
@@ -1065,6 +1155,23 @@ void launch_pool_bwd(int dt, const void* A, int lda, int64_t a_goff, const void*
         k_pool_bwd<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)A, av, (const bf16*)dP, ldp, (bf16*)dA, dav, npg, H, W, C, accumulate, total);
     else
         k_pool_bwd<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)A, av, (const float*)dP, ldp, (float*)dA, dav, npg, H, W, C, accumulate, total);
+}
+
+int skip_bwd_chunks(int B, int H, int W, int C) {
+    return (int)cdiv((int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8), 256);
+}
+void launch_skip_bwd(int dt, int mode, const void* A, int lda, int64_t a_goff, const void* Y, int ldy, const void* dD, int ldd,
+                     const void* dP, int ldp, void* dA, int ldda, int64_t da_goff, const float* stat, const float* mask, int B,
+                     int H, int W, int C, float* partial, hipStream_t s) {
+    const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+    GV av{lda, a_goff}, dav{ldda, da_goff};
+    dim3 grid((unsigned)skip_bwd_chunks(B, H, W, C), 2);
+    if (dt == BF16)
+        k_skip_bwd<bf16><<<grid, 256, 0, s>>>(mode, (const bf16*)A, av, (const bf16*)Y, ldy, (const bf16*)dD, ldd, (const bf16*)dP, ldp,
+                                              (bf16*)dA, dav, stat, mask, B, H, W, C, total, partial);
+    else
+        k_skip_bwd<float><<<grid, 256, 0, s>>>(mode, (const float*)A, av, (const float*)Y, ldy, (const float*)dD, ldd, (const float*)dP,
+                                               ldp, (float*)dA, dav, stat, mask, B, H, W, C, total, partial);
 }
 
 void launch_fuse(int dt, int mode, const void* A, int lda, int64_t a_goff, void* D, int ldd, int B, int64_t HW, int C,
