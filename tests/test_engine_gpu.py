@@ -198,27 +198,35 @@ def test_fp32_five_step_trajectory(golden):
     np.testing.assert_allclose(losses, g["losses"], atol=5e-3)
 
 
-def test_bf16_kernel_families_agree():
-    """The same bf16 step through (a) the reference FMA kernels, (b) the generic MFMA kernels with the separate
-    BN-statistics pass, (c) the default path (small-channel persistent kernel with fused statistics where eligible):
-    identical math up to summation order; a 1-ulp bf16 flip early in the net is amplified downstream, so the check is
-    mean |dlogit| < 2e-2, max < 0.2, loss within 1e-2, gradient cosine > 0.99, running stats within 2e-3."""
+_TOGGLES = ("STCD_FORCE_REF_KERNELS", "STCD_NO_SMALL_KERNEL", "STCD_NO_RES_KERNEL", "STCD_NO_WGRAD_GROUPS", "STCD_NO_SKIP_FUSED")
+
+
+@pytest.mark.parametrize("arch,n,h,w,min_cos", [("diff", 4, 64, 64, 0.99), ("sub", 4, 64, 64, 0.99), ("conc", 4, 64, 64, 0.99),
+                                                 ("diff", 4, 50, 38, 0.96), ("sub", 2, 50, 38, 0.96)])
+def test_bf16_kernel_families_agree(arch, n, h, w, min_cos):
+    """The same bf16 step through (a) the reference FMA kernels, (b) the generic MFMA kernels only (separate BN
+    statistics, one weight-gradient launch per layer, unfused skip backward), (c) the default path (small-channel and
+    resident-filter persistent kernels with fused statistics, grouped weight gradients, one-pass skip backward), also on
+    an odd-sized map (ReplicationPad2d branch): identical math up to summation order; a 1-ulp bf16 flip early in the net
+    is amplified downstream, so the check is mean |dlogit| < 2e-2, max < 0.2, loss within 1e-2, gradient cosine > 0.99
+    (> 0.96 on the 50x38 maps, whose 3x2 bottleneck normalises over a dozen samples), running stats within 2e-3."""
     import os
 
     seed, label = 123, 2
     rng = np.random.default_rng(seed)
-    x1 = t(rng.standard_normal((4, 3, 64, 64)).astype(np.float32)).to(DEV)
-    x2 = t(rng.standard_normal((4, 3, 64, 64)).astype(np.float32)).to(DEV)
-    tgt = t((rng.random((4, 64, 64)) < 0.3).astype(np.int64)).to(DEV)
-    st = R.synth_state("diff", 3, label, seed)
-    masks = R.synth_masks("diff", 4, seed + 1)
+    x1 = t(rng.standard_normal((n, 3, h, w)).astype(np.float32)).to(DEV)
+    x2 = t(rng.standard_normal((n, 3, h, w)).astype(np.float32)).to(DEV)
+    tgt = t((rng.random((n, h, w)) < 0.3).astype(np.int64)).to(DEV)
+    st = R.synth_state(arch, 3, label, seed)
+    masks = R.synth_masks(arch, n, seed + 1)
     res = {}
-    for tag, env in (("ref", {"STCD_FORCE_REF_KERNELS": "1"}), ("generic", {"STCD_NO_SMALL_KERNEL": "1"}), ("default", {})):
-        for k in ("STCD_FORCE_REF_KERNELS", "STCD_NO_SMALL_KERNEL"):
+    generic = {k: "1" for k in _TOGGLES[1:]}
+    for tag, env in (("ref", {"STCD_FORCE_REF_KERNELS": "1"}), ("generic", generic), ("default", {})):
+        for k in _TOGGLES:
             os.environ.pop(k, None)
         os.environ.update(env)
         try:
-            m = SiamUnet_diff(3, label, dtype="bf16")
+            m = CLS[arch](3, label, dtype="bf16")
         finally:
             for k in env:
                 os.environ.pop(k, None)
@@ -226,6 +234,7 @@ def test_bf16_kernel_families_agree():
         m.to(DEV).train()
         m.set_dropout_masks(masks)
         logits = m(x1, x2)
+        logits = logits[-1] if isinstance(logits, list) else logits
         loss = torch.nn.functional.cross_entropy(logits, tgt)
         loss.backward()
         g = torch.cat([p.grad.flatten() for p in m.parameters()]).cpu().double()
@@ -235,7 +244,7 @@ def test_bf16_kernel_families_agree():
         assert d.mean().item() < 2e-2 and d.max().item() < 0.2, (tag, d.mean().item(), d.max().item())
         assert abs(res[tag][1] - res["ref"][1]) < 1e-2, tag
         cos = (res[tag][2] @ res["ref"][2] / (res[tag][2].norm() * res["ref"][2].norm())).item()
-        assert cos > 0.99, (tag, cos)
+        assert cos > min_cos, (tag, cos)
         np.testing.assert_allclose(res[tag][3].numpy(), res["ref"][3].numpy(), rtol=2e-3)
 
 
