@@ -23,6 +23,7 @@ namespace stcd {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct ConvMfmaArgs {
     stcd_conv_geom g;
@@ -502,6 +503,8 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
     int tn = tile / tiles_img, trem = tile - tn * tiles_img, tty = trem / a.tiles_x, ttx = trem - tty * a.tiles_x;
 
     uint4 prex[MAXX], prey[NTW];
+    unsigned okx = 0, oky = 0;    // border flags of the pieces held in prex / prey: the zero-select is applied at the stash,
+                                  // never right behind the load (that would wait for the data at once and undo the prefetch)
 #define WG_FETCH(N_, Y_, X_)                                                                                          \
     do {                                                                                                              \
         const int my0_ = (Y_) * 8, mx0_ = (X_) * 16;                                                                   \
@@ -511,22 +514,23 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
         _Pragma("unroll") for (int p = 0; p < MAXX; ++p) {                                                            \
             if (p < npx) {                                                                                            \
                 const bool ok_ = (unsigned)(my0_ + xa[p]) < (unsigned)a.g.hi && (unsigned)(mx0_ + xb[p]) < (unsigned)a.g.wi; \
-                const uint4 v_ = *reinterpret_cast<const uint4*>(xo_ + (ok_ ? xg[p] : 0));                            \
-                prex[p] = ok_ ? v_ : make_uint4(0, 0, 0, 0);                                                          \
+                prex[p] = *reinterpret_cast<const uint4*>(xo_ + (ok_ ? xg[p] : 0));                                   \
+                okx = ok_ ? (okx | (1u << p)) : (okx & ~(1u << p));                                                   \
             }                                                                                                         \
         }                                                                                                             \
         _Pragma("unroll") for (int q = 0; q < NTW; ++q) {                                                             \
             const bool ok_ = (unsigned)(my0_ + ya[q]) < (unsigned)a.g.hm && mx0_ + yb[q] < a.g.wm;                     \
-            const uint4 v_ = *reinterpret_cast<const uint4*>(yo_ + (ok_ ? yg[q] : 0));                                \
-            prey[q] = ok_ ? v_ : make_uint4(0, 0, 0, 0);                                                              \
+            prey[q] = *reinterpret_cast<const uint4*>(yo_ + (ok_ ? yg[q] : 0));                                       \
+            oky = ok_ ? (oky | (1u << q)) : (oky & ~(1u << q));                                                       \
         }                                                                                                             \
     } while (0)
 #define WG_STASH(BUF_)                                                                                                \
     do {                                                                                                              \
         _Pragma("unroll") for (int p = 0; p < MAXX; ++p)                                                              \
-            if (p < npx && tid + p * 256 < nx) *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + xl[p]) = prex[p]; \
+            if (p < npx && tid + p * 256 < nx)                                                                        \
+                *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + xl[p]) = ((okx >> p) & 1u) ? prex[p] : make_uint4(0, 0, 0, 0); \
         _Pragma("unroll") for (int q = 0; q < NTW; ++q)                                                               \
-            *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + yl[q]) = prey[q];                                   \
+            *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + yl[q]) = ((oky >> q) & 1u) ? prey[q] : make_uint4(0, 0, 0, 0); \
     } while (0)
 
     // per-lane fragment geometry inside a k-step (32 positions = 2 tile rows): half h -> x = 8*(grp&1) + 4*h + qrow
@@ -1127,6 +1131,8 @@ struct ConvResArgs {
     int filt_bytes;        // LDS bytes of the filter slice
     float* stat_partial;   // nullable: [groups][P][2][cpad]
     int cpad;
+    unsigned in_bytes;     // size of the input tensor (buffer-load range check)
+    int8_t tix[3][3];      // tap index of every (row shift, column shift)
 };
 
 constexpr int RES_HW = 18;     // halo edge of the 16 x 16 output tile
@@ -1149,16 +1155,18 @@ k_conv_res(const ConvResArgs a) {
     const int ntaps = 9;
     const int nsteps = a.nchunks / KSC;                       // pipeline steps per tile (nchunks = Ci / 32)
 
-    // tap index of every (row shift, column shift)
-    int tix[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    // ---- the block's filter slice (once per block): wave w takes fragments w, w+4, ...  The first 9 loads per lane
+    //      (the whole slice of the common 36-fragment cases) are requested HERE, before any other work, so the staging
+    //      plan below is computed while they are in flight.
+    const int nfrag = a.nchunks * ntaps * NT;
+    constexpr int FB = 9;
+    auto filt_src = [&](int f) -> int64_t {
+        const int ntl = f % NT, ft = f / NT, t = ft % ntaps, c32 = ft / ntaps;
+        return ((int64_t)((c32 / a.KSp) * ntaps + t) * a.KSp + (c32 % a.KSp)) * a.NTtot + slice * NT + ntl;
+    };
+    uint4 fv[FB];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
-                if (a.g.dy[t] + 1 == dy && a.g.dx[t] + 1 == dx) tix[dy][dx] = t;
-    }
+    for (int k = 0; k < FB; ++k) fv[k] = *reinterpret_cast<const uint4*>(a.wf + (filt_src(min(wid + 4 * k, nfrag - 1)) * 64 + lane) * 8);
 
     // ---- halo staging plan: piece i = tid + p*256 = pixel (i >> LG8), 16-B chunk ch = tid & SW (the same for every p);
     //      only the halo coordinates are kept per piece, offsets are rebuilt from them (2 FMAs) at use.
@@ -1169,7 +1177,7 @@ k_conv_res(const ConvResArgs a) {
         const int pix = min((tid >> LG8) + p * PIXSTEP, RES_HW * RES_HW - 1);
         const int hx = pix % RES_HW, hy = pix / RES_HW;
         pyx[p] = ((hy - 1) << 16) | ((hx - 1) & 0xffff);
-        poff[p] = ((hy - 1) * a.g.wi + (hx - 1)) * a.g.ldi;
+        poff[p] = ((hy * a.g.wi + hx) * a.g.ldi + ch * 8) * 2;        // bytes past the halo's top-left pixel
         plds[p] = (pix * CH8 + (ch ^ ((hx >> 1) & SW))) * 16;
     }
     float bv[NT][4];
@@ -1201,6 +1209,12 @@ k_conv_res(const ConvResArgs a) {
     //      parked in the other LDS buffer after them; one barrier per step.  A step = (tile, CW-channel chunk).
     struct Pos { int tile, n, y, x, c; };
     uint4 pre[MAXP];
+    // Halo loads are raw buffer loads: the descriptor starts one row + one pixel BEFORE the tensor, so offsets relative
+    // to a tile's halo corner are never negative; a piece outside the image gets an offset beyond num_records and the
+    // hardware returns zeros -- no address select, no data select, no 64-bit address arithmetic per piece.
+    const int64_t lead = ((int64_t)a.g.wi + 1) * a.g.ldi * 2;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.in)) - lead, (short)0, (int)(a.in_bytes + (unsigned)lead), 0x00020000);
 #define RES_ADV(P_)                                                                                                    \
     do {                                                                                                               \
         if (++(P_).c == nsteps) {                                                                                      \
@@ -1213,12 +1227,12 @@ k_conv_res(const ConvResArgs a) {
 #define RES_FETCH(P_)                                                                                                  \
     do {                                                                                                               \
         const int gy0_ = (P_).y * 16, gx0_ = (P_).x * 16;                                                               \
-        const bf16* org_ = a.in + (((int64_t)(P_).n * a.g.hi + gy0_) * a.g.wi + gx0_) * a.g.ldi + (P_).c * CW + ch * 8; \
+        const unsigned soff_ = (unsigned)(((((int64_t)(P_).n * a.g.hi + gy0_) * a.g.wi + gx0_) * a.g.ldi + (P_).c * CW) * 2); \
         _Pragma("unroll") for (int p = 0; p < MAXP; ++p) {                                                             \
             const int hy_ = pyx[p] >> 16, hx_ = (int)(short)(pyx[p] & 0xffff);                                         \
             const bool ok_ = (unsigned)(gy0_ + hy_) < (unsigned)a.g.hi && (unsigned)(gx0_ + hx_) < (unsigned)a.g.wi;   \
-            const uint4 v_ = *reinterpret_cast<const uint4*>(org_ + (ok_ ? poff[p] : 0));                              \
-            pre[p] = ok_ ? v_ : make_uint4(0, 0, 0, 0);                                                                \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok_ ? (unsigned)poff[p] : 0x80000000u, soff_, 0); \
+            pre[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                           \
         }                                                                                                              \
     } while (0)
 #define RES_STASH(BUF_)                                                                                                \
@@ -1248,20 +1262,15 @@ k_conv_res(const ConvResArgs a) {
     Pos nxt = cur; RES_ADV(nxt);
     int buf = 0;
     if (cur.tile < tile_end) RES_FETCH(cur);               // first halo chunk in flight while the filter is staged
-    // ---- filter slice -> LDS (once per block): wave w takes fragments w, w+4, ...; 9 loads in flight per lane (the
-    //      common 36-fragment slices arrive in ONE round trip)
+    // ---- filter slice -> LDS: first batch was requested at kernel entry; deeper slices take more rounds
     {
-        const int nfrag = a.nchunks * ntaps * NT;
-        constexpr int FB = 9;
-        for (int f0 = wid; f0 < nfrag; f0 += 4 * FB) {
+#pragma unroll
+        for (int k = 0; k < FB; ++k)
+            if (wid + 4 * k < nfrag) *reinterpret_cast<uint4*>(filt + ((int64_t)(wid + 4 * k) * 64 + lane) * 16) = fv[k];
+        for (int f0 = wid + 4 * FB; f0 < nfrag; f0 += 4 * FB) {
             uint4 v[FB];
 #pragma unroll
-            for (int k = 0; k < FB; ++k) {
-                const int f = min(f0 + 4 * k, nfrag - 1);
-                const int ntl = f % NT, ft = f / NT, t = ft % ntaps, c32 = ft / ntaps;
-                const int64_t src = ((int64_t)((c32 / a.KSp) * ntaps + t) * a.KSp + (c32 % a.KSp)) * a.NTtot + slice * NT + ntl;
-                v[k] = *reinterpret_cast<const uint4*>(a.wf + (src * 64 + lane) * 8);
-            }
+            for (int k = 0; k < FB; ++k) v[k] = *reinterpret_cast<const uint4*>(a.wf + (filt_src(min(f0 + 4 * k, nfrag - 1)) * 64 + lane) * 8);
 #pragma unroll
             for (int k = 0; k < FB; ++k)
                 if (f0 + 4 * k < nfrag) *reinterpret_cast<uint4*>(filt + ((int64_t)(f0 + 4 * k) * 64 + lane) * 16) = v[k];
@@ -1284,7 +1293,7 @@ k_conv_res(const ConvResArgs a) {
                     afr[hr] = *reinterpret_cast<const bf16x8*>(hb + aoff[ks][dx] + hr * (RES_HW * CW * 2));
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
-                    const char* ft = fb + tix[dy][dx] * (NT * 1024);
+                    const char* ft = fb + a.tix[dy][dx] * (NT * 1024);
 #pragma unroll
                     for (int t2 = 0; t2 < NT; ++t2) {
                         const bf16x8 wfr = *reinterpret_cast<const bf16x8*>(ft + t2 * 1024);
@@ -1379,6 +1388,7 @@ ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int gr
     if (!p.ok || p.modeB || g.ntaps != 9 || g.in_stride != 1 || g.out_stride != 1 || g.oy0 != 0 || g.ox0 != 0) return rp;
     if (g.ci % 32 != 0 || g.ldi % 8 != 0 || g.ldo % 4 != 0 || g.hm > g.hi || g.wm > g.wi) return rp;
     if (groups < 1 || g.n % groups != 0) return rp;
+    if (((int64_t)g.n * g.hi + 2) * g.wi * g.ldi * 2 >= ((int64_t)1 << 31)) return rp;     // 32-bit buffer offsets
     bool seen[9] = {false};
     for (int t = 0; t < 9; ++t) {
         if (g.dy[t] < -1 || g.dy[t] > 1 || g.dx[t] < -1 || g.dx[t] > 1) return rp;
@@ -1437,6 +1447,8 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
     a.tiles_x = (g.wm + 15) / 16; a.tiles_y = (g.hm + 15) / 16; a.ntiles = g.n * a.tiles_x * a.tiles_y;
     a.filt_bytes = rp.filt_bytes;
     a.stat_partial = stat_partial; a.cpad = cpad;
+    a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
+    for (int t = 0; t < 9; ++t) a.tix[g.dy[t] + 1][g.dx[t] + 1] = (int8_t)t;
 #define LAUNCH_RES(N_, W_)                                                                                        \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
