@@ -150,6 +150,7 @@ struct WgradJob {
     int xrow_bytes;                        // LDS bytes of one halo row of the X tile (incl. bank padding)
     int x_bytes, y_bytes;                  // LDS bytes of one X halo tile / one dY tile
     int co_valid;                          // channels of dout that exist in memory (round8(co))
+    unsigned in_bytes, dout_bytes;         // tensor sizes (buffer-load range checks)
     int gx, gy, gz;                        // block grid of this job
     int start;                             // first block of the job inside a grouped launch
     int lds_bytes;

@@ -480,7 +480,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
         const int i = min(tid + p * 256, nx - 1);
         const int ch = i % XCH, pix = i / XCH, hx = pix % HWp, hy = pix / HWp;
         xa[p] = hy + a.dymin; xb[p] = hx + a.dxmin;
-        xg[p] = (xa[p] * a.g.wi + xb[p]) * a.g.ldi + ci0 + ch * 8;
+        xg[p] = ((hy * a.g.wi + hx) * a.g.ldi + ci0 + ch * 8) * 2;  // bytes past the tile's halo corner
         xl[p] = hy * a.xrow_bytes + px_off<CIB>(hx) + ch * 16;
         if (ci0 + ch * 8 >= a.g.ci) xa[p] = 1 << 28;                 // channels beyond Ci: zero
     }
@@ -489,7 +489,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
     for (int q = 0; q < NTW; ++q) {
         const int j = tid + q * 256, ch = j % YCH, pix = j / YCH, py = pix >> 4, pxx = pix & 15;
         ya[q] = py; yb[q] = pxx;
-        yg[q] = ((py * a.g.out_stride) * a.g.wo + pxx * a.g.out_stride) * a.g.ldo + co0 + ch * 8;
+        yg[q] = (((py * a.g.out_stride) * a.g.wo + pxx * a.g.out_stride) * a.g.ldo + co0 + ch * 8) * 2;   // bytes
         yl[q] = a.x_bytes + py * YROW + px_off<COB>(pxx) + ch * 16;
         if (co0 + ch * 8 >= a.co_valid) ya[q] = 1 << 28;
     }
@@ -502,35 +502,40 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
     int tile = bx;
     int tn = tile / tiles_img, trem = tile - tn * tiles_img, tty = trem / a.tiles_x, ttx = trem - tty * a.tiles_x;
 
+    // Raw buffer loads: the X descriptor starts `lead` bytes before the tensor so offsets relative to a tile's halo
+    // corner are never negative; a piece outside the image / beyond the channels gets an offset past num_records and the
+    // hardware returns zeros (no selects, no 64-bit address arithmetic per piece, nothing between load and use).
+    const int64_t lead = ((int64_t)(-a.dymin) * a.g.wi + (-a.dxmin)) * a.g.ldi * 2;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a_in)) - lead, (short)0, (int)(a.in_bytes + (unsigned)lead), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a_dout)), (short)0, (int)a.dout_bytes, 0x00020000);
     uint4 prex[MAXX], prey[NTW];
-    unsigned okx = 0, oky = 0;    // border flags of the pieces held in prex / prey: the zero-select is applied at the stash,
-                                  // never right behind the load (that would wait for the data at once and undo the prefetch)
 #define WG_FETCH(N_, Y_, X_)                                                                                          \
     do {                                                                                                              \
         const int my0_ = (Y_) * 8, mx0_ = (X_) * 16;                                                                   \
-        const bf16* xo_ = a_in + (((int64_t)(N_) * a.g.hi + my0_) * a.g.wi + mx0_) * a.g.ldi;                         \
-        const bf16* yo_ = a_dout + (((int64_t)(N_) * a.g.ho + my0_ * a.g.out_stride + a.g.oy0) * a.g.wo +             \
-                                    mx0_ * a.g.out_stride + a.g.ox0) * a.g.ldo;                                       \
+        const unsigned xs_ = (unsigned)(((((int64_t)(N_) * a.g.hi + my0_) * a.g.wi + mx0_) * a.g.ldi) * 2);            \
+        const unsigned ys_ = (unsigned)(((((int64_t)(N_) * a.g.ho + my0_ * a.g.out_stride + a.g.oy0) * a.g.wo +        \
+                                          mx0_ * a.g.out_stride + a.g.ox0) * a.g.ldo) * 2);                            \
         _Pragma("unroll") for (int p = 0; p < MAXX; ++p) {                                                            \
             if (p < npx) {                                                                                            \
                 const bool ok_ = (unsigned)(my0_ + xa[p]) < (unsigned)a.g.hi && (unsigned)(mx0_ + xb[p]) < (unsigned)a.g.wi; \
-                prex[p] = *reinterpret_cast<const uint4*>(xo_ + (ok_ ? xg[p] : 0));                                   \
-                okx = ok_ ? (okx | (1u << p)) : (okx & ~(1u << p));                                                   \
+                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok_ ? (unsigned)xg[p] : 0x80000000u, xs_, 0); \
+                prex[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                     \
             }                                                                                                         \
         }                                                                                                             \
         _Pragma("unroll") for (int q = 0; q < NTW; ++q) {                                                             \
             const bool ok_ = (unsigned)(my0_ + ya[q]) < (unsigned)a.g.hm && mx0_ + yb[q] < a.g.wm;                     \
-            prey[q] = *reinterpret_cast<const uint4*>(yo_ + (ok_ ? yg[q] : 0));                                       \
-            oky = ok_ ? (oky | (1u << q)) : (oky & ~(1u << q));                                                       \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(yrs, ok_ ? (unsigned)yg[q] : 0x80000000u, ys_, 0); \
+            prey[q] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                         \
         }                                                                                                             \
     } while (0)
 #define WG_STASH(BUF_)                                                                                                \
     do {                                                                                                              \
         _Pragma("unroll") for (int p = 0; p < MAXX; ++p)                                                              \
-            if (p < npx && tid + p * 256 < nx)                                                                        \
-                *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + xl[p]) = ((okx >> p) & 1u) ? prex[p] : make_uint4(0, 0, 0, 0); \
+            if (p < npx && tid + p * 256 < nx) *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + xl[p]) = prex[p]; \
         _Pragma("unroll") for (int q = 0; q < NTW; ++q)                                                               \
-            *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + yl[q]) = ((oky >> q) & 1u) ? prey[q] : make_uint4(0, 0, 0, 0); \
+            *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + yl[q]) = prey[q];                                   \
     } while (0)
 
     // per-lane fragment geometry inside a k-step (32 positions = 2 tile rows): half h -> x = 8*(grp&1) + 4*h + qrow
@@ -747,7 +752,8 @@ WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld) {
     taps_extent(g, &dymin, &dymax, &dxmin, &dxmax);
     const int HH = 7 * g.in_stride + (dymax - dymin) + 1, HWp = 15 * g.in_stride + (dxmax - dxmin) + 1;
     const int xpieces = HH * HWp * (p.WCI * 2);
-    p.ok = g.ci % 8 == 0 && g.ldi % 8 == 0 && g.ldo % 8 == 0 && g.in_stride == 1 && xpieces <= 3 * 256 && g.hm <= g.hi && g.wm <= g.wi;
+    p.ok = g.ci % 8 == 0 && g.ldi % 8 == 0 && g.ldo % 8 == 0 && g.in_stride == 1 && xpieces <= 3 * 256 && g.hm <= g.hi && g.wm <= g.wi &&
+           ((int64_t)g.n * g.hi + 4) * g.wi * g.ldi * 2 < ((int64_t)1 << 31) && (int64_t)g.n * g.ho * g.wo * g.ldo * 2 < ((int64_t)1 << 31);
     return p;
 }
 
@@ -770,6 +776,8 @@ WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t
     a.x_bytes = (a.HH * a.xrow_bytes + 255) & ~255;
     a.y_bytes = (8 * (16 * 2 * COB + 2 * ypad) + 255) & ~255;
     a.co_valid = (g.co + 7) & ~7;
+    a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
+    a.dout_bytes = (unsigned)((int64_t)g.n * g.ho * g.wo * g.ldo * 2);
     a.gx = p.gx; a.gy = p.gy; a.gz = p.gz; a.start = 0;
     const int WK = 4 / p.WCI;
     a.lds_bytes = (int)std::max<size_t>(2 * (size_t)(a.x_bytes + a.y_bytes), (size_t)(WK - 1) * p.WCI * 9 * p.NTW * 4 * 64 * 4);
