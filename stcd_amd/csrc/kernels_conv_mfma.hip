@@ -1316,11 +1316,14 @@ k_conv_res(const ConvResArgs a) {
         if (cur.c == nsteps - 1) {
             // ---- epilogue of this tile: lane (q, r) holds channels 4q..4q+3 of n-tile t2 at row 4*wid + m, column r
             const int mx = cur.x * 16 + r;
+            bf16* const obase = a.out + (((int64_t)cur.n * a.g.ho + cur.y * 16 + wid * 4) * a.g.wo + mx) * a.g.ldo + slice * NT * 16 + 4 * q;
+            const int64_t orstep = (int64_t)a.g.wo * a.g.ldo;
+            const bool want_stats = a.stat_partial != nullptr;          // data-gradient launches carry no statistics
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int my = cur.y * 16 + wid * 4 + m;
                 const bool inside = my < a.g.hm && mx < a.g.wm;
-                bf16* orow = a.out + (((int64_t)cur.n * a.g.ho + my) * a.g.wo + mx) * a.g.ldo + slice * NT * 16 + 4 * q;
+                bf16* orow = obase + m * orstep;
 #pragma unroll
                 for (int t2 = 0; t2 < NT; ++t2) {
                     const int cb = (slice * NT + t2) * 16 + 4 * q;
@@ -1340,11 +1343,13 @@ k_conv_res(const ConvResArgs a) {
                         for (int j = 0; j < 4; ++j)
                             if (cb + j < a.g.co) o[j] = (bf16)v[j];
                     }
+                    if (want_stats) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float rv = round_as<bf16>(v[j]);
-                        s1[t2][j] += rv;
-                        s2[t2][j] += rv * rv;
+                        for (int j = 0; j < 4; ++j) {
+                            const float rv = round_as<bf16>(v[j]);
+                            s1[t2][j] += rv;
+                            s2[t2][j] += rv * rv;
+                        }
                     }
                 }
             }
