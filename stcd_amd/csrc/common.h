@@ -59,6 +59,11 @@ __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. every global load AND STORE
+// the wave still has in flight: a persistent kernel that stores a tile and then meets at the loop barrier pays a full
+// HBM write round trip (~1.5 us) per tile for nothing.  Use where the only cross-wave traffic is through LDS.
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     bf16x2 t;

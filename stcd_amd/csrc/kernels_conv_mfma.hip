@@ -1033,7 +1033,7 @@ k_conv_small(const ConvSmallArgs a) {
             }
         }
         tn = nn; tty = ny; ttx = nx;
-        __syncthreads();
+        barrier_lds();     // NOT __syncthreads(): that would wait for this tile's output stores to reach memory
     }
 
     // ---- fused BN statistics: lanes sharing q hold the same 4 channels -> xor-reduce over r, then over the 4 waves
@@ -1355,7 +1355,7 @@ k_conv_res(const ConvResArgs a) {
             }
         }
         cur = nxt; RES_ADV(nxt); buf ^= 1;
-        __syncthreads();
+        barrier_lds();     // NOT __syncthreads(): that would wait for the tile's output stores to reach memory
     }
 #undef RES_ADV
 #undef RES_FETCH
