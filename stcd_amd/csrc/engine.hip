@@ -450,7 +450,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                 j.count = outs_pad * parts;
             }
             j.start = cur[op->stage];
-            cur[op->stage] += j.count;
+            cur[op->stage] += (j.count + 255) & ~(int64_t)255;     // block-aligned: one job per block
             e.rjobs[op->stage].push_back(j);
         }
         for (int st = 0; st < 2; ++st) {
@@ -464,7 +464,8 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
         std::vector<PackJob>& jobs = e.jobs[with_dgrad];
         jobs.clear();
         int64_t cur = 0;
-        auto push = [&](PackJob j) { j.start = cur; cur += j.count; jobs.push_back(j); };
+        // every job starts on a 256-element boundary: a block then belongs to ONE job and finds it with scalar loads
+        auto push = [&](PackJob j) { j.start = cur; cur += (j.count + 255) & ~(int64_t)255; jobs.push_back(j); };
         const bool mfma = e.dt == BF16 && e.use_mfma;
         if (!mfma) {
             for (auto& cv : e.convs)

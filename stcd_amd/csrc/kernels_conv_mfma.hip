@@ -296,15 +296,15 @@ __device__ __forceinline__ float ref_weight(const PackSpec& ps, const float* src
 
 __global__ void __launch_bounds__(256)
 k_pack_jobs(const PackJob* __restrict__ jobs, int njobs, int64_t total, const float* __restrict__ params, char* __restrict__ ws) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int lo = 0, hi = njobs - 1;            // last job with start <= i
-    while (lo < hi) {
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
+    int lo = 0, hi = njobs - 1;            // last job with start <= i0: jobs start on 256-element boundaries, so the
+    while (lo < hi) {                      // whole block shares it (uniform search: scalar loads)
         const int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
+        if (jobs[mid].start <= i0) lo = mid; else hi = mid - 1;
     }
     const PackJob& jb = jobs[lo];
     const int64_t e = i - jb.start;
+    if (e >= jb.count) return;
     const float* src = params + jb.src_off;
     if (jb.kind == 0) {
         const int n = (int)(e % jb.ps.wld);
@@ -695,15 +695,15 @@ k_reduce_dw(const float* __restrict__ slab, int gx, int64_t slab_stride, int nta
 // (the gradient buffer is zeroed at the start of backward; <= 48 adders per address, spread over the whole tensor).
 __global__ void __launch_bounds__(256)
 k_reduce_jobs(const ReduceJob* __restrict__ jobs, int njobs, int64_t total, const char* __restrict__ ws, float* __restrict__ grads) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int lo = 0, hi = njobs - 1;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
+    int lo = 0, hi = njobs - 1;            // block-uniform job (starts are 256-aligned)
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].start <= i) lo = mid; else hi = mid - 1;
+        if (jobs[mid].start <= i0) lo = mid; else hi = mid - 1;
     }
     const ReduceJob& jb = jobs[lo];
     const int64_t e = i - jb.start;
+    if (e >= jb.count) return;
     const int outs = jb.ntaps * jb.K * jb.N, outs_pad = (outs + 63) & ~63;
     const int part = (int)(e / outs_pad), o = (int)(e - (int64_t)part * outs_pad);
     if (o >= outs) return;
