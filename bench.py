@@ -78,6 +78,21 @@ def cpu_baseline(arch, label, size, pairs, steps):
                       f"median of {steps} full steps after 1 warm-up ({med * 1e3:.0f} ms/step)"}
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC summary of this same command: the counters need
+    their own rocprofv3 --pmc passes (tools/profile_round.sh; FETCH_SIZE doubled per the gfx950 correction), so they
+    cannot be read inside the timed run.  None when no summary holds the kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.txt")), reverse=True):
+        for line in open(path):
+            if line.startswith(kernel + " ") or line.startswith(kernel[:48] + " "):
+                try:
+                    return int(float(line.split()[-1])), os.path.relpath(path, REPO)
+                except ValueError:
+                    pass
+    return None, None
+
+
 def main():
     args = parse()
     from stcd_amd import synth
@@ -178,9 +193,10 @@ def main():
         else:
             ach, peak, unit = p["flops"] / secs / 1e12, peak_tf, "TFLOP/s"
         tot_ms = sum(v["ms"] for v in prof.values())
+        traffic, traffic_src = pmc_traffic("stcd::" + dom)
         result["roofline"] = {
             "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
-            "traffic": None,
+            "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "stcd::" + dom, "avg_launch_us": round(secs * 1e6 / max(p["launches"], 1), 3),
             "avg_launch_us_raw": round(raw_us, 3), "event_pair_overhead_us": round(ev_us, 3),
             "launches_per_step": p["launches"] // nprof,
