@@ -1379,8 +1379,9 @@ static void sn_block_backward(const Ctx& c, const NBlock& b) {
                             c.at<float>(b.stat1), c.at<float>(b.coef1), nullptr, b.C, b.groups, b.npg, HW, 1, c.s, nullptr, 0, nullptr, 0,
                             c.at(b.dZ2.off), b.dZ2.ld);
     }
-    // conv1's bias reaches the loss only through the identity branch (its BN path has zero gradient): db1 = sum dZ2
-    launch_bias_grad(e.dt, c.at(b.dZ2.off), b.dZ2.ld, px, b.C, c.grads + e.convs[b.c1].b_off, c.s);
+    // conv1's bias reaches the loss only through the identity branch (its BN path has zero gradient): db1 = sum dZ2,
+    // and dZ2 is exactly the gated gradient whose per-channel sum bn2's backward already formed as d(beta2)
+    (void)hipMemcpyAsync(c.grads + e.convs[b.c1].b_off, c.grads + bn2.b_off, (size_t)b.C * 4, hipMemcpyDeviceToDevice, c.s);
     exec_wgrad(c, b.w1, c.at(b.in.off), c.at(b.dA1.off));                   // dA1 now holds dY1
     if (b.dIn.off >= 0) exec_conv(c, b.d1, c.at(b.dA1.off), nullptr, c.at(b.dIn.off), false);
 }
