@@ -43,8 +43,8 @@ def parse():
     ap.add_argument("--label", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-pairs", type=int, default=8)      # bounded CPU sample: ~10-20 s of host work in total
+    ap.add_argument("--cpu-steps", type=int, default=20)
     return ap.parse_args()
 
 
