@@ -133,8 +133,9 @@ int stcd_profile_kernel(stcd_engine* e, int i, char* name, int name_cap, double*
 int64_t stcd_loss_scratch_bytes(void);
 int stcd_loss_ce(const float* logits, const int64_t* target, int batch, int classes, int64_t hw, int ignore_index,
                  float* loss_out, float* dlogits, void* scratch, void* hip_stream);
-/* from_logits != 0: x are logits, the loss is cd_loss(sigmoid(x), y) and dx is d loss / d logits (fused form used by the
- * script-shaped loop); from_logits == 0: x are probabilities, exactly cd_loss(x, y) with dx = d loss / d probability. */
+/* from_logits bit 0 set: x are logits, the loss is cd_loss(sigmoid(x), y) and dx is d loss / d logits (fused form used by
+ * the script-shaped loop); clear: x are probabilities, exactly cd_loss(x, y) with dx = d loss / d probability.
+ * bit 1 set: the Dice term alone (class Dice, train_pse_cd.py:436-447), without the BCE term. */
 int stcd_loss_bce_dice(const float* x, const float* target, int64_t numel, int from_logits, float* loss_out, float* dx,
                        void* scratch, void* hip_stream);
 /* ---- metric: replaces SegmentationMetric.genConfusionMatrix (train_pse_cd.py:361-368) without the

@@ -114,7 +114,7 @@ k_bd_reduce(const float* __restrict__ logits, const float* __restrict__ target, 
     __shared__ double sm[16];
     double v[4] = {0.0, 0.0, 0.0, 0.0};   // sum p, sum t, sum p*t, sum bce
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float p = from_logits ? sigmoidf(logits[i]) : logits[i], t = target[i];
+        float p = (from_logits & 1) ? sigmoidf(logits[i]) : logits[i], t = target[i];
         float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);   // torch clamps log at -100
         v[0] += p; v[1] += t; v[2] += (double)p * t;
         v[3] -= (double)(t * lp + (1.f - t) * l1p);
@@ -123,7 +123,7 @@ k_bd_reduce(const float* __restrict__ logits, const float* __restrict__ target, 
     if (threadIdx.x == 0)
         for (int k = 0; k < 4; ++k) sc->part[blockIdx.x][k] = v[k];
 }
-__global__ void k_bd_finalize(LossScratch* sc, int nblocks, int64_t n, float* loss) {
+__global__ void k_bd_finalize(LossScratch* sc, int nblocks, int64_t n, int flags, float* loss) {
     __shared__ double sm[16];
     double v[4] = {0.0, 0.0, 0.0, 0.0};
     for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
@@ -132,7 +132,7 @@ __global__ void k_bd_finalize(LossScratch* sc, int nblocks, int64_t n, float* lo
     if (threadIdx.x == 0) {
         double den = v[0] + v[1] + 1.0, num = 2.0 * v[2] + 1.0;
         sc->fin[0] = den; sc->fin[1] = num;
-        *loss = (float)(v[3] / (double)n + 1.0 - num / den);
+        *loss = (float)(((flags & 2) ? 0.0 : v[3] / (double)n) + 1.0 - num / den);      // bit 1: Dice term only
     }
 }
 __global__ void __launch_bounds__(256)
@@ -140,11 +140,11 @@ k_bd_grad(const float* __restrict__ logits, const float* __restrict__ target, in
           const LossScratch* sc, float* __restrict__ dlogits) {
     const float den = (float)sc->fin[0], num = (float)sc->fin[1], invn = 1.f / (float)n, invd2 = 1.f / (den * den);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float p = from_logits ? sigmoidf(logits[i]) : logits[i], t = target[i];
+        float p = (from_logits & 1) ? sigmoidf(logits[i]) : logits[i], t = target[i];
         float q = p * (1.f - p);
-        float dbce = (p - t) / fmaxf(q, 1e-12f) * invn;          // ATen binary_cross_entropy_backward (EPSILON 1e-12)
+        float dbce = (from_logits & 2) ? 0.f : (p - t) / fmaxf(q, 1e-12f) * invn;   // ATen binary_cross_entropy_backward (EPSILON 1e-12)
         float ddice = -(2.f * t * den - num) * invd2;
-        dlogits[i] = from_logits ? (dbce + ddice) * q : (dbce + ddice);   // chain through sigmoid only for logits
+        dlogits[i] = (from_logits & 1) ? (dbce + ddice) * q : (dbce + ddice);   // chain through sigmoid only for logits
     }
 }
 void launch_loss_bce_dice(const float* logits, const float* target, int64_t n, int from_logits, float* loss, float* dlogits,
@@ -152,7 +152,7 @@ void launch_loss_bce_dice(const float* logits, const float* target, int64_t n, i
     LossScratch* sc = (LossScratch*)scratch;
     int nb = (int)std::min<int64_t>(LOSS_BLOCKS, (n + 255) / 256);
     k_bd_reduce<<<nb, 256, 0, s>>>(logits, target, n, from_logits, sc);
-    k_bd_finalize<<<1, 256, 0, s>>>(sc, nb, n, loss);
+    k_bd_finalize<<<1, 256, 0, s>>>(sc, nb, n, from_logits, loss);
     if (dlogits) k_bd_grad<<<nb, 256, 0, s>>>(logits, target, n, from_logits, sc, dlogits);
 }
 

@@ -99,6 +99,14 @@ def bce_dice_with_logits(logits, target):
     return _BceDiceFn.apply(logits.contiguous().float(), target.contiguous().float(), True)
 
 
+class Dice(nn.Module):
+    """train_pse_cd.py:436-447: 1 - (2*sum(p*t) + 1) / (sum(p) + sum(t) + 1) on probabilities."""
+
+    def forward(self, pred, target):
+        _need_cuda(pred, "Dice")
+        return _BceDiceFn.apply(pred.contiguous().float(), target.contiguous().float(), 2)
+
+
 class BCE_DICE(nn.Module):
     """train_pse_cd.py:451-462: forward(pmask = sigmoid output, rmask = {0,1} target)."""
 

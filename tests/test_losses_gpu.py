@@ -59,6 +59,25 @@ def test_cd_loss_probability_form_and_fused_logit_form(golden, tag):
     assert isinstance(losses.BCE_DICE()(torch.sigmoid(lg2.detach()), tgt).item(), float)
 
 
+def test_dice_module_matches_its_formula(golden):
+    """class Dice (train_pse_cd.py:436-447): 1 - (2*sum(p*t) + 1) / (sum(p) + sum(t) + 1), value and gradient against the
+    same expression in fp64 autograd; and BCE_DICE == BCELoss(mean) + Dice on the same inputs."""
+    g = golden("g1_ops.npz")
+    p0 = torch.sigmoid(t(g["cd/logits"]).double())
+    tgt = t(g["cd/target"]).double()
+    pr = p0.clone().requires_grad_(True)
+    want = 1 - (2.0 * (pr.view(-1) * tgt.view(-1)).sum() + 1.0) / (pr.sum() + tgt.sum() + 1.0)
+    want.backward()
+    pd = p0.float().to(DEV).requires_grad_(True)
+    got = losses.Dice()(pd, tgt.float().to(DEV))
+    got.backward()
+    assert abs(got.item() - want.item()) < 1e-6
+    np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.float().numpy(), rtol=2e-4, atol=1e-9)
+    both = losses.BCE_DICE()(p0.float().to(DEV), tgt.float().to(DEV)).item()
+    bce = torch.nn.functional.binary_cross_entropy(p0.float(), tgt.float()).item()
+    assert abs(both - (bce + want.item())) < 1e-5
+
+
 def test_confusion_matrix_on_device(golden):
     g = golden("g5_metric.npz")
     lab, pred = t(g["label"]).to(DEV), t(g["pred"]).to(DEV)
