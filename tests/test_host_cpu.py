@@ -88,3 +88,57 @@ def test_shard_range_partitions_exactly():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_flat_optimizer_host_contract():
+    """FlatAdam[W] is a torch.optim.Optimizer over the module's parameters (schedulers / checkpoints work on it) and
+    refuses to step without a GPU -- there is no CPU fallback."""
+    import pytest
+    import torch
+    from stcd_amd._lib import StcdError
+    from stcd_amd.modules import SiamUnet_diff
+    from stcd_amd.optim import FlatAdam, FlatAdamW
+
+    m = SiamUnet_diff(3, 2)
+    opt = FlatAdamW(m, lr=2e-3, weight_decay=0.01)
+    assert isinstance(opt, torch.optim.Optimizer)
+    assert len(opt.param_groups) == 1 and opt.param_groups[0]["lr"] == 2e-3 and opt.param_groups[0]["weight_decay"] == 0.01
+    assert len(opt.param_groups[0]["params"]) == len(list(m.parameters()))
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)
+    assert sched.get_last_lr() == [2e-3]
+    sd = opt.state_dict()
+    assert sd["state"] == {} and sd["param_groups"][0]["betas"] == (0.9, 0.999)
+    with pytest.raises(StcdError):
+        opt.step()                                   # model on the CPU
+    with pytest.raises(StcdError):
+        FlatAdam(torch.nn.Linear(2, 2))              # not an engine module
+    with pytest.raises(ValueError):
+        FlatAdam(m, lr=-1.0)
+
+
+def test_pseudo_pairs_need_the_gpu():
+    import pytest
+    import torch
+    from stcd_amd._lib import StcdError
+    from stcd_amd.pseudo import pseudo_change_pairs
+
+    z = torch.zeros(1, 8, 8, 3, dtype=torch.uint8)
+    with pytest.raises(StcdError):
+        pseudo_change_pairs(z, z, z[..., 0], torch.ones(1))
+
+
+def test_bench_reads_pmc_traffic_from_profiles(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from the committed PMC summary (the counters need their own rocprofv3 passes)."""
+    import importlib.util
+    import os
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "r09_pmc_traffic.txt").write_text(
+        "# header\nkernel   launches read_B write_B total_B\nstcd::k_conv_res<2, 32>   56   100   50   150\n")
+    monkeypatch.setattr(b, "REPO", str(tmp_path))
+    assert b.pmc_traffic("stcd::k_conv_res<2, 32>") == (150, os.path.join("profiles", "r09_pmc_traffic.txt"))
+    assert b.pmc_traffic("stcd::k_other") == (None, None)
