@@ -230,6 +230,8 @@ struct BnActArgs {
     const void* res = nullptr; int ldres = 0; // optional residual added before the ReLU (plain [N,HW,ldres] tensor)
 };
 void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s);
+// skip layers (groups == 2, ReLU, no residual): also writes the bi-temporal fusion F = |a1-a2| (fmode 0) / a2-a1 (1)
+void launch_bn_act_pair(int dt, const BnActArgs& a, void* F, int ldf, int fmode, hipStream_t s);
 void launch_maxpool(int dt, const void* A, int lda, void* P, int ldp, int N, int H, int W, int C, hipStream_t s);
 
 // Grouped views: element (g, n_in_group, pix, c) of an activation lives at p + g*goff + (n_in_group*HW + pix)*ld + c.

@@ -81,6 +81,7 @@ struct Cbrd {                         // conv -> BN -> ReLU -> Dropout2d [-> poo
     TRef Y; GRef A; TRef P; TRef dPool; bool pool = false;
     GRef dA; TRef dY; TRef dIn; bool has_dIn = false;
     int64_t stat = -1, coef = -1;
+    TRef fuse_dst;                    // skip layers of diff / sub: the decoder's concat slice that receives |a1-a2| / a2-a1
 };
 struct UpConv {
     int conv = -1, level = 0;
@@ -176,7 +177,7 @@ struct stcd_engine_impl {
     TRef D[4], dD[4], P[4], dP[4];
     int64_t bn_partial2 = -1;
     int64_t bn_partial = -1, masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
-    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1;
+    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1, use_act_fuse = 1;
 };
 
 }  // namespace stcd
@@ -555,6 +556,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
                 L.dY = da;   // in place
             }
             if (last) { L.pool = true; L.P = e.P[s]; L.dPool = e.dP[s]; }
+            if (last && e.arch != STCD_ARCH_CONC) { L.fuse_dst.off = e.D[s].off + C * T; L.fuse_dst.ld = e.D[s].ld; }
             if (first && s == 0) L.has_dIn = false;
             else if (first) { L.has_dIn = true; L.dIn = e.dP[s - 1]; }
             else { L.has_dIn = true; L.dIn.off = e.enc.back().dA.off; L.dIn.ld = C; }
@@ -890,6 +892,11 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     a.stat = stat;
     a.mask = (training && e.drop_p > 0.f) ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
     a.C = C; a.groups = L.groups; a.npg = L.npg; a.H = L.H; a.W = L.W; a.relu = 1;
+    if (L.fuse_dst.off >= 0 && e.use_act_fuse && L.groups == 2) {
+        ProfScope ps(c, PC_BN_ACT, 0.0, act_bytes * 2.75, "k_bn_act_pair");
+        launch_bn_act_pair(e.dt, a, c.at(L.fuse_dst.off), L.fuse_dst.ld, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.s);
+        return;
+    }
     ProfScope ps(c, PC_BN_ACT, 0.0, act_bytes * (L.pool ? 2.25 : 2.0));
     launch_bn_act(e.dt, a, c.s);
 }
@@ -967,7 +974,7 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
         const int s_ = U.level, C = ENC_C[s_];
         upconv_forward(c, U);
         const Cbrd& skip = e.enc[SKIP_IDX[s_]];
-        if (e.arch != STCD_ARCH_CONC) {
+        if (e.arch != STCD_ARCH_CONC && !(e.use_act_fuse && skip.fuse_dst.off >= 0)) {
             ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.0 * B * e.Hs[s_] * e.Ws[s_] * C * (double)T);
             launch_fuse(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(skip.A.off), skip.A.ld, skip.A.goff,
                         c.at<char>(e.D[s_].off) + C * T, e.D[s_].ld, B, (int64_t)e.Hs[s_] * e.Ws[s_], C, s);
@@ -1493,6 +1500,8 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
     e->use_res = !(env && env[0] == '1');
     env = getenv("STCD_NO_WGRAD_GROUPS");
     e->use_wgroup = !(env && env[0] == '1');
+    env = getenv("STCD_NO_ACT_FUSE");
+    e->use_act_fuse = !(env && env[0] == '1');
     env = getenv("STCD_NO_SKIP_FUSED");
     e->use_skip_fused = !(env && env[0] == '1');
     env = getenv("STCD_WGRAD_ROUNDS");

@@ -11,6 +11,13 @@
 
 namespace stcd {
 
+// 8 consecutive fp32 values (16-B aligned) as two float4 loads
+__device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // grouped view: element (g, n_in_group, pix, c) at p + g*goff + (n_in_group*HW + pix)*ld + c
@@ -345,6 +352,73 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
     if (P && yc < Hp && xc < Wp) store8<T>(P + (((int64_t)n * Hp + yc) * Wp + xc) * ldp + c0, best);
 }
 
+// Skip layers (last conv of an encoder level): both dates of a pair in one thread, so the bi-temporal skip fusion
+// F = |a1 - a2| (mode 0) or a2 - a1 (mode 1) is written in the same pass -- the separate fusion kernel would re-read
+// both activations.  Same arithmetic as k_bn_act per date (affine, ReLU, Dropout2d mask, rounding, 2x2 max-pool).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_bn_act_pair(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restrict__ P, int ldp, T* __restrict__ F, int ldf,
+              int fmode, const float* __restrict__ stat, const float* __restrict__ mask, int C, int npg, int H, int W, int64_t total) {
+    const int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i64 >= total) return;
+    const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
+    uint32_t r = (uint32_t)i64;
+    const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
+    const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
+    const int yc = (int)(r % (uint32_t)Hc);
+    const int nb = (int)(r / (uint32_t)Hc);
+    bool ok[4];
+    int64_t pix[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+        ok[k] = y < H && x < W;
+        pix[k] = ((int64_t)nb * H + (ok[k] ? y : 2 * yc)) * W + (ok[k] ? x : 2 * xc);
+    }
+    float a0[4][8];                       // date 0 activations, kept for the fusion
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float* st = stat + (int64_t)g * 4 * C + c0;
+        float sc[8], sh[8], mk[8];
+        ld8f(st + 2 * C, sc); ld8f(st + 3 * C, sh);
+        if (mask) ld8f(mask + ((int64_t)g * npg + nb) * C + c0, mk);
+        float v[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load8<T>(Y + ((int64_t)g * npg * H * W + pix[k]) * ldy + c0, v[k]);
+        float best[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float z = fmaxf(v[k][j] * sc[j] + sh[j], 0.f);
+                v[k][j] = round_as<T>(mask ? z * mk[j] : z);
+                best[j] = k == 0 ? v[k][j] : fmaxf(best[j], v[k][j]);
+            }
+            if (ok[k]) store8<T>(A + g * av.goff + pix[k] * av.ld + c0, v[k]);
+            if (g == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a0[k][j] = v[k][j];
+            } else if (ok[k]) {
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = fmode == 0 ? fabsf(a0[k][j] - v[k][j]) : v[k][j] - a0[k][j];
+                store8<T>(F + pix[k] * ldf + c0, f);
+            }
+        }
+        if (P && yc < Hp && xc < Wp) store8<T>(P + ((((int64_t)g * npg + nb) * Hp + yc) * Wp + xc) * ldp + c0, best);
+    }
+}
+void launch_bn_act_pair(int dt, const BnActArgs& a, void* F, int ldf, int fmode, hipStream_t s) {
+    const int64_t total = (int64_t)a.npg * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.C / 8);
+    GV av{a.lda, a.a_group_off};
+    if (dt == BF16)
+        k_bn_act_pair<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)a.Y, a.ldy, (bf16*)a.A, av, (bf16*)a.P, a.ldp, (bf16*)F, ldf, fmode,
+                                                             a.stat, a.mask, a.C, a.npg, a.H, a.W, total);
+    else
+        k_bn_act_pair<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)a.Y, a.ldy, (float*)a.A, av, (float*)a.P, a.ldp, (float*)F, ldf,
+                                                              fmode, a.stat, a.mask, a.C, a.npg, a.H, a.W, total);
+}
+
 void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s) {
     int64_t total = (int64_t)a.groups * a.npg * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.C / 8);
     GV av{a.lda, a.a_group_off};
@@ -473,10 +547,6 @@ __global__ void k_fuse_bwd(int mode, const T* __restrict__ A, GV av, const T* __
     store8<T>(dA + dav.goff + p * dav.ld + c0, db);
 }
 
-__device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
-    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
 
 // ------------------------------------------------------------------ backward of an encoder skip layer, one pass
 // The last conv of an encoder level feeds the 2x2 max-pool AND the bi-temporal skip.  Its dA is the sum of the pool

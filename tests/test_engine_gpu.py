@@ -198,7 +198,8 @@ def test_fp32_five_step_trajectory(golden):
     np.testing.assert_allclose(losses, g["losses"], atol=5e-3)
 
 
-_TOGGLES = ("STCD_FORCE_REF_KERNELS", "STCD_NO_SMALL_KERNEL", "STCD_NO_RES_KERNEL", "STCD_NO_WGRAD_GROUPS", "STCD_NO_SKIP_FUSED")
+_TOGGLES = ("STCD_FORCE_REF_KERNELS", "STCD_NO_SMALL_KERNEL", "STCD_NO_RES_KERNEL", "STCD_NO_WGRAD_GROUPS", "STCD_NO_SKIP_FUSED",
+            "STCD_NO_ACT_FUSE")
 
 
 @pytest.mark.parametrize("arch,n,h,w,min_cos", [("diff", 4, 64, 64, 0.99), ("sub", 4, 64, 64, 0.99), ("conc", 4, 64, 64, 0.99),
