@@ -256,7 +256,7 @@ ConvMfmaPlan conv_mfma_plan(const stcd_conv_geom& g) {
     p.NT = p.NTtot >= 8 ? 8 : p.NTtot >= 4 ? 4 : p.NTtot >= 2 ? 2 : 1;
     {   // small-spatial, wide layers: halve the co block so the grid covers the chip with >= 2 blocks per CU
         const int64_t tiles = (int64_t)g.n * ((g.hm + 7) / 8) * ((g.wm + 15) / 16);
-        while (p.NT > 2 && tiles * ((p.NTtot + p.NT - 1) / p.NT) < 512) p.NT /= 2;
+        while (p.NT > 1 && tiles * ((p.NTtot + p.NT - 1) / p.NT) < 512) p.NT /= 2;
     }
     p.NTtot = ((p.NTtot + p.NT - 1) / p.NT) * p.NT;     // pad the n-tiles to whole blocks
     p.wf_elems = p.modeB ? (int64_t)p.KS * p.NTtot * 512 : (int64_t)p.nchunks * g.ntaps * p.KS * p.NTtot * 512;
