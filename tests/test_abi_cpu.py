@@ -88,3 +88,26 @@ def test_snunet_state_dict_layout_is_the_reference_layout():
         st = S.synth_state(3, label, seed=3, perturb_running=True)
         m.load_state_dict(st, strict=True)
         assert all(torch.equal(v, st[k]) for k, v in m.state_dict().items())
+
+
+def test_header_is_plain_c_and_usable_without_python(tmp_path):
+    """examples/abi_query.c: a C99 program including include/stcd_hip.h, linked against the library, reads the parameter
+    layout and workspace size through the ABI (no Python, torch or C++ on the caller's side)."""
+    import os
+    import shutil
+    import subprocess
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "abi_query")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(repo, "include"),
+                           os.path.join(repo, "examples", "abi_query.c"), "-o", exe, "-L", os.path.join(repo, "stcd_amd"),
+                           "-lstcd_hip", "-Wl,-rpath," + os.path.join(repo, "stcd_amd")])
+    out = subprocess.check_output([exe, "0", "2", "64"], text=True)
+    assert "params 86 tensors / 1350148 floats" in out and "conv11.weight" in out and "shape 16 3 3 3" in out
+    assert "workspace" in out and "rejected bad shape" in out
+    out = subprocess.check_output([exe, "3", "1", "32"], text=True)
+    assert "params 146 tensors / 12034980 floats" in out and "conv0_0.conv1.weight" in out
