@@ -305,3 +305,39 @@ def test_snunet_bf16_tracks_fp32_engine():
     assert abs(res["bf16"][1] - res["fp32"][1]) < 2e-2
     cos = (res["bf16"][2] @ res["fp32"][2] / (res["bf16"][2].norm() * res["fp32"][2].norm())).item()
     assert cos > 0.95, cos
+
+
+def test_full_size_properties_bf16():
+    """BASELINE.json's bench configuration (SiamUnet_diff, 256x256, 16 pairs, bf16) through size-independent properties:
+    (a) eval mode treats pairs independently: the 16-pair batch equals its two 8-pair halves bit for bit;
+    (b) backward is linear in the output gradient: scaling d(logits) by 2 (exact in fp32 / bf16) doubles every
+        parameter gradient exactly -- through every conv, BN, pool, fusion and the grouped weight-gradient reduction;
+    (c) the training forward is reproducible run to run with the same dropout seed (no atomics in the forward path)."""
+    from stcd_amd import synth
+
+    a, b, _ = synth.make_batch(16, 256, 256, seed=77)
+    A, B = t(a).to(DEV), t(b).to(DEV)
+    torch.manual_seed(5)
+    m = SiamUnet_diff(3, 2, dtype="bf16").to(DEV)
+    m.eval()
+    with torch.no_grad():
+        full = m(A, B)
+        h0, h1 = m(A[:8], B[:8]).clone(), m(A[8:], B[8:]).clone()
+    assert torch.equal(full, torch.cat([h0, h1]))
+    m.train()
+    m.set_dropout_p(0.2)
+    grads = []
+    outs = []
+    for scale in (1.0, 2.0):
+        m._steps = 0                       # same dropout masks for both passes
+        m.zero_grad(set_to_none=True)
+        out = m(A, B)
+        outs.append(out.detach().clone())
+        g0 = torch.ones_like(out) * 1e-3
+        out.backward(g0 * scale)
+        grads.append(torch.cat([p.grad.flatten() for p in m.parameters()]).clone())
+    assert torch.equal(outs[0], outs[1])
+    assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0
+    # linear kernels + power-of-two scale: equal up to the summation order of the atomically folded slab parts
+    rel = ((grads[1] - 2.0 * grads[0]).abs().max() / grads[1].abs().max()).item()
+    assert rel < 1e-5, rel
