@@ -97,3 +97,35 @@ def test_confusion_matrix_on_device(golden):
     cm = metrics.ConfuseMatrixMeter(2)
     cm.update_cm(g["pred"], g["label"])
     assert abs(cm.get_scores()["mf1"] - float(np.mean(g["f1"]))) < 1e-12
+
+
+def test_full_size_loss_and_metric_properties():
+    """Bench-sized tensors (16 x 2 x 256 x 256 logits): the confusion matrix is a checksum of its inputs (entries sum to
+    the pixel count, rows to the label histogram, accumulation over half-batches equals one call), and the
+    cross-entropy gradient sums to zero over the class axis at every valid pixel and to exactly zero at ignored ones."""
+    rng = np.random.default_rng(3)
+    B, H, W = 16, 256, 256
+    logits = t(rng.standard_normal((B, 2, H, W)).astype(np.float32)).to(DEV)
+    lab = t((rng.random((B, H, W)) < 0.2).astype(np.int64)).to(DEV)
+    whole = metrics.SegmentationMetric(2, DEV)
+    whole.add_logits(logits, lab.unsqueeze(1))
+    halves = metrics.SegmentationMetric(2, DEV)
+    halves.add_logits(logits[:8], lab[:8].unsqueeze(1))
+    halves.add_logits(logits[8:], lab[8:].unsqueeze(1))
+    cm = whole.confusionMatrix.cpu().numpy()
+    np.testing.assert_array_equal(cm, halves.confusionMatrix.cpu().numpy())
+    assert cm.sum() == B * H * W
+    np.testing.assert_array_equal(cm.sum(axis=1), np.bincount(lab.cpu().numpy().ravel(), minlength=2))
+    pred = logits.argmax(1).cpu().numpy().ravel()
+    np.testing.assert_array_equal(cm.sum(axis=0), np.bincount(pred, minlength=2))
+
+    lab_ig = lab.clone()
+    lab_ig[:, :8, :] = 255                                    # ignore_index rows
+    lg = logits.clone().requires_grad_(True)
+    loss = losses.cross_entropy(lg, lab_ig)
+    loss.backward()
+    g = lg.grad
+    assert torch.isfinite(loss) and float(g[:, :, :8, :].abs().max()) == 0.0
+    assert float(g.sum(1).abs().max()) < 1e-9                 # softmax - onehot sums to zero over classes
+    ref = torch.nn.functional.cross_entropy(logits.cpu().double(), lab_ig.cpu(), ignore_index=255).item()
+    assert abs(loss.item() - ref) < 1e-6
