@@ -150,3 +150,60 @@ def test_upconv_phases_and_stride2_dgrad(c):
     g = geom(n, h, w, c, c, h, w, 1, 2 * h, 2 * w, 2, 1, 1, c, ldcat, taps)
     d0, d1 = run_wgrad(0, g, x, dy_).cpu().numpy(), run_wgrad(1, g, x, dy_).cpu().numpy()
     np.testing.assert_allclose(d1 / np.abs(d0).max(), d0 / np.abs(d0).max(), atol=2e-4)
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", [(32, 256, 256, 16, 16), (32, 128, 128, 32, 32), (32, 64, 64, 64, 64), (32, 32, 32, 128, 128),
+                                         (16, 32, 32, 256, 128)])
+def test_full_size_conv_properties(n, h, w, ci, co):
+    """The bench-sized layers of the engine (too large for the CPU oracle) through properties of a convolution that
+    hold bit for bit, because every output position accumulates its (tap, channel) products in the same order
+    wherever its tile sits: (a) translation equivariance -- shifting the input by (3, 5) pixels shifts the interior of
+    the output; (b) batch independence -- image k of the batch equals the same image convolved alone; and
+    (c) agreement with the plain-FMA reference kernel to the rounding of the bf16 output on a sampled image."""
+    rng = np.random.default_rng(h + ci)
+    x = rnd(rng, n, h, w, ci).to(DEV)
+    wt = rnd(rng, 9, ci, co, scale=1.0 / np.sqrt(9 * ci)).float().to(DEV)
+    bias = torch.from_numpy(rng.standard_normal(co).astype(np.float32)).to(DEV)
+    g = geom(n, h, w, ci, ci, h, w, 1, h, w, 1, 0, 0, co, co, TAPS3)
+    out = torch.zeros(n, h, w, co, dtype=torch.bfloat16, device=DEV)
+    run_conv(1, g, x, wt, bias, out)
+    # (a) shift by (3, 5)
+    sy, sx = 3, 5
+    xs = torch.zeros_like(x)
+    xs[:, sy:, sx:, :] = x[:, :h - sy, :w - sx, :]
+    outs = torch.zeros_like(out)
+    run_conv(1, g, xs, wt, bias, outs)
+    assert torch.equal(outs[:, sy + 1:h - 1, sx + 1:w - 1, :], out[:, 1:h - 1 - sy, 1:w - 1 - sx, :])
+    # (b) one image alone
+    k = n // 2
+    g1 = geom(1, h, w, ci, ci, h, w, 1, h, w, 1, 0, 0, co, co, TAPS3)
+    o1 = torch.zeros(1, h, w, co, dtype=torch.bfloat16, device=DEV)
+    run_conv(1, g1, x[k:k + 1].contiguous(), wt, bias, o1)
+    assert torch.equal(o1[0], out[k])
+    # (c) reference kernel on that image
+    o0 = torch.zeros(1, h, w, co, dtype=torch.bfloat16, device=DEV)
+    run_conv(0, g1, x[k:k + 1].contiguous(), wt, bias, o0)
+    np.testing.assert_allclose(o1.float().cpu().numpy(), o0.float().cpu().numpy(), rtol=2 ** -7, atol=2e-3)
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", [(32, 256, 256, 16, 16), (32, 128, 128, 32, 32), (32, 32, 32, 128, 128), (16, 256, 256, 32, 16)])
+def test_full_size_wgrad_properties(n, h, w, ci, co):
+    """Bench-sized weight gradients: (a) exactly linear in dY for a power-of-two factor (fp32 slabs, fixed fold order);
+    (b) invariant under a permutation of the batch up to fp32 summation order; (c) the sum over a batch equals the sum of
+    the two half-batches' gradients (the K split over blocks must not lose or double-count positions)."""
+    rng = np.random.default_rng(h * 3 + ci)
+    x = rnd(rng, n, h, w, ci).to(DEV)
+    dout = rnd(rng, n, h, w, co).to(DEV)
+    g = geom(n, h, w, ci, ci, h, w, 1, h, w, 1, 0, 0, co, co, TAPS3)
+    dw = run_wgrad(1, g, x, dout)
+    assert torch.isfinite(dw).all()
+    dw2 = run_wgrad(1, g, x, (dout.float() * 2).bfloat16())
+    assert torch.equal(dw2, 2 * dw)
+    perm = torch.from_numpy(rng.permutation(n)).to(DEV)
+    dwp = run_wgrad(1, g, x[perm].contiguous(), dout[perm].contiguous())
+    scale = dw.abs().max().item()
+    assert (dwp - dw).abs().max().item() < 2e-5 * scale
+    gh = geom(n // 2, h, w, ci, ci, h, w, 1, h, w, 1, 0, 0, co, co, TAPS3)
+    halves = run_wgrad(1, gh, x[:n // 2].contiguous(), dout[:n // 2].contiguous()) + \
+             run_wgrad(1, gh, x[n // 2:].contiguous(), dout[n // 2:].contiguous())
+    assert (halves - dw).abs().max().item() < 2e-5 * scale
