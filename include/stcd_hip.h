@@ -185,6 +185,48 @@ int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, 
                   void* scratch, int64_t scratch_bytes, void* hip_stream);
 int64_t stcd_op_scratch_bytes(const stcd_conv_geom* g);
 
+/* ---- per-op entry points of the normalisation / pooling / fusion kernels (NHWC, activation dtype per `dtype`,
+ *      channels a power of two >= 8); each runs exactly the launch sequence the engine runs for that layer step.
+ *      n = images (date-0 images first, then date-1 images when groups == 2: BatchNorm statistics stay per date,
+ *      /root/reference/models/SiamUnet_diff.py:99 and :123 call the same bn module once per date). ---- */
+typedef struct stcd_map_geom {
+    int32_t n, h, w, c, groups;
+} stcd_map_geom;
+int64_t stcd_op_ew_scratch_bytes(const stcd_map_geom* g);
+/* a = dropout_mask * relu(BatchNorm2d(y)) (nn.BatchNorm2d + F.relu + nn.Dropout2d, SiamUnet_diff.py:19-20,99), optional
+ * pool = F.max_pool2d(a, 2, 2) (:101).  training != 0: batch statistics per group, running stats updated in place
+ * (momentum 0.1, unbiased variance; group 0 then group 1); else running statistics.  mask: nullable fp32 [n][c].
+ * stat (out): fp32 [groups][4][c] = mean, 1/sqrt(var+eps), scale, shift -- what the backward needs. */
+int stcd_op_bn_act(int dtype, const stcd_map_geom* g, const void* y, int ldy, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, const float* mask, int relu, int training, void* a, int lda,
+                   void* pool, int ldp, float* stat, void* scratch, int64_t scratch_bytes, void* hip_stream);
+/* the same for the last conv of an encoder level (groups == 2, training, ReLU), both dates in one pass, also writing the
+ * bi-temporal skip fused = |a1 - a2| (fuse_mode 0, SiamUnet_diff.py:150) or a2 - a1 (1, SiamUnet_sub.py:150): [n/2] images */
+int stcd_op_bn_act_pair(int dtype, const stcd_map_geom* g, const void* y, int ldy, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, const float* mask, int fuse_mode, void* a, int lda, void* pool,
+                        int ldp, void* fused, int ldf, float* stat, void* scratch, int64_t scratch_bytes, void* hip_stream);
+/* backward of stcd_op_bn_act (training): da -> dy (may alias da), dgamma, dbeta summed over the groups */
+int stcd_op_bn_act_bwd(int dtype, const stcd_map_geom* g, const void* da, int ldda, const void* y, int ldy, const float* stat,
+                       const float* mask, int relu, void* dy, int lddy, float* dgamma, float* dbeta, void* scratch,
+                       int64_t scratch_bytes, void* hip_stream);
+int stcd_op_maxpool(int dtype, const stcd_map_geom* g, const void* a, int lda, void* pool, int ldp, void* hip_stream);
+/* da (+)= dpool routed to the first maximum of each 2x2 window (torch's tie rule) */
+int stcd_op_maxpool_bwd(int dtype, const stcd_map_geom* g, const void* a, int lda, const void* dpool, int ldp, void* da, int ldda,
+                        int accumulate, void* hip_stream);
+/* skip fusion of the two dates (groups == 2): d[n/2 images] = |a1 - a2| (mode 0) or a2 - a1 (mode 1), and its gradient */
+int stcd_op_fuse(int dtype, int mode, const stcd_map_geom* g, const void* a, int lda, void* d, int ldd, void* hip_stream);
+int stcd_op_fuse_bwd(int dtype, int mode, const stcd_map_geom* g, const void* a, int lda, const void* dd, int ldd, void* da, int ldda,
+                     void* hip_stream);
+/* nn.ReplicationPad2d((0, w - w0, 0, h - h0)) in place on a [n,h,w] map whose valid region is h0 x w0
+ * (SiamUnet_diff.py:149), and its gradient (the replicas' gradients fold into the edge pixel) */
+int stcd_op_rep_pad(int dtype, const stcd_map_geom* g, void* d, int ld, int h0, int w0, void* hip_stream);
+int stcd_op_rep_pad_bwd(int dtype, const stcd_map_geom* g, void* dd, int ld, int h0, int w0, void* hip_stream);
+/* backward of an encoder level's last conv in one pass (groups == 2): da = max-pool gradient of dpool + skip-fusion
+ * gradient of dd, then the BatchNorm backward of it: dy, dgamma, dbeta */
+int stcd_op_skip_bwd(int dtype, int mode, const stcd_map_geom* g, const void* a, int lda, const void* y, int ldy, const void* dd,
+                     int ldd, const void* dpool, int ldp, const float* stat, const float* mask, void* da, int ldda, void* dy,
+                     int lddy, float* dgamma, float* dbeta, void* scratch, int64_t scratch_bytes, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

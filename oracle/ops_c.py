@@ -125,6 +125,22 @@ def maxpool2_bwd(x, gy):
     return dx
 
 
+def rep_pad_fwd(x, H, W):
+    x = _f(x)
+    n, c, h0, w0 = x.shape
+    y = np.empty((n, c, H, W), np.float32)
+    lib().ref_rep_pad_fwd(_p(x), _p(y), n, c, h0, w0, H, W)
+    return y
+
+
+def rep_pad_bwd(gy, h0, w0):
+    gy = _f(gy)
+    n, c, H, W = gy.shape
+    dx = np.empty((n, c, h0, w0), np.float32)
+    lib().ref_rep_pad_bwd(_p(gy), _p(dx), n, c, h0, w0, H, W)
+    return dx
+
+
 def fuse_fwd(a, b, mode):
     a, b = _f(a), _f(b)
     y = np.empty_like(a)

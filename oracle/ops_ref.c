@@ -252,6 +252,22 @@ void ref_maxpool2_bwd(const float* x, const float* gy, float* dx, int N, int C, 
             }
 }
 
+/* nn.ReplicationPad2d((0, W-w0, 0, H-h0)) (/root/reference/models/SiamUnet_diff.py:149): x [N,C,h0,w0] -> y [N,C,H,W],
+ * y(i,j) = x(min(i,h0-1), min(j,w0-1)); backward: every replica's gradient folds into its source pixel */
+void ref_rep_pad_fwd(const float* x, float* y, int N, int C, int h0, int w0, int H, int W) {
+    for (int64_t nc = 0; nc < (int64_t)N * C; ++nc)
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j)
+                y[(nc * H + i) * W + j] = x[(nc * h0 + (i < h0 ? i : h0 - 1)) * w0 + (j < w0 ? j : w0 - 1)];
+}
+void ref_rep_pad_bwd(const float* gy, float* dx, int N, int C, int h0, int w0, int H, int W) {
+    memset(dx, 0, sizeof(float) * (size_t)N * C * h0 * w0);
+    for (int64_t nc = 0; nc < (int64_t)N * C; ++nc)
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j)
+                dx[(nc * h0 + (i < h0 ? i : h0 - 1)) * w0 + (j < w0 ? j : w0 - 1)] += gy[(nc * H + i) * W + j];
+}
+
 /* mode 0: |a-b| ; mode 1: b-a.   backward: da, db from g (abs' = sign, 0 at ties) */
 void ref_fuse_fwd(const float* a, const float* b, float* y, int64_t n, int mode) {
     for (int64_t i = 0; i < n; ++i) y[i] = mode == 0 ? fabsf(a[i] - b[i]) : b[i] - a[i];

@@ -43,6 +43,10 @@ class ConvGeom(C.Structure):
                 ("dy", C.c_int8 * 9), ("dx", C.c_int8 * 9), ("pad_", C.c_int8 * 2)]
 
 
+class MapGeom(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("groups", C.c_int32)]
+
+
 _vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 _PROTOS = {
     "stcd_last_error": (C.c_char_p, []),
@@ -77,6 +81,17 @@ _PROTOS = {
     "stcd_op_conv": (_i, [_i, _i, C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "stcd_op_wgrad": (_i, [_i, _i, C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _i64, _vp]),
     "stcd_op_scratch_bytes": (_i64, [C.POINTER(ConvGeom)]),
+    "stcd_op_ew_scratch_bytes": (_i64, [C.POINTER(MapGeom)]),
+    "stcd_op_bn_act": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i64, _vp]),
+    "stcd_op_bn_act_pair": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i64, _vp]),
+    "stcd_op_bn_act_bwd": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp]),
+    "stcd_op_maxpool": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _vp, _i, _vp]),
+    "stcd_op_maxpool_bwd": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "stcd_op_fuse": (_i, [_i, _i, C.POINTER(MapGeom), _vp, _i, _vp, _i, _vp]),
+    "stcd_op_fuse_bwd": (_i, [_i, _i, C.POINTER(MapGeom), _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "stcd_op_rep_pad": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _i, _i, _vp]),
+    "stcd_op_rep_pad_bwd": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _i, _i, _vp]),
+    "stcd_op_skip_bwd": (_i, [_i, _i, C.POINTER(MapGeom), _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp]),
 }
 EXPORTS = tuple(_PROTOS)
 

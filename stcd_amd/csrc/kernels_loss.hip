@@ -13,8 +13,8 @@ namespace stcd {
 #define LOSS_BLOCKS 1024
 
 struct LossScratch {
-    double part[LOSS_BLOCKS][4];
-    double fin[4];
+    double part[LOSS_BLOCKS][5];
+    double fin[5];
 };
 int64_t loss_scratch_bytes() { return (int64_t)sizeof(LossScratch); }
 
@@ -23,20 +23,21 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-// block-reduce up to 4 doubles; result valid in thread 0
-__device__ __forceinline__ void block_sum4(double (&v)[4], double* sm) {
+// block-reduce K doubles (sm: 4 waves x K); result valid in thread 0
+template <int K>
+__device__ __forceinline__ void block_sum4(double (&v)[K], double* sm) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < K; ++k) {
         v[k] = wave_sum_d(v[k]);
-        if (lane == 0) sm[wid * 4 + k] = v[k];
+        if (lane == 0) sm[wid * K + k] = v[k];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < K; ++k) {
             double a = 0.0;
-            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += sm[w * 4 + k];
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += sm[w * K + k];
             v[k] = a;
         }
     }
@@ -51,6 +52,9 @@ k_ce_reduce(const float* __restrict__ logits, const int64_t* __restrict__ target
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t t = target[i];
         if (t == ignore) continue;
+        // a label outside [0, classes) that is not the ignore index is an ERROR (F.cross_entropy raises a device assert):
+        // it is never dereferenced; it poisons the loss (and, below, the gradient) with NaN so the caller cannot miss it
+        if (t < 0 || t >= Cn) { v[0] += (double)NAN; v[1] += 1.0; continue; }
         int64_t n = i / HW, p = i - n * HW;
         const float* l = logits + n * Cn * HW + p;
         float mx = l[0];
@@ -87,6 +91,10 @@ k_ce_grad(const float* __restrict__ logits, const int64_t* __restrict__ target, 
             for (int c = 0; c < Cn; ++c) d[(int64_t)c * HW] = 0.f;
             continue;
         }
+        if (t < 0 || t >= Cn) {      // out-of-range label: NaN gradient, no out-of-bounds read
+            for (int c = 0; c < Cn; ++c) d[(int64_t)c * HW] = NAN;
+            continue;
+        }
         float mx = l[0];
         for (int c = 1; c < Cn; ++c) mx = fmaxf(mx, l[(int64_t)c * HW]);
         float se = 0.f;
@@ -111,36 +119,43 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x
 
 __global__ void __launch_bounds__(256)
 k_bd_reduce(const float* __restrict__ logits, const float* __restrict__ target, int64_t n, int from_logits, LossScratch* sc) {
-    __shared__ double sm[16];
-    double v[4] = {0.0, 0.0, 0.0, 0.0};   // sum p, sum t, sum p*t, sum bce
+    __shared__ double sm[20];
+    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // sum p, sum t, sum p*t, sum bce, valid pixels
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float p = (from_logits & 1) ? sigmoidf(logits[i]) : logits[i], t = target[i];
+        // targets are probabilities in [0,1]; the cutout label 255 (stcd_pseudo_pair; data/dataset.py:24-57) marks pixels
+        // that take no part in the loss -- torch's BCELoss would assert on it.  Any other value outside [0,1]: NaN.
+        if (t == 255.f) continue;
+        if (!(t >= 0.f && t <= 1.f)) { v[3] += (double)NAN; v[4] += 1.0; continue; }
         float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);   // torch clamps log at -100
         v[0] += p; v[1] += t; v[2] += (double)p * t;
         v[3] -= (double)(t * lp + (1.f - t) * l1p);
+        v[4] += 1.0;
     }
     block_sum4(v, sm);
     if (threadIdx.x == 0)
-        for (int k = 0; k < 4; ++k) sc->part[blockIdx.x][k] = v[k];
+        for (int k = 0; k < 5; ++k) sc->part[blockIdx.x][k] = v[k];
 }
 __global__ void k_bd_finalize(LossScratch* sc, int nblocks, int64_t n, int flags, float* loss) {
-    __shared__ double sm[16];
-    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    __shared__ double sm[20];
+    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
-        for (int k = 0; k < 4; ++k) v[k] += sc->part[b][k];
+        for (int k = 0; k < 5; ++k) v[k] += sc->part[b][k];
     block_sum4(v, sm);
     if (threadIdx.x == 0) {
         double den = v[0] + v[1] + 1.0, num = 2.0 * v[2] + 1.0;
-        sc->fin[0] = den; sc->fin[1] = num;
-        *loss = (float)(((flags & 2) ? 0.0 : v[3] / (double)n) + 1.0 - num / den);      // bit 1: Dice term only
+        sc->fin[0] = den; sc->fin[1] = num; sc->fin[2] = v[4];
+        *loss = (float)(((flags & 2) ? 0.0 : v[3] / fmax(v[4], 1.0)) + 1.0 - num / den);      // bit 1: Dice term only
     }
 }
 __global__ void __launch_bounds__(256)
 k_bd_grad(const float* __restrict__ logits, const float* __restrict__ target, int64_t n, int from_logits,
           const LossScratch* sc, float* __restrict__ dlogits) {
-    const float den = (float)sc->fin[0], num = (float)sc->fin[1], invn = 1.f / (float)n, invd2 = 1.f / (den * den);
+    const float den = (float)sc->fin[0], num = (float)sc->fin[1], invn = 1.f / (float)fmax(sc->fin[2], 1.0), invd2 = 1.f / (den * den);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float p = (from_logits & 1) ? sigmoidf(logits[i]) : logits[i], t = target[i];
+        if (t == 255.f) { dlogits[i] = 0.f; continue; }
+        if (!(t >= 0.f && t <= 1.f)) { dlogits[i] = NAN; continue; }
         float q = p * (1.f - p);
         float dbce = (from_logits & 2) ? 0.f : (p - t) / fmaxf(q, 1e-12f) * invn;   // ATen binary_cross_entropy_backward (EPSILON 1e-12)
         float ddice = -(2.f * t * den - num) * invd2;

@@ -74,7 +74,8 @@ class FlatGradReducer:
                     if self._comm is None:
                         self._comm = torch.cuda.Stream(device=g.device)
                     self._comm.wait_stream(torch.cuda.current_stream(g.device))
-                    with torch.cuda.stream(self._comm):
+                    g.record_stream(self._comm)     # g may be a slice of a temporary (gradient accumulation): keep its
+                    with torch.cuda.stream(self._comm):   # memory from being recycled while the collective still reads it
                         self._works.append(dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
                 else:
                     dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)

@@ -57,6 +57,20 @@ class _EngineFn(torch.autograd.Function):
         return None, None, None, None
 
 
+class _NoEvalGradFn(torch.autograd.Function):
+    """Eval-mode outputs carry no saved activations: make a backward through them fail loudly instead of silently
+    handing autograd a constant (the engine's backward is the training-mode BatchNorm backward only)."""
+
+    @staticmethod
+    def forward(ctx, out, anchor):
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise StcdError("backward() through an eval-mode forward: the HIP engine differentiates training-mode forwards only "
+                        "(call .train(), or wrap inference in torch.no_grad()); see INTEGRATION.md, limits")
+
+
 class HipChangeDetector(nn.Module):
     """Common machinery: flat parameter / gradient / BN buffers shared with the engine."""
 
@@ -94,10 +108,9 @@ class HipChangeDetector(nn.Module):
         fp = self._flat_params
         if fp is None or fp.device != device:
             return False
-        ps = list(self.parameters())
-        infos = self._engine.params
-        for p, info in ((ps[0], infos[0]), (ps[-1], infos[-1])):
-            if p.data_ptr() != fp.data_ptr() + 4 * info.offset or p.dtype != torch.float32:
+        base = fp.data_ptr()
+        for p, info in zip(self.parameters(), self._engine.params):      # every parameter: a re-assigned p.data is noticed
+            if p.data_ptr() != base + 4 * info.offset or p.dtype != torch.float32:
                 return False
         b, m = self._bn_modules()[-1]
         return m.running_mean.data_ptr() == self._flat_bn.data_ptr() + 4 * b.offset
@@ -218,6 +231,8 @@ class HipChangeDetector(nn.Module):
                 out = _EngineFn.apply(self, self._anchor, x1, x2)
             else:
                 out = self._run_forward(x1, x2, self.training)
+                if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                    out = _NoEvalGradFn.apply(out, self._anchor)
         return [out] if self.RETURNS_LIST else out
 
 

@@ -27,10 +27,13 @@ from .networks import define_G, get_scheduler
 
 
 class Logger:
-    def __init__(self, path):
+    def __init__(self, path, enabled=True):
         self.path = path
+        self.enabled = enabled       # data-parallel runs: only rank 0 prints and appends to the shared log file
 
     def write(self, message):
+        if not self.enabled:
+            return
         print(message, end="")
         with open(self.path, "a") as f:
             f.write(message)
@@ -88,9 +91,14 @@ class CDTrainer:
         self.exp_lr_scheduler_G = get_scheduler(self.optimizer_G, args)
         self.running_metric = ConfuseMatrixMeter(n_class=2)
         self._dev_metric = None
+        # one process per GPU: every rank trains, rank 0 alone owns the files (log, checkpoints, curves); the confusion
+        # matrix is summed over the ranks before any score is formed, so all ranks agree on "best"
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self._rank = torch.distributed.get_rank() if dist_on else 0
+        self._world = torch.distributed.get_world_size() if dist_on else 1
         os.makedirs(args.checkpoint_dir, exist_ok=True)
         os.makedirs(args.vis_dir, exist_ok=True)
-        self.logger = Logger(os.path.join(args.checkpoint_dir, "log.txt"))
+        self.logger = Logger(os.path.join(args.checkpoint_dir, "log.txt"), enabled=self._rank == 0)
         self.logger.write_dict_str(args.__dict__)
         self.timer = Timer()
         self.batch_size = args.batch_size
@@ -138,7 +146,12 @@ class CDTrainer:
             self._reducer = FlatGradReducer(self.net_G)
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:130-163, 178-186)
+    def _barrier(self):
+        if self._world > 1:
+            torch.distributed.barrier()
+
     def _load_checkpoint(self, ckpt_name="last_ckpt.pt"):
+        self._barrier()              # rank 0 has finished writing before anyone reads
         path = os.path.join(self.checkpoint_dir, ckpt_name)
         if os.path.exists(path):
             self.logger.write("loading last checkpoint...\n")
@@ -162,6 +175,8 @@ class CDTrainer:
             print("training from scratch...")
 
     def _save_checkpoint(self, ckpt_name):
+        if self._rank != 0:
+            return
         torch.save({
             "epoch_id": self.epoch_id,
             "best_val_acc": self.best_val_acc,
@@ -219,8 +234,19 @@ class CDTrainer:
                               (self.is_training, self.epoch_id, self.max_num_epochs - 1, self.batch_id, m,
                                imps * self.batch_size, est, loss, running_acc))
 
+    def _sync_epoch_metric(self):
+        """Sum the epoch's confusion matrix over the ranks (each rank saw its own shard of the data)."""
+        if self._world <= 1:
+            return
+        cm = torch.as_tensor(np.asarray(self.running_metric.cm, np.float64))
+        if self.device.type == "cuda" and torch.distributed.get_backend() == "nccl":
+            cm = cm.to(self.device)
+        torch.distributed.all_reduce(cm, op=torch.distributed.ReduceOp.SUM)
+        self.running_metric.cm = cm.cpu().numpy()
+
     def _collect_epoch_states(self):
         self._flush_dev_metric()
+        self._sync_epoch_metric()
         scores = self.running_metric.get_scores()
         self.epoch_acc = scores["mf1"]
         self.logger.write("Is_training: %s. Epoch %d / %d, epoch_mF1= %.5f\n" %
@@ -239,11 +265,13 @@ class CDTrainer:
 
     def _update_training_acc_curve(self):
         self.TRAIN_ACC = np.append(self.TRAIN_ACC, [self.epoch_acc])
-        np.save(os.path.join(self.checkpoint_dir, "train_acc.npy"), self.TRAIN_ACC)
+        if self._rank == 0:
+            np.save(os.path.join(self.checkpoint_dir, "train_acc.npy"), self.TRAIN_ACC)
 
     def _update_val_acc_curve(self):
         self.VAL_ACC = np.append(self.VAL_ACC, [self.epoch_acc])
-        np.save(os.path.join(self.checkpoint_dir, "val_acc.npy"), self.VAL_ACC)
+        if self._rank == 0:
+            np.save(os.path.join(self.checkpoint_dir, "val_acc.npy"), self.VAL_ACC)
 
     def _clear_cache(self):
         self.running_metric.clear()
@@ -298,7 +326,8 @@ class CDTrainer:
             weight_dir = getattr(self.args, "weight_dir", None)
             if weight_dir and ((self.max_num_epochs == 100 and self.epoch_id > 50 and (self.epoch_id + 1) % 10 == 0) or
                                (self.max_num_epochs == 200 and self.epoch_id > 100 and (self.epoch_id + 1) % 20 == 0)):
-                torch.save(self.net_G, os.path.join(weight_dir, str(self.epoch_id) + ".pth"))
+                if self._rank == 0:
+                    torch.save(self.net_G, os.path.join(weight_dir, str(self.epoch_id) + ".pth"))
             self._collect_epoch_states()
             self._update_training_acc_curve()
             self._update_lr_schedulers()
@@ -314,3 +343,4 @@ class CDTrainer:
             self._collect_epoch_states()
             self._update_val_acc_curve()
             self._update_checkpoints()
+            self._barrier()

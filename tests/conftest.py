@@ -25,3 +25,13 @@ def golden():
         return cache[name]
 
     return load
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Achieved gradient parity (worst relative l2 error / worst cosine per whole-model test), next to the bounds."""
+    from tests import _util
+    if not _util.ACHIEVED:
+        return
+    terminalreporter.write_sep("-", f"gradient parity achieved (bounds: rel-l2 <= {_util.REL_L2_MAX}, cosine >= {_util.COS_MIN})")
+    for k, (a, b) in sorted(_util.ACHIEVED.items()):
+        terminalreporter.write_line(f"{k}: {a:.3e} / {b:.6f}")

@@ -80,8 +80,10 @@ def unwrap(out):
     return out[-1] if isinstance(out, (list, tuple)) else out
 
 
-def grad_summary(model, full_for=()):
-    """Per-parameter [sum, l2, first 8, 24 strided samples]; full tensors for a chosen few."""
+def grad_summary(model, full_for=None):
+    """Per-parameter [sum, l2, first 8, 24 strided samples] ("gs/") and the reference gradient itself ("gf/"): the whole
+    tensor up to tests/_util.GF_FULL elements, a fixed random sample of that many elements above (tests/_util.gf_index)."""
+    from tests._util import gf_index
     out = {}
     for name, p in model.named_parameters():
         g = p.grad.detach().flatten().double()
@@ -90,8 +92,7 @@ def grad_summary(model, full_for=()):
         summ = np.concatenate([[g.sum().item(), g.norm().item()], t2n(g[:8]) if n >= 8 else np.pad(t2n(g), (0, 8 - n)),
                                t2n(g[idx])])
         out["gs/" + name] = summ
-        if name in full_for:
-            out["gf/" + name] = t2n(p.grad)
+        out["gf/" + name] = t2n(p.grad).ravel()[gf_index(name, n)]
     return out
 
 
@@ -181,9 +182,6 @@ def g1_ops():
 
 
 # ------------------------------------------------------------------------------ G2
-FULL_GRADS = ("conv11.weight", "conv11.bias", "bn12.weight", "bn12.bias", "conv22.weight", "bn43.weight",
-              "upconv4.bias", "upconv1.weight", "conv12d.weight", "conv11d.weight", "conv11d.bias", "bn21d.bias")
-
 
 def g2_fcsiam():
     for arch in ("diff", "conc", "sub"):
@@ -217,7 +215,7 @@ def g2_fcsiam():
                 loss = ref_losses.cd_loss(torch.sigmoid(logits), tgt.float().unsqueeze(1))
             loss.backward()
             d["logits_train"], d["loss"] = t2n(logits), loss.item()
-            d.update(grad_summary(m, FULL_GRADS))
+            d.update(grad_summary(m))
             sd = m.state_dict()
             for k in ("bn11", "bn22", "bn43", "bn43d", "bn12d"):
                 d[f"rs/{k}.running_mean"] = t2n(sd[f"{k}.running_mean"])
@@ -251,9 +249,7 @@ def g2_snunet():
             loss = ref_losses.cd_loss(torch.sigmoid(logits), tgt.float().unsqueeze(1))
         loss.backward()
         d["logits_train"], d["loss"] = t2n(logits), loss.item()
-        d.update(grad_summary(m, ("conv0_0.conv1.weight", "conv0_0.bn1.weight", "conv0_4.conv2.bias", "Up1_3.up.weight",
-                                  "Up4_0.up.bias", "ca.fc1.weight", "ca1.fc2.weight", "conv_final.weight",
-                                  "conv_final.bias", "conv4_0.bn2.bias")))
+        d.update(grad_summary(m))
         sd = m.state_dict()
         for k in ("conv0_0.bn1", "conv3_0.bn2", "conv4_0.bn1", "conv0_4.bn2"):
             d[f"rs/{k}.running_mean"] = t2n(sd[f"{k}.running_mean"])

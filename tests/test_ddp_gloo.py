@@ -67,3 +67,86 @@ def test_two_rank_gradient_average_gloo():
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The REAL stage ranges of every engine family (stcd_grad_stage_range through the C ABI: no GPU needed for queries) drive
+# the reducer: the two slices must be disjoint, cover the flat gradient buffer, stage 0 must hold exactly the decoder's
+# tensors (final first, so its collective overlaps the encoder's backward), and a 2-rank run over those slices must
+# deliver the mean everywhere -- also with a trainer-shaped epoch metric all-reduce.
+ARCHES = [("diff", 0), ("conc", 1), ("sub", 2), ("snunet", 3)]
+
+
+def _engine_layout(arch):
+    from stcd_amd.engine import Engine
+    e = Engine(arch, 3, 2, "bf16")
+    return e.param_floats, e.stage0_range, e.stage1_range, [(p.name, p.offset, p.numel) for p in e.params]
+
+
+@pytest.mark.parametrize("arch,_id", ARCHES)
+def test_stage_ranges_partition_the_gradient_buffer(arch, _id):
+    total, s0, s1, params = _engine_layout(arch)
+    assert s0[0] <= s0[1] and s1[0] <= s1[1]
+    assert {s0[0], s1[0]} >= {0} and max(s0[1], s1[1]) == total          # one of them starts at 0, one ends at the end
+    assert s1[1] == s0[0] or s0[1] == s1[0]                              # adjacent
+    assert (s0[1] - s0[0]) + (s1[1] - s1[0]) == total                    # disjoint + covering
+    for name, off, numel in params:                                       # no tensor straddles the boundary
+        in0 = s0[0] <= off and off + numel <= s0[1]
+        in1 = s1[0] <= off and off + numel <= s1[1]
+        assert in0 != in1, name
+        if arch != "snunet":
+            dec = name.split(".")[0].endswith("d") or name.startswith("upconv")
+            assert in0 == dec, f"{name}: stage 0 must finalise exactly the decoder's gradients"
+    if arch == "snunet":
+        assert s1[1] - s1[0] == 0                                         # single-stage plan: everything final after stage 0
+
+
+class RangedModel(torch.nn.Module):
+    def __init__(self, total, s0, s1):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(total))
+        self.stage0_range, self.stage1_range = s0, s1
+        self.grad_stage_hook = None
+
+    def fake_backward(self, rank):
+        g = (torch.arange(self.w.numel(), dtype=torch.float32) % 977) * (rank + 1)
+        for stage, (b, e) in ((0, self.stage0_range), (1, self.stage1_range)):
+            self.grad_stage_hook(stage, g[b:e])
+        self.w.grad = g
+
+
+def _ranged_worker(rank, world, port, q, layouts):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from stcd_amd.ddp import FlatGradReducer, init_distributed
+    init_distributed(backend="gloo")
+    ok = True
+    for total, s0, s1 in layouts:
+        for overlap in (True, False):
+            m = RangedModel(total, s0, s1)
+            FlatGradReducer(m, overlap=overlap)
+            m.fake_backward(rank)
+            want = (torch.arange(total, dtype=torch.float32) % 977) * sum(range(1, world + 1)) / world
+            ok = ok and bool(torch.allclose(m.w.grad, want, rtol=1e-6))
+    cm = torch.tensor([[10.0 + rank, 1.0], [2.0, 3.0 * (rank + 1)]], dtype=torch.float64)     # trainer-shaped metric sync
+    dist.all_reduce(cm, op=dist.ReduceOp.SUM)
+    ok = ok and cm.tolist() == [[21.0, 2.0], [4.0, 9.0]]
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_real_stage_ranges_gloo():
+    layouts = []
+    for arch, _ in ARCHES:
+        total, s0, s1, _p = _engine_layout(arch)
+        layouts.append((total, s0, s1))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ranged_worker, args=(r, 2, port, q, layouts)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert res == {0: True, 1: True}

@@ -70,3 +70,77 @@ def test_two_ranks_equal_mean_of_micro_batches():
     for r in (0, 1):
         np.testing.assert_allclose(got[r], want.numpy(), rtol=1e-4, atol=1e-6 * float(want.abs().max()) + 1e-9)
     np.testing.assert_array_equal(got[0], got[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The RCCL path itself (backend "nccl": side-stream async all_reduce with ReduceOp.AVG, stage-1 wait ordering the
+# optimizer after both collectives).  Needs two GPUs: one process per GPU, spawned before any GPU call in the child.
+def _nccl_worker(rank, world, port, q, state, overlap):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from stcd_amd.ddp import FlatGradReducer, broadcast_parameters
+    from stcd_amd.modules import SiamUnet_diff
+    from stcd_amd.optim import FlatAdamW
+
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    m = SiamUnet_diff(3, 2, dtype="fp32")
+    m.load_state_dict(state)
+    m.to(dev).train()
+    m.set_dropout_p(0.0)
+    broadcast_parameters(m)
+    FlatGradReducer(m, overlap=overlap)
+    opt = FlatAdamW(m, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    x1, x2, y = _data(rank)
+    opt.zero_grad(set_to_none=True)
+    torch.nn.functional.cross_entropy(m(x1.to(dev), x2.to(dev)), y.to(dev)).backward()
+    grads = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    opt.step()                                   # must see fully reduced gradients (stage-1 wait)
+    torch.cuda.synchronize()
+    q.put((rank, grads.cpu().numpy(), torch.cat([p.detach().flatten() for p in m.parameters()]).cpu().numpy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_ranks_over_rccl(overlap):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the RCCL branch of FlatGradReducer); run on a multi-GPU lease")
+    from oracle import fcsiam_ref as R
+    from stcd_amd.modules import SiamUnet_diff
+    from stcd_amd.optim import FlatAdamW
+
+    state = R.synth_state("diff", 3, 2, seed=9)
+    want = (_grads_single(_data(0), state) + _grads_single(_data(1), state)) / 2
+    # single-process AdamW step from the averaged gradient
+    m = SiamUnet_diff(3, 2, dtype="fp32")
+    m.load_state_dict(state)
+    m.to("cuda:0").train()
+    m.set_dropout_p(0.0)
+    opt = FlatAdamW(m, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    x1, x2, y = _data(0)
+    torch.nn.functional.cross_entropy(m(x1.cuda(), x2.cuda()), y.cuda()).backward()
+    off = 0
+    for p in m.parameters():
+        p.grad.copy_(want[off:off + p.numel()].view_as(p).cuda())
+        off += p.numel()
+    opt.step()
+    want_params = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu().numpy()
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q, state, overlap)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, g, w = q.get(timeout=180)
+        got[r] = (g, w)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        np.testing.assert_allclose(got[r][0], want.numpy(), rtol=1e-4, atol=1e-6 * float(want.abs().max()) + 1e-9)
+        np.testing.assert_allclose(got[r][1], want_params, rtol=1e-5, atol=2e-6)
+    np.testing.assert_array_equal(got[0][1], got[1][1])

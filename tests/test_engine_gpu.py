@@ -7,7 +7,7 @@ import torch
 
 from oracle import fcsiam_ref as R
 from stcd_amd.modules import SiamUnet_conc, SiamUnet_diff, SiamUnet_sub
-from tests._util import FLIP_ATOL, check_grad, t
+from tests._util import check_grad, rel_l2_cos, t
 
 pytestmark = pytest.mark.gpu
 CLS = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub}
@@ -52,8 +52,8 @@ def test_fp32_matches_reference_vectors(golden, arch, label):
     loss = loss_fn(label, logits, t(g["target"]).to(DEV))
     assert abs(loss.item() - float(g["loss"])) < 1e-4
     loss.backward()
-    for name, p in m.named_parameters():
-        check_grad(name, p.grad, g, 3e-3, FLIP_ATOL)
+    for name, p in m.named_parameters():       # per-tensor relative l2 <= 2e-2 and cosine >= 0.9995 vs the reference's gradient
+        check_grad(name, p.grad, g, tag=f"fp32 {arch}({label}) vs reference G2")
     sd = m.state_dict()
     for k in [k for k in g if k.startswith("rs/")]:
         np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
@@ -97,13 +97,16 @@ def test_fp32_odd_size_backward_matches_oracle(arch):
     rl = R.cross_entropy(R.forward(arch, ref, x1, x2, training=True, masks=masks), tgt)
     rl.backward()
     assert abs(loss.item() - rl.item()) < 1e-4
+    from tests._util import ACHIEVED, COS_MIN, REL_L2_MAX
     for name, p in m.named_parameters():
         r = ref[name].grad
-        scale = r.abs().max().item() + 1e-7
-        if scale < 1e-5:
+        if r.abs().max().item() < 1e-5:
             assert p.grad.abs().max().item() < 1e-5, name
-        else:
-            np.testing.assert_allclose(p.grad.cpu().numpy() / scale, r.numpy() / scale, atol=FLIP_ATOL, err_msg=name)
+            continue
+        rel, cos = rel_l2_cos(p.grad.cpu().numpy(), r.numpy())
+        assert rel <= REL_L2_MAX and cos >= COS_MIN, f"{name}: relative l2 error {rel:.3e}, cosine {cos:.6f}"
+        w = ACHIEVED.get(f"fp32 {arch} 36x44 vs oracle", (0.0, 1.0))
+        ACHIEVED[f"fp32 {arch} 36x44 vs oracle"] = (max(w[0], rel), min(w[1], cos))
 
 
 @pytest.mark.parametrize("arch", ["diff", "conc"])
@@ -126,11 +129,17 @@ def test_bf16_tracks_reference_vectors(golden, arch):
     loss = loss_fn(label, logits, t(g["target"]).to(DEV))
     assert abs(loss.item() - float(g["loss"])) < 2e-2
     loss.backward()
-    for name, p in m.named_parameters():
-        if "gf/" + name in g and p.numel() >= 256:
-            a, b = p.grad.flatten().cpu().double(), t(g["gf/" + name]).flatten().double()
-            cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
-            assert cos > (0.97 if name.endswith("d.weight") else 0.8), (name, cos)   # decoder tight, encoder-first loose
+    from tests._util import ACHIEVED, gf_index, zero_grad_by_construction
+    worst = {"dec": 1.0, "enc": 1.0}
+    for name, p in m.named_parameters():       # EVERY parameter tensor with >= 256 elements, against the reference's gradient
+        if zero_grad_by_construction(name) or p.numel() < 256:
+            continue
+        a = p.grad.flatten().cpu().double().numpy()[gf_index(name, p.numel())]
+        _, cos = rel_l2_cos(a, g["gf/" + name])
+        dec = name.split(".")[0].endswith("d") or name.startswith("upconv")
+        worst["dec" if dec else "enc"] = min(worst["dec" if dec else "enc"], cos)
+        assert cos > (0.97 if dec else 0.8), (name, cos)   # decoder tight; encoder gradients pass through every bf16 rounding of the net
+    ACHIEVED[f"bf16 {arch}(2) vs reference G2 [worst cosine: decoder, encoder]"] = (worst["dec"], worst["enc"])
 
 
 def test_fp32_config1_step(golden):
@@ -163,7 +172,7 @@ def test_fp32_config1_step(golden):
         ref_mask = np.unpackbits(g[f"{tag}/mask_packed"])[:pred.size].reshape(pred.shape)
         assert (pred != ref_mask).mean() < 1e-3, "change mask differs from the reference on more than 0.1% of pixels"
         for name, p in m.named_parameters():
-            check_grad(name, p.grad, {"gs/" + name: g[f"{tag}/gs/{name}"]}, 5e-3, FLIP_ATOL)
+            check_grad(name, p.grad, g, prefix=f"{tag}/", tag=f"fp32 diff config-1 step ({tag}) vs reference G3")
         opt.step()
         for k in ("conv11.weight", "bn33.weight", "conv12d.weight"):
             d = (dict(m.named_parameters())[k].detach() - before[k]).cpu().numpy()
@@ -273,7 +282,7 @@ def test_snunet_fp32_matches_reference_vectors(golden, label):
     assert abs(loss.item() - float(g["loss"])) < 1e-4
     loss.backward()
     for name, p in m.named_parameters():
-        check_grad(name, p.grad, g, 3e-3, FLIP_ATOL)
+        check_grad(name, p.grad, g, tag=f"fp32 snunet({label}) vs reference G2")
     sd = m.state_dict()
     for k in [k for k in g if k.startswith("rs/")]:
         np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
@@ -339,5 +348,79 @@ def test_full_size_properties_bf16():
     assert torch.equal(outs[0], outs[1])
     assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0
     # linear kernels + power-of-two scale: equal up to the summation order of the atomically folded slab parts
+    rel = ((grads[1] - 2.0 * grads[0]).abs().max() / grads[1].abs().max()).item()
+    assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("label", [1, 2])
+def test_snunet_bf16_tracks_reference_vectors(golden, label):
+    """BASELINE config 3's arithmetic (SNUNet_ECAM, bf16 MFMA path incl. dense-concat slices, k2-s2 transposed convs, the
+    1x1 head and ECAM) against the vectors captured from the reference: mean |dlogit| < 4e-2, max < 0.35, loss within 2e-2,
+    gradient cosine vs the reference's gradient > 0.95 for every tensor of >= 256 elements outside the first encoder block
+    (> 0.8 there: its gradient passes through every bf16 rounding of the 5-level net on a 32x32 input)."""
+    from oracle import snunet_ref as S
+    from stcd_amd.modules import SNUNet_ECAM
+    from tests._util import ACHIEVED, gf_index, zero_grad_by_construction
+
+    g = golden(f"g2_snunet_{label}.npz")
+    seed = int(g["seed"])
+    x1, x2 = t(g["x1"]).to(DEV), t(g["x2"]).to(DEV)
+    m = SNUNet_ECAM(3, label, dtype="bf16")
+    m.load_state_dict(S.synth_state(3, label, seed))
+    m.to(DEV).train()
+    logits = m(x1, x2)
+    err = np.abs(logits.detach().cpu().numpy() - g["logits_train"])
+    scale = max(1.0, float(np.abs(g["logits_train"]).max()))
+    assert err.mean() < 4e-2 * scale and err.max() < 0.35 * scale, (err.mean(), err.max(), scale)
+    loss = loss_fn(label, logits, t(g["target"]).to(DEV))
+    assert abs(loss.item() - float(g["loss"])) < 2e-2 * max(1.0, abs(float(g["loss"])))
+    loss.backward()
+    worst = {"rest": 1.0, "first": 1.0}
+    for name, p in m.named_parameters():
+        if zero_grad_by_construction(name) or p.numel() < 256:
+            continue
+        a = p.grad.flatten().cpu().double().numpy()[gf_index(name, p.numel())]
+        _, cos = rel_l2_cos(a, g["gf/" + name])
+        k = "first" if name.startswith("conv0_0.") else "rest"
+        worst[k] = min(worst[k], cos)
+        assert cos > (0.8 if k == "first" else 0.95), (name, cos)
+    ACHIEVED[f"bf16 snunet({label}) vs reference G2 [worst cosine: all but conv0_0, conv0_0]"] = (worst["rest"], worst["first"])
+
+
+@pytest.mark.parametrize("arch", ["conc", "snunet"])
+def test_full_size_properties_other_configs_bf16(arch):
+    """BASELINE configs 2 and 3 at their per-GPU size (SiamUnet_conc / SNUNet_ECAM, 16 pairs of 256x256, bf16) through the
+    size-independent properties of test_full_size_properties_bf16: (a) eval mode treats pairs independently -- the
+    16-pair batch equals its two 8-pair halves bit for bit (every conv tile walk, the dense-concat slices, ECAM's
+    per-image pooling); (b) the backward is linear in d(logits): doubling it doubles every parameter gradient (up to the
+    order of the atomically folded partial sums); (c) everything finite, gradients non-zero for every parameter tensor
+    that can receive one."""
+    from stcd_amd import synth
+    from stcd_amd.modules import SNUNet_ECAM
+    from tests._util import zero_grad_by_construction
+
+    a, b, _ = synth.make_batch(16, 256, 256, seed=78)
+    A, B = t(a).to(DEV), t(b).to(DEV)
+    torch.manual_seed(6)
+    m = (SNUNet_ECAM(3, 2, dtype="bf16") if arch == "snunet" else SiamUnet_conc(3, 2, dtype="bf16")).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        full = m(A, B).clone()
+        h0, h1 = m(A[:8], B[:8]).clone(), m(A[8:], B[8:]).clone()
+    assert torch.isfinite(full).all()
+    assert torch.equal(full, torch.cat([h0, h1]))
+    m.train()
+    grads = []
+    for scale in (1.0, 2.0):
+        m._steps = 0                       # same dropout masks for both passes
+        m.zero_grad(set_to_none=True)
+        out = m(A, B)
+        out.backward(torch.ones_like(out) * 1e-3 * scale)
+        grads.append(torch.cat([p.grad.flatten() for p in m.parameters()]).clone())
+        if scale == 1.0:
+            for name, p in m.named_parameters():
+                assert torch.isfinite(p.grad).all(), name
+                if not zero_grad_by_construction(name):
+                    assert p.grad.abs().max().item() > 0, name
     rel = ((grads[1] - 2.0 * grads[0]).abs().max() / grads[1].abs().max()).item()
     assert rel < 1e-5, rel

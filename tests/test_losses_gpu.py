@@ -129,3 +129,44 @@ def test_full_size_loss_and_metric_properties():
     assert float(g.sum(1).abs().max()) < 1e-9                 # softmax - onehot sums to zero over classes
     ref = torch.nn.functional.cross_entropy(logits.cpu().double(), lab_ig.cpu(), ignore_index=255).item()
     assert abs(loss.item() - ref) < 1e-6
+
+
+def test_cross_entropy_out_of_range_label_is_loud():
+    """A label outside [0, classes) that is not the ignore index (label 2 with 2 classes, a negative value, a 0/255 mask
+    with ignore_index changed): F.cross_entropy raises a device assert; the kernel must never dereference it -- loss and
+    the gradient at that pixel come back NaN, every other pixel's gradient stays finite."""
+    rng = np.random.default_rng(8)
+    logits = t(rng.standard_normal((2, 2, 16, 16)).astype(np.float32)).to(DEV)
+    for bad, ignore in ((2, 255), (-1, 255), (255, 100), (10 ** 12, 255)):
+        lab = t((rng.random((2, 16, 16)) < 0.3).astype(np.int64)).to(DEV)
+        lab[1, 3, 5] = bad
+        lg = logits.clone().requires_grad_(True)
+        loss = losses.cross_entropy(lg, lab, ignore_index=ignore)
+        loss.backward()
+        assert torch.isnan(loss), (bad, ignore)
+        g = lg.grad
+        assert torch.isnan(g[1, :, 3, 5]).all()
+        g2 = g.clone(); g2[1, :, 3, 5] = 0
+        assert torch.isnan(g2).sum().item() == 0 or torch.isnan(g2).all()   # NaN 1/count scaling may poison all: still loud
+
+
+def test_bce_dice_ignores_cutout_label_255():
+    """stcd_pseudo_pair writes 255 into the change label of cutout pixels (data/dataset.py:24-57 cutout contract).  On the
+    1-channel loss those pixels take no part: loss and gradient equal the loss over the remaining pixels (oracle on the
+    valid subset), gradient exactly 0 at the cutout.  Any other target outside [0,1] is an error: NaN."""
+    from oracle import ops_c as O
+    rng = np.random.default_rng(9)
+    x = (2 * rng.standard_normal((2, 1, 16, 16))).astype(np.float32)
+    y = (rng.random((2, 1, 16, 16)) < 0.3).astype(np.float32)
+    cut = np.zeros_like(y, bool); cut[:, :, 4:9, 2:7] = True
+    y_cut = y.copy(); y_cut[cut] = 255.0
+    lg = t(x).to(DEV).requires_grad_(True)
+    loss = losses.bce_dice_with_logits(lg, t(y_cut).to(DEV))
+    loss.backward()
+    ref_loss, ref_dl = O.bce_dice_fwd_bwd(x[~cut], y[~cut])
+    assert abs(loss.item() - ref_loss) < 1e-5
+    g = lg.grad.cpu().numpy()
+    assert np.abs(g[cut]).max() == 0.0
+    np.testing.assert_allclose(g[~cut], ref_dl, rtol=1e-4, atol=1e-8)
+    y_bad = y.copy(); y_bad[0, 0, 0, 0] = 7.0
+    assert torch.isnan(losses.bce_dice_with_logits(t(x).to(DEV), t(y_bad).to(DEV)))

@@ -153,7 +153,11 @@ def test_upconv_phases_and_stride2_dgrad(c):
 
 
 @pytest.mark.parametrize("n,h,w,ci,co", [(32, 256, 256, 16, 16), (32, 128, 128, 32, 32), (32, 64, 64, 64, 64), (32, 32, 32, 128, 128),
-                                         (16, 32, 32, 256, 128)])
+                                         (16, 32, 32, 256, 128),
+                                         # SiamUnet_conc's widened first decoder conv of every stage (SiamUnet_conc.py:54,66,78,87)
+                                         (16, 32, 32, 384, 128), (16, 64, 64, 192, 64), (16, 128, 128, 96, 32), (16, 256, 256, 48, 16),
+                                         # SNUNet's dense-concat inputs (SNUNet.py:127-142): conv0_4, conv1_3, conv2_2, conv3_1
+                                         (16, 256, 256, 224, 32), (16, 128, 128, 384, 64), (16, 64, 64, 640, 128), (16, 32, 32, 1024, 256)])
 def test_full_size_conv_properties(n, h, w, ci, co):
     """The bench-sized layers of the engine (too large for the CPU oracle) through properties of a convolution that
     hold bit for bit, because every output position accumulates its (tap, channel) products in the same order
@@ -207,3 +211,143 @@ def test_full_size_wgrad_properties(n, h, w, ci, co):
     halves = run_wgrad(1, gh, x[:n // 2].contiguous(), dout[:n // 2].contiguous()) + \
              run_wgrad(1, gh, x[n // 2:].contiguous(), dout[n // 2:].contiguous())
     assert (halves - dw).abs().max().item() < 2e-5 * scale
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Transposed / point-wise convolutions against the reference's per-op vectors (G1) and the plain-C oracle -- every
+# implementation (reference FMA kernel in fp32 and bf16, MFMA auto-selected, MFMA generic), not MFMA vs FMA.
+def _nhwc(x, dtype, ld=None):
+    n, c, h, w = x.shape
+    ld = ld or (c + 7) // 8 * 8
+    t_ = torch.zeros(n, h, w, ld, dtype=dtype, device=DEV)
+    t_[..., :c] = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1))).to(DEV).to(dtype)
+    return t_
+
+
+def _nchw(t_, c):
+    return t_[..., :c].float().cpu().numpy().transpose(0, 3, 1, 2)
+
+
+def _run_conv_dt(dt, impl, g, x, w, bias, out):
+    l = _lib.lib()
+    nbytes = l.stcd_op_scratch_bytes(C.byref(g))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    _lib.check(l.stcd_op_conv(dt, impl, C.byref(g), C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()),
+                              C.c_void_p(bias.data_ptr()) if bias is not None else None, C.c_void_p(out.data_ptr()),
+                              C.c_void_p(scratch.data_ptr()), nbytes, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+
+
+def _run_wgrad_dt(dt, impl, g, x, dout):
+    l = _lib.lib()
+    nbytes = l.stcd_op_scratch_bytes(C.byref(g))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw = torch.full((g.ntaps, g.ci, g.co), float("nan"), dtype=torch.float32, device=DEV)
+    _lib.check(l.stcd_op_wgrad(dt, impl, C.byref(g), C.c_void_p(x.data_ptr()), C.c_void_p(dout.data_ptr()), C.c_void_p(dw.data_ptr()),
+                               C.c_void_p(scratch.data_ptr()), nbytes, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    return dw.cpu().numpy()
+
+
+IMPLS = [("fp32", 0), ("bf16", 0), ("bf16", 1), ("bf16", 2)]
+
+
+def _q(a, dt):
+    return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).float().numpy() if dt == "bf16" else np.asarray(a, np.float32)
+
+
+def _tol(dt):
+    return dict(rtol=2e-5, atol=2e-5) if dt == "fp32" else dict(rtol=2 ** -7, atol=4e-3)
+
+
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+@pytest.mark.parametrize("dt,impl", IMPLS)
+@pytest.mark.parametrize("tag,k", [("convT_s2_16_16", 3), ("convT_k2s2_32", 2)])
+def test_stride2_transposed_conv_against_reference_vectors(golden, tag, k, dt, impl):
+    """nn.ConvTranspose2d(k3,s2,p1,op1) (SiamUnet_diff.py:85) and ConvTranspose2d(k2,s2) (SNUNet.py:38): the four sub-pixel
+    phase launches (forward, writing stride-2 positions of the output), the data gradient as a stride-2 gather conv and the
+    per-phase weight gradients -- against the vectors captured from torch (fp32) / the oracle on bf16-rounded operands."""
+    g = golden("g1_ops.npz")
+    x, wt, b, gy = _q(g[f"{tag}/x"], dt), _q(g[f"{tag}/weight"], dt), g[f"{tag}/bias"], _q(g[f"{tag}/gy"], dt)
+    n, ci, h, w = x.shape
+    co = wt.shape[1]
+    tdt = torch.float32 if dt == "fp32" else torch.bfloat16
+    dcode = _lib.DTYPE_F32 if dt == "fp32" else _lib.DTYPE_BF16
+    s, p, op = (2, 1, 1) if k == 3 else (2, 0, 0)
+    if dt == "fp32":
+        y_ref, dx_ref, dw_ref = g[f"{tag}/y"], g[f"{tag}/dx"], g[f"{tag}/dweight"]
+    else:
+        y_ref = O.convT2d_fwd(x, wt, b, s, p, op)
+        dx_ref, dw_ref, _ = O.convT2d_bwd(x, wt, gy, s, p, op)
+    X = _nhwc(x, tdt)
+    Y = torch.zeros(n, 2 * h, 2 * w, _pad8(co), dtype=tdt, device=DEV)
+    dY = _nhwc(gy, tdt)
+    bias = torch.from_numpy(b).to(DEV)
+    dw_got = np.zeros_like(dw_ref)
+    for py in (0, 1):
+        for px in (0, 1):
+            if k == 3:      # out(2m+py, 2n+px) = sum_{dy<=py, dx<=px} in(m+dy, n+dx) W[ci][co][py+1-2dy][px+1-2dx]
+                taps = [(dy, dx) for dy in range(py + 1) for dx in range(px + 1)]
+                kk = [(py + 1 - 2 * dy, px + 1 - 2 * dx) for dy, dx in taps]
+            else:           # out(2m+py, 2n+px) = in(m, n) W[ci][co][py][px]
+                taps, kk = [(0, 0)], [(py, px)]
+            wp = torch.from_numpy(np.stack([wt[:, :, ky, kx] for ky, kx in kk]).astype(np.float32)).contiguous().to(DEV)   # [tap][ci][co]
+            geo = geom(n, h, w, ci, _pad8(ci), h, w, 1, 2 * h, 2 * w, 2, py, px, co, _pad8(co), taps)
+            _run_conv_dt(dcode, impl, geo, X, wp, bias, Y)
+            if impl != 2:
+                dwp = _run_wgrad_dt(dcode, min(impl, 1), geo, X, dY)
+                for ti, (ky, kx) in enumerate(kk):
+                    dw_got[:, :, ky, kx] = dwp[ti]
+    np.testing.assert_allclose(_nchw(Y, co), y_ref, **_tol(dt))
+    if impl != 2:
+        sc = np.abs(dw_ref).max()
+        np.testing.assert_allclose(dw_got / sc, dw_ref / sc, atol=2e-5 if dt == "fp32" else 2e-4)
+    # data gradient: dIn(m, n)[ci] = sum_taps dOut(2m + dy, 2n + dx)[co] W[ci][co][ky][kx]
+    if k == 3:
+        taps = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+        kk = [(ky, kx) for ky in range(3) for kx in range(3)]
+    else:
+        taps = kk = [(dy, dx) for dy in range(2) for dx in range(2)]
+    wd = torch.from_numpy(np.stack([wt[:, :, ky, kx].T for ky, kx in kk]).astype(np.float32)).contiguous().to(DEV)         # [tap][co][ci]
+    geo = geom(n, 2 * h, 2 * w, co, _pad8(co), h, w, 2, h, w, 1, 0, 0, ci, _pad8(ci), taps)
+    dX = torch.zeros(n, h, w, _pad8(ci), dtype=tdt, device=DEV)
+    _run_conv_dt(dcode, impl, geo, dY, wd, None, dX)
+    np.testing.assert_allclose(_nchw(dX, ci), dx_ref, **_tol(dt))
+
+
+@pytest.mark.parametrize("dt,impl", IMPLS)
+def test_pointwise_conv_against_reference_vectors(golden, dt, impl):
+    """nn.Conv2d(128, 2, kernel_size=1) (SNUNet.py:106 conv_final): forward, data gradient (2 -> 128 channels through the
+    zero-padded 8-channel gradient map) and weight gradient."""
+    g = golden("g1_ops.npz")
+    tag = "conv1x1_128_2"
+    x, wt, b, gy = _q(g[f"{tag}/x"], dt), _q(g[f"{tag}/weight"], dt), g[f"{tag}/bias"], _q(g[f"{tag}/gy"], dt)
+    n, ci, h, w = x.shape
+    co = wt.shape[0]
+    tdt = torch.float32 if dt == "fp32" else torch.bfloat16
+    dcode = _lib.DTYPE_F32 if dt == "fp32" else _lib.DTYPE_BF16
+    if dt == "fp32":
+        y_ref, dx_ref, dw_ref = g[f"{tag}/y"], g[f"{tag}/dx"], g[f"{tag}/dweight"]
+    else:
+        y_ref = O.conv2d_fwd(x, wt, b, 0)
+        dx_ref, dw_ref, _ = O.conv2d_bwd(x, wt, gy, 0)
+    X = _nhwc(x, tdt)
+    Y = torch.zeros(n, h, w, 8, dtype=tdt, device=DEV)
+    wp = torch.from_numpy(wt[:, :, 0, 0].T.astype(np.float32)[None]).contiguous().to(DEV)            # [1][ci][co]
+    geo = geom(n, h, w, ci, ci, h, w, 1, h, w, 1, 0, 0, co, 8, [(0, 0)])
+    _run_conv_dt(dcode, impl, geo, X, wp, torch.from_numpy(b).to(DEV), Y)
+    np.testing.assert_allclose(_nchw(Y, co), y_ref, **_tol(dt))
+    dY = _nhwc(gy, tdt)
+    if impl != 2:
+        dw = _run_wgrad_dt(dcode, min(impl, 1), geo, X, dY)                                             # [1][ci][co]
+        sc = np.abs(dw_ref).max()
+        np.testing.assert_allclose(dw[0].T[:, :, None, None] / sc, dw_ref / sc, atol=2e-5 if dt == "fp32" else 2e-4)
+    wd = torch.zeros(1, 8, ci, dtype=torch.float32, device=DEV)                                        # [1][co padded to 8][ci]
+    wd[0, :co] = torch.from_numpy(wt[:, :, 0, 0].astype(np.float32)).to(DEV)
+    geo = geom(n, h, w, 8, 8, h, w, 1, h, w, 1, 0, 0, ci, ci, [(0, 0)])
+    dX = torch.zeros(n, h, w, ci, dtype=tdt, device=DEV)
+    _run_conv_dt(dcode, impl, geo, dY, wd, None, dX)
+    np.testing.assert_allclose(_nchw(dX, ci), dx_ref, **_tol(dt))

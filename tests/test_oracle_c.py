@@ -51,6 +51,8 @@ def test_pool_and_fusion(golden):
     np.testing.assert_array_equal(da, g["fuse/abs_da"])
     np.testing.assert_array_equal(db, g["fuse/abs_db"])
     np.testing.assert_array_equal(O.fuse_fwd(a, b, 1), b - a)
+    np.testing.assert_array_equal(O.rep_pad_fwd(g["rpad/x"], 5, 6), g["rpad/y"])
+    np.testing.assert_allclose(O.rep_pad_bwd(g["rpad/gy"], 4, 5), g["rpad/dx"], rtol=1e-6, atol=1e-6)
 
 
 def test_losses(golden):

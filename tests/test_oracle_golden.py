@@ -43,8 +43,9 @@ def _check_grad(name, got_t, g, rtol, atol):
         return
     scale = max(ref[1], 1e-6)          # l2 of the tensor's gradient
     np.testing.assert_allclose(_grad_summary(got_t) / scale, ref / scale, rtol=rtol, atol=atol, err_msg=name)
-    if "gf/" + name in g:
-        np.testing.assert_allclose(got_t.numpy(), g["gf/" + name], rtol=rtol, atol=atol * scale, err_msg=name)
+    from tests._util import gf_index
+    np.testing.assert_allclose(got_t.numpy().ravel()[gf_index(name, got_t.numel())], g["gf/" + name], rtol=rtol, atol=atol * scale,
+                               err_msg=name)
 
 
 def _loss(label, logits, tgt):
