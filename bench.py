@@ -29,6 +29,9 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 MFMA_F32_PEAK_TF = 157.3
+# ALGORITHMIC work of one training step per image pair at 256x256 (measured on the reference's
+# modules with forward hooks: 2*MAC of every conv call; (in + out + weights) * 2 B per conv call; train = 3x forward)
+ALG_PER_PAIR_256 = {"diff": (25.37e9, 169e6), "sub": (25.37e9, 169e6), "conc": (28.99e9, 182e6), "snunet": (279.6e9, 1118e6)}
 
 
 def parse():
@@ -78,6 +81,19 @@ def cpu_baseline(arch, label, size, pairs, steps):
                       f"median of {steps} full steps after 1 warm-up ({med * 1e3:.0f} ms/step)"}
 
 
+def pmc_step_traffic(model):
+    """Whole-step HBM-side bytes (sum over every kernel of launches x bytes per launch / profiled steps) from the committed
+    PMC summary of the same command for this model (tools/collect_profiles.py writes the '# step_total_B' line)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", f"*_{model}_pmc_traffic.txt")) +
+                       (sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc_traffic.txt"))) if model == "diff" else []),
+                       reverse=True):
+        for line in open(path):
+            if line.startswith("# step_total_B"):
+                return int(float(line.split()[-1])), os.path.relpath(path, REPO)
+    return None, None
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed PMC summary of this same command: the counters need
     their own rocprofv3 --pmc passes (tools/profile_round.sh; FETCH_SIZE doubled per the gfx950 correction), so they
@@ -85,7 +101,7 @@ def pmc_traffic(kernel):
     import glob
     for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.txt")), reverse=True):
         for line in open(path):
-            if line.startswith(kernel + " ") or line.startswith(kernel[:48] + " "):
+            if line.startswith(kernel + " ") or (len(kernel) > 48 and line.startswith(kernel[:48] + " ")):
                 try:
                     return int(float(line.split()[-1])), os.path.relpath(path, REPO)
                 except ValueError:
@@ -145,6 +161,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     last_loss = loss.item()
+    my_rate = args.batch * args.steps / elapsed
+    rank_rates = [my_rate]
+    if world > 1:      # self-check of the first multi-GPU run: every rank's own pairs/s and the collective backend in use
+        rr = torch.tensor([0.0] * world, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        rr[rank] = my_rate
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        rank_rates = [round(v, 2) for v in rr.tolist()]
 
     result = {
         "metric": "image-pairs/sec (256x256 bf16 SiamUnet_diff train)" if (args.model, args.size, args.dtype) == ("diff", 256, "bf16")
@@ -160,7 +183,20 @@ def main():
                                f"{args.batch} pairs/GPU, synthetic LEVIR-CD-shaped pairs resident in HBM",
                    "global_batch": world * args.batch, "image": args.size, "parallelism": f"dp{world}",
                    "last_loss": round(last_loss, 5)},
+        "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
+        "collective_backend": dist.get_backend() if world > 1 else None,
+        "pairs_per_sec_per_rank": [round(v, 2) for v in rank_rates],
     }
+    # whole-step roofline: SURVEY 8d's algorithmic figures per pair x pairs per step / measured step time (all ranks)
+    fl_pp, by_pp = ALG_PER_PAIR_256[args.model]
+    sc = (args.size / 256.0) ** 2
+    step_s = elapsed / args.steps
+    peak_tf_ = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
+    by_scale = 1.0 if args.dtype == "bf16" else 2.0
+    step_roof = {"alg_flops": fl_pp * sc * args.batch, "alg_bytes": by_pp * sc * by_scale * args.batch,
+                 "hbm_frac": round(by_pp * sc * by_scale * args.batch / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                 "mfma_frac": round(fl_pp * sc * args.batch / step_s / 1e12 / peak_tf_, 4),
+                 "note": "per GPU: algorithmic bytes / flops of one step (SURVEY 8d per-pair figures x pairs per GPU) over the measured step time"}
 
     if rank == 0 and world == 1 and not args.no_roofline:
         eng = model._engine
@@ -206,7 +242,16 @@ def main():
             "class_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in prof.items()},
             "kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]},
             "instrumented_ms_per_step": round(tot_ms / nprof, 4),
+            "launches_per_step_all_kernels": sum(v["launches"] for v in kern.values()) // nprof,
+            "step": step_roof,
         }
+        ts, ts_src = pmc_step_traffic(args.model)
+        result["roofline"]["traffic_step"] = ts
+        result["roofline"]["traffic_step_source"] = ts_src
+        if ts:
+            result["roofline"]["traffic_step_over_algorithmic"] = round(ts / step_roof["alg_bytes"], 3)
+    elif rank == 0:
+        result["roofline"] = {"step": step_roof}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.model, args.label, args.size, args.cpu_pairs, args.cpu_steps)
     if rank == 0:

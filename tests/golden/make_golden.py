@@ -16,6 +16,7 @@ Groups:
   G4  5-step loss trajectory
   G5  confusion-matrix metrics (independent check through scikit-learn)
   G6  odd-size (100x100) forward -- ReplicationPad2d branch
+  G7  train-mode step at 2x128x128 (diff / conc / SNUNet): the bar of the bf16 production path
 """
 import os
 import sys
@@ -365,8 +366,40 @@ def g6_odd():
     save("g6_odd.npz", **d)
 
 
+# ------------------------------------------------------------------------------ G7
+def g7_train128():
+    """Train-mode step at 2 x 128 x 128 (bottleneck BatchNorm over 2*8*8 samples instead of G2's 2*2*2): the vectors the
+    bf16 production path is held to -- logits, loss and every parameter's (sampled) gradient of diff / conc / SNUNet."""
+    for arch in ("diff", "conc", "snunet"):
+        print(f"G7 {arch} 128x128")
+        seed = 700 + ("diff", "conc", "snunet").index(arch)
+        d = {"seed": seed}
+        x1, x2 = rand_pair(seed + 1, 2, 128, 128)
+        rng = np.random.default_rng(seed + 4)
+        tgt = torch.from_numpy((rng.random((2, 128, 128)) < 0.2).astype(np.int64))
+        if arch == "snunet":
+            m = SNUNet_ECAM(3, 2)
+            m.load_state_dict(snunet_ref.synth_state(3, 2, seed))
+        else:
+            m = REF_CLS[arch](3, 2)
+            m.load_state_dict(fcsiam_ref.synth_state(arch, 3, 2, seed))
+            install_masks(m, fcsiam_ref.synth_masks(arch, 2, seed + 3))
+        m.train()
+        logits = unwrap(m(x1, x2))
+        loss = ref_losses.cross_entropy(logits, tgt)
+        loss.backward()
+        d["loss"] = loss.item()
+        lf = logits.detach().flatten()
+        idx = (np.arange(8192) * 7) % lf.numel()
+        d["logits_sample_idx"], d["logits_sample"] = idx, t2n(lf[torch.from_numpy(idx)])
+        d["logits_absmean"] = lf.abs().mean().item()
+        d.update(grad_summary(m))
+        save(f"g7_{arch}_128.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6"]
-    fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd}
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7"]
+    fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd,
+          "g7": g7_train128}
     for w in which:
         fn[w]()

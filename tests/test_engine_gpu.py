@@ -113,8 +113,9 @@ def test_fp32_odd_size_backward_matches_oracle(arch):
 def test_bf16_tracks_reference_vectors(golden, arch):
     """bf16 storage + fp32 accumulation through ~20 layers on a 32x32 input (the bottleneck BN normalises over
     only 2x2x2 samples, which amplifies rounding): mean |dlogit| < 4e-2, max < 0.3 (|logit| ~ 1), loss within 2e-2,
-    gradient direction cosine > 0.97 for decoder filters (> 0.8 for the first encoder filters, whose gradient
-    passes through every bf16 rounding of the net).  The tight bf16 checks are per-op (test_ops_gpu.py)."""
+    gradient cosine vs the reference's gradient for EVERY tensor of >= 256 elements: > 0.97 for the decoder's levels 1-2,
+    > 0.8 for everything whose gradient passes the 2x2 bottleneck.  The tight bf16 checks are per-op (test_ops_gpu.py,
+    test_ew_ops_gpu.py); the production-shaped whole-model bound is the 128x128 test below."""
     label = 2
     g = golden(f"g2_{arch}_{label}.npz")
     seed = int(g["seed"])
@@ -136,9 +137,12 @@ def test_bf16_tracks_reference_vectors(golden, arch):
             continue
         a = p.grad.flatten().cpu().double().numpy()[gf_index(name, p.numel())]
         _, cos = rel_l2_cos(a, g["gf/" + name])
-        dec = name.split(".")[0].endswith("d") or name.startswith("upconv")
+        mod = name.split(".")[0]
+        dec = (mod.endswith("d") or mod.startswith("upconv")) and mod[-2 if mod.endswith("d") else -1] in "12"   # decoder levels 1-2
         worst["dec" if dec else "enc"] = min(worst["dec" if dec else "enc"], cos)
-        assert cos > (0.97 if dec else 0.8), (name, cos)   # decoder tight; encoder gradients pass through every bf16 rounding of the net
+        # shallow decoder tight; everything that passes the 2x2 bottleneck (BatchNorm over 8 samples amplifies every bf16
+        # rounding) loose -- the production-shaped bound is test_bf16_train_step_128_tracks_reference_vectors
+        assert cos > (0.97 if dec else 0.8), (name, cos)
     ACHIEVED[f"bf16 {arch}(2) vs reference G2 [worst cosine: decoder, encoder]"] = (worst["dec"], worst["enc"])
 
 
@@ -424,3 +428,59 @@ def test_full_size_properties_other_configs_bf16(arch):
                     assert p.grad.abs().max().item() > 0, name
     rel = ((grads[1] - 2.0 * grads[0]).abs().max() / grads[1].abs().max()).item()
     assert rel < 1e-5, rel
+
+
+def _g7_inputs(g, arch):
+    seed = int(g["seed"])
+    rng = np.random.default_rng(seed + 1)
+    a = rng.standard_normal((2, 3, 128, 128)).astype(np.float32)
+    b = (a + 0.5 * rng.standard_normal((2, 3, 128, 128))).astype(np.float32)
+    tgt = t((np.random.default_rng(seed + 4).random((2, 128, 128)) < 0.2).astype(np.int64))
+    if arch == "snunet":
+        from oracle import snunet_ref as S
+        from stcd_amd.modules import SNUNet_ECAM
+        return seed, t(a), t(b), tgt, S.synth_state(3, 2, seed), None, SNUNet_ECAM
+    return seed, t(a), t(b), tgt, R.synth_state(arch, 3, 2, seed), R.synth_masks(arch, 2, seed + 3), CLS[arch]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("arch", ["diff", "conc", "snunet"])
+def test_train_step_128_tracks_reference_vectors(golden, arch, dtype):
+    """G7: one train-mode step at 2 x 128 x 128 against the reference's logits, loss and EVERY parameter's gradient.
+    fp32 engine: logits 1e-3, loss 1e-4, per-tensor relative l2 <= 2e-2 / cosine >= 0.9995.
+    bf16 engine (the path the bench times -- MFMA kernels, fused statistics, grouped weight gradients): mean |dlogit|
+    <= 2 % of mean |logit|, loss within 5e-3, per-tensor gradient cosine >= 0.99 (>= 0.97 for the first encoder block,
+    whose gradient has passed every bf16 rounding of the network) and relative l2 error <= 0.15 (0.25)."""
+    from tests._util import ACHIEVED, gf_index, zero_grad_by_construction
+    g = golden(f"g7_{arch}_128.npz")
+    seed, x1, x2, tgt, st, masks, cls = _g7_inputs(g, arch)
+    m = cls(3, 2, dtype=dtype)
+    m.load_state_dict(st)
+    m.to(DEV).train()
+    if masks is not None:
+        m.set_dropout_masks(masks)
+    logits = unwrap(m(x1.to(DEV), x2.to(DEV)))
+    got = logits.detach().flatten().cpu().numpy()[g["logits_sample_idx"]]
+    loss = torch.nn.functional.cross_entropy(logits, tgt.to(DEV))
+    loss.backward()
+    if dtype == "fp32":
+        np.testing.assert_allclose(got, g["logits_sample"], rtol=1e-3, atol=1e-4)
+        assert abs(loss.item() - float(g["loss"])) < 1e-4
+        for name, p in m.named_parameters():
+            check_grad(name, p.grad, g, tag=f"fp32 {arch} 128x128 step vs reference G7")
+        return
+    err = np.abs(got - g["logits_sample"]).mean() / float(g["logits_absmean"])
+    assert err < 2e-2, err
+    assert abs(loss.item() - float(g["loss"])) < 5e-3, (loss.item(), float(g["loss"]))
+    worst = [0.0, 1.0, 0.0, 1.0]
+    for name, p in m.named_parameters():
+        if zero_grad_by_construction(name) or p.numel() < 64:
+            continue
+        a = p.grad.flatten().cpu().double().numpy()[gf_index(name, p.numel())]
+        rel, cos = rel_l2_cos(a, g["gf/" + name])
+        first = name.startswith(("conv11.", "bn11.", "conv12.", "bn12.", "conv0_0."))
+        k = 2 if first else 0
+        worst[k], worst[k + 1] = max(worst[k], rel), min(worst[k + 1], cos)
+        assert cos >= (0.97 if first else 0.99) and rel <= (0.25 if first else 0.15), (name, rel, cos)
+    ACHIEVED[f"bf16 {arch} 128x128 step vs reference G7 [all but first block]"] = (worst[0], worst[1])
+    ACHIEVED[f"bf16 {arch} 128x128 step vs reference G7 [first encoder block]"] = (worst[2], worst[3])

@@ -10,6 +10,7 @@ usage: python tools/collect_profiles.py r01
 import collections, csv, glob, json, os, re, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+STEPS = 4            # bench.py --steps 3 --warmup 1 in the --pmc passes of tools/profile_round.sh
 src, dst = f"gpurun_out/{tag}", "profiles"
 os.makedirs(dst, exist_ok=True)
 line = [l for l in open(f"{src}/bench.json") if l.startswith("{")][-1]
@@ -46,6 +47,7 @@ rows.sort(reverse=True)
 with open(f"{dst}/{tag}_pmc_traffic.txt", "w") as o:
     o.write("# HBM-side traffic per launch (bytes), averaged over the launches of 4 bench steps; separate --pmc passes\n")
     o.write("# read = 2 * 1024 * FETCH_SIZE (gfx950 correction), write = 1024 * WRITE_SIZE\n")
+    o.write(f"# step_total_B (sum over kernels of launches x total_B / {STEPS} steps): {sum(t * n for t, _, n, _, _ in rows) / STEPS:.0f}\n")
     o.write(f"{'kernel':48s} {'launches':>8s} {'read_B':>14s} {'write_B':>14s} {'total_B':>14s}\n")
     for tot, k, n, fb, wb in rows:
         o.write(f"{k[:48]:48s} {n:8d} {fb:14.0f} {wb:14.0f} {tot:14.0f}\n")
