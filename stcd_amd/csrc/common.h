@@ -88,13 +88,44 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ------------------------------------------------------------------ BatchNorm sum accumulators
+// Per-channel sums (forward: sum y, sum y^2; backward: sum dz, sum dz*xhat) meet in 64-bit FIXED-POINT integer
+// accumulators through global atomic adds: integer addition is exact and order-independent, so the result is
+// reproducible run to run (float atomics are not), and the kernel that CONSUMES the statistics derives mean / invstd /
+// scale / shift (or the backward coefficients) for its own channels from 2*C integers in its prologue -- there is no
+// separate "finalize" launch between the reduction and its consumer.  Every block adds one value per (group, channel,
+// sum); BN_REP replicas spread the adders (<= 1/8 of the blocks meet on one address), the consumer adds the replicas.
+// Layout: int64 [BN_REP][groups][2][C], zeroed by the engine (one memset per forward / per backward for ALL layers).
+// Resolution / range: forward sum(y) 2^-26 / +-1.4e11, sum(y^2) 2^-18 / 3.5e13; backward sums 2^-36 / +-1.3e8 -- each
+// block's contribution is an fp32 partial sum whose own rounding is coarser than these steps for any activation scale
+// a BatchNorm'd network produces.
+constexpr int BN_REP = 8;
+constexpr float BN_FS1 = 67108864.f;       // 2^26
+constexpr float BN_FS2 = 262144.f;         // 2^18
+constexpr float BN_BS = 68719476736.f;     // 2^36
+inline int64_t bn_acc_bytes(int groups, int C) { return (int64_t)BN_REP * groups * 2 * C * 8; }
+__device__ __forceinline__ void bn_acc_add(long long* acc, int rep, int groups, int C, int g, int which, int c, float v, float scale) {
+    const long long q = (long long)llrint((double)v * (double)scale);
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc + (((int64_t)(rep & (BN_REP - 1)) * groups + g) * 2 + which) * C + c),
+              (unsigned long long)q);
+}
+__device__ __forceinline__ double bn_acc_get(const long long* __restrict__ acc, int groups, int C, int g, int which, int c, float scale) {
+    long long s = 0;
+#pragma unroll
+    for (int r = 0; r < BN_REP; ++r) s += acc[(((int64_t)r * groups + g) * 2 + which) * C + c];
+    return (double)s / (double)scale;
+}
+
 // ------------------------------------------------------------------ host launchers (kernels_*.hip)
 // All tensors NHWC with an explicit pixel stride ("ld", in elements); channel counts are multiples of 8.
 
 // x1,x2 fp32 NCHW [B,cin,H,W] -> X [2B,H,W,8] (channels >= cin zero)
 void launch_in_pack(int dt, const float* x1, const float* x2, void* X, int B, int cin, int H, int W, hipStream_t s);
-// g fp32 NCHW [B,L,H,W] -> G [B,H,W,8]
-void launch_gout_pack(int dt, const float* g, void* G, int B, int L, int H, int W, hipStream_t s);
+// g fp32 NCHW [B,L,H,W] -> G [B,H,W,8]; optional bias_acc (int64 [BN_REP][1][2][8], scale BN_BS): per-channel sums of g
+void launch_gout_pack(int dt, const float* g, void* G, int B, int L, int H, int W, hipStream_t s, long long* bias_acc = nullptr);
+// bias gradients that conv / pack kernels accumulated as integer sums -> fp32 gradient entries (one launch per stage)
+struct BiasJob { int64_t acc_off; int64_t out_off; int C, valid; float scale; int pad_; };
+void launch_bias_finish(const BiasJob* jobs_dev, int njobs, const char* ws, float* grads, hipStream_t s);
 
 // generic tap-list convolution, reference FMA implementation.  w fp32 [ntaps][kpad][wld]; out_nchw_f32: write fp32
 // NCHW [n,co,ho,wo] instead of NHWC activations (network output).
@@ -128,13 +159,14 @@ struct ConvResPlan {
 };
 ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups);
 int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvResPlan& rp, const void* in, const void* wf,
-                    const float* bias, void* out, int groups, float* stat_partial, int cpad, hipStream_t s);
+                    const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0 = 0,
+                    float s1_scale = BN_FS1, float s2_scale = BN_FS2);
 // small-channel persistent kernel (filter in registers, double-buffered halo, optional fused BN statistics);
 // uses the mode-B fragment image of conv_mfma_plan.
 bool conv_small_ok(const stcd_conv_geom& g, const ConvMfmaPlan& p);
 int conv_small_blocks(const stcd_conv_geom& g, int groups);
 int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_modeB, const float* bias, void* out,
-                      bool out_nchw_f32, int groups, float* stat_partial, int cpad, hipStream_t s);
+                      bool out_nchw_f32, int groups, long long* stat_acc, int cpad, hipStream_t s);
 struct WgradMfmaPlan {
     int WCI = 1, NTW = 1, gx = 1, gy = 1, gz = 1;
     int64_t slab_floats = 0;
@@ -206,28 +238,30 @@ struct PackJob {
 };
 void launch_pack_jobs(const PackJob* jobs_dev, int njobs, int64_t total, const float* params, char* ws, hipStream_t s);
 
-// batch-norm (train): per-(group, channel) sums over a group's pixels.
-// partial: fp32 [groups][nchunk][2][C]; chunking is decided by the launcher, nchunk returned.
+// batch-norm (train): per-(group, channel) sums of y and y^2 over a group's pixels, added into acc (see BN accumulators)
 int bn_stats_chunks(int64_t pixels_per_group, int C);
-void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t pixels_per_group, float* partial,
-                     hipStream_t s);
-// stat: fp32 [groups][4][C] = mean, invstd, scale, shift.  running (mean|var at +C) updated sequentially per group.
-void launch_bn_finalize(const float* partial, int nchunk, int C, int groups, int64_t pixels_per_group,
-                        const float* gamma, const float* beta, float* running_mean, float* running_var, float* stat,
-                        float momentum, float eps, hipStream_t s);
+void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t pixels_per_group, long long* acc, hipStream_t s);
+// eval mode: stat fp32 [groups][4][C] = mean, invstd, scale, shift from the running statistics
 void launch_bn_eval_prepare(int C, int groups, const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float* stat, float eps, hipStream_t s);
 // A = relu(Y*scale+shift) * mask ; optional fused 2x2 max-pool output P (floor).
 // Images [g*npg, (g+1)*npg) belong to group g; A for group g starts at A_base + g*a_group_off (elements).
+// Training (facc != nullptr): every block derives scale / shift of all channels from the accumulators in its prologue;
+// block 0 also writes stat [groups][4][C] (kept for the backward) and updates the running statistics (group 0 then
+// group 1: the shared encoder BatchNorm sees date 0 then date 1).  Eval (facc == nullptr): stat is read.
 struct BnActArgs {
     const void* Y; int ldy;
     void* A; int lda; int64_t a_group_off;
     void* P; int ldp;                       // nullable
-    const float* stat;                      // [groups][4][C]
+    float* stat;                            // [groups][4][C]
     const float* mask;                      // nullable, [groups*npg][C]
     int C, groups, npg, H, W;
     int relu;                               // 0: affine only
     const void* res = nullptr; int ldres = 0; // optional residual added before the ReLU (plain [N,HW,ldres] tensor)
+    const long long* facc = nullptr;        // training: forward accumulators of this layer
+    const float* gamma = nullptr; const float* beta = nullptr;
+    float* running_mean = nullptr; float* running_var = nullptr;
+    float momentum = 0.1f, eps = 1e-5f;
 };
 void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s);
 // skip layers (groups == 2, ReLU, no residual): also writes the bi-temporal fusion F = |a1-a2| (fmode 0) / a2-a1 (1)
@@ -246,20 +280,19 @@ void launch_fuse_bwd(int dt, int mode, const void* A, int lda, int64_t a_goff, c
 void launch_rep_pad(int dt, void* D, int ld, int N, int H, int W, int h0, int w0, int C, hipStream_t s);
 void launch_rep_pad_bwd(int dt, void* dD, int ld, int N, int H, int W, int h0, int w0, int C, hipStream_t s);
 
-// backward of bn_act (train): dz = dA*mask*(z>0); sums of dz and dz*xhat per (group, channel)
+// backward of bn_act (train): dz = dA*mask*(z>0); sums of dz and dz*xhat per (group, channel), added into bacc
 void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, const void* Y, int ldy, const float* stat,
-                          const float* mask, int C, int groups, int npg, int64_t HW, int relu, float* partial,
+                          const float* mask, int C, int groups, int npg, int64_t HW, int relu, long long* bacc,
                           hipStream_t s, const void* res = nullptr, int ldres = 0);
-// coef fp32 [groups][5][C] = (scale, shift, b, mean, c) with dY = scale*dz + b*(y-mean) + c ; dgamma/dbeta summed over groups
-void launch_bn_bwd_finalize(const float* partial, int nchunk, int C, int groups, int64_t pixels_per_group,
-                            const float* stat, float* coef, float* dgamma, float* dbeta, hipStream_t s);
-// dY = scale*(dz - k1 - xhat*k2); dY is a plain tensor and may alias dA when dA is plain too
+// dY = scale*(dz - k1 - xhat*k2) = scale*dz + b*(y-mean) + c with (b, c) derived per block from bacc and stat in the
+// kernel's prologue (no finalize launch); block 0 also writes dgamma / dbeta (summed over the groups).  dY is a plain
+// tensor and may alias dA when dA is plain too.
 // optional: res (residual inside the ReLU gate), dZout (the gated dz is also written: the residual branch's gradient),
 // extra (added to dY: gradient arriving through a residual branch)
 void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
-                         const float* stat, const float* coef, const float* mask, int C, int groups, int npg, int64_t HW,
-                         int relu, hipStream_t s, const void* res = nullptr, int ldres = 0, void* dZout = nullptr,
-                         int lddz = 0, const void* extra = nullptr, int ldex = 0);
+                         const float* stat, const long long* bacc, float* dgamma, float* dbeta, const float* mask, int C, int groups,
+                         int npg, int64_t HW, int relu, hipStream_t s, const void* res = nullptr, int ldres = 0,
+                         void* dZout = nullptr, int lddz = 0, const void* extra = nullptr, int ldex = 0);
 // dst[.., 0:C] (ld ldd) = or += src[.., 0:C] (ld lds): dense concatenation by copy, and its gradient scatter
 void launch_slice(int dt, void* dst, int ldd, const void* src, int lds, int64_t pixels, int C, int accumulate, hipStream_t s);
 // ECAM head of SNUNet (SNUNet.py:46-59,144-149); scratch layouts documented at the kernels (kernels_ew.hip)
@@ -275,11 +308,10 @@ void launch_ecam_backward(int dt, const void* X, int ld, const void* dZ, int ldd
 void launch_pool_bwd(int dt, const void* A, int lda, int64_t a_goff, const void* dP, int ldp, void* dA, int ldda,
                      int64_t da_goff, int groups, int npg, int H, int W, int C, int accumulate, hipStream_t s);
 // encoder skip layer: dA = pool gradient + skip-fusion gradient and the BN-backward partial sums of it, in one pass
-// (mode 0: |a1-a2| skips, 1: a2-a1); partial rows as launch_bn_bwd_reduce, skip_bwd_chunks() rows per date
-int skip_bwd_chunks(int B, int H, int W, int C);
+// (mode 0: |a1-a2| skips, 1: a2-a1); the sums go into bacc as launch_bn_bwd_reduce's
 void launch_skip_bwd(int dt, int mode, const void* A, int lda, int64_t a_goff, const void* Y, int ldy, const void* dD, int ldd,
                      const void* dP, int ldp, void* dA, int ldda, int64_t da_goff, const float* stat, const float* mask, int B,
-                     int H, int W, int C, float* partial, hipStream_t s);
+                     int H, int W, int C, long long* bacc, hipStream_t s);
 // db[c] = sum over pixels of dY[.., c]  (db zeroed by caller; atomics)
 void launch_bias_grad(int dt, const void* dY, int ld, int64_t pixels, int C, float* db, hipStream_t s);
 // masks from a counter hash: mask[i] = (u(seed, i) >= p) / (1-p)

@@ -80,7 +80,10 @@ struct Cbrd {                         // conv -> BN -> ReLU -> Dropout2d [-> poo
     TRef in; int K = 0;               // input view and its channel count
     TRef Y; GRef A; TRef P; TRef dPool; bool pool = false;
     GRef dA; TRef dY; TRef dIn; bool has_dIn = false;
-    int64_t stat = -1, coef = -1;
+    int64_t stat = -1;
+    int64_t facc = -1, bacc = -1;     // BatchNorm accumulators (forward statistics / backward sums), see common.h
+    int64_t dgr_sum_acc = -1; int dgr_sum_c0 = 0, dgr_sum_C = 0;   // the data-gradient launch also sums a channel slice of its
+                                                                    // output (bias gradient of the transposed conv feeding it)
     TRef fuse_dst;                    // skip layers of diff / sub: the decoder's concat slice that receives |a1-a2| / a2-a1
 };
 struct UpConv {
@@ -88,6 +91,7 @@ struct UpConv {
     int N = 0, h = 0, w = 0, Ho = 0, Wo = 0, C = 0;   // input h x w, concat buffer Ho x Wo
     TRef in, out, dOut, dIn;
     ConvOp fwd[4], dgr; WgradOp wg[4];
+    int64_t bias_acc = -1; bool bias_fused = false;
 };
 
 // ---- optional event instrumentation: one hipEvent pair around every launch of a kernel class (bench.py's live
@@ -125,13 +129,16 @@ struct NBlock {                                              // conv_block_neste
     int up = -1;
     TRef Y1, A1, Y2, Out, P, dOut, dP, dZ2, dA1;
     bool pool = false;
-    int64_t stat1 = -1, coef1 = -1, stat2 = -1, coef2 = -1;
+    int64_t stat1 = -1, stat2 = -1;
+    int64_t facc1 = -1, bacc1 = -1, facc2 = -1, bacc2 = -1;
+    int64_t d1_sum_acc = -1; int d1_sum_c0 = 0, d1_sum_C = 0;
     ConvOp f1, f2, d1, d2; WgradOp w1, w2;
 };
 struct SnUp {                                                // up: ConvTranspose2d(C, C, 2, stride=2) (SNUNet.py:29-43)
     int conv = -1, N = 0, h = 0, w = 0, C = 0;
     TRef src, dsrc, out, dOut, tmp;                          // out/dOut: tail slice of the consumer's concat buffers
     ConvOp fwd[4], dgr; WgradOp wg[4];
+    int64_t bias_acc = -1; bool bias_fused = false; int coff = 0;
 };
 
 struct stcd_engine_impl {
@@ -175,8 +182,10 @@ struct stcd_engine_impl {
     TRef X0, G, finalIn, dFinalIn;
     int Hs[5] = {0}, Ws[5] = {0};
     TRef D[4], dD[4], P[4], dP[4];
-    int64_t bn_partial2 = -1;
-    int64_t bn_partial = -1, masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
+    int64_t zero_begin = -1, zero_end = -1;          // everything a step needs zeroed (accumulators, ...): ONE memset per forward
+    int64_t final_bias_acc = -1;
+    std::vector<BiasJob> bias_jobs; int64_t bias_jobs_off = -1;
+    int64_t masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
     int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1, use_act_fuse = 1;
 };
 
@@ -512,7 +521,6 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     e.Hs[0] = H; e.Ws[0] = W;
     for (int s = 0; s < 4; ++s) { e.Hs[s + 1] = e.Hs[s] / 2; e.Ws[s + 1] = e.Ws[s] / 2; }
     Bump ws;
-    int64_t max_partial = 0;
     auto add_drop = [&](const std::string& name, int rows, int C) {
         DropP d; d.name = name; d.rows = rows; d.C = C; d.off = e.drop_floats;
         e.drop_floats += (int64_t)rows * C;
@@ -530,6 +538,22 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         e.P[s] = plain(2 * B, e.Hs[s + 1], e.Ws[s + 1], ENC_C[s]);
         e.dP[s] = plain(2 * B, e.Hs[s + 1], e.Ws[s + 1], ENC_C[s]);
     }
+    // ---- zero arena, directly behind dP[3] (whose date-0 half must read as zero: the reference's T1 bottleneck pool is
+    //      dead work, SiamUnet_diff.py:119 overwritten at :143; the date-1 half is rewritten by upconv4's data gradient):
+    //      BatchNorm accumulators of every layer (forward + backward) and the bias-gradient accumulators
+    auto r256 = [](int64_t b) { return (b + 255) & ~(int64_t)255; };
+    int64_t arena_bytes = 0;
+    for (int s = 0; s < 4; ++s) arena_bytes += 2 * ENC_STAGE_CONVS[s] * r256(bn_acc_bytes(2, ENC_C[s]));
+    for (int k = 0; k < 4; ++k) {
+        for (int j = 0; j < DEC[k].n; ++j)
+            if (DEC[k].cout[j] >= 0) arena_bytes += 2 * r256(bn_acc_bytes(1, DEC[k].cout[j]));
+        arena_bytes += r256(bn_acc_bytes(1, DEC[k].C));
+    }
+    arena_bytes += r256(bn_acc_bytes(1, 8));
+    e.zero_begin = e.dP[3].off;
+    Bump za;
+    za.cur = ws.take(arena_bytes);
+    e.zero_end = za.cur + arena_bytes;
     // ---- encoder
     for (int s = 0; s < 4; ++s) {
         const int C = ENC_C[s], h = e.Hs[s], w = e.Ws[s];
@@ -561,9 +585,6 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             else if (first) { L.has_dIn = true; L.dIn = e.dP[s - 1]; }
             else { L.has_dIn = true; L.dIn.off = e.enc.back().dA.off; L.dIn.ld = C; }
             L.stat = ws.take((int64_t)2 * 4 * C * 4);
-            L.coef = ws.take((int64_t)2 * 5 * C * 4);
-            max_partial = std::max<int64_t>(max_partial, (int64_t)2 * bn_stats_chunks((int64_t)B * h * w, C) * 2 * C);
-            if (last) max_partial = std::max<int64_t>(max_partial, (int64_t)2 * skip_bwd_chunks(B, h, w, C) * 2 * C);
             e.enc.push_back(L);
         }
     }
@@ -600,15 +621,17 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             L.dY = da;
             L.has_dIn = true; L.dIn = dIn;
             L.stat = ws.take((int64_t)4 * C * 4);
-            L.coef = ws.take((int64_t)5 * C * 4);
-            max_partial = std::max<int64_t>(max_partial, (int64_t)bn_stats_chunks((int64_t)B * h * w, C) * 2 * C);
             e.dec.push_back(L);
             in = a; dIn = da; K = C;
             prevA = a; prevdA = da;
         }
     }
     e.G = plain(B, H, W, 8);
-    e.bn_partial = ws.take(max_partial * 4);
+    for (auto& L : e.enc) { L.facc = za.take(bn_acc_bytes(L.groups, e.convs[L.conv].cout)); L.bacc = za.take(bn_acc_bytes(L.groups, e.convs[L.conv].cout)); }
+    for (auto& L : e.dec) { L.facc = za.take(bn_acc_bytes(L.groups, e.convs[L.conv].cout)); L.bacc = za.take(bn_acc_bytes(L.groups, e.convs[L.conv].cout)); }
+    for (auto& U : e.ups) U.bias_acc = za.take(bn_acc_bytes(1, U.C));
+    e.final_bias_acc = za.take(bn_acc_bytes(1, 8));
+    if (za.cur > e.zero_end) { set_error("internal: zero arena overflow"); return 1; }
     e.scratch8 = ws.take(256);
     e.masks = ws.take(e.drop_floats * 4);
     for (auto& c : e.convs) {
@@ -681,18 +704,34 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         bind_wgrad(e.final_wg, geom3(B, H, W, cv.kin_p, e.finalIn.ld, e.label, 8), e.final_conv, 0, cv.cin, e.label, e.finalIn.off, e.G.off);
         bind_conv(e.final_dgr, geom3(B, H, W, cv.dgrad.kpad, 8, cv.cin, e.dFinalIn.ld), e.final_conv, true, 0, e.label, cv.cin);
     }
-    {   // the fused-statistics conv kernels write one partial row per block: make sure the shared slab holds them
-        int64_t need = 0;
-        auto rows = [&](const Cbrd& L) {
-            if (L.fwd.small) need = std::max<int64_t>(need, (int64_t)conv_small_blocks(L.fwd.g, L.groups) * 2 * L.fwd.g.co);
-            if (L.fwd.res.ok) need = std::max<int64_t>(need, (int64_t)L.fwd.res.P * L.groups * 2 * L.fwd.g.co);
-        };
-        for (auto& L : e.enc) rows(L);
-        for (auto& L : e.dec) rows(L);
-        e.bn_partial2 = need > max_partial ? ws.take(need * 4) : -1;
-        if (e.bn_partial2 >= 0) e.bn_partial = e.bn_partial2;
-    }
     e.slab = ws.take(e.slab_floats * 4);
+
+    // ---- bias gradients without a pass of their own: the transposed conv of stage k wrote channels [0, C) of the concat
+    //      buffer, so its bias gradient is the per-channel sum of that slice of d(concat) -- which the data-gradient launch
+    //      of the stage's first conv produces.  When that launch runs on the resident-filter kernel it sums the slice in its
+    //      epilogue (integer accumulators, as the BatchNorm statistics); one k_bias_finish launch per backward converts.
+    e.bias_jobs.clear();
+    {
+        size_t di = 0;
+        for (int k = 0; k < 4; ++k) {
+            UpConv& U = e.ups[k];
+            Cbrd& L = e.dec[di];
+            int nb = 0;
+            for (int j = 0; j < DEC[k].n; ++j) nb += DEC[k].cout[j] >= 0;
+            di += nb;
+            U.bias_fused = false;
+            const bool even = 2 * U.h == U.Ho && 2 * U.w == U.Wo;
+            if (e.dt == BF16 && e.use_mfma && nb > 0 && L.has_dIn && L.dIn.off == U.dOut.off && L.dgr.res.ok && L.dgr.wf >= 0 && even) {
+                U.bias_fused = true;
+                L.dgr_sum_acc = U.bias_acc; L.dgr_sum_c0 = 0; L.dgr_sum_C = U.C;
+                BiasJob jb{}; jb.acc_off = U.bias_acc; jb.out_off = e.convs[U.conv].b_off; jb.C = U.C; jb.valid = U.C; jb.scale = BN_BS;
+                e.bias_jobs.push_back(jb);
+            }
+        }
+        BiasJob jb{}; jb.acc_off = e.final_bias_acc; jb.out_off = e.convs[e.final_conv].b_off; jb.C = 8; jb.valid = e.label; jb.scale = BN_BS;
+        e.bias_jobs.push_back(jb);
+        e.bias_jobs_off = ws.take((int64_t)e.bias_jobs.size() * sizeof(BiasJob) + 16);
+    }
 
     build_pack_jobs(e, ws);
     e.jobs_uploaded_ws = nullptr;
@@ -740,10 +779,15 @@ static void conv_work(const stcd_engine& e, const stcd_conv_geom& g, int kreal, 
 
 static bool mfma_on(const stcd_engine& e) { return e.dt == BF16 && e.use_mfma; }
 
-// stat_groups > 0 asks for fused BN statistics (partials into e.bn_partial); *stat_chunks receives the number of
-// partial rows per group when the kernel delivered them, 0 when the caller must run the separate statistics pass.
+// A request for per-channel sums of the launch's output, fused into the conv's epilogue: BatchNorm statistics of a forward
+// conv (all channels, sum and sum of squares) or the sum of a channel slice of a data gradient (a bias gradient).
+struct StatReq { long long* acc = nullptr; int groups = 1; int c0 = 0; int C = 0; float s1 = BN_FS1, s2 = BN_FS2; };
+// *fused receives 1 when the kernel delivered the sums, 0 when the caller must run the separate pass.
 static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const float* bias, void* out, bool nchw,
-                      int stat_groups = 0, int* stat_chunks = nullptr) {
+                      const StatReq* sr = nullptr, int* stat_chunks = nullptr) {
+    const int stat_groups = (sr && sr->acc) ? sr->groups : 0;
+    long long* stat_acc = sr ? sr->acc : nullptr;
+    const bool bn_form = sr && sr->c0 == 0 && sr->C == op.g.co && sr->s1 == BN_FS1 && sr->s2 == BN_FS2;
     const ConvW& cv = c.e.convs[op.conv];
     const PackSpec& ps = op.dgrad ? cv.dgrad : cv.fwd;
     double fl, by;
@@ -759,18 +803,19 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     ProfScope prof(c, PC_CONV, fl, by, kname);
     if (stat_chunks) *stat_chunks = 0;
     if (mfma_on(c.e) && op.small && op.wf >= 0 && c.e.use_small) {
-        const int groups = stat_groups > 0 ? stat_groups : 1;
-        float* sp = stat_groups > 0 ? c.at<float>(c.e.bn_partial) : nullptr;
+        const int groups = (stat_groups > 0 && bn_form) ? stat_groups : 1;
+        long long* sp = (stat_groups > 0 && bn_form) ? stat_acc : nullptr;
         if (launch_conv_small(op.g, in, c.at(op.wf), bias, out, nchw, groups, sp, op.g.co, c.s) == 0) {
-            if (stat_chunks && stat_groups > 0) *stat_chunks = conv_small_blocks(op.g, groups) / groups;
+            if (stat_chunks && sp) *stat_chunks = 1;
             return;
         }
     }
     if (res_path) {
-        const bool want = stat_groups > 0 && stat_groups == op.res_groups;
-        float* sp = want ? c.at<float>(c.e.bn_partial) : nullptr;
-        if (launch_conv_res(op.g, op.plan, op.res, in, c.at(op.wf), bias, out, op.res_groups, sp, op.g.co, c.s) == 0) {
-            if (stat_chunks && want) *stat_chunks = op.res.P;
+        const bool want = stat_groups > 0 && stat_groups == op.res_groups && stat_acc;
+        long long* sp = want ? stat_acc : nullptr;
+        if (launch_conv_res(op.g, op.plan, op.res, in, c.at(op.wf), bias, out, op.res_groups, sp, want ? sr->C : op.g.co, c.s,
+                            want ? sr->c0 : 0, want ? sr->s1 : BN_FS1, want ? sr->s2 : BN_FS2) == 0) {
+            if (stat_chunks && want) *stat_chunks = 1;
             return;
         }
     }
@@ -841,6 +886,8 @@ static int pack_all_weights(const Ctx& c, bool with_dgrad) {
             for (WgradGroup& G : e.wgroups[k])
                 STCD_HIP(hipMemcpyAsync(c.at(G.table_off), G.jobs.data(), G.jobs.size() * sizeof(WgradJob), hipMemcpyHostToDevice, c.s));
         }
+        if (!e.bias_jobs.empty())
+            STCD_HIP(hipMemcpyAsync(c.at(e.bias_jobs_off), e.bias_jobs.data(), e.bias_jobs.size() * sizeof(BiasJob), hipMemcpyHostToDevice, c.s));
         e.jobs_uploaded_ws = c.ws;
     }
     const int k = with_dgrad ? 1 : 0;
@@ -870,17 +917,16 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     const BnP& bn = e.bns[L.bn];
     const int C = cv.cout;
     int fused_chunks = 0;
-    exec_conv(c, L.fwd, c.at(L.in.off), c.params + cv.b_off, c.at(L.Y.off), false, training ? L.groups : 0, &fused_chunks);
+    StatReq sr; sr.acc = training ? c.at<long long>(L.facc) : nullptr; sr.groups = L.groups; sr.C = C;
+    exec_conv(c, L.fwd, c.at(L.in.off), c.params + cv.b_off, c.at(L.Y.off), false, &sr, &fused_chunks);
     const int64_t ppg = (int64_t)L.npg * L.H * L.W;
     const double act_bytes = (double)L.N * L.H * L.W * C * (double)dsize(e.dt);
     float* stat = c.at<float>(L.stat);
     if (training) {
         if (!fused_chunks) {
             ProfScope ps(c, PC_BN_STATS, 0.0, act_bytes);
-            launch_bn_stats(e.dt, c.at(L.Y.off), L.Y.ld, C, L.groups, ppg, c.at<float>(e.bn_partial), c.s);
+            launch_bn_stats(e.dt, c.at(L.Y.off), L.Y.ld, C, L.groups, ppg, c.at<long long>(L.facc), c.s);
         }
-        launch_bn_finalize(c.at<float>(e.bn_partial), fused_chunks ? fused_chunks : bn_stats_chunks(ppg, C), C, L.groups, ppg, c.params + bn.g_off,
-                           c.params + bn.b_off, bn_running + bn.run_off, bn_running + bn.run_off + C, stat, 0.1f, 1e-5f, c.s);
     } else {
         launch_bn_eval_prepare(C, L.groups, c.params + bn.g_off, c.params + bn.b_off, bn_running + bn.run_off,
                                bn_running + bn.run_off + C, stat, 1e-5f, c.s);
@@ -892,6 +938,10 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     a.stat = stat;
     a.mask = (training && e.drop_p > 0.f) ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
     a.C = C; a.groups = L.groups; a.npg = L.npg; a.H = L.H; a.W = L.W; a.relu = 1;
+    if (training) {     // the activation kernel derives scale / shift from the accumulators itself (no finalize launch)
+        a.facc = c.at<long long>(L.facc); a.gamma = c.params + bn.g_off; a.beta = c.params + bn.b_off;
+        a.running_mean = bn_running + bn.run_off; a.running_var = bn_running + bn.run_off + C;
+    }
     if (L.fuse_dst.off >= 0 && e.use_act_fuse && L.groups == 2) {
         ProfScope ps(c, PC_BN_ACT, 0.0, act_bytes * 2.75, "k_bn_act_pair");
         launch_bn_act_pair(e.dt, a, c.at(L.fuse_dst.off), L.fuse_dst.ld, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.s);
@@ -910,23 +960,26 @@ static void cbrd_backward(const Ctx& c, const Cbrd& L, int skip_chunks = 0) {
     const int64_t HW = (int64_t)L.H * L.W, ppg = (int64_t)L.npg * HW;
     const float* stat = c.at<float>(L.stat);
     const float* mask = e.drop_p > 0.f ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
-    float* partial = c.at<float>(e.bn_partial);
+    long long* bacc = c.at<long long>(L.bacc);
     const double act_bytes = (double)L.N * HW * C * (double)dsize(e.dt);
+    (void)ppg;
     if (!skip_chunks) {
         ProfScope ps(c, PC_BN_BWD_REDUCE, 0.0, 2.0 * act_bytes);
         launch_bn_bwd_reduce(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.Y.off), L.Y.ld, stat, mask, C, L.groups, L.npg, HW, 1,
-                             partial, c.s);
+                             bacc, c.s);
     }
-    launch_bn_bwd_finalize(partial, skip_chunks ? skip_chunks : bn_stats_chunks(ppg, C), C, L.groups, ppg, stat, c.at<float>(L.coef),
-                           c.grads + bn.g_off, c.grads + bn.b_off, c.s);
     {
         ProfScope ps(c, PC_BN_BWD_APPLY, 0.0, 3.0 * act_bytes);
-        launch_bn_bwd_apply(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.dY.off), L.dY.ld, c.at(L.Y.off), L.Y.ld, stat,
-                            c.at<float>(L.coef), mask, C, L.groups, L.npg, HW, 1, c.s);
+        launch_bn_bwd_apply(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.dY.off), L.dY.ld, c.at(L.Y.off), L.Y.ld, stat, bacc,
+                            c.grads + bn.g_off, c.grads + bn.b_off, mask, C, L.groups, L.npg, HW, 1, c.s);
     }
     // weight gradient (the conv bias feeds only a train-mode BN: its gradient is exactly zero and stays zero)
     exec_wgrad(c, L.wg, c.at(L.in.off), c.at(L.dY.off));
-    if (L.has_dIn) exec_conv(c, L.dgr, c.at(L.dY.off), nullptr, c.at(L.dIn.off), false);
+    if (L.has_dIn) {
+        StatReq sr;
+        if (L.dgr_sum_acc >= 0) { sr.acc = c.at<long long>(L.dgr_sum_acc); sr.groups = 1; sr.c0 = L.dgr_sum_c0; sr.C = L.dgr_sum_C; sr.s1 = sr.s2 = BN_BS; }
+        exec_conv(c, L.dgr, c.at(L.dY.off), nullptr, c.at(L.dIn.off), false, L.dgr_sum_acc >= 0 ? &sr : nullptr);
+    }
 }
 
 static void upconv_forward(const Ctx& c, const UpConv& U) {
@@ -942,7 +995,9 @@ static void upconv_backward(const Ctx& c, const UpConv& U) {
     const ConvW& cv = e.convs[U.conv];
     launch_rep_pad_bwd(e.dt, c.at(U.dOut.off), U.dOut.ld, U.N, U.Ho, U.Wo, 2 * U.h, 2 * U.w, U.C, c.s);
     // bias gradient over the un-padded 2h x 2w region == all phases' positions
-    if (2 * U.h == U.Ho && 2 * U.w == U.Wo) {
+    if (U.bias_fused && mfma_on(e)) {
+        // summed by the data-gradient launch that produced dOut; converted by k_bias_finish at the end of the stage
+    } else if (2 * U.h == U.Ho && 2 * U.w == U.Wo) {
         launch_bias_grad(e.dt, c.at(U.dOut.off), U.dOut.ld, (int64_t)U.N * U.Ho * U.Wo, U.C, c.grads + cv.b_off, c.s);
     } else {
         const int64_t T = (int64_t)dsize(e.dt);
@@ -966,6 +1021,7 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
         else launch_dropout_gen(c.at<float>(e.masks), e.drop_floats, seed, e.drop_p, s);
     }
     if (pack_all_weights(c, training != 0)) return 1;
+    if (training) STCD_HIP(hipMemsetAsync(c.at(e.zero_begin), 0, e.zero_end - e.zero_begin, s));   // the step's ONE workspace memset
     launch_in_pack(dt, x1, x2, c.at(e.X0.off), B, e.in_ch, e.H, e.W, s);
     for (auto& L : e.enc) cbrd_forward(c, L, bn_running, training != 0);
     size_t di = 0;
@@ -998,14 +1054,9 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
     if (stage <= 0) {
         STCD_HIP(hipMemsetAsync(grads, 0, e.param_floats * 4, s));
         if (!mfma_on(e)) STCD_HIP(hipMemsetAsync(c.at(e.dwe_begin), 0, e.dwe_end - e.dwe_begin, s));
-        // T1 half of the bottleneck pool is dead work in the reference (SiamUnet_diff.py:119 overwritten at :143)
-        STCD_HIP(hipMemsetAsync(c.at(e.dP[3].off), 0, (int64_t)B * e.Hs[4] * e.Ws[4] * ENC_C[3] * T, s));
-        launch_gout_pack(dt, grad_logits, c.at(e.G.off), B, e.label, e.H, e.W, s);
-        // conv11d: bias, weight and data gradients straight from the packed output gradient
-        const ConvW& cv = e.convs[e.final_conv];
-        STCD_HIP(hipMemsetAsync(c.at(e.scratch8), 0, 32, s));
-        launch_bias_grad(dt, c.at(e.G.off), 8, (int64_t)B * e.H * e.W, 8, c.at<float>(e.scratch8), s);
-        STCD_HIP(hipMemcpyAsync(grads + cv.b_off, c.at(e.scratch8), (size_t)e.label * 4, hipMemcpyDeviceToDevice, s));
+        // (the date-0 half of dP[3] and every accumulator were zeroed by the forward's arena memset)
+        // conv11d: its bias gradient = per-channel sum of d(logits), formed while the gradient is packed
+        launch_gout_pack(dt, grad_logits, c.at(e.G.off), B, e.label, e.H, e.W, s, c.at<long long>(e.final_bias_acc));
         exec_wgrad(c, e.final_wg, c.at(e.finalIn.off), c.at(e.G.off));
         exec_conv(c, e.final_dgr, c.at(e.G.off), nullptr, c.at(e.dFinalIn.off), false);
         int di = (int)e.dec.size() - 1;
@@ -1025,6 +1076,7 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
             }
         }
         reduce_stage(c, 0);
+        launch_bias_finish(c.at<BiasJob>(e.bias_jobs_off), (int)e.bias_jobs.size(), c.ws, c.grads, s);
     }
     if (stage < 0 || stage == 1) {
         for (int li = (int)e.enc.size() - 1; li >= 0; --li) {
@@ -1039,8 +1091,8 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
                 launch_skip_bwd(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(L.A.off), L.A.ld, L.A.goff, c.at(L.Y.off), L.Y.ld,
                                 c.at<char>(e.dD[lvl].off) + C * T, e.dD[lvl].ld, c.at(L.dPool.off), L.dPool.ld, c.at(L.dA.off), L.dA.ld,
                                 L.dA.goff, c.at<float>(L.stat), e.drop_p > 0.f ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr,
-                                L.npg, L.H, L.W, C, c.at<float>(e.bn_partial), s);
-                skip_chunks = skip_bwd_chunks(L.npg, L.H, L.W, C);
+                                L.npg, L.H, L.W, C, c.at<long long>(L.bacc), s);
+                skip_chunks = 1;
             } else if (L.pool) {  // dA_skip += gradient routed back through the 2x2 max-pool
                 const int C = e.convs[L.conv].cout;
                 ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.25 * L.N * L.H * L.W * C * (double)T);
@@ -1124,7 +1176,6 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
     e.drops.clear(); e.drop_floats = 0;
     e.conv_ops.clear(); e.wgrad_ops.clear(); e.slab_floats = 0;
     Bump ws;
-    int64_t max_partial = 0;
     int hs[5], wsz[5];
     hs[0] = H; wsz[0] = W;
     for (int l = 0; l < 4; ++l) { hs[l + 1] = hs[l] / 2; wsz[l + 1] = wsz[l] / 2; }
@@ -1162,11 +1213,17 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
         b.dZ2 = plain(b.N, b.H, b.W, b.C); b.dA1 = plain(b.N, b.H, b.W, b.C);
         b.pool = enc && lvl < 4;
         if (b.pool) { b.P = plain(b.N, b.H / 2, b.W / 2, b.C); b.dP = plain(b.N, b.H / 2, b.W / 2, b.C); }
-        b.stat1 = ws.take((int64_t)b.groups * 4 * b.C * 4); b.coef1 = ws.take((int64_t)b.groups * 5 * b.C * 4);
-        b.stat2 = ws.take((int64_t)b.groups * 4 * b.C * 4); b.coef2 = ws.take((int64_t)b.groups * 5 * b.C * 4);
-        max_partial = std::max<int64_t>(max_partial, (int64_t)b.groups * bn_stats_chunks((int64_t)b.npg * b.H * b.W, b.C) * 2 * b.C);
-        max_partial = std::max<int64_t>(max_partial, (int64_t)1024 * 2 * b.C);   // fused-statistics rows of k_conv_res (<= 1024 blocks)
+        b.stat1 = ws.take((int64_t)b.groups * 4 * b.C * 4);
+        b.stat2 = ws.take((int64_t)b.groups * 4 * b.C * 4);
     }
+    e.zero_begin = ws.cur;
+    for (auto& b : e.sn_blocks) {
+        b.facc1 = ws.take(bn_acc_bytes(b.groups, b.C)); b.facc2 = ws.take(bn_acc_bytes(b.groups, b.C));
+        b.bacc1 = ws.take(bn_acc_bytes(b.groups, b.C)); b.bacc2 = ws.take(bn_acc_bytes(b.groups, b.C));
+    }
+    for (auto& u : e.sn_ups) u.bias_acc = ws.take(bn_acc_bytes(1, u.C));
+    e.final_bias_acc = ws.take(bn_acc_bytes(1, 8));
+    e.zero_end = ws.cur;
     // ---- inputs
     for (auto& b : e.sn_blocks) {
         const int lvl = b.name[4] - '0', j = b.name[6] - '0';
@@ -1209,6 +1266,7 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
         }
         u.out = TRef{b.in.off + (int64_t)coff * T, b.Cin};
         u.dOut = TRef{b.dIn.off + (int64_t)coff * T, b.Cin};
+        u.coff = coff;
         u.tmp = plain(B, u.h, u.w, u.C);
     }
     // ---- forward order (SNUNet.py:119-142)
@@ -1217,7 +1275,6 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
     e.sn_order.clear();
     for (auto n : ORDER) e.sn_order.push_back(sn_block_index(e, n));
 
-    e.bn_partial = ws.take(max_partial * 4);
     e.scratch8 = ws.take(256);
     e.masks = ws.take(256);
     e.sn_pool = ws.take((int64_t)B * 4 * c4 * 4); e.sn_argm = ws.take((int64_t)B * 2 * c4 * 8);
@@ -1295,6 +1352,25 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
         bind_conv(e.sn_final_dgr, geom1(B, H, W, cv.dgrad.kpad, 8, c4, e.sndZ.ld), e.sn_final, true, 0, e.label, c4);
     }
     e.slab = ws.take(e.slab_floats * 4);
+    // bias gradients of the transposed convs: summed by the consumer block's conv1 data gradient (see configure_fcsiam)
+    e.bias_jobs.clear();
+    for (auto& b : e.sn_blocks) {
+        b.d1_sum_acc = -1;
+        if (b.up < 0) continue;
+        SnUp& u = e.sn_ups[b.up];
+        u.bias_fused = false;
+        if (e.dt == BF16 && e.use_mfma && b.dIn.off >= 0 && b.d1.res.ok && b.d1.wf >= 0) {
+            u.bias_fused = true;
+            b.d1_sum_acc = u.bias_acc; b.d1_sum_c0 = u.coff; b.d1_sum_C = u.C;
+            BiasJob jb{}; jb.acc_off = u.bias_acc; jb.out_off = e.convs[u.conv].b_off; jb.C = u.C; jb.valid = u.C; jb.scale = BN_BS;
+            e.bias_jobs.push_back(jb);
+        }
+    }
+    {
+        BiasJob jb{}; jb.acc_off = e.final_bias_acc; jb.out_off = e.convs[e.sn_final].b_off; jb.C = 8; jb.valid = e.label; jb.scale = BN_BS;
+        e.bias_jobs.push_back(jb);
+        e.bias_jobs_off = ws.take((int64_t)e.bias_jobs.size() * sizeof(BiasJob) + 16);
+    }
     build_pack_jobs(e, ws);
     e.jobs_uploaded_ws = nullptr;
     e.ws_bytes = ws.cur;
@@ -1311,27 +1387,28 @@ static void sn_block_forward(const Ctx& c, const NBlock& b, float* bn_running, b
         launch_slice(e.dt, c.at<char>(b.in.off) + (int64_t)coff * T, b.in.ld, c.at(s_.src.off), s_.src.ld, px, s_.C, 0, c.s);
         coff += s_.C;
     }
-    auto bn_stage = [&](const ConvOp& f, const void* in, int conv, int bni, const TRef& Y, int64_t stat_off) {
+    BnActArgs a;
+    auto bn_stage = [&](const ConvOp& f, const void* in, int conv, int bni, const TRef& Y, int64_t stat_off, int64_t facc_off) {
         const ConvW& cv = e.convs[conv];
         const BnP& bn = e.bns[bni];
         int fused = 0;
-        exec_conv(c, f, in, c.params + cv.b_off, c.at(Y.off), false, training ? b.groups : 0, &fused);
+        StatReq sr; sr.acc = training ? c.at<long long>(facc_off) : nullptr; sr.groups = b.groups; sr.C = b.C;
+        exec_conv(c, f, in, c.params + cv.b_off, c.at(Y.off), false, &sr, &fused);
         float* stat = c.at<float>(stat_off);
         if (training) {
             if (!fused) {
                 ProfScope ps(c, PC_BN_STATS, 0.0, act_bytes);
-                launch_bn_stats(e.dt, c.at(Y.off), Y.ld, b.C, b.groups, ppg, c.at<float>(e.bn_partial), c.s);
+                launch_bn_stats(e.dt, c.at(Y.off), Y.ld, b.C, b.groups, ppg, c.at<long long>(facc_off), c.s);
             }
-            launch_bn_finalize(c.at<float>(e.bn_partial), fused ? fused : bn_stats_chunks(ppg, b.C), b.C, b.groups, ppg,
-                               c.params + bn.g_off, c.params + bn.b_off, bn_running + bn.run_off, bn_running + bn.run_off + b.C,
-                               stat, 0.1f, 1e-5f, c.s);
+            a.facc = c.at<long long>(facc_off); a.gamma = c.params + bn.g_off; a.beta = c.params + bn.b_off;
+            a.running_mean = bn_running + bn.run_off; a.running_var = bn_running + bn.run_off + b.C;
         } else {
             launch_bn_eval_prepare(b.C, b.groups, c.params + bn.g_off, c.params + bn.b_off, bn_running + bn.run_off,
                                    bn_running + bn.run_off + b.C, stat, 1e-5f, c.s);
+            a.facc = nullptr;
         }
     };
-    bn_stage(b.f1, c.at(b.in.off), b.c1, b.bn1, b.Y1, b.stat1);
-    BnActArgs a;
+    bn_stage(b.f1, c.at(b.in.off), b.c1, b.bn1, b.Y1, b.stat1, b.facc1);
     a.Y = c.at(b.Y1.off); a.ldy = b.Y1.ld; a.A = c.at(b.A1.off); a.lda = b.A1.ld; a.a_group_off = ppg * b.A1.ld;
     a.P = nullptr; a.ldp = 0; a.stat = c.at<float>(b.stat1); a.mask = nullptr;
     a.C = b.C; a.groups = b.groups; a.npg = b.npg; a.H = b.H; a.W = b.W; a.relu = 1;
@@ -1339,7 +1416,7 @@ static void sn_block_forward(const Ctx& c, const NBlock& b, float* bn_running, b
         ProfScope ps(c, PC_BN_ACT, 0.0, 2.0 * act_bytes);
         launch_bn_act(e.dt, a, c.s);
     }
-    bn_stage(b.f2, c.at(b.A1.off), b.c2, b.bn2, b.Y2, b.stat2);
+    bn_stage(b.f2, c.at(b.A1.off), b.c2, b.bn2, b.Y2, b.stat2, b.facc2);
     a.Y = c.at(b.Y2.off); a.ldy = b.Y2.ld; a.A = c.at(b.Out.off); a.lda = b.Out.ld; a.a_group_off = ppg * b.Out.ld;
     a.P = b.pool ? c.at(b.P.off) : nullptr; a.ldp = b.P.ld; a.stat = c.at<float>(b.stat2);
     a.res = c.at(b.Y1.off); a.ldres = b.Y1.ld;        // identity = conv1's raw output (SNUNet.py:19,25)
@@ -1353,44 +1430,44 @@ static void sn_block_backward(const Ctx& c, const NBlock& b) {
     stcd_engine& e = c.e;
     const int64_t T = (int64_t)dsize(e.dt), HW = (int64_t)b.H * b.W, px = (int64_t)b.N * HW, ppg = (int64_t)b.npg * HW;
     const double act_bytes = (double)px * b.C * (double)T;
-    float* partial = c.at<float>(e.bn_partial);
     const BnP& bn1 = e.bns[b.bn1];
     const BnP& bn2 = e.bns[b.bn2];
+    (void)ppg;
     const int64_t goff_out = ppg * b.dOut.ld, goff_a1 = ppg * b.dA1.ld;
     // out = relu(bn2(y2) + y1): gate on z2 + y1; dZ2 (gated) is also the gradient of the identity branch
     {
         ProfScope ps(c, PC_BN_BWD_REDUCE, 0.0, 3.0 * act_bytes);
         launch_bn_bwd_reduce(e.dt, c.at(b.dOut.off), b.dOut.ld, goff_out, c.at(b.Y2.off), b.Y2.ld, c.at<float>(b.stat2), nullptr, b.C,
-                             b.groups, b.npg, HW, 1, partial, c.s, c.at(b.Y1.off), b.Y1.ld);
+                             b.groups, b.npg, HW, 1, c.at<long long>(b.bacc2), c.s, c.at(b.Y1.off), b.Y1.ld);
     }
-    launch_bn_bwd_finalize(partial, bn_stats_chunks(ppg, b.C), b.C, b.groups, ppg, c.at<float>(b.stat2), c.at<float>(b.coef2),
-                           c.grads + bn2.g_off, c.grads + bn2.b_off, c.s);
     {
         ProfScope ps(c, PC_BN_BWD_APPLY, 0.0, 5.0 * act_bytes);
         launch_bn_bwd_apply(e.dt, c.at(b.dOut.off), b.dOut.ld, goff_out, c.at(b.dOut.off), b.dOut.ld, c.at(b.Y2.off), b.Y2.ld,
-                            c.at<float>(b.stat2), c.at<float>(b.coef2), nullptr, b.C, b.groups, b.npg, HW, 1, c.s, c.at(b.Y1.off), b.Y1.ld,
-                            c.at(b.dZ2.off), b.dZ2.ld, nullptr, 0);
+                            c.at<float>(b.stat2), c.at<long long>(b.bacc2), c.grads + bn2.g_off, c.grads + bn2.b_off, nullptr, b.C,
+                            b.groups, b.npg, HW, 1, c.s, c.at(b.Y1.off), b.Y1.ld, c.at(b.dZ2.off), b.dZ2.ld, nullptr, 0);
     }
     exec_wgrad(c, b.w2, c.at(b.A1.off), c.at(b.dOut.off));                   // dOut now holds dY2
     exec_conv(c, b.d2, c.at(b.dOut.off), nullptr, c.at(b.dA1.off), false);
     {
         ProfScope ps(c, PC_BN_BWD_REDUCE, 0.0, 2.0 * act_bytes);
         launch_bn_bwd_reduce(e.dt, c.at(b.dA1.off), b.dA1.ld, goff_a1, c.at(b.Y1.off), b.Y1.ld, c.at<float>(b.stat1), nullptr, b.C,
-                             b.groups, b.npg, HW, 1, partial, c.s);
+                             b.groups, b.npg, HW, 1, c.at<long long>(b.bacc1), c.s);
     }
-    launch_bn_bwd_finalize(partial, bn_stats_chunks(ppg, b.C), b.C, b.groups, ppg, c.at<float>(b.stat1), c.at<float>(b.coef1),
-                           c.grads + bn1.g_off, c.grads + bn1.b_off, c.s);
     {
         ProfScope ps(c, PC_BN_BWD_APPLY, 0.0, 4.0 * act_bytes);
         launch_bn_bwd_apply(e.dt, c.at(b.dA1.off), b.dA1.ld, goff_a1, c.at(b.dA1.off), b.dA1.ld, c.at(b.Y1.off), b.Y1.ld,
-                            c.at<float>(b.stat1), c.at<float>(b.coef1), nullptr, b.C, b.groups, b.npg, HW, 1, c.s, nullptr, 0, nullptr, 0,
-                            c.at(b.dZ2.off), b.dZ2.ld);
+                            c.at<float>(b.stat1), c.at<long long>(b.bacc1), c.grads + bn1.g_off, c.grads + bn1.b_off, nullptr, b.C,
+                            b.groups, b.npg, HW, 1, c.s, nullptr, 0, nullptr, 0, c.at(b.dZ2.off), b.dZ2.ld);
     }
     // conv1's bias reaches the loss only through the identity branch (its BN path has zero gradient): db1 = sum dZ2,
     // and dZ2 is exactly the gated gradient whose per-channel sum bn2's backward already formed as d(beta2)
     (void)hipMemcpyAsync(c.grads + e.convs[b.c1].b_off, c.grads + bn2.b_off, (size_t)b.C * 4, hipMemcpyDeviceToDevice, c.s);
     exec_wgrad(c, b.w1, c.at(b.in.off), c.at(b.dA1.off));                   // dA1 now holds dY1
-    if (b.dIn.off >= 0) exec_conv(c, b.d1, c.at(b.dA1.off), nullptr, c.at(b.dIn.off), false);
+    if (b.dIn.off >= 0) {
+        StatReq sr;
+        if (b.d1_sum_acc >= 0) { sr.acc = c.at<long long>(b.d1_sum_acc); sr.groups = 1; sr.c0 = b.d1_sum_c0; sr.C = b.d1_sum_C; sr.s1 = sr.s2 = BN_BS; }
+        exec_conv(c, b.d1, c.at(b.dA1.off), nullptr, c.at(b.dIn.off), false, b.d1_sum_acc >= 0 ? &sr : nullptr);
+    }
 }
 
 static void sn_up_forward(const Ctx& c, const SnUp& u) {
@@ -1402,7 +1479,8 @@ static void sn_up_backward(const Ctx& c, const SnUp& u) {
     stcd_engine& e = c.e;
     const ConvW& cv = e.convs[u.conv];
     const int64_t T = (int64_t)dsize(e.dt);
-    launch_bias_grad(e.dt, c.at(u.dOut.off), u.dOut.ld, (int64_t)u.N * 4 * u.h * u.w, u.C, c.grads + cv.b_off, c.s);
+    if (!(u.bias_fused && mfma_on(e)))
+        launch_bias_grad(e.dt, c.at(u.dOut.off), u.dOut.ld, (int64_t)u.N * 4 * u.h * u.w, u.C, c.grads + cv.b_off, c.s);
     for (int ph = 0; ph < 4; ++ph) exec_wgrad(c, u.wg[ph], c.at(u.src.off), c.at(u.dOut.off));
     exec_conv(c, u.dgr, c.at(u.dOut.off), nullptr, c.at(u.tmp.off), false);
     ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.0 * u.N * u.h * u.w * u.C * (double)T);
@@ -1413,6 +1491,7 @@ static int forward_snunet(stcd_engine& e, const float* x1, const float* x2, cons
                           float* logits, void* workspace, hipStream_t s) {
     Ctx c{e, (char*)workspace, params, nullptr, s};
     if (pack_all_weights(c, training != 0)) return 1;
+    if (training) STCD_HIP(hipMemsetAsync(c.at(e.zero_begin), 0, e.zero_end - e.zero_begin, s));
     launch_in_pack(e.dt, x1, x2, c.at(e.X0.off), e.B, e.in_ch, e.H, e.W, s);
     for (int bi : e.sn_order) {
         const NBlock& b = e.sn_blocks[bi];
@@ -1440,11 +1519,7 @@ static int backward_snunet(stcd_engine& e, const float* grad_logits, const float
     STCD_HIP(hipMemsetAsync(c.at(e.sn_dout_begin), 0, e.sn_dout_end - e.sn_dout_begin, s));
     for (auto& b : e.sn_blocks)          // pooled gradients of the A half of conv3_0 never get written (x4_0A does not exist)
         if (b.pool && b.name == "conv3_0") STCD_HIP(hipMemsetAsync(c.at(b.dP.off), 0, (int64_t)B * (b.H / 2) * (b.W / 2) * b.C * T, s));
-    launch_gout_pack(dt, grad_logits, c.at(e.G.off), B, e.label, e.H, e.W, s);
-    const ConvW& cf = e.convs[e.sn_final];
-    STCD_HIP(hipMemsetAsync(c.at(e.scratch8), 0, 32, s));
-    launch_bias_grad(dt, c.at(e.G.off), 8, (int64_t)B * e.H * e.W, 8, c.at<float>(e.scratch8), s);
-    STCD_HIP(hipMemcpyAsync(grads + cf.b_off, c.at(e.scratch8), (size_t)e.label * 4, hipMemcpyDeviceToDevice, s));
+    launch_gout_pack(dt, grad_logits, c.at(e.G.off), B, e.label, e.H, e.W, s, c.at<long long>(e.final_bias_acc));
     exec_wgrad(c, e.sn_final_wg, c.at(e.snZ.off), c.at(e.G.off));
     exec_conv(c, e.sn_final_dgr, c.at(e.G.off), nullptr, c.at(e.sndZ.off), false);
     launch_ecam_backward(dt, c.at(e.snE.off), e.snE.ld, c.at(e.sndZ.off), e.sndZ.ld, c.at(e.sndE.off), e.sndE.ld, B, (int64_t)e.H * e.W, c4,
@@ -1472,6 +1547,7 @@ static int backward_snunet(stcd_engine& e, const float* grad_logits, const float
         if (b.up >= 0) sn_up_backward(c, e.sn_ups[b.up]);
     }
     reduce_stage(c, 0);
+    launch_bias_finish(c.at<BiasJob>(e.bias_jobs_off), (int)e.bias_jobs.size(), c.ws, c.grads, s);
     STCD_HIP(hipGetLastError());
     return 0;
 }

@@ -860,7 +860,7 @@ struct ConvSmallArgs {
     int dymin, dxmin, HH, HWp;
     int tiles_x, tiles_y, ntiles, groups;
     int halo_bytes;
-    float* stat_partial;   // nullable: [groups][blocks_per_group][2][cpad]
+    long long* stat_acc;   // nullable: BatchNorm forward accumulators int64 [BN_REP][groups][2][cpad] (common.h)
     int cpad;
 };
 
@@ -1037,7 +1037,7 @@ k_conv_small(const ConvSmallArgs a) {
     }
 
     // ---- fused BN statistics: lanes sharing q hold the same 4 channels -> xor-reduce over r, then over the 4 waves
-    if (a.stat_partial) {
+    if (a.stat_acc) {
         float* red = reinterpret_cast<float*>(smem);     // [4 waves][NT][4 q][4 j][2]
 #pragma unroll
         for (int t2 = 0; t2 < NT; ++t2)
@@ -1052,14 +1052,13 @@ k_conv_small(const ConvSmallArgs a) {
                 }
             }
         __syncthreads();
-        float* outp = a.stat_partial + ((int64_t)grp * bpg + bl) * 2 * a.cpad;
         for (int i = tid; i < NT * 16 * 2; i += 256) {
             const int which = i / (NT * 16), c = i - which * NT * 16;
             const int t2 = c >> 4, qq = (c >> 2) & 3, j = c & 3;
             float acc_ = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) acc_ += red[(((w * NT + t2) * 4 + qq) * 4 + j) * 2 + which];
-            if (c < a.cpad) outp[which * a.cpad + c] = acc_;
+            if (c < a.cpad) bn_acc_add(a.stat_acc, bl, a.groups, a.cpad, grp, which, c, acc_, which ? BN_FS2 : BN_FS1);
         }
     }
 }
@@ -1087,7 +1086,7 @@ int conv_small_blocks(const stcd_conv_geom& g, int groups) {
 }
 
 int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_modeB, const float* bias, void* out,
-                      bool out_nchw, int groups, float* stat_partial, int cpad, hipStream_t s) {
+                      bool out_nchw, int groups, long long* stat_acc, int cpad, hipStream_t s) {
     ConvSmallArgs a;
     a.g = g;
     a.in = (const bf16*)in; a.wf = (const bf16*)wf_modeB; a.bias = bias; a.out = out; a.out_nchw = out_nchw ? 1 : 0;
@@ -1104,7 +1103,7 @@ int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_mo
     a.ntiles = g.n * a.tiles_x * a.tiles_y;
     a.groups = groups;
     a.halo_bytes = (a.HH * a.HWp * g.ci * 2 + 255) & ~255;
-    a.stat_partial = stat_partial;
+    a.stat_acc = stat_acc;
     a.cpad = cpad;
     if (g.n % groups != 0) return 1;
     const int blocks = conv_small_blocks(g, groups);
@@ -1137,8 +1136,10 @@ struct ConvResArgs {
     int nslices, P, groups;
     int tiles_x, tiles_y, ntiles;
     int filt_bytes;        // LDS bytes of the filter slice
-    float* stat_partial;   // nullable: [groups][P][2][cpad]
-    int cpad;
+    long long* stat_acc;   // nullable: per-channel sum accumulators int64 [BN_REP][groups][2][cpad] (common.h)
+    int cpad;              // channels [stat_c0, stat_c0 + cpad) of the output are summed (BatchNorm statistics of a forward
+    int stat_c0;           // conv: all of them; bias gradient of the transposed conv that produced a concat slice: that slice)
+    float s1_scale, s2_scale;
     unsigned in_bytes;     // size of the input tensor (buffer-load range check)
     int8_t tix[3][3];      // tap index of every (row shift, column shift)
 };
@@ -1318,7 +1319,7 @@ k_conv_res(const ConvResArgs a) {
             const int mx = cur.x * 16 + r;
             bf16* const obase = a.out + (((int64_t)cur.n * a.g.ho + cur.y * 16 + wid * 4) * a.g.wo + mx) * a.g.ldo + slice * NT * 16 + 4 * q;
             const int64_t orstep = (int64_t)a.g.wo * a.g.ldo;
-            const bool want_stats = a.stat_partial != nullptr;          // data-gradient launches carry no statistics
+            const bool want_stats = a.stat_acc != nullptr;              // data-gradient launches carry no statistics
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int my = cur.y * 16 + wid * 4 + m;
@@ -1361,8 +1362,8 @@ k_conv_res(const ConvResArgs a) {
 #undef RES_FETCH
 #undef RES_STASH
 
-    // ---- fused BN statistics: one partial row per block; slices fill disjoint channel ranges of row (grp, bl)
-    if (a.stat_partial) {
+    // ---- fused BN statistics: one atomic add per (channel, sum) and block; slices cover disjoint channel ranges
+    if (a.stat_acc) {
         float* red = reinterpret_cast<float*>(smem);     // [4 waves][NT][4 q][4 j][2]  (the filter is dead by now)
         __syncthreads();
 #pragma unroll
@@ -1378,15 +1379,14 @@ k_conv_res(const ConvResArgs a) {
                 }
             }
         __syncthreads();
-        float* outp = a.stat_partial + ((int64_t)grp * P + bl) * 2 * a.cpad;
         for (int i = tid; i < NT * 16 * 2; i += 256) {
             const int which = i / (NT * 16), c = i - which * NT * 16;
             const int t2 = c >> 4, qq = (c >> 2) & 3, j = c & 3;
             float acc_ = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) acc_ += red[(((w * NT + t2) * 4 + qq) * 4 + j) * 2 + which];
-            const int chn = slice * NT * 16 + c;
-            if (chn < a.cpad) outp[which * a.cpad + chn] = acc_;
+            const int chn = slice * NT * 16 + c - a.stat_c0;
+            if (chn >= 0 && chn < a.cpad) bn_acc_add(a.stat_acc, bl, a.groups, a.cpad, grp, which, chn, acc_, which ? a.s2_scale : a.s1_scale);
         }
     }
 }
@@ -1450,7 +1450,8 @@ ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int gr
 }
 
 int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvResPlan& rp, const void* in, const void* wf,
-                    const float* bias, void* out, int groups, float* stat_partial, int cpad, hipStream_t s) {
+                    const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0, float s1_scale,
+                    float s2_scale) {
     if (!rp.ok) return 1;
     ConvResArgs a;
     a.g = g;
@@ -1459,7 +1460,7 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
     a.nslices = rp.nslices; a.P = rp.P; a.groups = groups;
     a.tiles_x = (g.wm + 15) / 16; a.tiles_y = (g.hm + 15) / 16; a.ntiles = g.n * a.tiles_x * a.tiles_y;
     a.filt_bytes = rp.filt_bytes;
-    a.stat_partial = stat_partial; a.cpad = cpad;
+    a.stat_acc = stat_acc; a.cpad = cpad; a.stat_c0 = stat_c0; a.s1_scale = s1_scale; a.s2_scale = s2_scale;
     a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
     for (int t = 0; t < 9; ++t) a.tix[g.dy[t] + 1][g.dx[t] + 1] = (int8_t)t;
 #define LAUNCH_RES(N_, W_)                                                                                        \

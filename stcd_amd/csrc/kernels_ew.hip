@@ -19,6 +19,9 @@ __device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
 
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// grid of the kernels that build a per-block BatchNorm table in their prologue: capped at ~2 resident rounds of the
+// chip so the table (one dependent round trip + a few double operations per channel) is built <= 2048 times per launch
+static inline int ew_grid(int64_t total_threads) { return (int)std::min<int64_t>(cdiv(total_threads, 256), 2048); }
 
 // grouped view: element (g, n_in_group, pix, c) at p + g*goff + (n_in_group*HW + pix)*ld + c
 struct GV {
@@ -48,21 +51,46 @@ void launch_in_pack(int dt, const float* x1, const float* x2, void* X, int B, in
 }
 
 template <typename T>
-__global__ void k_gout_pack(const float* __restrict__ g, T* __restrict__ G, int B, int L, int64_t HW) {
+__global__ void __launch_bounds__(256)
+k_gout_pack(const float* __restrict__ g, T* __restrict__ G, int B, int L, int64_t HW, long long* __restrict__ bias_acc) {
+    __shared__ float red[4][8];
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)B * HW) return;
-    int n = (int)(i / HW);
-    int64_t p = i - (int64_t)n * HW;
     float v[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) v[c] = c < L ? g[((int64_t)n * L + c) * HW + p] : 0.f;
-    store8<T>(G + i * 8, v);
+    for (int c = 0; c < 8; ++c) v[c] = 0.f;
+    if (i < (int64_t)B * HW) {
+        int n = (int)(i / HW);
+        int64_t p = i - (int64_t)n * HW;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = c < L ? g[((int64_t)n * L + c) * HW + p] : 0.f;
+        store8<T>(G + i * 8, v);
+    }
+    if (bias_acc) {      // the last conv's bias gradient = sum over pixels of d(logits): summed here, from the fp32 values
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float t_ = wave_sum(v[c]);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = t_;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < L)
+            bn_acc_add(bias_acc, blockIdx.x, 1, 8, 0, 0, threadIdx.x,
+                       (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]), BN_BS);
+    }
 }
 
-void launch_gout_pack(int dt, const float* g, void* G, int B, int L, int H, int W, hipStream_t s) {
+void launch_gout_pack(int dt, const float* g, void* G, int B, int L, int H, int W, hipStream_t s, long long* bias_acc) {
     int64_t HW = (int64_t)H * W, n = (int64_t)B * HW;
-    if (dt == BF16) k_gout_pack<bf16><<<cdiv(n, 256), 256, 0, s>>>(g, (bf16*)G, B, L, HW);
-    else k_gout_pack<float><<<cdiv(n, 256), 256, 0, s>>>(g, (float*)G, B, L, HW);
+    if (dt == BF16) k_gout_pack<bf16><<<cdiv(n, 256), 256, 0, s>>>(g, (bf16*)G, B, L, HW, bias_acc);
+    else k_gout_pack<float><<<cdiv(n, 256), 256, 0, s>>>(g, (float*)G, B, L, HW, bias_acc);
+}
+
+__global__ void k_bias_finish(const BiasJob* __restrict__ jobs, const char* __restrict__ ws, float* __restrict__ grads) {
+    const BiasJob& jb = jobs[blockIdx.x];
+    const long long* acc = reinterpret_cast<const long long*>(ws + jb.acc_off);
+    for (int c = threadIdx.x; c < jb.valid; c += blockDim.x) grads[jb.out_off + c] = (float)bn_acc_get(acc, 1, jb.C, 0, 0, c, jb.scale);
+}
+void launch_bias_finish(const BiasJob* jobs_dev, int njobs, const char* ws, float* grads, hipStream_t s) {
+    if (njobs > 0) k_bias_finish<<<njobs, 128, 0, s>>>(jobs_dev, ws, grads);
 }
 
 // ------------------------------------------------------------------ weight pack / unpack (tiny)
@@ -115,7 +143,7 @@ template <typename T, int MODE>
 __global__ void __launch_bounds__(256)
 k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, const float* __restrict__ stat,
             const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg, int64_t HW, int relu,
-            int64_t ppg, int nchunk, float* __restrict__ partial) {
+            int64_t ppg, int nchunk, long long* __restrict__ acc) {
     __shared__ float red[256 * 16];
     const int g = blockIdx.y, chunk = blockIdx.x;
     const int cb = C >> 3;                   // channel blocks (power of two, <= 256)
@@ -181,91 +209,87 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s1[j]; red[threadIdx.x * 16 + 8 + j] = s2[j]; }
     __syncthreads();
-    float* out = partial + ((int64_t)g * nchunk + chunk) * 2 * C;
     for (int o = threadIdx.x; o < 2 * C; o += 256) {
         int which = o / C, c = o - which * C;
-        float acc = 0.f;
-        for (int l = 0; l < lanes; ++l) acc += red[(l * cb + (c >> 3)) * 16 + which * 8 + (c & 7)];
-        out[o] = acc;
+        float a_ = 0.f;
+        for (int l = 0; l < lanes; ++l) a_ += red[(l * cb + (c >> 3)) * 16 + which * 8 + (c & 7)];
+        bn_acc_add(acc, chunk, gridDim.y, C, g, which, c, a_, MODE == 0 ? (which ? BN_FS2 : BN_FS1) : BN_BS);
     }
 }
 
-void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t ppg, float* partial, hipStream_t s) {
+void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t ppg, long long* acc, hipStream_t s) {
     int nchunk = bn_stats_chunks(ppg, C);
     dim3 grid(nchunk, groups);
     GV z{0, 0};
     if (dt == BF16)
-        k_bn_reduce<bf16, 0><<<grid, 256, 0, s>>>((const bf16*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, partial);
+        k_bn_reduce<bf16, 0><<<grid, 256, 0, s>>>((const bf16*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, acc);
     else
-        k_bn_reduce<float, 0><<<grid, 256, 0, s>>>((const float*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, partial);
+        k_bn_reduce<float, 0><<<grid, 256, 0, s>>>((const float*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, acc);
 }
 
 
-// sum the per-chunk partials of 16 channels with 64 threads each (1024-thread block); 4 independent row loads in
-// flight per thread (the fused-statistics convs deliver up to ~1000 rows per group).  Result in part 0's registers.
-constexpr int FIN_PARTS = 64, FIN_THREADS = 16 * FIN_PARTS, FIN_U = 4;
-__device__ __forceinline__ void chunk_sums(const float* __restrict__ partial, int nchunk, int C, int g, int c, int part,
-                                           double* sm, double* s1, double* s2) {
-    double a1 = 0.0, a2 = 0.0;
-    if (c < C) {
-        const float* base = partial + (int64_t)g * nchunk * 2 * C + c;
-        for (int k = part; k < nchunk; k += FIN_U * FIN_PARTS) {
-            float v1[FIN_U], v2[FIN_U];
-#pragma unroll
-            for (int u = 0; u < FIN_U; ++u) {
-                const int kk = k + u * FIN_PARTS;
-                const bool ok = kk < nchunk;
-                const float* p = base + (int64_t)(ok ? kk : part) * 2 * C;
-                const float x = p[0], y = p[C];
-                v1[u] = ok ? x : 0.f; v2[u] = ok ? y : 0.f;
+// ---- consumer-side "finalize": every block of a kernel that APPLIES a BatchNorm derives the per-channel constants of all
+//      its channels from the integer accumulators (2*C*BN_REP loads per block) into an LDS table; block 0 also publishes
+//      them (stat, running statistics / dgamma, dbeta) for later kernels.  Same arithmetic as torch: biased variance for
+//      the normalisation, unbiased for running_var, momentum 0.1, double precision for the moments.
+// tab: [groups][2][C] = scale, shift.  Thread c handles channel c for all groups IN ORDER (the shared encoder BatchNorm
+// sees date 0 then date 1: /root/reference/models/SiamUnet_diff.py:99,123).
+__device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __restrict__ facc, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                             float* __restrict__ stat, int C, int groups, int64_t ppg, float momentum, float eps,
+                                             bool publish) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        if (facc) {
+            const float gam = gamma[c], bet = beta[c];
+            float rm = (publish && rmean) ? rmean[c] : 0.f, rv = (publish && rvar) ? rvar[c] : 0.f;
+            for (int g = 0; g < groups; ++g) {
+                const double s1 = bn_acc_get(facc, groups, C, g, 0, c, BN_FS1), s2 = bn_acc_get(facc, groups, C, g, 1, c, BN_FS2);
+                const double mean = s1 / (double)ppg;
+                double var = s2 / (double)ppg - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const double invstd = 1.0 / sqrt(var + (double)eps);
+                const float sc = (float)(gam * invstd), sh = (float)(bet - mean * gam * invstd);
+                tab[(g * 2 + 0) * C + c] = sc;
+                tab[(g * 2 + 1) * C + c] = sh;
+                if (publish) {
+                    float* st = stat + (int64_t)g * 4 * C;
+                    st[c] = (float)mean; st[C + c] = (float)invstd; st[2 * C + c] = sc; st[3 * C + c] = sh;
+                    const double unb = ppg > 1 ? var * ((double)ppg / (double)(ppg - 1)) : var;
+                    rm = (float)((1.0 - momentum) * rm + momentum * mean);
+                    rv = (float)((1.0 - momentum) * rv + momentum * unb);
+                }
             }
-#pragma unroll
-            for (int u = 0; u < FIN_U; ++u) { a1 += v1[u]; a2 += v2[u]; }
+            if (publish && rmean) rmean[c] = rm;
+            if (publish && rvar) rvar[c] = rv;
+        } else {
+            for (int g = 0; g < groups; ++g) {
+                tab[(g * 2 + 0) * C + c] = stat[(int64_t)g * 4 * C + 2 * C + c];
+                tab[(g * 2 + 1) * C + c] = stat[(int64_t)g * 4 * C + 3 * C + c];
+            }
         }
     }
-    __syncthreads();
-    sm[threadIdx.x] = a1;
-    sm[FIN_THREADS + threadIdx.x] = a2;
-    __syncthreads();
-    a1 = 0.0; a2 = 0.0;
-    if (part == 0)
-        for (int q = 0; q < FIN_PARTS; ++q) { a1 += sm[q * 16 + (threadIdx.x & 15)]; a2 += sm[FIN_THREADS + q * 16 + (threadIdx.x & 15)]; }
-    *s1 = a1; *s2 = a2;
 }
-
-__global__ void __launch_bounds__(FIN_THREADS)
-k_bn_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg,
-              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
-              float* __restrict__ rvar, float* __restrict__ stat, float momentum, float eps) {
-    __shared__ double sm[2 * FIN_THREADS];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
-    const bool owner = part == 0 && c < C;
-    float rm = (owner && rmean) ? rmean[c] : 0.f, rv = (owner && rvar) ? rvar[c] : 0.f;
-    const float gam = owner ? gamma[c] : 0.f, bet = owner ? beta[c] : 0.f;   // in flight together with the partial rows
-    for (int g = 0; g < groups; ++g) {   // sequential: the shared encoder BN sees T1 then T2 (SiamUnet_diff.py:99,123)
-        double s1, s2;
-        chunk_sums(partial, nchunk, C, g, c, part, sm, &s1, &s2);
-        if (!owner) continue;
-        double mean = s1 / ppg, var = s2 / ppg - mean * mean;
-        if (var < 0.0) var = 0.0;
-        double invstd = 1.0 / sqrt(var + (double)eps);
-        float sc = (float)(gam * invstd);
-        float* st = stat + (int64_t)g * 4 * C;
-        st[c] = (float)mean;
-        st[C + c] = (float)invstd;
-        st[2 * C + c] = sc;
-        st[3 * C + c] = (float)(bet - mean * gam * invstd);
-        double unb = ppg > 1 ? var * ((double)ppg / (double)(ppg - 1)) : var;
-        rm = (float)((1.0 - momentum) * rm + momentum * mean);
-        rv = (float)((1.0 - momentum) * rv + momentum * unb);
+// tab: [groups][5][C] = (scale, shift, b, mean, c) of dY = scale*dz + b*(y - mean) + c  (see k_bn_bwd_apply)
+__device__ __forceinline__ void bn_bwd_table(float* tab, const long long* __restrict__ bacc, const float* __restrict__ stat,
+                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int groups, int64_t ppg,
+                                             bool publish) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double tg = 0.0, tb = 0.0;
+        for (int g = 0; g < groups; ++g) {
+            const double s1 = bn_acc_get(bacc, groups, C, g, 0, c, BN_BS), s2 = bn_acc_get(bacc, groups, C, g, 1, c, BN_BS);
+            const float* st = stat + (int64_t)g * 4 * C;
+            const double mean = st[c], invstd = st[C + c], scale = st[2 * C + c];
+            const double k1 = s1 / (double)ppg, k2 = s2 / (double)ppg;
+            float* bw = tab + (int64_t)g * 5 * C;
+            bw[c] = (float)scale;
+            bw[C + c] = st[3 * C + c];
+            bw[2 * C + c] = (float)(-scale * k2 * invstd);
+            bw[3 * C + c] = (float)mean;
+            bw[4 * C + c] = (float)(-scale * k1);
+            tb += s1; tg += s2;
+        }
+        if (publish && dgamma) { dgamma[c] = (float)tg; dbeta[c] = (float)tb; }
     }
-    if (owner && rmean) rmean[c] = rm;
-    if (owner && rvar) rvar[c] = rv;
-}
-void launch_bn_finalize(const float* partial, int nchunk, int C, int groups, int64_t ppg, const float* gamma,
-                        const float* beta, float* rmean, float* rvar, float* stat, float momentum, float eps,
-                        hipStream_t s) {
-    k_bn_finalize<<<cdiv(C, 16), FIN_THREADS, 0, s>>>(partial, nchunk, C, groups, ppg, gamma, beta, rmean, rvar, stat, momentum, eps);
 }
 
 __global__ void k_bn_eval_prepare(int C, int groups, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -293,10 +317,14 @@ void launch_bn_eval_prepare(int C, int groups, const float* gamma, const float* 
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restrict__ P, int ldp,
-         const float* __restrict__ stat, const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg,
-         int H, int W, int relu, int64_t total) {
-    const int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i64 >= total) return;
+         float* __restrict__ stat, const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg,
+         int H, int W, int relu, int64_t total, const long long* __restrict__ facc, const float* __restrict__ gamma,
+         const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, int groups, float momentum, float eps) {
+    extern __shared__ float bn_tab[];           // [groups][2][C]
+    bn_fwd_table(bn_tab, facc, gamma, beta, rmean, rvar, stat, C, groups, (int64_t)npg * H * W, momentum, eps, blockIdx.x == 0);
+    __syncthreads();
+    // grid-stride walk: the table above is built once per block, the grid is capped (see the launcher)
+    for (int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i64 < total; i64 += (int64_t)gridDim.x * blockDim.x) {
     const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
     // 32-bit index arithmetic (the launcher guarantees total < 2^31)
     uint32_t r = (uint32_t)i64;
@@ -305,13 +333,10 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
     const int yc = (int)(r % (uint32_t)Hc);
     const int n = (int)(r / (uint32_t)Hc);
     const int g = n / npg, nig = n - g * npg;
-    const float* st = stat + (int64_t)g * 4 * C + c0;
     float sc[8], sh[8], mk[8];
     {
-        const float4 a0 = *reinterpret_cast<const float4*>(st + 2 * C), a1 = *reinterpret_cast<const float4*>(st + 2 * C + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(st + 3 * C), b1 = *reinterpret_cast<const float4*>(st + 3 * C + 4);
-        sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
-        sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = bn_tab[(g * 2 + 0) * C + c0 + j]; sh[j] = bn_tab[(g * 2 + 1) * C + c0 + j]; }
         if (mask) {
             const float4* mp = reinterpret_cast<const float4*>(mask + (int64_t)n * C + c0);
             const float4 m0 = mp[0], m1 = mp[1];
@@ -350,6 +375,7 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
         }
     }
     if (P && yc < Hp && xc < Wp) store8<T>(P + (((int64_t)n * Hp + yc) * Wp + xc) * ldp + c0, best);
+    }
 }
 
 // Skip layers (last conv of an encoder level): both dates of a pair in one thread, so the bi-temporal skip fusion
@@ -358,9 +384,13 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_bn_act_pair(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restrict__ P, int ldp, T* __restrict__ F, int ldf,
-              int fmode, const float* __restrict__ stat, const float* __restrict__ mask, int C, int npg, int H, int W, int64_t total) {
-    const int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i64 >= total) return;
+              int fmode, float* __restrict__ stat, const float* __restrict__ mask, int C, int npg, int H, int W, int64_t total,
+              const long long* __restrict__ facc, const float* __restrict__ gamma, const float* __restrict__ beta,
+              float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps) {
+    extern __shared__ float bn_tab[];           // [2][2][C]
+    bn_fwd_table(bn_tab, facc, gamma, beta, rmean, rvar, stat, C, 2, (int64_t)npg * H * W, momentum, eps, blockIdx.x == 0);
+    __syncthreads();
+    for (int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i64 < total; i64 += (int64_t)gridDim.x * blockDim.x) {
     const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
     uint32_t r = (uint32_t)i64;
     const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
@@ -378,9 +408,9 @@ k_bn_act_pair(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __r
     float a0[4][8];                       // date 0 activations, kept for the fusion
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const float* st = stat + (int64_t)g * 4 * C + c0;
         float sc[8], sh[8], mk[8];
-        ld8f(st + 2 * C, sc); ld8f(st + 3 * C, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = bn_tab[(g * 2 + 0) * C + c0 + j]; sh[j] = bn_tab[(g * 2 + 1) * C + c0 + j]; }
         if (mask) ld8f(mask + ((int64_t)g * npg + nb) * C + c0, mk);
         float v[4][8];
 #pragma unroll
@@ -407,27 +437,36 @@ k_bn_act_pair(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __r
         }
         if (P && yc < Hp && xc < Wp) store8<T>(P + ((((int64_t)g * npg + nb) * Hp + yc) * Wp + xc) * ldp + c0, best);
     }
+    }
 }
 void launch_bn_act_pair(int dt, const BnActArgs& a, void* F, int ldf, int fmode, hipStream_t s) {
     const int64_t total = (int64_t)a.npg * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.C / 8);
     GV av{a.lda, a.a_group_off};
+    const size_t lds = (size_t)2 * 2 * a.C * 4;
+    const int grid = ew_grid(total);
     if (dt == BF16)
-        k_bn_act_pair<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)a.Y, a.ldy, (bf16*)a.A, av, (bf16*)a.P, a.ldp, (bf16*)F, ldf, fmode,
-                                                             a.stat, a.mask, a.C, a.npg, a.H, a.W, total);
+        k_bn_act_pair<bf16><<<grid, 256, lds, s>>>((const bf16*)a.Y, a.ldy, (bf16*)a.A, av, (bf16*)a.P, a.ldp, (bf16*)F, ldf, fmode,
+                                                               a.stat, a.mask, a.C, a.npg, a.H, a.W, total, a.facc, a.gamma, a.beta,
+                                                               a.running_mean, a.running_var, a.momentum, a.eps);
     else
-        k_bn_act_pair<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)a.Y, a.ldy, (float*)a.A, av, (float*)a.P, a.ldp, (float*)F, ldf,
-                                                              fmode, a.stat, a.mask, a.C, a.npg, a.H, a.W, total);
+        k_bn_act_pair<float><<<grid, 256, lds, s>>>((const float*)a.Y, a.ldy, (float*)a.A, av, (float*)a.P, a.ldp, (float*)F, ldf,
+                                                                fmode, a.stat, a.mask, a.C, a.npg, a.H, a.W, total, a.facc, a.gamma, a.beta,
+                                                                a.running_mean, a.running_var, a.momentum, a.eps);
 }
 
 void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s) {
     int64_t total = (int64_t)a.groups * a.npg * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.C / 8);
     GV av{a.lda, a.a_group_off};
+    const size_t lds = (size_t)a.groups * 2 * a.C * 4;
+    const int grid = ew_grid(total);
     if (dt == BF16)
-        k_bn_act<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)a.Y, a.ldy, (bf16*)a.A, av, (bf16*)a.P, a.ldp, a.stat,
-                                                        a.mask, (const bf16*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total);
+        k_bn_act<bf16><<<grid, 256, lds, s>>>((const bf16*)a.Y, a.ldy, (bf16*)a.A, av, (bf16*)a.P, a.ldp, a.stat,
+                                                          a.mask, (const bf16*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total, a.facc,
+                                                          a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps);
     else
-        k_bn_act<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)a.Y, a.ldy, (float*)a.A, av, (float*)a.P, a.ldp,
-                                                         a.stat, a.mask, (const float*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total);
+        k_bn_act<float><<<grid, 256, lds, s>>>((const float*)a.Y, a.ldy, (float*)a.A, av, (float*)a.P, a.ldp,
+                                                           a.stat, a.mask, (const float*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total,
+                                                           a.facc, a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps);
 }
 
 template <typename T>
@@ -558,7 +597,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_skip_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int ldd,
            const T* __restrict__ dP, int ldp, T* __restrict__ dA, GV dav, const float* __restrict__ stat,
-           const float* __restrict__ mask, int B, int H, int W, int C, int64_t total, float* __restrict__ partial) {
+           const float* __restrict__ mask, int B, int H, int W, int C, int64_t total, long long* __restrict__ bacc) {
     __shared__ float red[256 * 16];
     const int g = blockIdx.y;
     const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
@@ -628,12 +667,11 @@ k_skip_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ Y, in
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s1[j]; red[threadIdx.x * 16 + 8 + j] = s2[j]; }
     __syncthreads();
-    float* out = partial + ((int64_t)g * gridDim.x + blockIdx.x) * 2 * C;
     for (int o = threadIdx.x; o < 2 * C; o += 256) {
         const int which = o / C, c = o - which * C;
-        float acc = 0.f;
-        for (int l = 0; l < lanes; ++l) acc += red[(l * cb + (c >> 3)) * 16 + which * 8 + (c & 7)];
-        out[o] = acc;
+        float a_ = 0.f;
+        for (int l = 0; l < lanes; ++l) a_ += red[(l * cb + (c >> 3)) * 16 + which * 8 + (c & 7)];
+        bn_acc_add(bacc, blockIdx.x, 2, C, g, which, c, a_, BN_BS);
     }
 }
 
@@ -687,11 +725,14 @@ __global__ void k_rep_pad_bwd(T* __restrict__ dD, int ld, int H, int W, int h0, 
 template <typename T, int PX>
 __global__ void __launch_bounds__(256)
 k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, const T* __restrict__ Y, int ldy,
-               const float* __restrict__ bw, const float* __restrict__ mask, const T* __restrict__ res, int ldres,
+               const float* __restrict__ stat, const long long* __restrict__ bacc, float* __restrict__ dgamma, float* __restrict__ dbeta,
+               int groups, const float* __restrict__ mask, const T* __restrict__ res, int ldres,
                T* __restrict__ dZout, int lddz, const T* __restrict__ extra, int ldex, int C, int npg, int64_t HW, int relu,
                int64_t total) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+    extern __shared__ float bw_tab[];           // [groups][5][C]
+    bn_bwd_table(bw_tab, bacc, stat, dgamma, dbeta, C, groups, (int64_t)npg * HW, blockIdx.x == 0);
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int cb = C >> 3;
     const uint32_t iu = (uint32_t)i;               // launcher guarantees total < 2^31
     const int c0 = (int)(iu % (uint32_t)cb) * 8;
@@ -700,8 +741,9 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
     const int g = n / npg;
     const int64_t pig0 = p0 - (int64_t)g * npg * HW;
     float sc[8], sh[8], kb[8], mu[8], kc[8], mk[8];
-    const float* w = bw + (int64_t)g * 5 * C + c0;
-    ld8f(w, sc); ld8f(w + C, sh); ld8f(w + 2 * C, kb); ld8f(w + 3 * C, mu); ld8f(w + 4 * C, kc);
+    const float* w = bw_tab + (int64_t)g * 5 * C + c0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = w[j]; sh[j] = w[C + j]; kb[j] = w[2 * C + j]; mu[j] = w[3 * C + j]; kc[j] = w[4 * C + j]; }
     if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
     // all loads of the PX pixels first (dY may alias dA: every thread reads its own elements before it writes them)
     float y[PX][8], d[PX][8], rs[PX][8], ex[PX][8];
@@ -728,46 +770,8 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
         if (dZout) store8<T>(dZout + (p0 + k) * lddz + c0, dzv);
         store8<T>(dY + (p0 + k) * lddy + c0, o);
     }
-}
-__global__ void __launch_bounds__(FIN_THREADS)
-k_bn_bwd_finalize(const float* __restrict__ partial, int nchunk, int C, int groups, int64_t ppg, const float* __restrict__ stat,
-                  float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double sm[2 * FIN_THREADS];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
-    const bool owner = part == 0 && c < C;
-    double tg = 0.0, tb = 0.0;
-    float stv[2][4];                     // this channel's (mean, invstd, scale, shift) per group: loaded up front so the
-#pragma unroll                           // misses overlap the partial-row loads (groups <= 2)
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) stv[g][k] = (owner && g < groups) ? stat[(int64_t)g * 4 * C + k * C + c] : 0.f;
-    for (int g = 0; g < groups; ++g) {
-        double s1, s2;
-        chunk_sums(partial, nchunk, C, g, c, part, sm, &s1, &s2);
-        if (!owner) continue;
-        {   // coefficients of dY = a*dz + b*y + c  (see k_bn_bwd_apply)
-            const double mean = stv[g & 1][0], invstd = stv[g & 1][1], scale = stv[g & 1][2];
-            const double k1 = s1 / ppg, k2 = s2 / ppg;
-            float* bw = coef + (int64_t)g * 5 * C;
-            bw[c] = (float)scale;
-            bw[C + c] = stv[g & 1][3];
-            bw[2 * C + c] = (float)(-scale * k2 * invstd);
-            bw[3 * C + c] = (float)mean;
-            bw[4 * C + c] = (float)(-scale * k1);
-        }
-        tb += s1;
-        tg += s2;
-    }
-    if (owner) {
-        dgamma[c] = (float)tg;
-        dbeta[c] = (float)tb;
     }
 }
-void launch_bn_bwd_finalize(const float* partial, int nchunk, int C, int groups, int64_t ppg, const float* stat, float* coef,
-                            float* dgamma, float* dbeta, hipStream_t s) {
-    k_bn_bwd_finalize<<<cdiv(C, 16), FIN_THREADS, 0, s>>>(partial, nchunk, C, groups, ppg, stat, coef, dgamma, dbeta);
-}
-
 // ------------------------------------------------------------------ bias gradient (layers without a following BN)
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -1191,27 +1195,27 @@ void launch_ecam_backward(int dt, const void* X, int ld, const void* dZ, int ldd
     } while (0)
 
 void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, const void* Y, int ldy, const float* stat,
-                          const float* mask, int C, int groups, int npg, int64_t HW, int relu, float* partial,
+                          const float* mask, int C, int groups, int npg, int64_t HW, int relu, long long* bacc,
                           hipStream_t s, const void* res, int ldres) {
     int64_t ppg = (int64_t)npg * HW;
     int nchunk = bn_stats_chunks(ppg, C);
     dim3 grid(nchunk, groups);
     GV dav{ldda, da_goff};
     if (dt == BF16)
-        k_bn_reduce<bf16, 1><<<grid, 256, 0, s>>>((const bf16*)Y, ldy, (const bf16*)dA, dav, stat, mask, (const bf16*)res, ldres, C, npg, HW, relu, ppg, nchunk, partial);
+        k_bn_reduce<bf16, 1><<<grid, 256, 0, s>>>((const bf16*)Y, ldy, (const bf16*)dA, dav, stat, mask, (const bf16*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc);
     else
-        k_bn_reduce<float, 1><<<grid, 256, 0, s>>>((const float*)Y, ldy, (const float*)dA, dav, stat, mask, (const float*)res, ldres, C, npg, HW, relu, ppg, nchunk, partial);
+        k_bn_reduce<float, 1><<<grid, 256, 0, s>>>((const float*)Y, ldy, (const float*)dA, dav, stat, mask, (const float*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc);
 }
 
 void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
-                         const float* stat, const float* coef, const float* mask, int C, int groups, int npg, int64_t HW,
-                         int relu, hipStream_t s, const void* res, int ldres, void* dZout, int lddz, const void* extra,
-                         int ldex) {
+                         const float* stat, const long long* bacc, float* dgamma, float* dbeta, const float* mask, int C, int groups,
+                         int npg, int64_t HW, int relu, hipStream_t s, const void* res, int ldres, void* dZout, int lddz,
+                         const void* extra, int ldex) {
     GV dav{ldda, da_goff};
-    (void)stat;
+    const size_t lds = (size_t)groups * 5 * C * 4;
     const int px = (HW % 4 == 0) ? 4 : 1;        // odd-sized maps (ReplicationPad2d branch): one pixel per thread
     int64_t total = (int64_t)groups * npg * HW / px * (C / 8);
-#define BWD_APPLY(T_, PX_) k_bn_bwd_apply<T_, PX_><<<cdiv(total, 256), 256, 0, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, coef, mask, (const T_*)res, ldres, (T_*)dZout, lddz, (const T_*)extra, ldex, C, npg, HW, relu, total)
+#define BWD_APPLY(T_, PX_) k_bn_bwd_apply<T_, PX_><<<ew_grid(total), 256, lds, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, stat, bacc, dgamma, dbeta, groups, mask, (const T_*)res, ldres, (T_*)dZout, lddz, (const T_*)extra, ldex, C, npg, HW, relu, total)
     if (dt == BF16) { if (px == 4) BWD_APPLY(bf16, 4); else BWD_APPLY(bf16, 1); }
     else { if (px == 4) BWD_APPLY(float, 4); else BWD_APPLY(float, 1); }
 #undef BWD_APPLY
@@ -1227,15 +1231,12 @@ void launch_pool_bwd(int dt, const void* A, int lda, int64_t a_goff, const void*
         k_pool_bwd<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)A, av, (const float*)dP, ldp, (float*)dA, dav, npg, H, W, C, accumulate, total);
 }
 
-int skip_bwd_chunks(int B, int H, int W, int C) {
-    return (int)cdiv((int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8), 256);
-}
 void launch_skip_bwd(int dt, int mode, const void* A, int lda, int64_t a_goff, const void* Y, int ldy, const void* dD, int ldd,
                      const void* dP, int ldp, void* dA, int ldda, int64_t da_goff, const float* stat, const float* mask, int B,
-                     int H, int W, int C, float* partial, hipStream_t s) {
+                     int H, int W, int C, long long* partial, hipStream_t s) {
     const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
     GV av{lda, a_goff}, dav{ldda, da_goff};
-    dim3 grid((unsigned)skip_bwd_chunks(B, H, W, C), 2);
+    dim3 grid((unsigned)cdiv(total, 256), 2);
     if (dt == BF16)
         k_skip_bwd<bf16><<<grid, 256, 0, s>>>(mode, (const bf16*)A, av, (const bf16*)Y, ldy, (const bf16*)dD, ldd, (const bf16*)dP, ldp,
                                               (bf16*)dA, dav, stat, mask, B, H, W, C, total, partial);

@@ -24,12 +24,7 @@ int check_map(const stcd_map_geom* g) {
     return 0;
 }
 
-int64_t partial_floats(const stcd_map_geom& g) {
-    const int64_t ppg = (int64_t)(g.n / g.groups) * g.h * g.w;
-    int64_t rows = bn_stats_chunks(ppg, g.c);
-    if (g.groups == 2) rows = std::max<int64_t>(rows, skip_bwd_chunks(g.n / 2, g.h, g.w, g.c));
-    return (int64_t)g.groups * rows * 2 * g.c;
-}
+int64_t acc_bytes(const stcd_map_geom& g) { return bn_acc_bytes(g.groups, g.c); }
 
 }  // namespace
 
@@ -37,7 +32,7 @@ extern "C" {
 
 int64_t stcd_op_ew_scratch_bytes(const stcd_map_geom* g) {
     if (!g || g->c < 8 || g->groups < 1) return 0;
-    return (partial_floats(*g) + (int64_t)g->groups * 5 * g->c + 64) * 4;
+    return acc_bytes(*g) + 256;
 }
 
 int stcd_op_bn_act(int dtype, const stcd_map_geom* g, const void* y, int ldy, const float* gamma, const float* beta,
@@ -51,15 +46,15 @@ int stcd_op_bn_act(int dtype, const stcd_map_geom* g, const void* y, int ldy, co
     hipStream_t s = (hipStream_t)hip_stream;
     const int npg = g->n / g->groups;
     const int64_t ppg = (int64_t)npg * g->h * g->w;
-    float* partial = (float*)scratch;
+    long long* acc = (long long*)scratch;
+    BnActArgs aa;
     if (training) {
-        launch_bn_stats(dtype, y, ldy, g->c, g->groups, ppg, partial, s);
-        launch_bn_finalize(partial, bn_stats_chunks(ppg, g->c), g->c, g->groups, ppg, gamma, beta, running_mean, running_var, stat,
-                           0.1f, 1e-5f, s);
+        STCD_HIP(hipMemsetAsync(acc, 0, (size_t)acc_bytes(*g), s));
+        launch_bn_stats(dtype, y, ldy, g->c, g->groups, ppg, acc, s);
+        aa.facc = acc; aa.gamma = gamma; aa.beta = beta; aa.running_mean = running_mean; aa.running_var = running_var;
     } else {
         launch_bn_eval_prepare(g->c, g->groups, gamma, beta, running_mean, running_var, stat, 1e-5f, s);
     }
-    BnActArgs aa;
     aa.Y = y; aa.ldy = ldy; aa.A = a; aa.lda = lda; aa.a_group_off = ppg * lda;
     aa.P = pool; aa.ldp = ldp; aa.stat = stat; aa.mask = mask;
     aa.C = g->c; aa.groups = g->groups; aa.npg = npg; aa.H = g->h; aa.W = g->w; aa.relu = relu ? 1 : 0;
@@ -80,10 +75,11 @@ int stcd_op_bn_act_pair(int dtype, const stcd_map_geom* g, const void* y, int ld
     hipStream_t s = (hipStream_t)hip_stream;
     const int npg = g->n / 2;
     const int64_t ppg = (int64_t)npg * g->h * g->w;
-    float* partial = (float*)scratch;
-    launch_bn_stats(dtype, y, ldy, g->c, 2, ppg, partial, s);
-    launch_bn_finalize(partial, bn_stats_chunks(ppg, g->c), g->c, 2, ppg, gamma, beta, running_mean, running_var, stat, 0.1f, 1e-5f, s);
+    long long* acc = (long long*)scratch;
+    STCD_HIP(hipMemsetAsync(acc, 0, (size_t)acc_bytes(*g), s));
+    launch_bn_stats(dtype, y, ldy, g->c, 2, ppg, acc, s);
     BnActArgs aa;
+    aa.facc = acc; aa.gamma = gamma; aa.beta = beta; aa.running_mean = running_mean; aa.running_var = running_var;
     aa.Y = y; aa.ldy = ldy; aa.A = a; aa.lda = lda; aa.a_group_off = ppg * lda;
     aa.P = pool; aa.ldp = ldp; aa.stat = stat; aa.mask = mask;
     aa.C = g->c; aa.groups = 2; aa.npg = npg; aa.H = g->h; aa.W = g->w; aa.relu = 1;
@@ -102,11 +98,11 @@ int stcd_op_bn_act_bwd(int dtype, const stcd_map_geom* g, const void* da, int ld
     hipStream_t s = (hipStream_t)hip_stream;
     const int npg = g->n / g->groups;
     const int64_t HW = (int64_t)g->h * g->w, ppg = npg * HW;
-    float* partial = (float*)scratch;
-    float* coef = partial + partial_floats(*g);
-    launch_bn_bwd_reduce(dtype, da, ldda, ppg * ldda, y, ldy, stat, mask, g->c, g->groups, npg, HW, relu ? 1 : 0, partial, s);
-    launch_bn_bwd_finalize(partial, bn_stats_chunks(ppg, g->c), g->c, g->groups, ppg, stat, coef, dgamma, dbeta, s);
-    launch_bn_bwd_apply(dtype, da, ldda, ppg * ldda, dy, lddy, y, ldy, stat, coef, mask, g->c, g->groups, npg, HW, relu ? 1 : 0, s);
+    long long* acc = (long long*)scratch;
+    STCD_HIP(hipMemsetAsync(acc, 0, (size_t)acc_bytes(*g), s));
+    launch_bn_bwd_reduce(dtype, da, ldda, ppg * ldda, y, ldy, stat, mask, g->c, g->groups, npg, HW, relu ? 1 : 0, acc, s);
+    launch_bn_bwd_apply(dtype, da, ldda, ppg * ldda, dy, lddy, y, ldy, stat, acc, dgamma, dbeta, mask, g->c, g->groups, npg, HW,
+                        relu ? 1 : 0, s);
     STCD_HIP(hipGetLastError());
     return 0;
 }
@@ -179,12 +175,11 @@ int stcd_op_skip_bwd(int dtype, int mode, const stcd_map_geom* g, const void* a,
     hipStream_t s = (hipStream_t)hip_stream;
     const int b = g->n / 2;
     const int64_t HW = (int64_t)g->h * g->w, ppg = b * HW;
-    float* partial = (float*)scratch;
-    float* coef = partial + partial_floats(*g);
+    long long* acc = (long long*)scratch;
+    STCD_HIP(hipMemsetAsync(acc, 0, (size_t)acc_bytes(*g), s));
     launch_skip_bwd(dtype, mode, a, lda, ppg * lda, y, ldy, dd, ldd, dpool, ldp, da, ldda, ppg * ldda, stat, mask, b, g->h, g->w, g->c,
-                    partial, s);
-    launch_bn_bwd_finalize(partial, skip_bwd_chunks(b, g->h, g->w, g->c), g->c, 2, ppg, stat, coef, dgamma, dbeta, s);
-    launch_bn_bwd_apply(dtype, da, ldda, ppg * ldda, dy, lddy, y, ldy, stat, coef, mask, g->c, 2, b, HW, 1, s);
+                    acc, s);
+    launch_bn_bwd_apply(dtype, da, ldda, ppg * ldda, dy, lddy, y, ldy, stat, acc, dgamma, dbeta, mask, g->c, 2, b, HW, 1, s);
     STCD_HIP(hipGetLastError());
     return 0;
 }
