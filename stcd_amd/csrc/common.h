@@ -249,6 +249,16 @@ void launch_bn_eval_prepare(int C, int groups, const float* gamma, const float* 
 // Training (facc != nullptr): every block derives scale / shift of all channels from the accumulators in its prologue;
 // block 0 also writes stat [groups][4][C] (kept for the backward) and updates the running statistics (group 0 then
 // group 1: the shared encoder BatchNorm sees date 0 then date 1).  Eval (facc == nullptr): stat is read.
+// extra destinations of an activation (dense concatenation without copy kernels: the producer also writes its output into
+// the channel slice of every consumer's concat buffer) and extra sources of a gradient (the consumers' concat-gradient
+// slices are summed by the producer's BatchNorm-backward reduction instead of by scatter-add kernels).
+// Element (g, image-in-group n, pixel, c) of view k lives at p + (both ? g*goff : 0) + (n*HW + pixel)*ld + c; a view with
+// gmask == 2 exists for group 1 only (a tensor of the date-1 images alone), gmask == 3 for both groups.
+constexpr int MAX_VIEWS = 6;
+struct SliceViews {
+    int n = 0;
+    void* p[MAX_VIEWS]; int ld[MAX_VIEWS]; int64_t goff[MAX_VIEWS]; int gmask[MAX_VIEWS];
+};
 struct BnActArgs {
     const void* Y; int ldy;
     void* A; int lda; int64_t a_group_off;
@@ -262,6 +272,7 @@ struct BnActArgs {
     const float* gamma = nullptr; const float* beta = nullptr;
     float* running_mean = nullptr; float* running_var = nullptr;
     float momentum = 0.1f, eps = 1e-5f;
+    SliceViews extra;                       // extra destinations of A
 };
 void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s);
 // skip layers (groups == 2, ReLU, no residual): also writes the bi-temporal fusion F = |a1-a2| (fmode 0) / a2-a1 (1)
@@ -283,7 +294,9 @@ void launch_rep_pad_bwd(int dt, void* dD, int ld, int N, int H, int W, int h0, i
 // backward of bn_act (train): dz = dA*mask*(z>0); sums of dz and dz*xhat per (group, channel), added into bacc
 void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, const void* Y, int ldy, const float* stat,
                           const float* mask, int C, int groups, int npg, int64_t HW, int relu, long long* bacc,
-                          hipStream_t s, const void* res = nullptr, int ldres = 0);
+                          hipStream_t s, const void* res = nullptr, int ldres = 0, const SliceViews* extra_src = nullptr,
+                          int base_valid = 1, void* dA_sum = nullptr);
+// (extra_src: dA := [base_valid ? dA : 0] + sum of the views, rounded once and written to dA_sum -- a plain view like dA)
 // dY = scale*(dz - k1 - xhat*k2) = scale*dz + b*(y-mean) + c with (b, c) derived per block from bacc and stat in the
 // kernel's prologue (no finalize launch); block 0 also writes dgamma / dbeta (summed over the groups).  dY is a plain
 // tensor and may alias dA when dA is plain too.

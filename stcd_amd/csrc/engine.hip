@@ -119,7 +119,8 @@ struct Prof {
 };
 
 // ---- SNUNet-ECAM plan (SNUNet.py:63-152)
-struct SrcSlice { TRef src; TRef dsrc; int C = 0; };        // a producer tensor copied into / scattered from a concat slice
+struct SrcSlice { TRef src; TRef dsrc; int C = 0; int prod = -1; int grp = -1; };   // a producer's output inside a consumer's concat
+struct ViewRef { int64_t off = 0; int ld = 0; int64_t goff = 0; int gmask = 1; };    // workspace-relative SliceViews entry
 struct NBlock {                                              // conv_block_nested (SNUNet.py:8-26)
     std::string name;
     int c1 = -1, bn1 = -1, c2 = -1, bn2 = -1;
@@ -132,6 +133,9 @@ struct NBlock {                                              // conv_block_neste
     int64_t stat1 = -1, stat2 = -1;
     int64_t facc1 = -1, bacc1 = -1, facc2 = -1, bacc2 = -1;
     int64_t d1_sum_acc = -1; int d1_sum_c0 = 0, d1_sum_C = 0;
+    std::vector<ViewRef> extra_dst;                          // consumers' concat slices that receive Out (forward)
+    std::vector<ViewRef> grad_src;                           // consumers' concat-gradient slices (+ up-sampling paths) summed into dOut
+    bool grad_base = false;                                  // dOut already holds a gradient (max-pool / ECAM) before the sum
     ConvOp f1, f2, d1, d2; WgradOp w1, w2;
 };
 struct SnUp {                                                // up: ConvTranspose2d(C, C, 2, stride=2) (SNUNet.py:29-43)
@@ -1244,14 +1248,16 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
         NBlock& enc = e.sn_blocks[sn_block_index(e, std::string("conv") + char('0' + lvl) + "_0")];
         const int64_t half = (int64_t)B * enc.H * enc.W * enc.C * T;
         int coff = 0;
-        auto add_src = [&](TRef src, TRef dsrc, int C) {
-            SrcSlice s_; s_.src = src; s_.dsrc = dsrc; s_.C = C; b.srcs.push_back(s_); coff += C;
+        auto add_src = [&](TRef src, TRef dsrc, int C, int prod, int grp) {
+            SrcSlice s_; s_.src = src; s_.dsrc = dsrc; s_.C = C; s_.prod = prod; s_.grp = grp; b.srcs.push_back(s_); coff += C;
         };
-        add_src(enc.Out, enc.dOut, enc.C);                                                 // x{lvl}_0A
-        add_src(TRef{enc.Out.off + half, enc.Out.ld}, TRef{enc.dOut.off + half, enc.dOut.ld}, enc.C);   // x{lvl}_0B
+        const int enc_i = sn_block_index(e, std::string("conv") + char('0' + lvl) + "_0");
+        add_src(enc.Out, enc.dOut, enc.C, enc_i, 0);                                                      // x{lvl}_0A
+        add_src(TRef{enc.Out.off + half, enc.Out.ld}, TRef{enc.dOut.off + half, enc.dOut.ld}, enc.C, enc_i, 1);   // x{lvl}_0B
         for (int k = 1; k < j; ++k) {
-            NBlock& d = e.sn_blocks[sn_block_index(e, std::string("conv") + char('0' + lvl) + "_" + char('0' + k))];
-            add_src(d.Out, d.dOut, d.C);
+            const int di = sn_block_index(e, std::string("conv") + char('0' + lvl) + "_" + char('0' + k));
+            NBlock& d = e.sn_blocks[di];
+            add_src(d.Out, d.dOut, d.C, di, -1);
         }
         // up-sampled tail: Up{lvl+1}_{j-1}( x{lvl+1}_{j-1} ), the B date for j == 1
         const std::string upname = std::string("Up") + char('0' + lvl + 1) + "_" + char('0' + j - 1);
@@ -1269,6 +1275,39 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
         u.coff = coff;
         u.tmp = plain(B, u.h, u.w, u.C);
     }
+    // ---- dense concatenation without copy kernels: every producer writes its output straight into its consumers' concat
+    //      slices (extra destinations of its last activation kernel), and gathers its gradient from their concat-gradient
+    //      slices (extra sources of its BatchNorm-backward reduction).  The two dates of an encoder level sit side by side
+    //      in a consumer (A at coff, B at coff + C): one view with a per-date channel offset.
+    for (auto& b : e.sn_blocks) { b.extra_dst.clear(); b.grad_src.clear(); }
+    for (auto& b : e.sn_blocks) {
+        int coff = 0;
+        for (auto& s_ : b.srcs) {
+            if (s_.grp != 1) {       // (the date-1 slice of an encoder level rides on its date-0 view)
+                NBlock& P = e.sn_blocks[s_.prod];
+                ViewRef v; v.ld = b.in.ld; v.off = b.in.off + (int64_t)coff * T;
+                if (s_.grp == 0) { v.gmask = 3; v.goff = s_.C; } else { v.gmask = 1; v.goff = 0; }
+                P.extra_dst.push_back(v);
+                ViewRef gv = v; gv.off = b.dIn.off + (int64_t)coff * T; gv.ld = b.dIn.ld;
+                P.grad_src.push_back(gv);
+            }
+            coff += s_.C;
+        }
+    }
+    for (auto& b : e.sn_blocks) {
+        const int lvl = b.name[4] - '0', j = b.name[6] - '0';
+        b.grad_base = (b.pool) || (lvl == 0 && j >= 1);          // max-pool gradient / ECAM gradient is written first
+        if (b.up >= 0) {        // gradient arriving through the transposed conv that up-samples the LOWER block's output
+            SnUp& u = e.sn_ups[b.up];
+            NBlock& lower = e.sn_blocks[sn_block_index(e, std::string("conv") + char('0' + lvl + 1) + "_" + char('0' + j - 1))];
+            ViewRef v; v.off = u.tmp.off; v.ld = u.tmp.ld; v.goff = 0;
+            v.gmask = (lower.groups == 2) ? 2 : 1;               // an encoder level feeds its date-1 half only (SNUNet.py:127-142)
+            lower.grad_src.push_back(v);
+        }
+    }
+    for (auto& b : e.sn_blocks)
+        if ((int)b.extra_dst.size() > MAX_VIEWS || (int)b.grad_src.size() > MAX_VIEWS) { set_error("internal: too many concat views"); return 1; }
+
     // ---- forward order (SNUNet.py:119-142)
     static const char* ORDER[] = {"conv0_0", "conv1_0", "conv2_0", "conv3_0", "conv4_0", "conv0_1", "conv1_1", "conv0_2", "conv2_1",
                                   "conv1_2", "conv0_3", "conv3_1", "conv2_2", "conv1_3", "conv0_4"};
@@ -1381,12 +1420,7 @@ static void sn_block_forward(const Ctx& c, const NBlock& b, float* bn_running, b
     stcd_engine& e = c.e;
     const int64_t T = (int64_t)dsize(e.dt), px = (int64_t)b.N * b.H * b.W, ppg = (int64_t)b.npg * b.H * b.W;
     const double act_bytes = (double)px * b.C * (double)T;
-    int coff = 0;
-    for (auto& s_ : b.srcs) {
-        ProfScope ps(c, PC_POOL_FUSE, 0.0, 2.0 * px * s_.C * (double)T);
-        launch_slice(e.dt, c.at<char>(b.in.off) + (int64_t)coff * T, b.in.ld, c.at(s_.src.off), s_.src.ld, px, s_.C, 0, c.s);
-        coff += s_.C;
-    }
+    (void)px; (void)T;      // (the concat prefix of b.in was written by the producers: NBlock::extra_dst)
     BnActArgs a;
     auto bn_stage = [&](const ConvOp& f, const void* in, int conv, int bni, const TRef& Y, int64_t stat_off, int64_t facc_off) {
         const ConvW& cv = e.convs[conv];
@@ -1420,6 +1454,11 @@ static void sn_block_forward(const Ctx& c, const NBlock& b, float* bn_running, b
     a.Y = c.at(b.Y2.off); a.ldy = b.Y2.ld; a.A = c.at(b.Out.off); a.lda = b.Out.ld; a.a_group_off = ppg * b.Out.ld;
     a.P = b.pool ? c.at(b.P.off) : nullptr; a.ldp = b.P.ld; a.stat = c.at<float>(b.stat2);
     a.res = c.at(b.Y1.off); a.ldres = b.Y1.ld;        // identity = conv1's raw output (SNUNet.py:19,25)
+    a.extra.n = (int)b.extra_dst.size();
+    for (int k = 0; k < a.extra.n; ++k) {
+        a.extra.p[k] = c.at(b.extra_dst[k].off); a.extra.ld[k] = b.extra_dst[k].ld; a.extra.goff[k] = b.extra_dst[k].goff;
+        a.extra.gmask[k] = b.extra_dst[k].gmask;
+    }
     {
         ProfScope ps(c, PC_BN_ACT, 0.0, (b.pool ? 3.25 : 3.0) * act_bytes);
         launch_bn_act(e.dt, a, c.s);
@@ -1437,8 +1476,14 @@ static void sn_block_backward(const Ctx& c, const NBlock& b) {
     // out = relu(bn2(y2) + y1): gate on z2 + y1; dZ2 (gated) is also the gradient of the identity branch
     {
         ProfScope ps(c, PC_BN_BWD_REDUCE, 0.0, 3.0 * act_bytes);
+        SliceViews xs;
+        xs.n = (int)b.grad_src.size();
+        for (int k = 0; k < xs.n; ++k) {
+            xs.p[k] = c.at(b.grad_src[k].off); xs.ld[k] = b.grad_src[k].ld; xs.goff[k] = b.grad_src[k].goff; xs.gmask[k] = b.grad_src[k].gmask;
+        }
         launch_bn_bwd_reduce(e.dt, c.at(b.dOut.off), b.dOut.ld, goff_out, c.at(b.Y2.off), b.Y2.ld, c.at<float>(b.stat2), nullptr, b.C,
-                             b.groups, b.npg, HW, 1, c.at<long long>(b.bacc2), c.s, c.at(b.Y1.off), b.Y1.ld);
+                             b.groups, b.npg, HW, 1, c.at<long long>(b.bacc2), c.s, c.at(b.Y1.off), b.Y1.ld, &xs, b.grad_base ? 1 : 0,
+                             c.at(b.dOut.off));
     }
     {
         ProfScope ps(c, PC_BN_BWD_APPLY, 0.0, 5.0 * act_bytes);
@@ -1482,9 +1527,8 @@ static void sn_up_backward(const Ctx& c, const SnUp& u) {
     if (!(u.bias_fused && mfma_on(e)))
         launch_bias_grad(e.dt, c.at(u.dOut.off), u.dOut.ld, (int64_t)u.N * 4 * u.h * u.w, u.C, c.grads + cv.b_off, c.s);
     for (int ph = 0; ph < 4; ++ph) exec_wgrad(c, u.wg[ph], c.at(u.src.off), c.at(u.dOut.off));
-    exec_conv(c, u.dgr, c.at(u.dOut.off), nullptr, c.at(u.tmp.off), false);
-    ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.0 * u.N * u.h * u.w * u.C * (double)T);
-    launch_slice(e.dt, c.at(u.dsrc.off), u.dsrc.ld, c.at(u.tmp.off), u.tmp.ld, (int64_t)u.N * u.h * u.w, u.C, 1, c.s);
+    exec_conv(c, u.dgr, c.at(u.dOut.off), nullptr, c.at(u.tmp.off), false);     // summed into the lower block's dOut by ITS reduction
+    (void)T;
 }
 
 static int forward_snunet(stcd_engine& e, const float* x1, const float* x2, const float* params, float* bn_running, int training,
@@ -1516,7 +1560,7 @@ static int backward_snunet(stcd_engine& e, const float* grad_logits, const float
     const int c4 = SN_F[0] * 4;
     STCD_HIP(hipMemsetAsync(grads, 0, e.param_floats * 4, s));
     if (!mfma_on(e)) STCD_HIP(hipMemsetAsync(c.at(e.dwe_begin), 0, e.dwe_end - e.dwe_begin, s));
-    STCD_HIP(hipMemsetAsync(c.at(e.sn_dout_begin), 0, e.sn_dout_end - e.sn_dout_begin, s));
+    // (no bulk zeroing of the dOut buffers: each is fully written -- max-pool / ECAM gradient, or the gathered sum)
     for (auto& b : e.sn_blocks)          // pooled gradients of the A half of conv3_0 never get written (x4_0A does not exist)
         if (b.pool && b.name == "conv3_0") STCD_HIP(hipMemsetAsync(c.at(b.dP.off), 0, (int64_t)B * (b.H / 2) * (b.W / 2) * b.C * T, s));
     launch_gout_pack(dt, grad_logits, c.at(e.G.off), B, e.label, e.H, e.W, s, c.at<long long>(e.final_bias_acc));
@@ -1532,18 +1576,9 @@ static int backward_snunet(stcd_engine& e, const float* grad_logits, const float
             ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.25 * b.N * b.H * b.W * b.C * (double)T);
             const int64_t goff = (int64_t)b.npg * b.H * b.W;
             launch_pool_bwd(dt, c.at(b.Out.off), b.Out.ld, goff * b.Out.ld, c.at(b.dP.off), b.dP.ld, c.at(b.dOut.off), b.dOut.ld,
-                            goff * b.dOut.ld, b.groups, b.npg, b.H, b.W, b.C, 1, s);
+                            goff * b.dOut.ld, b.groups, b.npg, b.H, b.W, b.C, 0, s);
         }
-        sn_block_backward(c, b);
-        if (b.dIn.off >= 0 && !b.srcs.empty()) {
-            const int64_t px = (int64_t)b.N * b.H * b.W;
-            int coff = 0;
-            for (auto& s_ : b.srcs) {
-                ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.0 * px * s_.C * (double)T);
-                launch_slice(dt, c.at(s_.dsrc.off), s_.dsrc.ld, c.at<char>(b.dIn.off) + (int64_t)coff * T, b.dIn.ld, px, s_.C, 1, s);
-                coff += s_.C;
-            }
-        }
+        sn_block_backward(c, b);       // (its concat gradient b.dIn is gathered by the producers' reductions later on)
         if (b.up >= 0) sn_up_backward(c, e.sn_ups[b.up]);
     }
     reduce_stage(c, 0);

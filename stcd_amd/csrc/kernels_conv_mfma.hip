@@ -653,7 +653,13 @@ k_wgrad_group(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
     }
     const WgradJob& a = jobs[lo];
     const int lb = blockIdx.x - a.start;
-    const int bx = lb % a.gx, r = lb / a.gx;
+    // XCD-aware order: the gy*gz blocks that walk the SAME tile sequence (K slice bx) over different (ci, co) groups re-read
+    // the same X / dY tiles; workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share one), so those blocks
+    // get ids 8 apart: they run side by side on one XCD and the re-reads hit its L2 instead of crossing the fabric.
+    const int G = a.gy * a.gz, full = (a.gx >> 3) << 3;
+    int bx, r;
+    if (lb < full * G) { const int rem = lb % (8 * G); bx = (lb / (8 * G)) * 8 + (rem & 7); r = rem >> 3; }
+    else { const int l2 = lb - full * G, tail = a.gx - full; bx = full + l2 % tail; r = l2 / tail; }
     wgrad_body<WCI, NTW, T9>(a, base, bx, r % a.gy, r / a.gy);
 }
 

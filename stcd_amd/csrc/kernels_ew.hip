@@ -18,6 +18,24 @@ __device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
 }
 
 
+// 8 consecutive activation values as they sit in memory: the load is issued now, the conversion happens at first use
+// (software pipelining across a barrier / a table build: load8 would convert -- and therefore wait -- immediately)
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+    uint4 v;
+    __device__ __forceinline__ void ld(const bf16* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+};
+template <> struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void ld(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    __device__ __forceinline__ void get(float (&o)[8]) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
+};
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // grid of the kernels that build a per-block BatchNorm table in their prologue: capped at ~2 resident rounds of the
 // chip so the table (one dependent round trip + a few double operations per channel) is built <= 2048 times per launch
@@ -139,11 +157,13 @@ int bn_stats_chunks(int64_t ppg, int C) {
     return (int)c;
 }
 
-template <typename T, int MODE>
+// NS > 0: the gradient is first GATHERED from up to NS extra views (dense-concat consumers, see SliceViews): all loads of a
+// trip are issued before any arithmetic (predicated, branch-free), two pixels per trip to bound the registers.
+template <typename T, int MODE, int NS = 0>
 __global__ void __launch_bounds__(256)
 k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, const float* __restrict__ stat,
             const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg, int64_t HW, int relu,
-            int64_t ppg, int nchunk, long long* __restrict__ acc) {
+            int64_t ppg, int nchunk, long long* __restrict__ acc, const SliceViews xs, int base_valid, T* __restrict__ dA_sum) {
     __shared__ float red[256 * 16];
     const int g = blockIdx.y, chunk = blockIdx.x;
     const int cb = C >> 3;                   // channel blocks (power of two, <= 256)
@@ -165,10 +185,11 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
     const T* yb = Y + ((int64_t)g * ppg) * ldy + mycb * 8;
     // 4 pixels per trip, every load of the trip issued before the arithmetic (a block owns only ~8 pixels per thread:
     // one load in flight at a time made the small maps pure latency)
-    constexpr int U = 4;
+    constexpr int U = NS > 0 ? 2 : 4;
     for (int64_t p = p0 + lane; p < p1; p += U * lanes) {
         float y[U][8], d[U][8], rs[U][8], mk[U][8];
         bool ok[U];
+        float ex[U][NS > 0 ? NS : 1][8];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t pu = p + (int64_t)u * lanes;
@@ -176,7 +197,19 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
             const int64_t pc = ok[u] ? pu : p;
             load8<T>(yb + pc * ldy, y[u]);
             if (MODE == 1) {
-                load8<T>(dA + g * dav.goff + pc * dav.ld + mycb * 8, d[u]);
+                if (xs.n == 0 || base_valid) load8<T>(dA + g * dav.goff + pc * dav.ld + mycb * 8, d[u]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d[u][j] = 0.f;
+                }
+                if constexpr (NS > 0) {   // every consumer's concat-gradient slice: requested here, summed below
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const bool on = k < xs.n && ((xs.gmask[k] >> g) & 1);
+                        const int kk = on ? k : 0;                       // an inactive slot re-reads view 0 (valid address), x 0
+                        load8<T>(reinterpret_cast<const T*>(xs.p[kk]) + (xs.gmask[kk] == 3 ? g * xs.goff[kk] : 0) + pc * xs.ld[kk] + mycb * 8, ex[u][k]);
+                    }
+                }
                 if (res) load8<T>(res + ((int64_t)g * ppg + pc) * ldres + mycb * 8, rs[u]);
                 if (mask) {
                     const int nig = (int)((uint32_t)pc / (uint32_t)HW);
@@ -184,6 +217,23 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
                     const float4 m0 = mp[0], m1 = mp[1];
                     mk[u][0] = m0.x; mk[u][1] = m0.y; mk[u][2] = m0.z; mk[u][3] = m0.w;
                     mk[u][4] = m1.x; mk[u][5] = m1.y; mk[u][6] = m1.z; mk[u][7] = m1.w;
+                }
+            }
+        }
+        if constexpr (NS > 0) {       // fp32 sum of the gathered slices, ONE rounding, written back for the apply pass
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const bool on = k < xs.n && ((xs.gmask[k] >> g) & 1);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d[u][j] += on ? ex[u][k][j] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[u][j] = round_as<T>(d[u][j]);
+                if (ok[u]) {
+                    const int64_t pu = p + (int64_t)u * lanes;
+                    store8<T>(dA_sum + g * dav.goff + pu * dav.ld + mycb * 8, d[u]);
                 }
             }
         }
@@ -222,9 +272,9 @@ void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t p
     dim3 grid(nchunk, groups);
     GV z{0, 0};
     if (dt == BF16)
-        k_bn_reduce<bf16, 0><<<grid, 256, 0, s>>>((const bf16*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, acc);
+        k_bn_reduce<bf16, 0><<<grid, 256, 0, s>>>((const bf16*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, acc, SliceViews(), 1, nullptr);
     else
-        k_bn_reduce<float, 0><<<grid, 256, 0, s>>>((const float*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, acc);
+        k_bn_reduce<float, 0><<<grid, 256, 0, s>>>((const float*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, acc, SliceViews(), 1, nullptr);
 }
 
 
@@ -319,62 +369,78 @@ __global__ void __launch_bounds__(256)
 k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restrict__ P, int ldp,
          float* __restrict__ stat, const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg,
          int H, int W, int relu, int64_t total, const long long* __restrict__ facc, const float* __restrict__ gamma,
-         const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, int groups, float momentum, float eps) {
+         const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, int groups, float momentum, float eps,
+         const SliceViews xd) {
     extern __shared__ float bn_tab[];           // [groups][2][C]
+    const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // the first quad's loads are requested BEFORE the scale / shift table is built (they are in flight during the
+    // accumulator round trip, the double arithmetic and the barrier); later quads are requested one ahead
+    Raw8<T> rv[4], rr[4];
+    auto fetch = [&](int64_t i64) {
+        uint32_t r = (uint32_t)i64;                // 32-bit index arithmetic (the launcher guarantees total < 2^31)
+        const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
+        const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
+        const int yc = (int)(r % (uint32_t)Hc);
+        const int n = (int)(r / (uint32_t)Hc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {              // clamped inside the map
+            const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+            const bool ok = y < H && x < W;
+            const int64_t pix = ((int64_t)n * H + (ok ? y : 2 * yc)) * W + (ok ? x : 2 * xc);
+            rv[k].ld(Y + pix * ldy + c0);
+            if (res) rr[k].ld(res + pix * ldres + c0);
+        }
+    };
+    int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i64 < total) fetch(i64);
     bn_fwd_table(bn_tab, facc, gamma, beta, rmean, rvar, stat, C, groups, (int64_t)npg * H * W, momentum, eps, blockIdx.x == 0);
     __syncthreads();
-    // grid-stride walk: the table above is built once per block, the grid is capped (see the launcher)
-    for (int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i64 < total; i64 += (int64_t)gridDim.x * blockDim.x) {
-    const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
-    // 32-bit index arithmetic (the launcher guarantees total < 2^31)
-    uint32_t r = (uint32_t)i64;
-    const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
-    const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
-    const int yc = (int)(r % (uint32_t)Hc);
-    const int n = (int)(r / (uint32_t)Hc);
-    const int g = n / npg, nig = n - g * npg;
-    float sc[8], sh[8], mk[8];
-    {
+    while (i64 < total) {
+        uint32_t r = (uint32_t)i64;
+        const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
+        const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
+        const int yc = (int)(r % (uint32_t)Hc);
+        const int n = (int)(r / (uint32_t)Hc);
+        const int g = n / npg, nig = n - g * npg;
+        float sc[8], sh[8], mk[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { sc[j] = bn_tab[(g * 2 + 0) * C + c0 + j]; sh[j] = bn_tab[(g * 2 + 1) * C + c0 + j]; }
-        if (mask) {
-            const float4* mp = reinterpret_cast<const float4*>(mask + (int64_t)n * C + c0);
-            const float4 m0 = mp[0], m1 = mp[1];
-            mk[0] = m0.x; mk[1] = m0.y; mk[2] = m0.z; mk[3] = m0.w; mk[4] = m1.x; mk[5] = m1.y; mk[6] = m1.z; mk[7] = m1.w;
-        } else {
+        if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
+        else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) mk[j] = 1.f;
         }
-    }
-    // the 2x2 quad: all loads first (clamped inside the map), then the arithmetic and the stores
-    float v[4][8], rs[4][8];
-    bool ok[4];
-    int64_t pix[4];
+        float v[4][8], rs[4][8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
-        ok[k] = y < H && x < W;
-        pix[k] = ((int64_t)n * H + (ok[k] ? y : 2 * yc)) * W + (ok[k] ? x : 2 * xc);
-        load8<T>(Y + pix[k] * ldy + c0, v[k]);
-        if (res) load8<T>(res + pix[k] * ldres + c0, rs[k]);
-    }
-    float best[8];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float z = v[k][j] * sc[j] + sh[j];
-            if (res) z += rs[k][j];              // residual add before the ReLU (SNUNet conv_block_nested, SNUNet.py:25)
-            if (relu) z = fmaxf(z, 0.f);
-            v[k][j] = round_as<T>(z * mk[j]);
-            best[j] = k == 0 ? v[k][j] : fmaxf(best[j], v[k][j]);   // pooled cells are complete quads: every k is inside
+        for (int k = 0; k < 4; ++k) {
+            rv[k].get(v[k]);
+            if (res) rr[k].get(rs[k]);
         }
-        if (ok[k]) {
+        const int64_t nxt = i64 + stride;
+        if (nxt < total) fetch(nxt);
+        float best[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float z = v[k][j] * sc[j] + sh[j];
+                if (res) z += rs[k][j];              // residual add before the ReLU (SNUNet conv_block_nested, SNUNet.py:25)
+                if (relu) z = fmaxf(z, 0.f);
+                v[k][j] = round_as<T>(z * mk[j]);
+                best[j] = k == 0 ? v[k][j] : fmaxf(best[j], v[k][j]);   // pooled cells are complete quads: every k is inside
+            }
             const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
-            store8<T>(A + g * av.goff + (((int64_t)nig * H + y) * W + x) * av.ld + c0, v[k]);
+            if (y < H && x < W) {
+                const int64_t pg = ((int64_t)nig * H + y) * W + x;
+                store8<T>(A + g * av.goff + pg * av.ld + c0, v[k]);
+                for (int e = 0; e < xd.n; ++e)      // dense concatenation: the consumers' input slices, written here (no copy kernels)
+                    if ((xd.gmask[e] >> g) & 1)
+                        store8<T>(reinterpret_cast<T*>(xd.p[e]) + (xd.gmask[e] == 3 ? g * xd.goff[e] : 0) + pg * xd.ld[e] + c0, v[k]);
+            }
         }
-    }
-    if (P && yc < Hp && xc < Wp) store8<T>(P + (((int64_t)n * Hp + yc) * Wp + xc) * ldp + c0, best);
+        if (P && yc < Hp && xc < Wp) store8<T>(P + (((int64_t)n * Hp + yc) * Wp + xc) * ldp + c0, best);
+        i64 = nxt;
     }
 }
 
@@ -388,55 +454,75 @@ k_bn_act_pair(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __r
               const long long* __restrict__ facc, const float* __restrict__ gamma, const float* __restrict__ beta,
               float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps) {
     extern __shared__ float bn_tab[];           // [2][2][C]
-    bn_fwd_table(bn_tab, facc, gamma, beta, rmean, rvar, stat, C, 2, (int64_t)npg * H * W, momentum, eps, blockIdx.x == 0);
-    __syncthreads();
-    for (int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i64 < total; i64 += (int64_t)gridDim.x * blockDim.x) {
     const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
-    uint32_t r = (uint32_t)i64;
-    const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
-    const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
-    const int yc = (int)(r % (uint32_t)Hc);
-    const int nb = (int)(r / (uint32_t)Hc);
-    bool ok[4];
-    int64_t pix[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
-        ok[k] = y < H && x < W;
-        pix[k] = ((int64_t)nb * H + (ok[k] ? y : 2 * yc)) * W + (ok[k] ? x : 2 * xc);
-    }
-    float a0[4][8];                       // date 0 activations, kept for the fusion
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        float sc[8], sh[8], mk[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = bn_tab[(g * 2 + 0) * C + c0 + j]; sh[j] = bn_tab[(g * 2 + 1) * C + c0 + j]; }
-        if (mask) ld8f(mask + ((int64_t)g * npg + nb) * C + c0, mk);
-        float v[4][8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) load8<T>(Y + ((int64_t)g * npg * H * W + pix[k]) * ldy + c0, v[k]);
-        float best[8];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    Raw8<T> rv[2][4];                            // both dates' quad, requested before the table is built (see k_bn_act)
+    auto fetch = [&](int64_t i64) {
+        uint32_t r = (uint32_t)i64;
+        const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
+        const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
+        const int yc = (int)(r % (uint32_t)Hc);
+        const int nb = (int)(r / (uint32_t)Hc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+            const bool ok = y < H && x < W;
+            const int64_t pix = ((int64_t)nb * H + (ok ? y : 2 * yc)) * W + (ok ? x : 2 * xc);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float z = fmaxf(v[k][j] * sc[j] + sh[j], 0.f);
-                v[k][j] = round_as<T>(mask ? z * mk[j] : z);
-                best[j] = k == 0 ? v[k][j] : fmaxf(best[j], v[k][j]);
-            }
-            if (ok[k]) store8<T>(A + g * av.goff + pix[k] * av.ld + c0, v[k]);
-            if (g == 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a0[k][j] = v[k][j];
-            } else if (ok[k]) {
-                float f[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = fmode == 0 ? fabsf(a0[k][j] - v[k][j]) : v[k][j] - a0[k][j];
-                store8<T>(F + pix[k] * ldf + c0, f);
-            }
+            for (int g = 0; g < 2; ++g) rv[g][k].ld(Y + ((int64_t)g * npg * H * W + pix) * ldy + c0);
         }
-        if (P && yc < Hp && xc < Wp) store8<T>(P + ((((int64_t)g * npg + nb) * Hp + yc) * Wp + xc) * ldp + c0, best);
-    }
+    };
+    int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i64 < total) fetch(i64);
+    bn_fwd_table(bn_tab, facc, gamma, beta, rmean, rvar, stat, C, 2, (int64_t)npg * H * W, momentum, eps, blockIdx.x == 0);
+    __syncthreads();
+    while (i64 < total) {
+        uint32_t r = (uint32_t)i64;
+        const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
+        const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
+        const int yc = (int)(r % (uint32_t)Hc);
+        const int nb = (int)(r / (uint32_t)Hc);
+        bool ok[4];
+        int64_t pix[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+            ok[k] = y < H && x < W;
+            pix[k] = ((int64_t)nb * H + (ok[k] ? y : 2 * yc)) * W + (ok[k] ? x : 2 * xc);
+        }
+        float vv[2][4][8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rv[g][k].get(vv[g][k]);
+        const int64_t nxt = i64 + stride;
+        if (nxt < total) fetch(nxt);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float sc[8], sh[8], mk[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sc[j] = bn_tab[(g * 2 + 0) * C + c0 + j]; sh[j] = bn_tab[(g * 2 + 1) * C + c0 + j]; }
+            if (mask) ld8f(mask + ((int64_t)g * npg + nb) * C + c0, mk);
+            float best[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float z = fmaxf(vv[g][k][j] * sc[j] + sh[j], 0.f);
+                    vv[g][k][j] = round_as<T>(mask ? z * mk[j] : z);
+                    best[j] = k == 0 ? vv[g][k][j] : fmaxf(best[j], vv[g][k][j]);
+                }
+                if (ok[k]) store8<T>(A + g * av.goff + pix[k] * av.ld + c0, vv[g][k]);
+                if (g == 1 && ok[k]) {
+                    float f[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = fmode == 0 ? fabsf(vv[0][k][j] - vv[1][k][j]) : vv[1][k][j] - vv[0][k][j];
+                    store8<T>(F + pix[k] * ldf + c0, f);
+                }
+            }
+            if (P && yc < Hp && xc < Wp) store8<T>(P + ((((int64_t)g * npg + nb) * Hp + yc) * Wp + xc) * ldp + c0, best);
+        }
+        i64 = nxt;
     }
 }
 void launch_bn_act_pair(int dt, const BnActArgs& a, void* F, int ldf, int fmode, hipStream_t s) {
@@ -462,11 +548,12 @@ void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s) {
     if (dt == BF16)
         k_bn_act<bf16><<<grid, 256, lds, s>>>((const bf16*)a.Y, a.ldy, (bf16*)a.A, av, (bf16*)a.P, a.ldp, a.stat,
                                                           a.mask, (const bf16*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total, a.facc,
-                                                          a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps);
+                                                          a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps, a.extra);
     else
         k_bn_act<float><<<grid, 256, lds, s>>>((const float*)a.Y, a.ldy, (float*)a.A, av, (float*)a.P, a.ldp,
                                                            a.stat, a.mask, (const float*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total,
-                                                           a.facc, a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps);
+                                                           a.facc, a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps,
+                                                           a.extra);
 }
 
 template <typename T>
@@ -730,46 +817,66 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
                T* __restrict__ dZout, int lddz, const T* __restrict__ extra, int ldex, int C, int npg, int64_t HW, int relu,
                int64_t total) {
     extern __shared__ float bw_tab[];           // [groups][5][C]
+    const int cb = C >> 3;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // the first item's loads are requested BEFORE the coefficient table is built (one dependent round trip to the
+    // accumulators + double arithmetic + a barrier): they are in flight meanwhile; later items are requested one ahead
+    Raw8<T> ry[PX], rd[PX], rr[PX], re[PX];
+    auto fetch = [&](int64_t i) {
+        const uint32_t iu = (uint32_t)i;               // launcher guarantees total < 2^31
+        const int c0 = (int)(iu % (uint32_t)cb) * 8;
+        const int64_t p0 = (int64_t)(iu / (uint32_t)cb) * PX;
+        const int g = (int)((uint32_t)p0 / (uint32_t)HW) / npg;
+        const int64_t pig0 = p0 - (int64_t)g * npg * HW;
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            ry[k].ld(Y + (p0 + k) * ldy + c0);
+            rd[k].ld(dA + g * dav.goff + (pig0 + k) * dav.ld + c0);
+            if (res) rr[k].ld(res + (p0 + k) * ldres + c0);
+            if (extra) re[k].ld(extra + (p0 + k) * ldex + c0);
+        }
+    };
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) fetch(i);
     bn_bwd_table(bw_tab, bacc, stat, dgamma, dbeta, C, groups, (int64_t)npg * HW, blockIdx.x == 0);
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cb = C >> 3;
-    const uint32_t iu = (uint32_t)i;               // launcher guarantees total < 2^31
-    const int c0 = (int)(iu % (uint32_t)cb) * 8;
-    const int64_t p0 = (int64_t)(iu / (uint32_t)cb) * PX;  // first of PX pixels (PX > 1 only when HW % PX == 0: same image)
-    const int n = (int)((uint32_t)p0 / (uint32_t)HW);
-    const int g = n / npg;
-    const int64_t pig0 = p0 - (int64_t)g * npg * HW;
-    float sc[8], sh[8], kb[8], mu[8], kc[8], mk[8];
-    const float* w = bw_tab + (int64_t)g * 5 * C + c0;
+    while (i < total) {
+        const uint32_t iu = (uint32_t)i;
+        const int c0 = (int)(iu % (uint32_t)cb) * 8;
+        const int64_t p0 = (int64_t)(iu / (uint32_t)cb) * PX;  // first of PX pixels (PX > 1 only when HW % PX == 0: same image)
+        const int n = (int)((uint32_t)p0 / (uint32_t)HW);
+        const int g = n / npg;
+        float sc[8], sh[8], kb[8], mu[8], kc[8], mk[8];
+        const float* w = bw_tab + (int64_t)g * 5 * C + c0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = w[j]; sh[j] = w[C + j]; kb[j] = w[2 * C + j]; mu[j] = w[3 * C + j]; kc[j] = w[4 * C + j]; }
-    if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
-    // all loads of the PX pixels first (dY may alias dA: every thread reads its own elements before it writes them)
-    float y[PX][8], d[PX][8], rs[PX][8], ex[PX][8];
+        for (int j = 0; j < 8; ++j) { sc[j] = w[j]; sh[j] = w[C + j]; kb[j] = w[2 * C + j]; mu[j] = w[3 * C + j]; kc[j] = w[4 * C + j]; }
+        if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
+        float y[PX][8], d[PX][8], rs[PX][8], ex[PX][8];
 #pragma unroll
-    for (int k = 0; k < PX; ++k) {
-        load8<T>(Y + (p0 + k) * ldy + c0, y[k]);
-        load8<T>(dA + g * dav.goff + (pig0 + k) * dav.ld + c0, d[k]);
-        if (res) load8<T>(res + (p0 + k) * ldres + c0, rs[k]);
-        if (extra) load8<T>(extra + (p0 + k) * ldex + c0, ex[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < PX; ++k) {
-        float o[8], dzv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float dz = mask ? d[k][j] * mk[j] : d[k][j];
-            float z = y[k][j] * sc[j] + sh[j];
-            if (res) z += rs[k][j];
-            if (relu && !(z > 0.f)) dz = 0.f;
-            dzv[j] = dz;
-            o[j] = sc[j] * dz + kb[j] * (y[k][j] - mu[j]) + kc[j];
-            if (extra) o[j] += ex[k][j];
+        for (int k = 0; k < PX; ++k) {
+            ry[k].get(y[k]); rd[k].get(d[k]);
+            if (res) rr[k].get(rs[k]);
+            if (extra) re[k].get(ex[k]);
         }
-        if (dZout) store8<T>(dZout + (p0 + k) * lddz + c0, dzv);
-        store8<T>(dY + (p0 + k) * lddy + c0, o);
-    }
+        const int64_t nxt = i + stride;
+        if (nxt < total) fetch(nxt);      // (dY may alias dA: a thread only ever touches its own elements, and reads them first)
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            float o[8], dzv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float dz = mask ? d[k][j] * mk[j] : d[k][j];
+                float z = y[k][j] * sc[j] + sh[j];
+                if (res) z += rs[k][j];
+                if (relu && !(z > 0.f)) dz = 0.f;
+                dzv[j] = dz;
+                o[j] = sc[j] * dz + kb[j] * (y[k][j] - mu[j]) + kc[j];
+                if (extra) o[j] += ex[k][j];
+            }
+            if (dZout) store8<T>(dZout + (p0 + k) * lddz + c0, dzv);
+            store8<T>(dY + (p0 + k) * lddy + c0, o);
+        }
+        i = nxt;
     }
 }
 // ------------------------------------------------------------------ bias gradient (layers without a following BN)
@@ -1196,15 +1303,24 @@ void launch_ecam_backward(int dt, const void* X, int ld, const void* dZ, int ldd
 
 void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, const void* Y, int ldy, const float* stat,
                           const float* mask, int C, int groups, int npg, int64_t HW, int relu, long long* bacc,
-                          hipStream_t s, const void* res, int ldres) {
+                          hipStream_t s, const void* res, int ldres, const SliceViews* extra_src, int base_valid, void* dA_sum) {
+    const SliceViews xs = extra_src ? *extra_src : SliceViews();
+    if (xs.n > 0) {
+        const int ns = xs.n <= 2 ? 2 : xs.n <= 4 ? 4 : MAX_VIEWS;
+#define RED_NS(T_, N_) k_bn_reduce<T_, 1, N_><<<dim3(bn_stats_chunks((int64_t)npg * HW, C), groups), 256, 0, s>>>((const T_*)Y, ldy, (const T_*)dA, GV{ldda, da_goff}, stat, mask, (const T_*)res, ldres, C, npg, HW, relu, (int64_t)npg * HW, bn_stats_chunks((int64_t)npg * HW, C), bacc, xs, base_valid, (T_*)dA_sum)
+        if (dt == BF16) { if (ns == 2) RED_NS(bf16, 2); else if (ns == 4) RED_NS(bf16, 4); else RED_NS(bf16, MAX_VIEWS); }
+        else { if (ns == 2) RED_NS(float, 2); else if (ns == 4) RED_NS(float, 4); else RED_NS(float, MAX_VIEWS); }
+#undef RED_NS
+        return;
+    }
     int64_t ppg = (int64_t)npg * HW;
     int nchunk = bn_stats_chunks(ppg, C);
     dim3 grid(nchunk, groups);
     GV dav{ldda, da_goff};
     if (dt == BF16)
-        k_bn_reduce<bf16, 1><<<grid, 256, 0, s>>>((const bf16*)Y, ldy, (const bf16*)dA, dav, stat, mask, (const bf16*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc);
+        k_bn_reduce<bf16, 1><<<grid, 256, 0, s>>>((const bf16*)Y, ldy, (const bf16*)dA, dav, stat, mask, (const bf16*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc, xs, base_valid, (bf16*)dA_sum);
     else
-        k_bn_reduce<float, 1><<<grid, 256, 0, s>>>((const float*)Y, ldy, (const float*)dA, dav, stat, mask, (const float*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc);
+        k_bn_reduce<float, 1><<<grid, 256, 0, s>>>((const float*)Y, ldy, (const float*)dA, dav, stat, mask, (const float*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc, xs, base_valid, (float*)dA_sum);
 }
 
 void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
