@@ -197,10 +197,13 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
             const int64_t pc = ok[u] ? pu : p;
             load8<T>(yb + pc * ldy, y[u]);
             if (MODE == 1) {
-                if (xs.n == 0 || base_valid) load8<T>(dA + g * dav.goff + pc * dav.ld + mycb * 8, d[u]);
+                if constexpr (NS == 0) load8<T>(dA + g * dav.goff + pc * dav.ld + mycb * 8, d[u]);
                 else {
+                    if (base_valid) load8<T>(dA + g * dav.goff + pc * dav.ld + mycb * 8, d[u]);
+                    else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) d[u][j] = 0.f;
+                        for (int j = 0; j < 8; ++j) d[u][j] = 0.f;
+                    }
                 }
                 if constexpr (NS > 0) {   // every consumer's concat-gradient slice: requested here, summed below
 #pragma unroll
@@ -372,75 +375,64 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
          const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, int groups, float momentum, float eps,
          const SliceViews xd) {
     extern __shared__ float bn_tab[];           // [groups][2][C]
-    const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // the first quad's loads are requested BEFORE the scale / shift table is built (they are in flight during the
-    // accumulator round trip, the double arithmetic and the barrier); later quads are requested one ahead
-    Raw8<T> rv[4], rr[4];
-    auto fetch = [&](int64_t i64) {
-        uint32_t r = (uint32_t)i64;                // 32-bit index arithmetic (the launcher guarantees total < 2^31)
-        const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
-        const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
-        const int yc = (int)(r % (uint32_t)Hc);
-        const int n = (int)(r / (uint32_t)Hc);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {              // clamped inside the map
-            const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
-            const bool ok = y < H && x < W;
-            const int64_t pix = ((int64_t)n * H + (ok ? y : 2 * yc)) * W + (ok ? x : 2 * xc);
-            rv[k].ld(Y + pix * ldy + c0);
-            if (res) rr[k].ld(res + pix * ldres + c0);
-        }
-    };
-    int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i64 < total) fetch(i64);
     bn_fwd_table(bn_tab, facc, gamma, beta, rmean, rvar, stat, C, groups, (int64_t)npg * H * W, momentum, eps, blockIdx.x == 0);
     __syncthreads();
-    while (i64 < total) {
-        uint32_t r = (uint32_t)i64;
-        const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
-        const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
-        const int yc = (int)(r % (uint32_t)Hc);
-        const int n = (int)(r / (uint32_t)Hc);
-        const int g = n / npg, nig = n - g * npg;
-        float sc[8], sh[8], mk[8];
+    // grid-stride walk: the table above is built once per block, the grid is capped (see the launcher)
+    for (int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i64 < total; i64 += (int64_t)gridDim.x * blockDim.x) {
+    const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
+    // 32-bit index arithmetic (the launcher guarantees total < 2^31)
+    uint32_t r = (uint32_t)i64;
+    const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
+    const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
+    const int yc = (int)(r % (uint32_t)Hc);
+    const int n = (int)(r / (uint32_t)Hc);
+    const int g = n / npg, nig = n - g * npg;
+    float sc[8], sh[8], mk[8];
+    {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { sc[j] = bn_tab[(g * 2 + 0) * C + c0 + j]; sh[j] = bn_tab[(g * 2 + 1) * C + c0 + j]; }
-        if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
-        else {
+        if (mask) {
+            const float4* mp = reinterpret_cast<const float4*>(mask + (int64_t)n * C + c0);
+            const float4 m0 = mp[0], m1 = mp[1];
+            mk[0] = m0.x; mk[1] = m0.y; mk[2] = m0.z; mk[3] = m0.w; mk[4] = m1.x; mk[5] = m1.y; mk[6] = m1.z; mk[7] = m1.w;
+        } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) mk[j] = 1.f;
         }
-        float v[4][8], rs[4][8];
+    }
+    // the 2x2 quad: all loads first (clamped inside the map), then the arithmetic and the stores
+    float v[4][8], rs[4][8];
+    bool ok[4];
+    int64_t pix[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            rv[k].get(v[k]);
-            if (res) rr[k].get(rs[k]);
+    for (int k = 0; k < 4; ++k) {
+        const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
+        ok[k] = y < H && x < W;
+        pix[k] = ((int64_t)n * H + (ok[k] ? y : 2 * yc)) * W + (ok[k] ? x : 2 * xc);
+        load8<T>(Y + pix[k] * ldy + c0, v[k]);
+        if (res) load8<T>(res + pix[k] * ldres + c0, rs[k]);
+    }
+    float best[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = v[k][j] * sc[j] + sh[j];
+            if (res) z += rs[k][j];              // residual add before the ReLU (SNUNet conv_block_nested, SNUNet.py:25)
+            if (relu) z = fmaxf(z, 0.f);
+            v[k][j] = round_as<T>(z * mk[j]);
+            best[j] = k == 0 ? v[k][j] : fmaxf(best[j], v[k][j]);   // pooled cells are complete quads: every k is inside
         }
-        const int64_t nxt = i64 + stride;
-        if (nxt < total) fetch(nxt);
-        float best[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float z = v[k][j] * sc[j] + sh[j];
-                if (res) z += rs[k][j];              // residual add before the ReLU (SNUNet conv_block_nested, SNUNet.py:25)
-                if (relu) z = fmaxf(z, 0.f);
-                v[k][j] = round_as<T>(z * mk[j]);
-                best[j] = k == 0 ? v[k][j] : fmaxf(best[j], v[k][j]);   // pooled cells are complete quads: every k is inside
-            }
+        if (ok[k]) {
             const int y = 2 * yc + (k >> 1), x = 2 * xc + (k & 1);
-            if (y < H && x < W) {
-                const int64_t pg = ((int64_t)nig * H + y) * W + x;
-                store8<T>(A + g * av.goff + pg * av.ld + c0, v[k]);
-                for (int e = 0; e < xd.n; ++e)      // dense concatenation: the consumers' input slices, written here (no copy kernels)
-                    if ((xd.gmask[e] >> g) & 1)
-                        store8<T>(reinterpret_cast<T*>(xd.p[e]) + (xd.gmask[e] == 3 ? g * xd.goff[e] : 0) + pg * xd.ld[e] + c0, v[k]);
-            }
+            const int64_t pg = ((int64_t)nig * H + y) * W + x;
+            store8<T>(A + g * av.goff + pg * av.ld + c0, v[k]);
+            for (int e = 0; e < xd.n; ++e)      // dense concatenation: the consumers' input slices, written here (no copy kernels)
+                if ((xd.gmask[e] >> g) & 1)
+                    store8<T>(reinterpret_cast<T*>(xd.p[e]) + (xd.gmask[e] == 3 ? g * xd.goff[e] : 0) + pg * xd.ld[e] + c0, v[k]);
         }
-        if (P && yc < Hp && xc < Wp) store8<T>(P + (((int64_t)n * Hp + yc) * Wp + xc) * ldp + c0, best);
-        i64 = nxt;
+    }
+    if (P && yc < Hp && xc < Wp) store8<T>(P + (((int64_t)n * Hp + yc) * Wp + xc) * ldp + c0, best);
     }
 }
 
@@ -817,66 +809,46 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
                T* __restrict__ dZout, int lddz, const T* __restrict__ extra, int ldex, int C, int npg, int64_t HW, int relu,
                int64_t total) {
     extern __shared__ float bw_tab[];           // [groups][5][C]
-    const int cb = C >> 3;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // the first item's loads are requested BEFORE the coefficient table is built (one dependent round trip to the
-    // accumulators + double arithmetic + a barrier): they are in flight meanwhile; later items are requested one ahead
-    Raw8<T> ry[PX], rd[PX], rr[PX], re[PX];
-    auto fetch = [&](int64_t i) {
-        const uint32_t iu = (uint32_t)i;               // launcher guarantees total < 2^31
-        const int c0 = (int)(iu % (uint32_t)cb) * 8;
-        const int64_t p0 = (int64_t)(iu / (uint32_t)cb) * PX;
-        const int g = (int)((uint32_t)p0 / (uint32_t)HW) / npg;
-        const int64_t pig0 = p0 - (int64_t)g * npg * HW;
-#pragma unroll
-        for (int k = 0; k < PX; ++k) {
-            ry[k].ld(Y + (p0 + k) * ldy + c0);
-            rd[k].ld(dA + g * dav.goff + (pig0 + k) * dav.ld + c0);
-            if (res) rr[k].ld(res + (p0 + k) * ldres + c0);
-            if (extra) re[k].ld(extra + (p0 + k) * ldex + c0);
-        }
-    };
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) fetch(i);
     bn_bwd_table(bw_tab, bacc, stat, dgamma, dbeta, C, groups, (int64_t)npg * HW, blockIdx.x == 0);
     __syncthreads();
-    while (i < total) {
-        const uint32_t iu = (uint32_t)i;
-        const int c0 = (int)(iu % (uint32_t)cb) * 8;
-        const int64_t p0 = (int64_t)(iu / (uint32_t)cb) * PX;  // first of PX pixels (PX > 1 only when HW % PX == 0: same image)
-        const int n = (int)((uint32_t)p0 / (uint32_t)HW);
-        const int g = n / npg;
-        float sc[8], sh[8], kb[8], mu[8], kc[8], mk[8];
-        const float* w = bw_tab + (int64_t)g * 5 * C + c0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cb = C >> 3;
+    const uint32_t iu = (uint32_t)i;               // launcher guarantees total < 2^31
+    const int c0 = (int)(iu % (uint32_t)cb) * 8;
+    const int64_t p0 = (int64_t)(iu / (uint32_t)cb) * PX;  // first of PX pixels (PX > 1 only when HW % PX == 0: same image)
+    const int n = (int)((uint32_t)p0 / (uint32_t)HW);
+    const int g = n / npg;
+    const int64_t pig0 = p0 - (int64_t)g * npg * HW;
+    float sc[8], sh[8], kb[8], mu[8], kc[8], mk[8];
+    const float* w = bw_tab + (int64_t)g * 5 * C + c0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = w[j]; sh[j] = w[C + j]; kb[j] = w[2 * C + j]; mu[j] = w[3 * C + j]; kc[j] = w[4 * C + j]; }
-        if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
-        float y[PX][8], d[PX][8], rs[PX][8], ex[PX][8];
+    for (int j = 0; j < 8; ++j) { sc[j] = w[j]; sh[j] = w[C + j]; kb[j] = w[2 * C + j]; mu[j] = w[3 * C + j]; kc[j] = w[4 * C + j]; }
+    if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
+    // all loads of the PX pixels first (dY may alias dA: every thread reads its own elements before it writes them)
+    float y[PX][8], d[PX][8], rs[PX][8], ex[PX][8];
 #pragma unroll
-        for (int k = 0; k < PX; ++k) {
-            ry[k].get(y[k]); rd[k].get(d[k]);
-            if (res) rr[k].get(rs[k]);
-            if (extra) re[k].get(ex[k]);
+    for (int k = 0; k < PX; ++k) {
+        load8<T>(Y + (p0 + k) * ldy + c0, y[k]);
+        load8<T>(dA + g * dav.goff + (pig0 + k) * dav.ld + c0, d[k]);
+        if (res) load8<T>(res + (p0 + k) * ldres + c0, rs[k]);
+        if (extra) load8<T>(extra + (p0 + k) * ldex + c0, ex[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        float o[8], dzv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float dz = mask ? d[k][j] * mk[j] : d[k][j];
+            float z = y[k][j] * sc[j] + sh[j];
+            if (res) z += rs[k][j];
+            if (relu && !(z > 0.f)) dz = 0.f;
+            dzv[j] = dz;
+            o[j] = sc[j] * dz + kb[j] * (y[k][j] - mu[j]) + kc[j];
+            if (extra) o[j] += ex[k][j];
         }
-        const int64_t nxt = i + stride;
-        if (nxt < total) fetch(nxt);      // (dY may alias dA: a thread only ever touches its own elements, and reads them first)
-#pragma unroll
-        for (int k = 0; k < PX; ++k) {
-            float o[8], dzv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float dz = mask ? d[k][j] * mk[j] : d[k][j];
-                float z = y[k][j] * sc[j] + sh[j];
-                if (res) z += rs[k][j];
-                if (relu && !(z > 0.f)) dz = 0.f;
-                dzv[j] = dz;
-                o[j] = sc[j] * dz + kb[j] * (y[k][j] - mu[j]) + kc[j];
-                if (extra) o[j] += ex[k][j];
-            }
-            if (dZout) store8<T>(dZout + (p0 + k) * lddz + c0, dzv);
-            store8<T>(dY + (p0 + k) * lddy + c0, o);
-        }
-        i = nxt;
+        if (dZout) store8<T>(dZout + (p0 + k) * lddz + c0, dzv);
+        store8<T>(dY + (p0 + k) * lddy + c0, o);
+    }
     }
 }
 // ------------------------------------------------------------------ bias gradient (layers without a following BN)
