@@ -138,6 +138,12 @@ int stcd_loss_ce(const float* logits, const int64_t* target, int batch, int clas
  * bit 1 set: the Dice term alone (class Dice, train_pse_cd.py:436-447), without the BCE term. */
 int stcd_loss_bce_dice(const float* x, const float* target, int64_t numel, int from_logits, float* loss_out, float* dx,
                        void* scratch, void* hip_stream);
+/* contrastive loss of the semi-supervised stage (replaces contrastive_loss, /root/reference/train_stcd.py:334-385):
+ * pred fp32 [2*numel_half] PROBABILITIES, first half = change prediction of the real pairs (cd), second half = of the
+ * pseudo pairs (pse); labels int64 [numel_half] each.  loss = masked MSE(pse, cd) over (cd_label == pse_label) + masked
+ * MSE(pse, |cd - 1|) over the rest, each divided by (count + 1e-8); dpred (nullable) = d loss / d pred, both halves. */
+int stcd_loss_contrastive(const float* pred, const int64_t* cd_label, const int64_t* pse_label, int64_t numel_half, float* loss_out,
+                          float* dpred, void* scratch, void* hip_stream);
 /* ---- metric: replaces SegmentationMetric.genConfusionMatrix (train_pse_cd.py:361-368) without the
  *      per-step .cpu() sync (train_pse_cd.py:231).  cm[2*label+pred] += count; cm is 4 int64 on the device.
  *      pred = argmax over classes (classes==2) or logit > 0 (classes==1, i.e. sigmoid > 0.5). */

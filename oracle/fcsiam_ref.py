@@ -297,6 +297,19 @@ def cd_loss(prob, target):
     return dice + bce
 
 
+def contrastive_loss(pred, cd_label, pse_label):
+    """/root/reference/train_stcd.py:334-385: pred = cat(cd_pred, pse_pred) on dim 0 (probabilities);
+    M = (cd_label == pse_label), N = its complement;
+    sum((pse - cd)^2 M) / (sum M + 1e-8) + sum((pse - |cd - 1|)^2 N) / (sum N + 1e-8)."""
+    b = cd_label.shape[0]
+    cd_pred, pse_pred = pred[:b], pred[b:]
+    M = (cd_label == pse_label).to(pred.dtype)
+    N = 1.0 - M
+    pos = ((pse_pred - cd_pred) ** 2 * M).sum() / (M.sum() + 1e-8)
+    neg = ((pse_pred - torch.abs(cd_pred - 1.0)) ** 2 * N).sum() / (N.sum() + 1e-8)
+    return pos + neg
+
+
 # ----------------------------------------------------------------------- metrics
 def confusion_matrix(pred, label, num_class=2):
     """train_pse_cd.py:361-368: bincount(numClass*label + pred) -> [label, pred] counts (float64)."""

@@ -337,6 +337,8 @@ void launch_loss_ce(const float* logits, const int64_t* target, int B, int Cn, i
                     float* dlogits, void* scratch, hipStream_t s);
 void launch_loss_bce_dice(const float* logits, const float* target, int64_t n, int from_logits, float* loss,
                           float* dlogits, void* scratch, hipStream_t s);
+void launch_loss_contrastive(const float* pred, const int64_t* cd_label, const int64_t* pse_label, int64_t n_half, float* loss,
+                             float* dpred, void* scratch, hipStream_t s);
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float omb1, float beta2, float omb2, float eps,
                  float wd, int decoupled, float step_size, float inv_bc2_sqrt, hipStream_t s);
 void launch_pseudo_pair(const uint8_t* A, const uint8_t* donor, const uint8_t* mask, const uint8_t* change, const float* alpha,

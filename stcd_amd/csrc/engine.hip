@@ -1767,6 +1767,14 @@ int stcd_loss_bce_dice(const float* logits, const float* target, int64_t numel, 
     STCD_HIP(hipGetLastError());
     return 0;
 }
+int stcd_loss_contrastive(const float* pred, const int64_t* cd_label, const int64_t* pse_label, int64_t numel_half, float* loss_out,
+                          float* dpred, void* scratch, void* hip_stream) {
+    STCD_CHECK(pred && cd_label && pse_label && loss_out && scratch, "null pointer argument");
+    STCD_CHECK(numel_half >= 1, "bad shape");
+    launch_loss_contrastive(pred, cd_label, pse_label, numel_half, loss_out, dpred, scratch, (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
 int stcd_confusion_update(const float* logits, const int64_t* target, int batch, int classes, int64_t hw, int64_t* cm,
                           void* hip_stream) {
     STCD_CHECK(logits && target && cm, "null pointer argument");

@@ -171,6 +171,61 @@ void launch_loss_bce_dice(const float* logits, const float* target, int64_t n, i
     if (dlogits) k_bd_grad<<<nb, 256, 0, s>>>(logits, target, n, from_logits, sc, dlogits);
 }
 
+// ------------------------------------------------------------------ contrastive loss of the semi-supervised stage
+// /root/reference/train_stcd.py:334-385: pred [2b,1,H,W] probabilities = cat(real change pairs, pseudo change pairs);
+// M = (cd_label == pse_label), N = (cd_label != pse_label);
+//   loss = sum((pse - cd)^2 * M) / (sum M + 1e-8) + sum((pse - |cd - 1|)^2 * N) / (sum N + 1e-8)
+// with gradients to BOTH halves (d|cd-1|/dcd = sign(cd - 1)).
+__global__ void __launch_bounds__(256)
+k_ct_reduce(const float* __restrict__ pred, const int64_t* __restrict__ cd_label, const int64_t* __restrict__ pse_label, int64_t n,
+            LossScratch* sc) {
+    __shared__ double sm[16];
+    double v[4] = {0.0, 0.0, 0.0, 0.0};   // sum pos, sum M, sum neg, sum N
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float cd = pred[i], ps = pred[n + i];
+        if (cd_label[i] == pse_label[i]) { const float d = ps - cd; v[0] += (double)(d * d); v[1] += 1.0; }
+        else { const float d = ps - fabsf(cd - 1.f); v[2] += (double)(d * d); v[3] += 1.0; }
+    }
+    block_sum4(v, sm);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 4; ++k) sc->part[blockIdx.x][k] = v[k];
+}
+__global__ void k_ct_finalize(LossScratch* sc, int nblocks, float* loss) {
+    __shared__ double sm[16];
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+        for (int k = 0; k < 4; ++k) v[k] += sc->part[b][k];
+    block_sum4(v, sm);
+    if (threadIdx.x == 0) {
+        sc->fin[0] = v[1] + 1e-8; sc->fin[1] = v[3] + 1e-8;
+        *loss = (float)(v[0] / (v[1] + 1e-8) + v[2] / (v[3] + 1e-8));
+    }
+}
+__global__ void __launch_bounds__(256)
+k_ct_grad(const float* __restrict__ pred, const int64_t* __restrict__ cd_label, const int64_t* __restrict__ pse_label, int64_t n,
+          const LossScratch* sc, float* __restrict__ dpred) {
+    const float im = (float)(1.0 / sc->fin[0]), in_ = (float)(1.0 / sc->fin[1]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float cd = pred[i], ps = pred[n + i];
+        if (cd_label[i] == pse_label[i]) {
+            const float g = 2.f * (ps - cd) * im;
+            dpred[n + i] = g; dpred[i] = -g;
+        } else {
+            const float t = cd - 1.f, g = 2.f * (ps - fabsf(t)) * in_;
+            dpred[n + i] = g;
+            dpred[i] = -g * (float)((t > 0.f) - (t < 0.f));
+        }
+    }
+}
+void launch_loss_contrastive(const float* pred, const int64_t* cd_label, const int64_t* pse_label, int64_t n_half, float* loss,
+                             float* dpred, void* scratch, hipStream_t s) {
+    LossScratch* sc = (LossScratch*)scratch;
+    int nb = (int)std::min<int64_t>(LOSS_BLOCKS, (n_half + 255) / 256);
+    k_ct_reduce<<<nb, 256, 0, s>>>(pred, cd_label, pse_label, n_half, sc);
+    k_ct_finalize<<<1, 256, 0, s>>>(sc, nb, loss);
+    if (dpred) k_ct_grad<<<nb, 256, 0, s>>>(pred, cd_label, pse_label, n_half, sc, dpred);
+}
+
 // ------------------------------------------------------------------ 2x2 confusion matrix: cm[2*label+pred] += count
 __global__ void __launch_bounds__(256)
 k_confusion(const float* __restrict__ logits, const int64_t* __restrict__ target, int Cn, int64_t HW, int64_t npix,

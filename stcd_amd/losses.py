@@ -99,6 +99,35 @@ def bce_dice_with_logits(logits, target):
     return _BceDiceFn.apply(logits.contiguous().float(), target.contiguous().float(), True)
 
 
+class _ContrastiveFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, cd_label, pse_label):
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        need_grad = pred.requires_grad
+        dp = torch.empty_like(pred) if need_grad else None
+        with torch.cuda.device(pred.device):
+            _lib.check(_lib.lib().stcd_loss_contrastive(_p(pred), _p(cd_label), _p(pse_label), cd_label.numel(), _p(loss),
+                                                        _p(dp) if need_grad else None, _p(_scratch_for(pred.device)), _stream()))
+        ctx.dp = dp
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.dp * g, None, None
+
+
+def contrastive_loss(pred, cd_label, pse_label, img_name=None):
+    """/root/reference/train_stcd.py:334-385, same arguments (``img_name`` only fed the reference's commented-out
+    visualisation): ``pred`` = change PROBABILITIES of cat(real pairs, pseudo pairs) along the batch axis, the labels of
+    the two halves [b,1,H,W]; masked MSE between the halves where the labels agree plus masked MSE against the inverted
+    real prediction where they differ.  One fused HIP pass for value and gradient (both halves receive gradient)."""
+    _need_cuda(pred, "contrastive_loss")
+    b = cd_label.shape[0]
+    if pred.shape[0] != 2 * b or cd_label.shape != pse_label.shape or pred[:b].shape != cd_label.shape:
+        raise StcdError(f"contrastive_loss: pred {tuple(pred.shape)} must hold 2 x the label batch {tuple(cd_label.shape)}")
+    return _ContrastiveFn.apply(pred.contiguous().float(), cd_label.contiguous().long(), pse_label.contiguous().long())
+
+
 class Dice(nn.Module):
     """train_pse_cd.py:436-447: 1 - (2*sum(p*t) + 1) / (sum(p) + sum(t) + 1) on probabilities."""
 

@@ -17,6 +17,7 @@ Groups:
   G5  confusion-matrix metrics (independent check through scikit-learn)
   G6  odd-size (100x100) forward -- ReplicationPad2d branch
   G7  train-mode step at 2x128x128 (diff / conc / SNUNet): the bar of the bf16 production path
+  G8  contrastive_loss of train_stcd.py (the reference's own function, compiled from its file)
 """
 import os
 import sys
@@ -397,9 +398,44 @@ def g7_train128():
         save(f"g7_{arch}_128.npz", **d)
 
 
+# ------------------------------------------------------------------------------ G8
+def g8_contrastive():
+    """contrastive_loss of /root/reference/train_stcd.py:334-385.  The module cannot be imported (argparse at import time,
+    pytorch_grad_cam / smp / timm absent), so the reference's OWN function is compiled from its file (ast: that one
+    FunctionDef, nothing is copied into this repository) and run on CPU with Tensor.cuda() made a no-op."""
+    import ast
+    print("G8 contrastive_loss")
+    src = open("/root/reference/train_stcd.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "contrastive_loss"][0]
+    ns = {"torch": torch, "F": F}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "/root/reference/train_stcd.py", "exec"), ns)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    rng = np.random.default_rng(800)
+    d = {}
+    for tag, shape in (("a", (2, 1, 16, 16)), ("b", (3, 1, 9, 11))):
+        b = shape[0]
+        pred = torch.from_numpy(rng.random((2 * b,) + shape[1:]).astype(np.float32))
+        pred[0, 0, 0, 0] = 1.0                     # |cd - 1| at its kink (sign 0)
+        cd = torch.from_numpy(rng.integers(0, 2, size=shape)).long()
+        ps = torch.from_numpy(rng.integers(0, 2, size=shape)).long()
+        cd[0, 0, 0, 0], ps[0, 0, 0, 0] = 0, 1
+        pred.requires_grad_(True)
+        loss = ns["contrastive_loss"](pred, cd, ps, None)
+        loss.backward()
+        d[f"{tag}/pred"], d[f"{tag}/cd_label"], d[f"{tag}/pse_label"] = t2n(pred), t2n(cd), t2n(ps)
+        d[f"{tag}/loss"], d[f"{tag}/dpred"] = loss.item(), t2n(pred.grad)
+    # all labels equal -> N empty (0 / 1e-8 = 0)
+    pred = torch.from_numpy(rng.random((4, 1, 8, 8)).astype(np.float32)).requires_grad_(True)
+    lab = torch.from_numpy(rng.integers(0, 2, size=(2, 1, 8, 8))).long()
+    loss = ns["contrastive_loss"](pred, lab, lab.clone(), None)
+    loss.backward()
+    d["same/pred"], d["same/cd_label"], d["same/pse_label"], d["same/loss"], d["same/dpred"] = t2n(pred), t2n(lab), t2n(lab), loss.item(), t2n(pred.grad)
+    save("g8_contrastive.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8"]
     fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd,
-          "g7": g7_train128}
+          "g7": g7_train128, "g8": g8_contrastive}
     for w in which:
         fn[w]()

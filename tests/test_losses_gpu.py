@@ -170,3 +170,26 @@ def test_bce_dice_ignores_cutout_label_255():
     np.testing.assert_allclose(g[~cut], ref_dl, rtol=1e-4, atol=1e-8)
     y_bad = y.copy(); y_bad[0, 0, 0, 0] = 7.0
     assert torch.isnan(losses.bce_dice_with_logits(t(x).to(DEV), t(y_bad).to(DEV)))
+
+
+def test_contrastive_loss_against_reference_vectors(golden):
+    """stcd_loss_contrastive (train_stcd.py:334-385) against the vectors produced by the reference's own function: value and
+    the gradient of BOTH halves, incl. the |cd - 1| kink, an odd map and the all-labels-equal case (empty N mask)."""
+    g = golden("g8_contrastive.npz")
+    for tag in ("a", "b", "same"):
+        pred = t(g[f"{tag}/pred"]).to(DEV).requires_grad_(True)
+        loss = losses.contrastive_loss(pred, t(g[f"{tag}/cd_label"]).to(DEV), t(g[f"{tag}/pse_label"]).to(DEV), None)
+        (2.0 * loss).backward()
+        assert abs(loss.item() - float(g[f"{tag}/loss"])) < 1e-6
+        np.testing.assert_allclose(pred.grad.cpu().numpy(), 2.0 * g[f"{tag}/dpred"], rtol=1e-5, atol=1e-8)
+    # bench-sized: against the oracle
+    from oracle import fcsiam_ref as R
+    rng = np.random.default_rng(12)
+    p = rng.random((16, 1, 256, 256)).astype(np.float32)
+    cd, ps = rng.integers(0, 2, size=(8, 1, 256, 256)), rng.integers(0, 2, size=(8, 1, 256, 256))
+    pr = t(p).requires_grad_(True)
+    ref = R.contrastive_loss(pr, t(cd), t(ps)); ref.backward()
+    pg = t(p).to(DEV).requires_grad_(True)
+    got = losses.contrastive_loss(pg, t(cd).to(DEV), t(ps).to(DEV)); got.backward()
+    assert abs(got.item() - ref.item()) < 1e-6
+    np.testing.assert_allclose(pg.grad.cpu().numpy(), pr.grad.numpy(), rtol=1e-4, atol=1e-10)

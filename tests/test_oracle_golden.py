@@ -177,3 +177,14 @@ def test_train_step_128_against_reference_vectors(golden, arch):
         if r:
             worst = (max(worst[0], r[0]), min(worst[1], r[1]))
     print(f"oracle vs reference at 128x128 ({arch}): worst relative l2 {worst[0]:.2e}, worst cosine {worst[1]:.6f}")
+
+
+def test_contrastive_loss_against_reference_vectors(golden):
+    """G8: the reference's own contrastive_loss (train_stcd.py:334-385, compiled from its file by make_golden.py)."""
+    g = golden("g8_contrastive.npz")
+    for tag in ("a", "b", "same"):
+        pred = _t(g[f"{tag}/pred"]).requires_grad_(True)
+        loss = R.contrastive_loss(pred, _t(g[f"{tag}/cd_label"]), _t(g[f"{tag}/pse_label"]))
+        loss.backward()
+        assert abs(loss.item() - float(g[f"{tag}/loss"])) < 1e-6
+        np.testing.assert_allclose(pred.grad.numpy(), g[f"{tag}/dpred"], rtol=1e-5, atol=1e-8)
