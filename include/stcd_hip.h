@@ -170,6 +170,18 @@ int stcd_pseudo_pair(const uint8_t* img_a, const uint8_t* donor, const uint8_t* 
                      const float* std3, float* x1, float* x2, int64_t* c_label, int64_t* s_label_a, int64_t* s_label_b,
                      void* hip_stream);
 
+/* ---- photometric augmentation on the device: counterpart of the host-side PIL/torchvision path of the datasets
+ *      (/root/reference/data/dataset.py:488-495 ColorJitter(0.5,0.5,0.5,0.25) w.p. 0.5, RandomGrayscale(0.2), blur() :120-124)
+ *      on normalised fp32 NCHW images [n_images,3,H,W] already on the device (e.g. the x1/x2 of stcd_pseudo_pair).
+ *      params: device fp32 [n_images][8] = {jitter_on, brightness, contrast, saturation, hue, gray_on, sigma (0: no blur), 0};
+ *      torchvision's float functional formulas, fixed order brightness -> contrast -> saturation -> hue, then grayscale, then a
+ *      separable Gaussian (radius ceil(3 sigma), replicated edges).  The reference holds no device arithmetic for this:
+ *      parity is unpinned beyond the per-op formulas (oracle/pseudo_ref.py restates them; tests pin them to PIL).
+ *      out must not alias x; scratch >= stcd_augment_scratch_bytes() bytes. */
+int64_t stcd_augment_scratch_bytes(int n_images, int height, int width);
+int stcd_augment(const float* x, const float* params, int n_images, int height, int width, const float* mean3, const float* std3,
+                 float* out, void* scratch, int64_t scratch_bytes, void* hip_stream);
+
 /* ---- per-op entry points (NHWC, activation dtype per `dtype`); used by the parity tests.
  *      Geometry is the engine's generic "tap list" convolution: see DESIGN.md section 3. ---- */
 typedef struct stcd_conv_geom {

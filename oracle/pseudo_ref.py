@@ -51,3 +51,66 @@ def pseudo_pair(img_a, donor, mask, change, alpha=None, erase_xywh=None, seed=0,
     inv = np.float32(1.0) / std.astype(np.float32)
     norm = lambda t: np.ascontiguousarray(((t * np.float32(1.0 / 255.0) - mean) * inv).transpose(0, 3, 1, 2)).astype(np.float32)
     return norm(a), norm(b), c_label, s_a, s_b
+
+
+# ------------------------------------------------------------------------------------------ photometric augmentation
+def _gray(rgb):
+    return np.float32(0.299) * rgb[0] + np.float32(0.587) * rgb[1] + np.float32(0.114) * rgb[2]
+
+
+def _hue(rgb, hf):
+    """torchvision.transforms._functional_tensor._rgb2hsv / _hsv2rgb on float images, hue shifted by hf (mod 1)."""
+    r, g, b = rgb
+    mx, mn = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    eqc = mx == mn
+    cr = mx - mn
+    sat = cr / np.where(eqc, np.float32(1), mx)
+    crd = np.where(eqc, np.float32(1), cr)
+    rc, gc, bc = (mx - r) / crd, (mx - g) / crd, (mx - b) / crd
+    h = np.where(mx == r, bc - gc, 0) + np.where((mx == g) & (mx != r), 2 + rc - bc, 0) + np.where((mx != g) & (mx != r), 4 + gc - rc, 0)
+    h = (h / 6 + 1) % 1
+    h = (h + np.float32(hf)) % 1
+    v = mx
+    i6 = np.floor(h * 6)
+    f = h * 6 - i6
+    i = i6.astype(np.int64) % 6
+    p = np.clip(v * (1 - sat), 0, 1); q = np.clip(v * (1 - sat * f), 0, 1); t = np.clip(v * (1 - sat * (1 - f)), 0, 1)
+    out = np.empty_like(rgb)
+    out[0] = np.choose(i, [v, q, p, p, t, v]); out[1] = np.choose(i, [t, v, v, q, p, p]); out[2] = np.choose(i, [p, p, t, v, v, q])
+    return out.astype(np.float32)
+
+
+def _blur1d(img, sigma, axis):
+    rad = min(8, int(np.ceil(3.0 * sigma)))
+    d = np.arange(-rad, rad + 1)
+    w = np.exp(np.float32(-0.5 / (sigma * sigma)) * (d * d).astype(np.float32)).astype(np.float32)
+    n = img.shape[axis]
+    acc = np.zeros_like(img)
+    for k, dd in enumerate(d):
+        idx = np.clip(np.arange(n) + dd, 0, n - 1)
+        acc += w[k] * np.take(img, idx, axis=axis)
+    return acc / w.sum()
+
+
+def augment(x, params, mean=MEAN, std=STD):
+    """Restatement of stcd_augment: x normalised fp32 [N,3,H,W]; params [N,8] = {jitter_on, brightness, contrast,
+    saturation, hue, gray_on, sigma, 0}.  Per-op formulas = torchvision F.adjust_* on float tensors
+    (the reference calls them through T.ColorJitter / T.RandomGrayscale, data/dataset.py:488-495)."""
+    x = np.asarray(x, np.float32)
+    out = np.empty_like(x)
+    m, s = mean.reshape(3, 1, 1), std.reshape(3, 1, 1)
+    for n in range(x.shape[0]):
+        on, br, ct, st, hf, gr, sigma, _ = (np.float32(v) for v in params[n])
+        img = x[n] * s + m
+        if on:
+            img = np.clip(br * img, 0, 1)
+            img = np.clip(ct * img + (1 - ct) * np.float32(_gray(img).mean(dtype=np.float64)), 0, 1)
+            img = np.clip(st * img + (1 - st) * _gray(img)[None], 0, 1)
+            if hf != 0:
+                img = _hue(img, hf)
+        if gr:
+            img = np.repeat(_gray(img)[None], 3, 0)
+        if sigma > 0:
+            img = _blur1d(_blur1d(img.astype(np.float32), float(sigma), 2), float(sigma), 1)
+        out[n] = (img - m) / s
+    return out.astype(np.float32)

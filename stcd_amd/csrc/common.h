@@ -344,6 +344,9 @@ void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float 
 void launch_pseudo_pair(const uint8_t* A, const uint8_t* donor, const uint8_t* mask, const uint8_t* change, const float* alpha,
                         const int32_t* erase, uint64_t seed, int B, int H, int W, const float* mean, const float* std_,
                         float* x1, float* x2, int64_t* c_label, int64_t* s_label_a, int64_t* s_label_b, hipStream_t s);
+void launch_augment(const float* x, const float* params, int N, int H, int W, const float* mean, const float* std_, float* out,
+                    void* scratch, hipStream_t s);
+int64_t augment_scratch_bytes(int N, int H, int W);
 void launch_confusion(const float* logits, const int64_t* target, int B, int Cn, int64_t HW, int64_t* cm,
                       hipStream_t s);
 

@@ -1812,6 +1812,21 @@ int stcd_pseudo_pair(const uint8_t* img_a, const uint8_t* donor, const uint8_t* 
     return 0;
 }
 
+int64_t stcd_augment_scratch_bytes(int n_images, int height, int width) {
+    return (n_images >= 1 && height >= 1 && width >= 1) ? augment_scratch_bytes(n_images, height, width) : 0;
+}
+int stcd_augment(const float* x, const float* params, int n_images, int height, int width, const float* mean3, const float* std3,
+                 float* out, void* scratch, int64_t scratch_bytes, void* hip_stream) {
+    STCD_CHECK(x && params && mean3 && std3 && out && scratch, "null pointer argument");
+    STCD_CHECK(n_images >= 1 && n_images <= 65535 && height >= 1 && width >= 1, "bad shape");
+    STCD_CHECK(std3[0] > 0.f && std3[1] > 0.f && std3[2] > 0.f, "std must be positive");
+    STCD_CHECK(scratch_bytes >= augment_scratch_bytes(n_images, height, width), "scratch too small");
+    STCD_CHECK(x != out, "in-place augmentation is not supported (the blur reads neighbours)");
+    launch_augment(x, params, n_images, height, width, mean3, std3, out, scratch, (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
 static int check_geom(const stcd_conv_geom* g) {
     STCD_CHECK(g != nullptr, "geometry is null");
     STCD_CHECK(g->ntaps >= 1 && g->ntaps <= 9, "ntaps must be in [1,9]");

@@ -363,4 +363,131 @@ void launch_pseudo_pair(const uint8_t* A, const uint8_t* donor, const uint8_t* m
                                                                   c_label, s_label_a, s_label_b);
 }
 
+// ------------------------------------------------------------------ photometric augmentation on the device
+// Counterpart of the PIL / torchvision host path of the pseudo-change / change datasets
+// (/root/reference/data/dataset.py:488-495: T.ColorJitter(0.5, 0.5, 0.5, 0.25) w.p. 0.5, T.RandomGrayscale(p=0.2),
+// blur(): GaussianBlur(sigma ~ U(0.1, 2)) w.p. 0.5 (:120-124); then ToTensor + Normalize :499-500), on normalised fp32
+// NCHW images that are already resident on the device.  Per image n the caller supplies
+//   params[n] = {jitter_on, brightness, contrast, saturation, hue, gray_on, sigma, 0}
+// (stcd_amd.augment draws them with the reference's probabilities).  Arithmetic = torchvision's float-tensor functional
+// ops (F.adjust_brightness / _contrast / _saturation / _hue, rgb_to_grayscale) in the fixed order brightness -> contrast
+// -> saturation -> hue (ColorJitter shuffles that order: this build fixes it, PARITY UNPINNED beyond the per-op formulas,
+// which tests pin to PIL's ImageEnhance on the CPU), then RandomGrayscale, then a separable true Gaussian of radius
+// ceil(3 sigma) with replicated edges (PIL approximates its GaussianBlur by box filters).
+__device__ __forceinline__ float aug_gray(float r, float g, float b) { return 0.299f * r + 0.587f * g + 0.114f * b; }
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+__global__ void __launch_bounds__(256)
+k_aug_mean(const float* __restrict__ x, const float* __restrict__ params, int64_t HW, float m0, float m1, float m2, float s0, float s1,
+           float s2, unsigned long long* __restrict__ acc) {
+    const int n = blockIdx.y;
+    const float* p = params + n * 8;
+    if (p[0] == 0.f) return;                                        // no jitter for this image: the mean is not needed
+    const float br = p[1];
+    const float* xr = x + (int64_t)n * 3 * HW;
+    float sum = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (int64_t)gridDim.x * blockDim.x) {
+        const float r = clamp01(br * (xr[i] * s0 + m0)), g = clamp01(br * (xr[HW + i] * s1 + m1)), b = clamp01(br * (xr[2 * HW + i] * s2 + m2));
+        sum += aug_gray(r, g, b);
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc + n, (unsigned long long)llrint((double)sum * 1048576.0));   // 2^20 fixed point: exact, order-free
+}
+
+__device__ __forceinline__ void aug_hue(float& r, float& g, float& b, float hf) {
+    // torchvision _rgb2hsv / _hsv2rgb on floats
+    const float mx = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b));
+    const float eqc = mx == mn ? 1.f : 0.f, cr = mx - mn;
+    const float sat = cr / (eqc != 0.f ? 1.f : mx), crd = eqc != 0.f ? 1.f : cr;
+    const float rc = (mx - r) / crd, gc = (mx - g) / crd, bc = (mx - b) / crd;
+    float h = (mx == r ? (bc - gc) : 0.f) + ((mx == g && mx != r) ? (2.f + rc - bc) : 0.f) + ((mx != g && mx != r) ? (4.f + gc - rc) : 0.f);
+    h = h / 6.f + 1.f;
+    h = h - floorf(h);
+    h = h + hf;
+    h = h - floorf(h);
+    const float v = mx, i6 = floorf(h * 6.f), f = h * 6.f - i6;
+    const int i = ((int)i6) % 6;
+    const float p = clamp01(v * (1.f - sat)), q = clamp01(v * (1.f - sat * f)), t = clamp01(v * (1.f - sat * (1.f - f)));
+    switch (i) {
+        case 0: r = v; g = t; b = p; break;
+        case 1: r = q; g = v; b = p; break;
+        case 2: r = p; g = v; b = t; break;
+        case 3: r = p; g = q; b = v; break;
+        case 4: r = t; g = p; b = v; break;
+        default: r = v; g = p; b = q; break;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_aug_point(const float* __restrict__ x, const float* __restrict__ params, int64_t HW, float m0, float m1, float m2, float s0, float s1,
+            float s2, const unsigned long long* __restrict__ acc, float* __restrict__ out01) {
+    const int n = blockIdx.y;
+    const float* p = params + n * 8;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const float* xr = x + (int64_t)n * 3 * HW;
+    float r = xr[i] * s0 + m0, g = xr[HW + i] * s1 + m1, b = xr[2 * HW + i] * s2 + m2;     // back to [0,1] RGB
+    if (p[0] != 0.f) {
+        const float br = p[1], ct = p[2], st = p[3], hf = p[4];
+        r = clamp01(br * r); g = clamp01(br * g); b = clamp01(br * b);
+        const float mean = (float)((double)acc[n] / 1048576.0 / (double)HW);
+        r = clamp01(ct * r + (1.f - ct) * mean); g = clamp01(ct * g + (1.f - ct) * mean); b = clamp01(ct * b + (1.f - ct) * mean);
+        const float gr = aug_gray(r, g, b);
+        r = clamp01(st * r + (1.f - st) * gr); g = clamp01(st * g + (1.f - st) * gr); b = clamp01(st * b + (1.f - st) * gr);
+        if (hf != 0.f) aug_hue(r, g, b, hf);
+    }
+    if (p[5] != 0.f) { const float gr = aug_gray(r, g, b); r = g = b = gr; }
+    float* o = out01 + (int64_t)n * 3 * HW;
+    o[i] = r; o[HW + i] = g; o[2 * HW + i] = b;
+}
+
+// one separable pass (dir 0: along x, 1: along y); the last pass also re-normalises
+__global__ void __launch_bounds__(256)
+k_aug_blur(const float* __restrict__ in, const float* __restrict__ params, int H, int W, int dir, int normalise, float m0, float m1,
+           float m2, float is0, float is1, float is2, float* __restrict__ out) {
+    const int n = blockIdx.z, c = blockIdx.y;
+    const int64_t HW = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const float sigma = params[n * 8 + 6];
+    const float* pl = in + ((int64_t)n * 3 + c) * HW;
+    const int y = (int)(i / W), xq = (int)(i - (int64_t)y * W);
+    float v;
+    if (sigma > 0.f) {
+        const int rad = min(8, (int)ceilf(3.f * sigma));
+        const float k = -0.5f / (sigma * sigma);
+        float acc_ = 0.f, wsum = 0.f;
+        for (int d = -rad; d <= rad; ++d) {
+            const float wgt = expf(k * (float)(d * d));
+            const int yy = dir ? min(max(y + d, 0), H - 1) : y, xx = dir ? xq : min(max(xq + d, 0), W - 1);
+            acc_ += wgt * pl[(int64_t)yy * W + xx];
+            wsum += wgt;
+        }
+        v = acc_ / wsum;
+    } else {
+        v = pl[i];
+    }
+    if (normalise) {
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), istd = c == 0 ? is0 : (c == 1 ? is1 : is2);
+        v = (v - mean) * istd;
+    }
+    out[((int64_t)n * 3 + c) * HW + i] = v;
+}
+
+void launch_augment(const float* x, const float* params, int N, int H, int W, const float* mean, const float* std_, float* out,
+                    void* scratch, hipStream_t s) {
+    const int64_t HW = (int64_t)H * W;
+    unsigned long long* acc = (unsigned long long*)scratch;                     // [N] fixed-point gray sums
+    float* t0 = (float*)((char*)scratch + (((size_t)N * 8 + 255) & ~(size_t)255));
+    float* t1 = t0 + (size_t)N * 3 * HW;
+    (void)hipMemsetAsync(acc, 0, (size_t)N * 8, s);
+    const int chunks = (int)std::min<int64_t>(64, (HW + 1023) / 1024);
+    k_aug_mean<<<dim3(chunks, N), 256, 0, s>>>(x, params, HW, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], acc);
+    k_aug_point<<<dim3((unsigned)((HW + 255) / 256), N), 256, 0, s>>>(x, params, HW, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], acc, t0);
+    dim3 gb((unsigned)((HW + 255) / 256), 3, N);
+    k_aug_blur<<<gb, 256, 0, s>>>(t0, params, H, W, 0, 0, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, t1);
+    k_aug_blur<<<gb, 256, 0, s>>>(t1, params, H, W, 1, 1, mean[0], mean[1], mean[2], 1.f / std_[0], 1.f / std_[1], 1.f / std_[2], out);
+}
+int64_t augment_scratch_bytes(int N, int H, int W) { return (((int64_t)N * 8 + 255) & ~(int64_t)255) + (int64_t)2 * N * 3 * H * W * 4 + 256; }
+
 }  // namespace stcd
