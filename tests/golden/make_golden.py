@@ -18,6 +18,7 @@ Groups:
   G6  odd-size (100x100) forward -- ReplicationPad2d branch
   G7  train-mode step at 2x128x128 (diff / conc / SNUNet): the bar of the bf16 production path
   G8  contrastive_loss of train_stcd.py (the reference's own function, compiled from its file)
+  G10 SegCD (ResNet-50 UNet, the model the scripts train): eval / train outputs, loss, sampled gradients
 """
 import os
 import sys
@@ -433,9 +434,95 @@ def g8_contrastive():
     save("g8_contrastive.npz", **d)
 
 
+# ------------------------------------------------------------------------------ G10
+def _reference_segcd(classes=1):
+    """The reference's own pieces, assembled exactly as SegCD.__init__ / forward state (decoders/unet/model.py:267-332).
+    The package `segmentation_models_pytorch` cannot be imported (its __init__ pulls timm; encoders/resnet.py pulls
+    torchvision), so: the ResNet is the reference's models/resnet.py (the torchvision code ResNetEncoder subclasses), and
+    base/ (Conv2dReLU, SegmentationHead) and decoders/unet/decoder.py (UnetDecoder) are loaded as files under a bare
+    package object -- no stand-in for any missing library is written."""
+    import importlib.util
+    import types
+    from models.resnet import ResNet, Bottleneck
+    root = "/root/reference/segmentation_models_pytorch"
+    if "segmentation_models_pytorch" not in sys.modules:
+        pkg = types.ModuleType("segmentation_models_pytorch")
+        pkg.__path__ = [root]
+        sys.modules["segmentation_models_pytorch"] = pkg
+    from segmentation_models_pytorch.base import SegmentationHead
+    spec = importlib.util.spec_from_file_location("_ref_unet_decoder", root + "/decoders/unet/decoder.py")
+    dec_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dec_mod)
+
+    class RefSegCD(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = ResNet(Bottleneck, [3, 4, 6, 3])            # resnet50 (encoders/resnet.py:"resnet50" params)
+            del self.encoder.fc, self.encoder.avgpool                   # ResNetEncoder.__init__ (encoders/resnet.py:44-45)
+            self.decoder = dec_mod.UnetDecoder(encoder_channels=(3, 64, 256, 512, 1024, 2048), decoder_channels=(256, 128, 64, 32, 16),
+                                               n_blocks=5, use_batchnorm=True, center=False, attention_type=None)
+            self.segmentation_head = SegmentationHead(in_channels=16, out_channels=classes, activation=None, kernel_size=3)
+
+        def features(self, x):                                          # ResNetEncoder.get_stages / forward (:47-66)
+            e = self.encoder
+            f = [x]
+            x = e.relu(e.bn1(e.conv1(x))); f.append(x)
+            x = e.layer1(e.maxpool(x)); f.append(x)
+            x = e.layer2(x); f.append(x)
+            x = e.layer3(x); f.append(x)
+            x = e.layer4(x); f.append(x)
+            return f
+
+        def forward(self, A, B):                                        # SegCD.forward (model.py:316-332)
+            x1_decode = self.decoder(*self.features(A))
+            x2_decode = self.decoder(*self.features(B))
+            mask_t1 = self.segmentation_head(x1_decode)
+            mask_t2 = self.segmentation_head(x2_decode)
+            diffea = self.segmentation_head(torch.abs(x1_decode - x2_decode))
+            diffseg = torch.abs(mask_t1 - mask_t2)
+            return mask_t1, mask_t2, torch.min(diffea, diffseg)
+
+    return RefSegCD()
+
+
+def g10_segcd():
+    from oracle import segcd_ref
+    print("G10 SegCD (ResNet-50 UNet)")
+    seed = 1000
+    d = {"seed": seed}
+    m = _reference_segcd(1)
+    names = [k for k in m.state_dict().keys()]
+    assert names == [n for n, _, _ in segcd_ref.param_specs(3, 1)], "state_dict order differs from oracle.segcd_ref.param_specs"
+    x1, x2 = rand_pair(seed + 1, 2, 64, 64)
+    d["x1"], d["x2"] = t2n(x1), t2n(x2)
+    m.load_state_dict(segcd_ref.synth_state(3, 1, seed, perturb_running=True))
+    m.eval()
+    with torch.no_grad():
+        o = m(x1, x2)
+    d["eval/m1"], d["eval/m2"], d["eval/change"] = (t2n(t) for t in o)
+    m = _reference_segcd(1)
+    m.load_state_dict(segcd_ref.synth_state(3, 1, seed))
+    m.train()
+    m1, m2, ch = m(x1, x2)
+    rng = np.random.default_rng(seed + 4)
+    tgt = torch.from_numpy((rng.random((2, 1, 64, 64)) < 0.2).astype(np.float32))
+    seg = torch.from_numpy((rng.random((2, 1, 64, 64)) < 0.3).astype(np.float32))
+    d["target"], d["seg_target"] = t2n(tgt), t2n(seg)
+    # the semi-supervised stage's sum (train_stcd.py:427-445 without the contrastive term): seg loss on mask_t1 + cd loss
+    loss = ref_losses.cd_loss(torch.sigmoid(m1), seg) + ref_losses.cd_loss(torch.sigmoid(ch), tgt) + 0.5 * m2.mean()
+    loss.backward()
+    d["train/m1"], d["train/m2"], d["train/change"], d["loss"] = t2n(m1), t2n(m2), t2n(ch), loss.item()
+    d.update(grad_summary(m))
+    sd = m.state_dict()
+    for k in ("encoder.bn1", "encoder.layer1.0.downsample.1", "encoder.layer4.2.bn3", "decoder.blocks.0.conv1.1", "decoder.blocks.4.conv2.1"):
+        d[f"rs/{k}.running_mean"], d[f"rs/{k}.running_var"] = t2n(sd[f"{k}.running_mean"]), t2n(sd[f"{k}.running_var"])
+        d[f"rs/{k}.num_batches_tracked"] = t2n(sd[f"{k}.num_batches_tracked"])
+    save("g10_segcd.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10"]
     fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd,
-          "g7": g7_train128, "g8": g8_contrastive}
+          "g7": g7_train128, "g8": g8_contrastive, "g10": g10_segcd}
     for w in which:
         fn[w]()

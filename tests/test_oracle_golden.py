@@ -188,3 +188,42 @@ def test_contrastive_loss_against_reference_vectors(golden):
         loss.backward()
         assert abs(loss.item() - float(g[f"{tag}/loss"])) < 1e-6
         np.testing.assert_allclose(pred.grad.numpy(), g[f"{tag}/dpred"], rtol=1e-5, atol=1e-8)
+
+
+def test_segcd_eval_and_train_step_against_reference_vectors(golden):
+    """G10: the ResNet-50 UNet change detector the reference's scripts train (smp.SegCD), assembled from the reference's own
+    ResNet / UnetDecoder / SegmentationHead: the three outputs in eval and train mode, the loss, every parameter's
+    (sampled) gradient and BatchNorm running statistics (each BatchNorm sees date A, then date B)."""
+    from oracle import segcd_ref as G
+    from tests._util import check_grad
+    g = golden("g10_segcd.npz")
+    seed = int(g["seed"])
+    x1, x2 = _t(g["x1"]), _t(g["x2"])
+    st = G.synth_state(3, 1, seed, perturb_running=True)
+    with torch.no_grad():
+        o = G.forward(st, x1, x2)
+    for k, v in zip(("m1", "m2", "change"), o):
+        np.testing.assert_allclose(v.numpy(), g[f"eval/{k}"], rtol=2e-4, atol=2e-4)
+    st = G.synth_state(3, 1, seed)
+    params = [k for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
+    for k in params:
+        st[k].requires_grad_(True)
+    m1, m2, ch = G.forward(st, x1, x2, training=True)
+    for k, v in zip(("m1", "m2", "change"), (m1, m2, ch)):
+        np.testing.assert_allclose(v.detach().numpy(), g[f"train/{k}"], rtol=5e-4, atol=5e-4)
+    loss = R.cd_loss(torch.sigmoid(m1), _t(g["seg_target"])) + R.cd_loss(torch.sigmoid(ch), _t(g["target"])) + 0.5 * m2.mean()
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    worst = (0.0, 1.0)
+    for k in params:
+        if st[k].grad is None or float(np.abs(g["gs/" + k][1])) < 1e-12:
+            continue
+        # ~110 piecewise-linear layers (ReLU gates, a 3x3 max-pool, |a-b|, min) with BatchNorms over as few as 2*2*2 samples at
+        # this fixture's size: two fp32 evaluation orders of the same arithmetic (torch's fused batch_norm vs the explicit
+        # formula here) already differ by 2e-2 at the stem -- the bound is 5e-2 / 0.998 for this network
+        r = check_grad(k, st[k].grad, g, rel_max=5e-2, cos_min=0.998)
+        if r:
+            worst = (max(worst[0], r[0]), min(worst[1], r[1]))
+    print(f"SegCD oracle vs reference: worst relative l2 {worst[0]:.2e}, worst cosine {worst[1]:.6f}")
+    for k in [k for k in g if k.startswith("rs/")]:
+        np.testing.assert_allclose(st[k[3:]].detach().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
