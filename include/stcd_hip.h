@@ -36,6 +36,10 @@ extern "C" {
 #define STCD_ARCH_CONC 1   /* "SiamUnet_conc" -> SiamUnet_conc  */
 #define STCD_ARCH_SUB 2    /* "SiamUnet_sub"  -> SiamUnet_sub   */
 #define STCD_ARCH_SNUNET 3 /* "SNUNet"        -> SNUNet_ECAM    */
+#define STCD_ARCH_SEGCD 4  /* smp.SegCD(encoder_name="resnet50"): the model the scripts train (train_pse_cd.py:419-427,
+                            * segmentation_models_pytorch/decoders/unet/model.py:267-332).  Its forward returns THREE maps
+                            * (mask_t1, mask_t2, change): `logits` / `grad_logits` of stcd_forward / stcd_backward hold
+                            * [3*batch, label_ch, H, W] floats in that order; H and W must be divisible by 32. */
 
 /* arithmetic / storage type of activations. Parameters, gradients, BN statistics, logits: always fp32. */
 #define STCD_DTYPE_F32 0  /* parity mode: fp32 storage, fp32 FMA */

@@ -15,9 +15,9 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstcd_hip.so")
 
-ARCH_DIFF, ARCH_CONC, ARCH_SUB, ARCH_SNUNET = 0, 1, 2, 3
+ARCH_DIFF, ARCH_CONC, ARCH_SUB, ARCH_SNUNET, ARCH_SEGCD = 0, 1, 2, 3, 4
 DTYPE_F32, DTYPE_BF16 = 0, 1
-ARCH_IDS = {"diff": ARCH_DIFF, "conc": ARCH_CONC, "sub": ARCH_SUB, "snunet": ARCH_SNUNET}
+ARCH_IDS = {"diff": ARCH_DIFF, "conc": ARCH_CONC, "sub": ARCH_SUB, "snunet": ARCH_SNUNET, "segcd": ARCH_SEGCD}
 DTYPE_IDS = {"fp32": DTYPE_F32, "f32": DTYPE_F32, "bf16": DTYPE_BF16}
 
 

@@ -331,6 +331,17 @@ void launch_bias_grad(int dt, const void* dY, int ld, int64_t pixels, int C, flo
 void launch_dropout_gen(float* mask, int64_t n, uint64_t seed, float p, hipStream_t s);
 void launch_fill(float* p, int64_t n, float v, hipStream_t s);
 
+// ---- ResNet-50 UNet (SegCD) specific kernels (kernels_ew.hip)
+void launch_stem_fwd(int dt, const void* X, const float* w, void* Y, int N, int H, int W, int cin, int Co, hipStream_t s);
+void launch_stem_wgrad(int dt, const void* X, const void* dY, float* dW, int N, int H, int W, int cin, int Co, hipStream_t s);
+void launch_maxpool3(int dt, const void* A, int lda, void* P, int ldp, int N, int H, int W, int C, hipStream_t s);
+void launch_maxpool3_bwd(int dt, const void* A, int lda, const void* dP, int ldp, void* dA, int ldda, int N, int H, int W, int C,
+                         hipStream_t s);
+void launch_upsample2(int dt, const void* X, int ldx, void* D, int ldd, int N, int h, int w, int C, hipStream_t s);
+void launch_upsample2_bwd(int dt, const void* dD, int ldd, void* dX, int ldx, int N, int h, int w, int C, hipStream_t s);
+void launch_segcd_combine(const float* raw, float* out, int64_t n, hipStream_t s);
+void launch_segcd_combine_bwd(const float* raw, const float* g, float* draw, int64_t n, hipStream_t s);
+
 // losses / metric (kernels_loss.hip)
 int64_t loss_scratch_bytes();
 void launch_loss_ce(const float* logits, const int64_t* target, int B, int Cn, int64_t HW, int ignore, float* loss,

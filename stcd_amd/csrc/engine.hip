@@ -11,6 +11,7 @@
 // Layer tables restate /root/reference/models/SiamUnet_diff.py:13-92 (+ SiamUnet_conc.py:54-87); the forward
 // order follows SiamUnet_diff.py:94-181.
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -22,7 +23,7 @@ namespace stcd {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
-enum ConvKind { K_CONV3 = 0, K_CONVT3_S1 = 1, K_UPCONV = 2, K_CONV1 = 3, K_CONVT2 = 4 };
+enum ConvKind { K_CONV3 = 0, K_CONVT3_S1 = 1, K_UPCONV = 2, K_CONV1 = 3, K_CONVT2 = 4, K_CONV3_S2 = 5, K_CONV1_S2 = 6, K_STEM7 = 7 };
 
 struct TRef { int64_t off = -1; int ld = 0; };                 // byte offset in workspace, pixel stride (elements)
 struct GRef { int64_t off = -1; int ld = 0; int64_t goff = 0; }; // grouped view (see common.h)
@@ -118,9 +119,27 @@ struct Prof {
     ~Prof() { for (auto ev : pool) (void)hipEventDestroy(ev); }
 };
 
+// ---- SegCD plan: one generic layer = conv (1x1 / 3x3 / strided / the 7x7 stem) -> BatchNorm [-> + residual] [-> ReLU]
+struct ViewRef { int64_t off = 0; int ld = 0; int64_t goff = 0; int gmask = 1; };    // workspace-relative SliceViews entry
+struct GLayer {
+    std::string name;
+    int conv = -1, bn = -1, kind = K_CONV3;
+    int N = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0, K = 0, C = 0, groups = 2, npg = 0;
+    bool relu = true;
+    TRef in, Y, A, res;                   // res.off < 0: no residual
+    TRef dA, dIn, dRes;                   // dA: summed gradient of A (dY is formed in place); dIn: this layer's contribution to
+    bool has_dIn = true;                  // d(in); dRes: gated gradient of the residual branch (dZout), off < 0: none
+    std::vector<ViewRef> extra_dst;       // decoder concat slices that also receive A
+    std::vector<ViewRef> grad_src;        // gradient contributions gathered into dA by the BatchNorm-backward reduction
+    bool grad_base = true;                // dA already holds a contribution when the backward of this layer starts
+    ConvOp fwd, dgr[4]; int ndgr = 0; WgradOp wg;
+    int64_t stat = -1, coef = -1, facc = -1, bacc = -1;
+};
+enum GStepKind { GS_LAYER = 0, GS_MAXPOOL = 1, GS_UPSAMPLE = 2 };
+struct GStep { int kind = GS_LAYER; int layer = -1; TRef src, dst, dsrc, ddst; int N = 0, h = 0, w = 0, C = 0; };
+
 // ---- SNUNet-ECAM plan (SNUNet.py:63-152)
 struct SrcSlice { TRef src; TRef dsrc; int C = 0; int prod = -1; int grp = -1; };   // a producer's output inside a consumer's concat
-struct ViewRef { int64_t off = 0; int ld = 0; int64_t goff = 0; int gmask = 1; };    // workspace-relative SliceViews entry
 struct NBlock {                                              // conv_block_nested (SNUNet.py:8-26)
     std::string name;
     int c1 = -1, bn1 = -1, c2 = -1, bn2 = -1;
@@ -156,6 +175,15 @@ struct stcd_engine_impl {
     int64_t sn_pool = -1, sn_argm = -1, sn_att = -1, sn_hid = -1, sn_sums = -1, sn_dpool = -1, sn_part = -1;
     int64_t sn_dout_begin = -1, sn_dout_end = -1;
     ConvOp sn_final_fwd, sn_final_dgr; WgradOp sn_final_wg;
+    // ---- SegCD (ResNet-50 UNet) plan
+    std::vector<GLayer> g_layers;                            // every conv + BatchNorm (+ residual) (+ ReLU) layer, forward order
+    std::vector<GStep> g_fwd;                                // forward program (the backward walks it in reverse)
+    int g_stem = -1, g_head_conv = -1;
+    std::vector<std::array<int, 4>> g_blocks;                // (L1, L2, L3, Ld or -1) per bottleneck
+    std::vector<std::array<int, 2>> g_dec;                   // (conv1, conv2) per decoder block
+    TRef gP0, gdP0, gX3, gdX3, gFuseTmp;
+    int64_t g_raw3 = -1, g_draw3 = -1;
+    ConvOp g_head_fwd, g_head_dgr; WgradOp g_head_wg;
     int arch = 0, in_ch = 3, label = 2, dt = F32;
     float drop_p = 0.2f;
     std::vector<stcd_tensor_info> params;
@@ -220,8 +248,26 @@ static void add_param(stcd_engine& e, const std::string& name, std::initializer_
 }
 
 static void make_specs(ConvW& c, bool need_dgrad) {
-    if (c.kind == K_CONV1 || c.kind == K_CONVT2) {
-        const int ks = c.kind == K_CONV1 ? 1 : 2;
+    if (c.kind == K_STEM7) {      // dedicated kernels read / write the reference layout directly: nothing to pack
+        c.fwd = PackSpec{}; c.dgrad = PackSpec{};
+        c.fwd.ks = 7; c.fwd.K = c.cin; c.fwd.N = c.cout; c.fwd.kpad = c.kin_p; c.fwd.wld = c.nout_p;
+        return;
+    }
+    if (c.kind == K_CONV3_S2) {   // Conv2d(k3, s2, p1): forward = stride-2 gather; data gradient = 4 sub-pixel phases (as K_UPCONV's forward)
+        PackSpec& f = c.fwd;
+        f.ks = 3; f.K = c.cin; f.N = c.cout; f.kpad = c.kin_p; f.wld = c.nout_p; f.ntaps = 9; f.kn_major = 0;
+        for (int k = 0; k < 9; ++k) { f.ky[k] = k / 3; f.kx[k] = k % 3; }
+        PackSpec& d = c.dgrad;
+        d.ks = 3; d.K = c.cout; d.N = c.cin; d.kpad = c.nout_p; d.wld = round8(c.cin); d.ntaps = need_dgrad ? 9 : 0; d.kn_major = 1;
+        int t = 0;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px)
+                for (int dy = 0; dy <= py; ++dy)
+                    for (int dx = 0; dx <= px; ++dx) { d.ky[t] = py + 1 - 2 * dy; d.kx[t] = px + 1 - 2 * dx; ++t; }
+        return;
+    }
+    if (c.kind == K_CONV1 || c.kind == K_CONVT2 || c.kind == K_CONV1_S2) {
+        const int ks = c.kind == K_CONVT2 ? 2 : 1;
         PackSpec& f = c.fwd;
         f.ks = ks; f.K = c.cin; f.N = c.cout; f.kpad = c.kin_p; f.wld = c.nout_p;
         f.ntaps = ks * ks;
@@ -230,7 +276,7 @@ static void make_specs(ConvW& c, bool need_dgrad) {
         PackSpec& d = c.dgrad;
         d.ks = ks; d.K = c.cout; d.N = c.cin; d.kpad = c.nout_p; d.wld = round8(c.cin);
         d.ntaps = need_dgrad ? ks * ks : 0;
-        d.kn_major = c.kind == K_CONV1;
+        d.kn_major = c.kind != K_CONVT2;
         for (int t = 0; t < ks * ks; ++t) { d.ky[t] = t / ks; d.kx[t] = t % ks; }   // K_CONVT2: tap (dy,dx) of the stride-2 gather
         return;
     }
@@ -278,15 +324,17 @@ static void make_specs(ConvW& c, bool need_dgrad) {
     }
 }
 
-static int add_conv(stcd_engine& e, const std::string& name, int kind, int cin, int cout, bool need_dgrad) {
+static int add_conv(stcd_engine& e, const std::string& name, int kind, int cin, int cout, bool need_dgrad, bool bias = true) {
     ConvW c;
     c.name = name; c.kind = kind; c.cin = cin; c.cout = cout;
     c.kin_p = round8(cin); c.nout_p = round8(cout);
-    if (kind == K_CONV3) add_param(e, name + ".weight", {cout, cin, 3, 3}, &c.w_off);
-    else if (kind == K_CONV1) add_param(e, name + ".weight", {cout, cin, 1, 1}, &c.w_off);
+    if (kind == K_CONV3 || kind == K_CONV3_S2) add_param(e, name + ".weight", {cout, cin, 3, 3}, &c.w_off);
+    else if (kind == K_CONV1 || kind == K_CONV1_S2) add_param(e, name + ".weight", {cout, cin, 1, 1}, &c.w_off);
+    else if (kind == K_STEM7) add_param(e, name + ".weight", {cout, cin, 7, 7}, &c.w_off);
     else if (kind == K_CONVT2) add_param(e, name + ".weight", {cin, cout, 2, 2}, &c.w_off);
     else add_param(e, name + ".weight", {cin, cout, 3, 3}, &c.w_off);
-    add_param(e, name + ".bias", {cout}, &c.b_off);
+    c.b_off = -1;
+    if (bias) add_param(e, name + ".bias", {cout}, &c.b_off);
     make_specs(c, need_dgrad);
     e.convs.push_back(c);
     return (int)e.convs.size() - 1;
@@ -1587,6 +1635,384 @@ static int backward_snunet(stcd_engine& e, const float* grad_logits, const float
     return 0;
 }
 
+
+// ================================================================================================ SegCD (ResNet-50 UNet)
+// smp.SegCD(encoder_name="resnet50"): the model the reference's scripts train (train_pse_cd.py:419-427, train_stcd.py:631-638).
+//   SegCD.forward            /root/reference/segmentation_models_pytorch/decoders/unet/model.py:316-332
+//   ResNet-50 encoder        /root/reference/segmentation_models_pytorch/encoders/resnet.py:37-70, /root/reference/models/resnet.py:78-190
+//   UnetDecoder              /root/reference/segmentation_models_pytorch/decoders/unet/decoder.py:8-123
+// Both dates run as ONE batch of 2B images through the shared encoder + decoder (every BatchNorm keeps per-date statistics:
+// the modules are called once per date); only the head combines them.  Gradients of tensors with several consumers
+// (identity branches, decoder skips) are never accumulated by extra kernels: every consumer writes its own contribution
+// buffer and the producer's BatchNorm-backward reduction gathers them (SliceViews).
+static const int RS_LAYERS[4] = {3, 4, 6, 3}, RS_PLANES[4] = {64, 128, 256, 512};
+static const int SEG_DEC[5] = {256, 128, 64, 32, 16};
+
+static int add_glayer(stcd_engine& e, const std::string& conv_name, const std::string& bn_name, int kind, int cin, int cout, bool relu,
+                      bool need_dgrad) {
+    GLayer L;
+    L.name = conv_name; L.kind = kind; L.relu = relu; L.has_dIn = need_dgrad;
+    L.conv = add_conv(e, conv_name, kind, cin, cout, need_dgrad, false);
+    L.bn = add_bn(e, bn_name, cout, 2);
+    e.g_layers.push_back(L);
+    return (int)e.g_layers.size() - 1;
+}
+
+static void build_segcd_tables(stcd_engine& e) {
+    e.g_layers.clear(); e.g_blocks.clear(); e.g_dec.clear();
+    e.g_stem = add_glayer(e, "encoder.conv1", "encoder.bn1", K_STEM7, e.in_ch, 64, true, false);
+    int inpl = 64;
+    for (int li = 0; li < 4; ++li)
+        for (int b = 0; b < RS_LAYERS[li]; ++b) {
+            const int w = RS_PLANES[li], stride = (b == 0 && li > 0) ? 2 : 1;
+            const std::string pre = "encoder.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            std::array<int, 4> blk;
+            blk[0] = add_glayer(e, pre + ".conv1", pre + ".bn1", K_CONV1, inpl, w, true, true);
+            blk[1] = add_glayer(e, pre + ".conv2", pre + ".bn2", stride == 2 ? K_CONV3_S2 : K_CONV3, w, w, true, true);
+            blk[2] = add_glayer(e, pre + ".conv3", pre + ".bn3", K_CONV1, w, 4 * w, true, true);
+            blk[3] = b == 0 ? add_glayer(e, pre + ".downsample.0", pre + ".downsample.1", stride == 2 ? K_CONV1_S2 : K_CONV1, inpl, 4 * w, false, true) : -1;
+            e.g_blocks.push_back(blk);
+            inpl = 4 * w;
+        }
+    static const int ENC_OUT[5] = {2048, 1024, 512, 256, 64};
+    int cin = ENC_OUT[0];
+    for (int i = 0; i < 5; ++i) {
+        const int cskip = i < 4 ? ENC_OUT[i + 1] : 0, cout = SEG_DEC[i];
+        const std::string pre = "decoder.blocks." + std::to_string(i);
+        std::array<int, 2> d;
+        d[0] = add_glayer(e, pre + ".conv1.0", pre + ".conv1.1", K_CONV3, cin + cskip, cout, true, true);
+        d[1] = add_glayer(e, pre + ".conv2.0", pre + ".conv2.1", K_CONV3, cout, cout, true, true);
+        e.g_dec.push_back(d);
+        cin = cout;
+    }
+    e.g_head_conv = add_conv(e, "segmentation_head.0", K_CONV3, SEG_DEC[4], e.label, true, true);
+    e.enc_param_end = 0;      // one backward stage
+}
+
+static int configure_segcd(stcd_engine& e, int B, int H, int W) {
+    const int64_t T = (int64_t)dsize(e.dt);
+    const int N = 2 * B;
+    e.drops.clear(); e.drop_floats = 0;
+    e.conv_ops.clear(); e.wgrad_ops.clear(); e.slab_floats = 0;
+    e.g_fwd.clear();
+    Bump ws;
+    auto plain = [&](int n, int h, int w, int C) { TRef t; t.off = ws.take((int64_t)n * h * w * C * T); t.ld = C; return t; };
+    auto view = [&](const TRef& t, int coff, int ld, int h, int w) {       // both dates of a plain [2B,h,w,ld] tensor, channel offset coff
+        ViewRef v; v.off = t.off + (int64_t)coff * T; v.ld = ld; v.goff = (int64_t)B * h * w * ld; v.gmask = 3; return v;
+    };
+    for (auto& L : e.g_layers) { L.extra_dst.clear(); L.grad_src.clear(); L.grad_base = true; L.res = TRef(); L.dRes = TRef(); L.ndgr = 0; }
+    e.X0 = plain(N, H, W, 8);
+    // ---- shapes + activation buffers, forward order
+    auto shape = [&](GLayer& L, const TRef& in, int K, int hi, int wi, int stride) {
+        const ConvW& cv = e.convs[L.conv];
+        L.N = N; L.groups = 2; L.npg = B; L.in = in; L.K = K; L.Hi = hi; L.Wi = wi; L.Ho = hi / stride; L.Wo = wi / stride; L.C = cv.cout;
+        L.Y = plain(N, L.Ho, L.Wo, L.C); L.A = plain(N, L.Ho, L.Wo, L.C); L.dA = plain(N, L.Ho, L.Wo, L.C);
+        L.stat = ws.take((int64_t)2 * 4 * L.C * 4); L.coef = ws.take((int64_t)2 * 5 * L.C * 4);
+    };
+    GLayer& S = e.g_layers[e.g_stem];
+    shape(S, e.X0, 8, H, W, 2);
+    S.has_dIn = false;
+    { GStep st; st.kind = GS_LAYER; st.layer = e.g_stem; e.g_fwd.push_back(st); }
+    e.gP0 = plain(N, H / 4, W / 4, 64); e.gdP0 = plain(N, H / 4, W / 4, 64);
+    { GStep st; st.kind = GS_MAXPOOL; st.src = S.A; st.dst = e.gP0; st.dsrc = S.dA; st.ddst = e.gdP0; st.N = N; st.h = H / 2; st.w = W / 2; st.C = 64; e.g_fwd.push_back(st); }
+    TRef cur = e.gP0; int curC = 64, h = H / 4, w = W / 4, prev_out = -1;      // prev_out: layer whose A is `cur` (-1: the max-pool)
+    std::vector<int> stage_out;                                               // L3 of the last block of layer1..4
+    size_t bi = 0;
+    for (int li = 0; li < 4; ++li)
+        for (int b = 0; b < RS_LAYERS[li]; ++b, ++bi) {
+            const std::array<int, 4>& blk = e.g_blocks[bi];
+            const int stride = (b == 0 && li > 0) ? 2 : 1;
+            GLayer& L1 = e.g_layers[blk[0]]; GLayer& L2 = e.g_layers[blk[1]]; GLayer& L3 = e.g_layers[blk[2]];
+            shape(L1, cur, curC, h, w, 1);
+            shape(L2, L1.A, L1.C, h, w, stride);
+            const int ho = h / stride, wo = w / stride;
+            if (blk[3] >= 0) { GLayer& Ld = e.g_layers[blk[3]]; shape(Ld, cur, curC, h, w, stride); }
+            shape(L3, L2.A, L2.C, ho, wo, 1);
+            L3.res = blk[3] >= 0 ? e.g_layers[blk[3]].A : cur;
+            // gradient wiring: single-consumer tensors are written in place, the block input gets contribution buffers
+            L2.dIn = L1.dA; L3.dIn = L2.dA;
+            L1.dIn = (prev_out < 0) ? e.gdP0 : plain(N, h, w, curC);
+            TRef idc;                                                          // identity-branch contribution to d(cur)
+            if (blk[3] >= 0) { GLayer& Ld = e.g_layers[blk[3]]; L3.dRes = Ld.dA; Ld.dIn = plain(N, h, w, curC); idc = Ld.dIn; }
+            else { L3.dRes = plain(N, h, w, curC); idc = L3.dRes; }
+            if (prev_out >= 0) {
+                GLayer& Pv = e.g_layers[prev_out];
+                Pv.grad_base = false;
+                Pv.grad_src.push_back(view(L1.dIn, 0, curC, h, w));
+                Pv.grad_src.push_back(view(idc, 0, curC, h, w));
+            }
+            for (int k : {blk[0], blk[1]}) { GStep st; st.layer = k; e.g_fwd.push_back(st); }
+            if (blk[3] >= 0) { GStep st; st.layer = blk[3]; e.g_fwd.push_back(st); }
+            { GStep st; st.layer = blk[2]; e.g_fwd.push_back(st); }
+            cur = L3.A; curC = L3.C; h = ho; w = wo; prev_out = blk[2];
+            if (b == RS_LAYERS[li] - 1) stage_out.push_back(blk[2]);
+        }
+    // ---- decoder: x = f5; block i: nearest x2 into cat_i[:, :Cx], skip (written by its encoder producer) in cat_i[:, Cx:]
+    const int skip_layer[4] = {stage_out[2], stage_out[1], stage_out[0], e.g_stem};          // f4, f3, f2, f1
+    int xl = stage_out[3];                                                                  // layer producing x
+    e.g_layers[xl].grad_base = true;                                                        // f5: the up-sampling gradient alone
+    for (int i = 0; i < 5; ++i) {
+        GLayer& X = e.g_layers[xl];
+        const int Cx = X.C, hh = 2 * X.Ho, ww = 2 * X.Wo;
+        const int Cs = i < 4 ? e.g_layers[skip_layer[i]].C : 0;
+        TRef cat = plain(N, hh, ww, Cx + Cs), dcat = plain(N, hh, ww, Cx + Cs);
+        { GStep st; st.kind = GS_UPSAMPLE; st.src = X.A; st.dst = cat; st.dsrc = X.dA; st.ddst = dcat; st.N = N; st.h = X.Ho; st.w = X.Wo; st.C = Cx; e.g_fwd.push_back(st); }
+        if (i < 4) {
+            GLayer& Sk = e.g_layers[skip_layer[i]];
+            Sk.extra_dst.push_back(view(cat, Cx, Cx + Cs, hh, ww));
+            Sk.grad_src.push_back(view(dcat, Cx, Cx + Cs, hh, ww));
+        }
+        GLayer& D1 = e.g_layers[e.g_dec[i][0]]; GLayer& D2 = e.g_layers[e.g_dec[i][1]];
+        shape(D1, cat, Cx + Cs, hh, ww, 1);
+        shape(D2, D1.A, D1.C, hh, ww, 1);
+        D1.dIn = dcat; D2.dIn = D1.dA;
+        for (int k : {e.g_dec[i][0], e.g_dec[i][1]}) { GStep st; st.layer = k; e.g_fwd.push_back(st); }
+        xl = e.g_dec[i][1];
+    }
+    // ---- head: X3 = [d1; d2; |d1 - d2|] (3B images), one conv launch; the last decoder layer writes d1, d2 straight into X3
+    GLayer& DL = e.g_layers[xl];
+    e.gX3 = plain(3 * B, H, W, 16); e.gdX3 = plain(3 * B, H, W, 16); e.gFuseTmp = plain(N, H, W, 16);
+    DL.A = e.gX3; DL.dA = e.gdX3;
+    DL.grad_base = true;
+    DL.grad_src.push_back(view(e.gFuseTmp, 0, 16, H, W));
+    e.g_raw3 = ws.take((int64_t)3 * B * e.label * H * W * 4); e.g_draw3 = ws.take((int64_t)3 * B * e.label * H * W * 4);
+    e.G = plain(3 * B, H, W, 8);
+    for (auto& L : e.g_layers)
+        if ((int)L.extra_dst.size() > MAX_VIEWS || (int)L.grad_src.size() > MAX_VIEWS) { set_error("internal: too many views"); return 1; }
+    // ---- zero arena: accumulators, tickets-free (consumer-side tables), bias accumulator of the head
+    e.zero_begin = ws.cur;
+    for (auto& L : e.g_layers) { L.facc = ws.take(bn_acc_bytes(2, L.C)); L.bacc = ws.take(bn_acc_bytes(2, L.C)); }
+    e.final_bias_acc = ws.take(bn_acc_bytes(1, 8));
+    e.zero_end = ws.cur;
+    e.scratch8 = ws.take(256);
+    e.masks = ws.take(256);
+    for (auto& c : e.convs) {
+        c.wpk_fwd = ws.take((int64_t)c.fwd.ntaps * c.fwd.kpad * c.fwd.wld * 4);
+        if (c.dgrad.ntaps) c.wpk_dgrad = ws.take((int64_t)c.dgrad.ntaps * c.dgrad.kpad * c.dgrad.wld * 4);
+    }
+    e.dwe_begin = ws.cur;
+    for (auto& c : e.convs) {
+        c.dwe_floats = (int64_t)c.fwd.ntaps * c.fwd.kpad * c.fwd.wld;
+        c.dwe = ws.take(c.dwe_floats * 8);
+    }
+    e.dwe_end = ws.cur;
+    // ---- bind every conv-shaped launch
+    auto bind_conv = [&](ConvOp& op, const stcd_conv_geom& g, int conv, bool dgrad, int tap0, int kreal, int nreal, int groups = 1) {
+        op.g = g; op.conv = conv; op.dgrad = dgrad; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
+        op.plan = ConvMfmaPlan(); op.wf = -1; op.small = false; op.res = ConvResPlan(); op.res_groups = groups;
+        if (e.dt == BF16) {
+            op.plan = conv_mfma_plan(g);
+            if (op.plan.ok) op.wf = ws.take(op.plan.wf_elems * 2);
+            op.small = conv_small_ok(g, op.plan);
+            if (e.use_res && !op.small) op.res = conv_res_plan(g, op.plan, groups);
+        }
+        e.conv_ops.push_back(&op);
+    };
+    auto bind_wgrad = [&](WgradOp& op, const stcd_conv_geom& g, int conv, int64_t in_off, int64_t dout_off) {
+        const ConvW& cv = e.convs[conv];
+        op.g = g; op.conv = conv; op.tap0 = 0; op.kreal = cv.cin; op.nreal = cv.cout;
+        op.in_off = in_off; op.dout_off = dout_off; op.grouped = false;
+        op.plan = WgradMfmaPlan(); op.slab = -1; op.stage = 0;
+        if (e.dt == BF16) op.plan = wgrad_mfma_plan(g, cv.fwd.kpad, cv.fwd.wld);
+        e.wgrad_ops.push_back(&op);
+    };
+    for (auto& L : e.g_layers) {
+        if (L.kind == K_STEM7) continue;
+        const ConvW& cv = e.convs[L.conv];
+        stcd_conv_geom g;
+        const int stride = L.Hi / L.Ho;
+        if (L.kind == K_CONV3 && stride == 1) g = geom3(L.N, L.Hi, L.Wi, L.K, L.in.ld, cv.cout, L.Y.ld);
+        else if (L.kind == K_CONV1 && stride == 1) g = geom1(L.N, L.Hi, L.Wi, L.K, L.in.ld, cv.cout, L.Y.ld);
+        else {      // stride-2 gathers (3x3 p1 or 1x1)
+            memset(&g, 0, sizeof(g));
+            g.n = L.N; g.hi = L.Hi; g.wi = L.Wi; g.ci = L.K; g.ldi = L.in.ld;
+            g.hm = L.Ho; g.wm = L.Wo; g.in_stride = 2; g.ho = L.Ho; g.wo = L.Wo; g.out_stride = 1;
+            g.co = cv.cout; g.ldo = L.Y.ld;
+            if (L.kind == K_CONV3_S2) { g.ntaps = 9; for (int t = 0; t < 9; ++t) { g.dy[t] = (int8_t)(t / 3 - 1); g.dx[t] = (int8_t)(t % 3 - 1); } }
+            else { g.ntaps = 1; g.dy[0] = 0; g.dx[0] = 0; }
+        }
+        bind_conv(L.fwd, g, L.conv, false, 0, cv.cin, cv.cout, L.groups);
+        stcd_conv_geom gw = g; gw.ldo = L.dA.ld;
+        bind_wgrad(L.wg, gw, L.conv, L.in.off, L.dA.off);
+        if (!L.has_dIn) continue;
+        if (stride == 1) {
+            stcd_conv_geom gd = L.kind == K_CONV3 ? geom3(L.N, L.Ho, L.Wo, cv.dgrad.kpad, L.dA.ld, cv.cin, L.dIn.ld)
+                                                  : geom1(L.N, L.Ho, L.Wo, cv.dgrad.kpad, L.dA.ld, cv.cin, L.dIn.ld);
+            bind_conv(L.dgr[0], gd, L.conv, true, 0, cv.cout, cv.cin);
+            L.ndgr = 1;
+        } else if (L.kind == K_CONV3_S2) {      // d(in)(2m+py, 2n+px) = sum_{dy<=py, dx<=px} dY(m+dy, n+dx) W[.][.][py+1-2dy][px+1-2dx]
+            static const int start[4] = {0, 1, 3, 5};
+            for (int ph = 0; ph < 4; ++ph) {
+                const int py = ph >> 1, px = ph & 1;
+                stcd_conv_geom gd;
+                memset(&gd, 0, sizeof(gd));
+                gd.n = L.N; gd.hi = L.Ho; gd.wi = L.Wo; gd.ci = cv.dgrad.kpad; gd.ldi = L.dA.ld;
+                gd.hm = L.Ho; gd.wm = L.Wo; gd.in_stride = 1; gd.ho = L.Hi; gd.wo = L.Wi; gd.out_stride = 2; gd.oy0 = py; gd.ox0 = px;
+                gd.co = cv.cin; gd.ldo = L.dIn.ld;
+                int t = 0;
+                for (int dy = 0; dy <= py; ++dy) for (int dx = 0; dx <= px; ++dx) { gd.dy[t] = (int8_t)dy; gd.dx[t] = (int8_t)dx; ++t; }
+                gd.ntaps = t;
+                bind_conv(L.dgr[ph], gd, L.conv, true, start[ph], cv.cout, cv.cin);
+            }
+            L.ndgr = 4;
+        } else {                                // 1x1 stride 2: only the even positions receive a gradient (the rest is zeroed)
+            stcd_conv_geom gd;
+            memset(&gd, 0, sizeof(gd));
+            gd.n = L.N; gd.hi = L.Ho; gd.wi = L.Wo; gd.ci = cv.dgrad.kpad; gd.ldi = L.dA.ld;
+            gd.hm = L.Ho; gd.wm = L.Wo; gd.in_stride = 1; gd.ho = L.Hi; gd.wo = L.Wi; gd.out_stride = 2;
+            gd.co = cv.cin; gd.ldo = L.dIn.ld; gd.ntaps = 1;
+            bind_conv(L.dgr[0], gd, L.conv, true, 0, cv.cout, cv.cin);
+            L.ndgr = 1;
+        }
+    }
+    {
+        const ConvW& cv = e.convs[e.g_head_conv];
+        bind_conv(e.g_head_fwd, geom3(3 * B, H, W, 16, 16, e.label, e.label), e.g_head_conv, false, 0, 16, e.label);
+        bind_wgrad(e.g_head_wg, geom3(3 * B, H, W, 16, 16, e.label, 8), e.g_head_conv, e.gX3.off, e.G.off);
+        bind_conv(e.g_head_dgr, geom3(3 * B, H, W, cv.dgrad.kpad, 8, 16, 16), e.g_head_conv, true, 0, e.label, 16);
+    }
+    e.slab = ws.take(e.slab_floats * 4);
+    e.bias_jobs.clear();
+    {
+        BiasJob jb{}; jb.acc_off = e.final_bias_acc; jb.out_off = e.convs[e.g_head_conv].b_off; jb.C = 8; jb.valid = e.label; jb.scale = BN_BS;
+        e.bias_jobs.push_back(jb);
+        e.bias_jobs_off = ws.take((int64_t)e.bias_jobs.size() * sizeof(BiasJob) + 16);
+    }
+    build_pack_jobs(e, ws);
+    e.jobs_uploaded_ws = nullptr;
+    e.ws_bytes = ws.cur;
+    return 0;
+}
+
+static SliceViews to_views(const Ctx& c, const std::vector<ViewRef>& v) {
+    SliceViews xs;
+    xs.n = (int)v.size();
+    for (int k = 0; k < xs.n; ++k) { xs.p[k] = c.at(v[k].off); xs.ld[k] = v[k].ld; xs.goff[k] = v[k].goff; xs.gmask[k] = v[k].gmask; }
+    return xs;
+}
+
+static void glayer_forward(const Ctx& c, GLayer& L, float* bn_running, bool training) {
+    stcd_engine& e = c.e;
+    const ConvW& cv = e.convs[L.conv];
+    const BnP& bn = e.bns[L.bn];
+    const int64_t ppg = (int64_t)L.npg * L.Ho * L.Wo;
+    float* stat = c.at<float>(L.stat);
+    int fused = 0;
+    if (L.kind == K_STEM7) {
+        ProfScope ps(c, PC_CONV, 2.0 * L.N * L.Ho * L.Wo * 49.0 * cv.cin * cv.cout, 0.0, "k_stem_fwd");
+        launch_stem_fwd(e.dt, c.at(L.in.off), c.params + cv.w_off, c.at(L.Y.off), L.N, L.Hi, L.Wi, cv.cin, cv.cout, c.s);
+    } else {
+        StatReq sr; sr.acc = training ? c.at<long long>(L.facc) : nullptr; sr.groups = L.groups; sr.C = L.C;
+        exec_conv(c, L.fwd, c.at(L.in.off), nullptr, c.at(L.Y.off), false, &sr, &fused);
+    }
+    BnActArgs a;
+    if (training) {
+        if (!fused) launch_bn_stats(e.dt, c.at(L.Y.off), L.Y.ld, L.C, L.groups, ppg, c.at<long long>(L.facc), c.s);
+        a.facc = c.at<long long>(L.facc); a.gamma = c.params + bn.g_off; a.beta = c.params + bn.b_off;
+        a.running_mean = bn_running + bn.run_off; a.running_var = bn_running + bn.run_off + L.C;
+    } else {
+        launch_bn_eval_prepare(L.C, L.groups, c.params + bn.g_off, c.params + bn.b_off, bn_running + bn.run_off,
+                               bn_running + bn.run_off + L.C, stat, 1e-5f, c.s);
+    }
+    a.Y = c.at(L.Y.off); a.ldy = L.Y.ld; a.A = c.at(L.A.off); a.lda = L.A.ld; a.a_group_off = ppg * L.A.ld;
+    a.P = nullptr; a.ldp = 0; a.stat = stat; a.mask = nullptr;
+    a.C = L.C; a.groups = L.groups; a.npg = L.npg; a.H = L.Ho; a.W = L.Wo; a.relu = L.relu ? 1 : 0;
+    if (L.res.off >= 0) { a.res = c.at(L.res.off); a.ldres = L.res.ld; }
+    a.extra = to_views(c, L.extra_dst);
+    ProfScope ps(c, PC_BN_ACT, 0.0, 2.0 * L.N * L.Ho * L.Wo * L.C * (double)dsize(e.dt));
+    launch_bn_act(e.dt, a, c.s);
+}
+
+static void glayer_backward(const Ctx& c, GLayer& L) {
+    stcd_engine& e = c.e;
+    const ConvW& cv = e.convs[L.conv];
+    const BnP& bn = e.bns[L.bn];
+    const int64_t HW = (int64_t)L.Ho * L.Wo, ppg = (int64_t)L.npg * HW;
+    const float* stat = c.at<float>(L.stat);
+    const void* res = L.res.off >= 0 ? c.at(L.res.off) : nullptr;
+    const double act_bytes = (double)L.N * HW * L.C * (double)dsize(e.dt);
+    {
+        ProfScope ps(c, PC_BN_BWD_REDUCE, 0.0, 2.0 * act_bytes);
+        const SliceViews xs = to_views(c, L.grad_src);
+        launch_bn_bwd_reduce(e.dt, c.at(L.dA.off), L.dA.ld, ppg * L.dA.ld, c.at(L.Y.off), L.Y.ld, stat, nullptr, L.C, L.groups, L.npg, HW,
+                             L.relu ? 1 : 0, c.at<long long>(L.bacc), c.s, res, L.res.ld, &xs, L.grad_base ? 1 : 0, c.at(L.dA.off));
+    }
+    {
+        ProfScope ps(c, PC_BN_BWD_APPLY, 0.0, 3.0 * act_bytes);
+        launch_bn_bwd_apply(e.dt, c.at(L.dA.off), L.dA.ld, ppg * L.dA.ld, c.at(L.dA.off), L.dA.ld, c.at(L.Y.off), L.Y.ld, stat,
+                            c.at<long long>(L.bacc), c.grads + bn.g_off, c.grads + bn.b_off, nullptr, L.C, L.groups, L.npg, HW, L.relu ? 1 : 0,
+                            c.s, res, L.res.ld, L.dRes.off >= 0 ? c.at(L.dRes.off) : nullptr, L.dRes.ld);
+    }
+    if (L.kind == K_STEM7) {
+        ProfScope ps(c, PC_WGRAD, 2.0 * L.N * HW * 49.0 * cv.cin * cv.cout, 0.0, "k_stem_wgrad");
+        launch_stem_wgrad(e.dt, c.at(L.in.off), c.at(L.dA.off), c.grads + cv.w_off, L.N, L.Hi, L.Wi, cv.cin, cv.cout, c.s);
+        return;
+    }
+    exec_wgrad(c, L.wg, c.at(L.in.off), c.at(L.dA.off));
+    if (!L.has_dIn) return;
+    if (L.kind == K_CONV1_S2)
+        (void)hipMemsetAsync(c.at(L.dIn.off), 0, (size_t)L.N * L.Hi * L.Wi * L.dIn.ld * dsize(e.dt), c.s);
+    if (L.ndgr == 4) {
+        if (!exec_conv_x4(c, L.dgr, c.at(L.dA.off), nullptr, c.at(L.dIn.off)))
+            for (int ph = 0; ph < 4; ++ph) exec_conv(c, L.dgr[ph], c.at(L.dA.off), nullptr, c.at(L.dIn.off), false);
+    } else {
+        exec_conv(c, L.dgr[0], c.at(L.dA.off), nullptr, c.at(L.dIn.off), false);
+    }
+}
+
+static int forward_segcd(stcd_engine& e, const float* x1, const float* x2, const float* params, float* bn_running, int training,
+                         float* logits, void* workspace, hipStream_t s) {
+    Ctx c{e, (char*)workspace, params, nullptr, s};
+    const int B = e.B, dt = e.dt;
+    const int64_t T = (int64_t)dsize(dt), HW = (int64_t)e.H * e.W;
+    if (pack_all_weights(c, training != 0)) return 1;
+    if (training) STCD_HIP(hipMemsetAsync(c.at(e.zero_begin), 0, e.zero_end - e.zero_begin, s));
+    launch_in_pack(dt, x1, x2, c.at(e.X0.off), B, e.in_ch, e.H, e.W, s);
+    for (const GStep& st : e.g_fwd) {
+        if (st.kind == GS_LAYER) glayer_forward(c, e.g_layers[st.layer], bn_running, training != 0);
+        else if (st.kind == GS_MAXPOOL) launch_maxpool3(dt, c.at(st.src.off), st.src.ld, c.at(st.dst.off), st.dst.ld, st.N, st.h, st.w, st.C, s);
+        else launch_upsample2(dt, c.at(st.src.off), st.src.ld, c.at(st.dst.off), st.dst.ld, st.N, st.h, st.w, st.C, s);
+    }
+    // head: X3[2B:3B] = |d1 - d2| ; raw = conv(X3) = [m1; m2; diffea] ; logits = [m1; m2; min(diffea, |m1 - m2|)]
+    launch_fuse(dt, 0, c.at(e.gX3.off), 16, (int64_t)B * HW * 16, c.at<char>(e.gX3.off) + (int64_t)2 * B * HW * 16 * T, 16, B, HW, 16, s);
+    exec_conv(c, e.g_head_fwd, c.at(e.gX3.off), params + e.convs[e.g_head_conv].b_off, c.at(e.g_raw3), true);
+    launch_segcd_combine(c.at<float>(e.g_raw3), logits, (int64_t)B * e.label * HW, s);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
+static int backward_segcd(stcd_engine& e, const float* grad_logits, const float* params, float* grads, void* workspace, int stage,
+                          hipStream_t s) {
+    if (stage == 1) return 0;
+    Ctx c{e, (char*)workspace, params, grads, s};
+    const int B = e.B, dt = e.dt;
+    const int64_t T = (int64_t)dsize(dt), HW = (int64_t)e.H * e.W;
+    STCD_HIP(hipMemsetAsync(grads, 0, e.param_floats * 4, s));
+    if (!mfma_on(e)) STCD_HIP(hipMemsetAsync(c.at(e.dwe_begin), 0, e.dwe_end - e.dwe_begin, s));
+    launch_segcd_combine_bwd(c.at<float>(e.g_raw3), grad_logits, c.at<float>(e.g_draw3), (int64_t)B * e.label * HW, s);
+    launch_gout_pack(dt, c.at<float>(e.g_draw3), c.at(e.G.off), 3 * B, e.label, e.H, e.W, s, c.at<long long>(e.final_bias_acc));
+    exec_wgrad(c, e.g_head_wg, c.at(e.gX3.off), c.at(e.G.off));
+    exec_conv(c, e.g_head_dgr, c.at(e.G.off), nullptr, c.at(e.gdX3.off), false);
+    // d(d1), d(d2) += -/+ sign(d1 - d2) * d|d1 - d2| : written to a contribution buffer the last decoder layer gathers
+    launch_fuse_bwd(dt, 0, c.at(e.gX3.off), 16, (int64_t)B * HW * 16, c.at<char>(e.gdX3.off) + (int64_t)2 * B * HW * 16 * T, 16,
+                    c.at(e.gFuseTmp.off), 16, (int64_t)B * HW * 16, B, HW, 16, s);
+    for (int k = (int)e.g_fwd.size() - 1; k >= 0; --k) {
+        const GStep& st = e.g_fwd[k];
+        if (st.kind == GS_LAYER) glayer_backward(c, e.g_layers[st.layer]);
+        else if (st.kind == GS_UPSAMPLE)
+            launch_upsample2_bwd(dt, c.at(st.ddst.off), st.ddst.ld, c.at(st.dsrc.off), st.dsrc.ld, st.N, st.h, st.w, st.C, s);
+        else {      // max-pool: d(P0) = conv1 contribution (written in place) + down-sample branch contribution of layer1.0
+            const GLayer& Ld = e.g_layers[e.g_blocks[0][3]];
+            launch_slice(dt, c.at(st.ddst.off), st.ddst.ld, c.at(Ld.dIn.off), Ld.dIn.ld, (int64_t)st.N * (st.h / 2) * (st.w / 2), st.C, 1, s);
+            launch_maxpool3_bwd(dt, c.at(st.src.off), st.src.ld, c.at(st.ddst.off), st.ddst.ld, c.at(st.dsrc.off), st.dsrc.ld, st.N, st.h, st.w, st.C, s);
+        }
+    }
+    reduce_stage(c, 0);
+    launch_bias_finish(c.at<BiasJob>(e.bias_jobs_off), (int)e.bias_jobs.size(), c.ws, c.grads, s);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace stcd
 
 // ================================================================================================ C ABI
@@ -1597,7 +2023,7 @@ int stcd_abi_version(void) { return STCD_ABI_VERSION; }
 
 int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out) {
     STCD_CHECK(out != nullptr, "out is null");
-    STCD_CHECK(arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SNUNET, "unknown arch");
+    STCD_CHECK(arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD, "unknown arch");
     STCD_CHECK(in_ch >= 1 && in_ch <= 8, "in_ch must be in [1,8]");
     STCD_CHECK(label_ch >= 1 && label_ch <= 8, "label_ch must be in [1,8]");
     STCD_CHECK(dtype == STCD_DTYPE_F32 || dtype == STCD_DTYPE_BF16, "unknown dtype");
@@ -1620,6 +2046,7 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
     env = getenv("STCD_WGRAD_MIN_TILES");
     if (env && atoi(env) > 0) e->wgroup_min_tiles = atoi(env);
     if (arch == STCD_ARCH_SNUNET) build_snunet_tables(*e);
+    else if (arch == STCD_ARCH_SEGCD) build_segcd_tables(*e);
     else build_fcsiam_tables(*e);
     *out = e.release();
     return 0;
@@ -1655,6 +2082,10 @@ int stcd_configure(stcd_engine* e, int batch, int height, int width) {
     if (e->arch == STCD_ARCH_SNUNET) {
         STCD_CHECK(height % 16 == 0 && width % 16 == 0, "SNUNet needs height and width divisible by 16 (the reference's cat of up-sampled maps fails otherwise)");
         if (configure_snunet(*e, batch, height, width)) return 1;
+    } else if (e->arch == STCD_ARCH_SEGCD) {
+        STCD_CHECK(height % 32 == 0 && width % 32 == 0, "SegCD needs height and width divisible by 32 (five stride-2 stages; the reference's cat of the x2 up-sampled maps fails otherwise)");
+        STCD_CHECK((int64_t)3 * batch * height * width * 16 < ((int64_t)1 << 31), "tensor too large for 32-bit pixel indexing");
+        if (configure_segcd(*e, batch, height, width)) return 1;
     } else if (configure_fcsiam(*e, batch, height, width)) return 1;
     e->configured = true;
     e->fwd_training = false;
@@ -1687,8 +2118,10 @@ int stcd_forward(stcd_engine* e, const float* x1, const float* x2, const float* 
     e->fwd_training = false;
     int rc = e->arch == STCD_ARCH_SNUNET
                  ? forward_snunet(*e, x1, x2, params, bn_running, training, logits, workspace, (hipStream_t)hip_stream)
-                 : forward_fcsiam(*e, x1, x2, params, bn_running, dropout_masks, dropout_seed, training, logits, workspace,
-                                  (hipStream_t)hip_stream);
+                 : e->arch == STCD_ARCH_SEGCD
+                       ? forward_segcd(*e, x1, x2, params, bn_running, training, logits, workspace, (hipStream_t)hip_stream)
+                       : forward_fcsiam(*e, x1, x2, params, bn_running, dropout_masks, dropout_seed, training, logits, workspace,
+                                        (hipStream_t)hip_stream);
     if (rc == 0) e->fwd_training = training != 0;
     return rc;
 }
@@ -1700,6 +2133,7 @@ int stcd_backward(stcd_engine* e, const float* grad_logits, const float* params,
     STCD_CHECK(grad_logits && params && grads && workspace, "null pointer argument");
     STCD_CHECK(stage >= -1 && stage <= 1, "stage must be -1, 0 or 1");
     if (e->arch == STCD_ARCH_SNUNET) return backward_snunet(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
+    if (e->arch == STCD_ARCH_SEGCD) return backward_segcd(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
     return backward_fcsiam(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
 }
 

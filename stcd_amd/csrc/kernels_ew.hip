@@ -1363,3 +1363,259 @@ void launch_rep_pad_bwd(int dt, void* dD, int ld, int N, int H, int W, int h0, i
 }
 
 }  // namespace stcd
+
+// =====================================================================================================================
+// Kernels of the ResNet-50 UNet change detector (smp.SegCD, the model the reference's scripts train):
+//   nn.Conv2d(3, 64, 7, stride 2, padding 3, bias=False)     /root/reference/models/resnet.py:152-153
+//   nn.MaxPool2d(3, stride 2, padding 1)                     /root/reference/models/resnet.py:156
+//   F.interpolate(scale_factor=2, mode="nearest") + cat      /root/reference/segmentation_models_pytorch/decoders/unet/decoder.py:36-38
+//   change = min(head(|d1 - d2|), |m1 - m2|)                 /root/reference/segmentation_models_pytorch/decoders/unet/model.py:323-330
+namespace stcd {
+
+// ---- stem: direct 7x7 stride-2 convolution over the packed 8-channel input (cin <= 8 real channels), Co = 64.
+// thread = (output pixel, 8 output channels); the 7x7xcin x 8 filter slice of a thread's channel block sits in LDS.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_stem_fwd(const T* __restrict__ X, const float* __restrict__ w, T* __restrict__ Y, int N, int H, int W, int cin, int Ho, int Wo, int Co) {
+    extern __shared__ float wl[];                  // [49][cin][Co]
+    for (int i = threadIdx.x; i < 49 * cin * Co; i += blockDim.x) {
+        const int co = i % Co, ci = (i / Co) % cin, t = i / (Co * cin);
+        wl[i] = w[((int64_t)co * cin + ci) * 49 + t];
+    }
+    __syncthreads();
+    const int cb = Co >> 3;
+    const int64_t total = (int64_t)N * Ho * Wo * cb;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c0 = (int)(i % cb) * 8;
+    int64_t r = i / cb;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int ky = 0; ky < 7; ++ky) {
+        const int iy = 2 * oy - 3 + ky;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < 7; ++kx) {
+            const int ix = 2 * ox - 3 + kx;
+            if (ix < 0 || ix >= W) continue;
+            float x[8];
+            load8<T>(X + (((int64_t)n * H + iy) * W + ix) * 8, x);
+            const float* wt = wl + (int64_t)(ky * 7 + kx) * cin * Co + c0;
+            for (int ci = 0; ci < cin; ++ci) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += x[ci] * wt[ci * Co + j];
+            }
+        }
+    }
+    store8<T>(Y + (((int64_t)n * Ho + oy) * Wo + ox) * Co + c0, acc);
+}
+void launch_stem_fwd(int dt, const void* X, const float* w, void* Y, int N, int H, int W, int cin, int Co, hipStream_t s) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)N * Ho * Wo * (Co / 8);
+    const size_t lds = (size_t)49 * cin * Co * 4;
+    if (dt == BF16) k_stem_fwd<bf16><<<cdiv(total, 256), 256, lds, s>>>((const bf16*)X, w, (bf16*)Y, N, H, W, cin, Ho, Wo, Co);
+    else k_stem_fwd<float><<<cdiv(total, 256), 256, lds, s>>>((const float*)X, w, (float*)Y, N, H, W, cin, Ho, Wo, Co);
+}
+// dW[co][ci][ky][kx] += sum over positions of X(2oy-3+ky, 2ox-3+kx)[ci] * dY(oy,ox)[co]; grid = (position chunks, 49 taps),
+// block = 4 position lanes x 64 output channels; dW zeroed by the caller (float atomics: ~chunks adders per address)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_stem_wgrad(const T* __restrict__ X, const T* __restrict__ dY, float* __restrict__ dW, int N, int H, int W, int cin, int Ho, int Wo, int Co) {
+    __shared__ float red[4][64][8];
+    const int t = blockIdx.y, ky = t / 7, kx = t % 7;
+    const int co = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int64_t npos = (int64_t)N * Ho * Wo;
+    const int64_t per = (npos + gridDim.x - 1) / gridDim.x, p0 = (int64_t)blockIdx.x * per, p1 = min(npos, p0 + per);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int64_t p = p0 + lane; p < p1; p += 4) {
+        const int ox = (int)(p % Wo);
+        const int64_t r = p / Wo;
+        const int oy = (int)(r % Ho), n = (int)(r / Ho);
+        const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        float x[8];
+        load8<T>(X + (((int64_t)n * H + iy) * W + ix) * 8, x);
+        const float g = co < Co ? (float)dY[p * Co + co] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += x[j] * g;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[lane][co][j] = acc[j];
+    __syncthreads();
+    if (lane == 0 && co < Co)
+        for (int ci = 0; ci < cin; ++ci)
+            atomicAdd(dW + ((int64_t)co * cin + ci) * 49 + t, (red[0][co][ci] + red[1][co][ci]) + (red[2][co][ci] + red[3][co][ci]));
+}
+void launch_stem_wgrad(int dt, const void* X, const void* dY, float* dW, int N, int H, int W, int cin, int Co, hipStream_t s) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int chunks = (int)std::min<int64_t>(256, ((int64_t)N * Ho * Wo + 1023) / 1024);
+    dim3 grid(chunks, 49);
+    if (dt == BF16) k_stem_wgrad<bf16><<<grid, 256, 0, s>>>((const bf16*)X, (const bf16*)dY, dW, N, H, W, cin, Ho, Wo, Co);
+    else k_stem_wgrad<float><<<grid, 256, 0, s>>>((const float*)X, (const float*)dY, dW, N, H, W, cin, Ho, Wo, Co);
+}
+
+// ---- 3x3 stride-2 padding-1 max-pool (H, W even) and its gradient (first maximum in scan order, as torch)
+template <typename T>
+__global__ void k_maxpool3(const T* __restrict__ A, int lda, T* __restrict__ P, int ldp, int H, int W, int C, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3, Ho = H / 2, Wo = W / 2;
+    const int c0 = (int)(i % cb) * 8;
+    int64_t r = i / cb;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float best[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) best[j] = -INFINITY;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int y = 2 * oy - 1 + ky;
+        if (y < 0 || y >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int x = 2 * ox - 1 + kx;
+            if (x < 0 || x >= W) continue;
+            float v[8];
+            load8<T>(A + (((int64_t)n * H + y) * W + x) * lda + c0, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], v[j]);
+        }
+    }
+    store8<T>(P + (((int64_t)n * Ho + oy) * Wo + ox) * ldp + c0, best);
+}
+void launch_maxpool3(int dt, const void* A, int lda, void* P, int ldp, int N, int H, int W, int C, hipStream_t s) {
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+    if (dt == BF16) k_maxpool3<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)A, lda, (bf16*)P, ldp, H, W, C, total);
+    else k_maxpool3<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)A, lda, (float*)P, ldp, H, W, C, total);
+}
+// dA(y,x) = sum over the (up to 4) windows that contain (y,x) of dP(window) * [(y,x) is the window's FIRST maximum]
+template <typename T>
+__global__ void k_maxpool3_bwd(const T* __restrict__ A, int lda, const T* __restrict__ dP, int ldp, T* __restrict__ dA, int ldda, int H,
+                               int W, int C, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3, Ho = H / 2, Wo = W / 2;
+    const int c0 = (int)(i % cb) * 8;
+    int64_t r = i / cb;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    float me[8], out[8];
+    load8<T>(A + (((int64_t)n * H + y) * W + x) * lda + c0, me);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = 0.f;
+    // windows oy with 2*oy-1 <= y <= 2*oy+1
+    for (int oy = (y + 1) / 2 - ((y & 1) ? 0 : 0); oy >= 0 && 2 * oy + 1 >= y; --oy) {
+        if (oy >= Ho || 2 * oy - 1 > y) continue;
+        for (int ox = (x + 1) / 2; ox >= 0 && 2 * ox + 1 >= x; --ox) {
+            if (ox >= Wo || 2 * ox - 1 > x) continue;
+            // is (y,x) the first maximum of window (oy,ox) ?
+            bool first[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) first[j] = true;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = 2 * oy - 1 + ky;
+                if (yy < 0 || yy >= H) continue;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int xx = 2 * ox - 1 + kx;
+                    if (xx < 0 || xx >= W || (yy == y && xx == x)) continue;
+                    float v[8];
+                    load8<T>(A + (((int64_t)n * H + yy) * W + xx) * lda + c0, v);
+                    const bool before = yy < y || (yy == y && xx < x);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) first[j] = first[j] && (before ? v[j] < me[j] : v[j] <= me[j]);
+                }
+            }
+            float g[8];
+            load8<T>(dP + (((int64_t)n * Ho + oy) * Wo + ox) * ldp + c0, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] += first[j] ? g[j] : 0.f;
+        }
+    }
+    store8<T>(dA + (((int64_t)n * H + y) * W + x) * ldda + c0, out);
+}
+void launch_maxpool3_bwd(int dt, const void* A, int lda, const void* dP, int ldp, void* dA, int ldda, int N, int H, int W, int C,
+                         hipStream_t s) {
+    const int64_t total = (int64_t)N * H * W * (C / 8);
+    if (dt == BF16) k_maxpool3_bwd<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)A, lda, (const bf16*)dP, ldp, (bf16*)dA, ldda, H, W, C, total);
+    else k_maxpool3_bwd<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)A, lda, (const float*)dP, ldp, (float*)dA, ldda, H, W, C, total);
+}
+
+// ---- nearest x2 up-sampling into a channel slice of the decoder's concat buffer, and its gradient (sum of the 2x2 block)
+template <typename T>
+__global__ void k_upsample2(const T* __restrict__ X, int ldx, T* __restrict__ D, int ldd, int h, int w, int C, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3;
+    const int c0 = (int)(i % cb) * 8;
+    int64_t r = i / cb;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h);
+    const int n = (int)(r / h);
+    const uint4* src = reinterpret_cast<const uint4*>(X + (((int64_t)n * h + y) * w + x) * ldx + c0);
+    float v[8];
+    load8<T>(reinterpret_cast<const T*>(src), v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        store8<T>(D + (((int64_t)n * 2 * h + 2 * y + (k >> 1)) * 2 * w + 2 * x + (k & 1)) * ldd + c0, v);
+}
+void launch_upsample2(int dt, const void* X, int ldx, void* D, int ldd, int N, int h, int w, int C, hipStream_t s) {
+    const int64_t total = (int64_t)N * h * w * (C / 8);
+    if (dt == BF16) k_upsample2<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)X, ldx, (bf16*)D, ldd, h, w, C, total);
+    else k_upsample2<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)X, ldx, (float*)D, ldd, h, w, C, total);
+}
+template <typename T>
+__global__ void k_upsample2_bwd(const T* __restrict__ dD, int ldd, T* __restrict__ dX, int ldx, int h, int w, int C, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = C >> 3;
+    const int c0 = (int)(i % cb) * 8;
+    int64_t r = i / cb;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h);
+    const int n = (int)(r / h);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v[8];
+        load8<T>(dD + (((int64_t)n * 2 * h + 2 * y + (k >> 1)) * 2 * w + 2 * x + (k & 1)) * ldd + c0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+    store8<T>(dX + (((int64_t)n * h + y) * w + x) * ldx + c0, acc);
+}
+void launch_upsample2_bwd(int dt, const void* dD, int ldd, void* dX, int ldx, int N, int h, int w, int C, hipStream_t s) {
+    const int64_t total = (int64_t)N * h * w * (C / 8);
+    if (dt == BF16) k_upsample2_bwd<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)dD, ldd, (bf16*)dX, ldx, h, w, C, total);
+    else k_upsample2_bwd<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)dD, ldd, (float*)dX, ldx, h, w, C, total);
+}
+
+// ---- SegCD output combination on fp32 NCHW maps raw = [m1; m2; diffea] (3 x n elements):
+//      out = [m1; m2; min(diffea, |m1 - m2|)]; gradient g = [g1; g2; gc] -> d raw (torch.min splits ties 0.5 / 0.5, abs' = sign)
+__global__ void k_segcd_combine(const float* __restrict__ raw, float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float m1 = raw[i], m2 = raw[n + i], df = raw[2 * n + i];
+    out[i] = m1; out[n + i] = m2; out[2 * n + i] = fminf(df, fabsf(m1 - m2));
+}
+__global__ void k_segcd_combine_bwd(const float* __restrict__ raw, const float* __restrict__ g, float* __restrict__ draw, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float m1 = raw[i], m2 = raw[n + i], df = raw[2 * n + i], gc = g[2 * n + i];
+    const float d = m1 - m2, ds = fabsf(d);
+    const float wf = df < ds ? 1.f : (df == ds ? 0.5f : 0.f);
+    const float gs = gc * (1.f - wf) * (float)((d > 0.f) - (d < 0.f));
+    draw[i] = g[i] + gs; draw[n + i] = g[n + i] - gs; draw[2 * n + i] = gc * wf;
+}
+void launch_segcd_combine(const float* raw, float* out, int64_t n, hipStream_t s) { k_segcd_combine<<<cdiv(n, 256), 256, 0, s>>>(raw, out, n); }
+void launch_segcd_combine_bwd(const float* raw, const float* g, float* draw, int64_t n, hipStream_t s) {
+    k_segcd_combine_bwd<<<cdiv(n, 256), 256, 0, s>>>(raw, g, draw, n);
+}
+
+}  // namespace stcd

@@ -76,6 +76,7 @@ class HipChangeDetector(nn.Module):
 
     ARCH = None
     RETURNS_LIST = False
+    OUT_MAPS = 1          # maps per pair in the engine's output buffer ([OUT_MAPS*B, label, H, W])
 
     def __init__(self, in_ch: int, label_ch: int, dtype: Optional[str] = None):
         super().__init__()
@@ -178,7 +179,7 @@ class HipChangeDetector(nn.Module):
     def _run_forward(self, x1, x2, training: bool):
         eng = self._engine
         B, _, H, W = x1.shape
-        logits = torch.empty((B, eng.label_ch, H, W), dtype=torch.float32, device=x1.device)
+        logits = torch.empty((self.OUT_MAPS * B, eng.label_ch, H, W), dtype=torch.float32, device=x1.device)
         masks = None
         pend = getattr(self, "_pending_masks", None)
         if training and pend is not None:
@@ -233,6 +234,9 @@ class HipChangeDetector(nn.Module):
                 out = self._run_forward(x1, x2, self.training)
                 if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                     out = _NoEvalGradFn.apply(out, self._anchor)
+        return self._wrap_output(out, B)
+
+    def _wrap_output(self, out, B):
         return [out] if self.RETURNS_LIST else out
 
 

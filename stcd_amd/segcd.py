@@ -1,0 +1,172 @@
+"""``SegCD``: the ResNet-50 UNet change detector the reference's scripts train
+(``smp.SegCD(encoder_name="resnet50", encoder_weights="imagenet")``, /root/reference/train_pse_cd.py:419-427,
+train_stcd.py:631-638), as a drop-in module over the HIP engine.
+
+Same constructor arguments, ``forward(A, B) -> (mask_t1, mask_t2, change)`` contract and ``state_dict`` keys / shapes as
+/root/reference/segmentation_models_pytorch/decoders/unet/model.py:267-332 (encoder: encoders/resnet.py:37-70 over
+models/resnet.py:78-190 with ``fc`` / ``avgpool`` removed; decoder: decoders/unet/decoder.py:8-123; head: base/heads.py:5-11),
+so checkpoints interchange both ways.  The sub-modules are parameter holders only -- they are never called; forward and
+backward are single calls into libstcd_hip.so (both dates batched through the shared encoder / decoder, per-date
+BatchNorm statistics).  No CPU fallback.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from ._lib import StcdError
+from .modules import HipChangeDetector
+
+_LAYERS = (3, 4, 6, 3)
+_PLANES = (64, 128, 256, 512)
+_ENC_OUT = (3, 64, 256, 512, 1024, 2048)
+_IMAGENET_URL = "https://download.pytorch.org/models/resnet50-19c8e357.pth"      # what `encoder_weights="imagenet"` names
+
+
+class _Bottleneck(nn.Module):
+    """torchvision-style v1.5 bottleneck (models/resnet.py:78-124): stride on the 3x3."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class _ResNet50Encoder(nn.Module):
+    """ResNetEncoder(resnet50) holders (encoders/resnet.py:37-70)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.out_channels = (in_channels,) + _ENC_OUT[1:]
+        self._depth, self._in_channels = 5, in_channels
+        self.conv1 = nn.Conv2d(in_channels, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        inpl = 64
+        for li, (nb, pl) in enumerate(zip(_LAYERS, _PLANES)):
+            blocks = []
+            for b in range(nb):
+                stride = 2 if (b == 0 and li > 0) else 1
+                down = None
+                if b == 0:
+                    down = nn.Sequential(nn.Conv2d(inpl, pl * 4, kernel_size=1, stride=stride, bias=False), nn.BatchNorm2d(pl * 4))
+                blocks.append(_Bottleneck(inpl, pl, stride, down))
+                inpl = pl * 4
+            setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
+        for m in self.modules():                      # models/resnet.py:157-163
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+
+class _DecoderBlock(nn.Module):
+    """DecoderBlock holders (decoders/unet/decoder.py:8-46): two bias-free Conv2dReLU (conv, BN, ReLU)."""
+
+    def __init__(self, in_ch, skip_ch, out_ch):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.Conv2d(in_ch + skip_ch, out_ch, 3, padding=1, bias=False), nn.BatchNorm2d(out_ch), nn.ReLU(inplace=True))
+        self.attention1 = nn.Identity()
+        self.conv2 = nn.Sequential(nn.Conv2d(out_ch, out_ch, 3, padding=1, bias=False), nn.BatchNorm2d(out_ch), nn.ReLU(inplace=True))
+        self.attention2 = nn.Identity()
+
+
+class _UnetDecoder(nn.Module):
+    def __init__(self, decoder_channels):
+        super().__init__()
+        enc = list(_ENC_OUT[1:])[::-1]
+        ins = [enc[0]] + list(decoder_channels[:-1])
+        skips = enc[1:] + [0]
+        self.center = nn.Identity()
+        self.blocks = nn.ModuleList([_DecoderBlock(i, s, o) for i, s, o in zip(ins, skips, decoder_channels)])
+        for m in self.modules():                      # base/initialization.py:4-20
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+
+class SegCD(HipChangeDetector):
+    """``SegCD(encoder_name="resnet50", encoder_weights=..., in_channels=3, classes=1).forward(A, B)`` ->
+    ``(mask_t1, mask_t2, change)`` with ``change = min(head(|d1 - d2|), |mask_t1 - mask_t2|)`` (model.py:316-332).
+
+    Supported configuration = the one the scripts use: ResNet-50 encoder, depth 5, BatchNorm decoder (256,128,64,32,16), no
+    attention, no activation, no aux head; anything else raises NotImplementedError.  ``encoder_weights``: None (the
+    encoder's own random init), a path to a ResNet-50 ``state_dict`` file, or "imagenet" (fetched through torch.hub like the
+    reference does: needs the file in the hub cache when there is no network).  H and W must be multiples of 32."""
+
+    ARCH = "segcd"
+    OUT_MAPS = 3
+
+    def __init__(self, encoder_name: str = "resnet50", encoder_depth: int = 5, encoder_weights: Optional[str] = None,
+                 decoder_use_batchnorm: bool = True, decoder_channels: List[int] = (256, 128, 64, 32, 16),
+                 decoder_attention_type: Optional[str] = None, in_channels: int = 3, classes: int = 1, activation=None,
+                 aux_params: Optional[dict] = None, dtype: Optional[str] = None):
+        if (encoder_name != "resnet50" or encoder_depth != 5 or decoder_use_batchnorm is not True or tuple(decoder_channels) != (256, 128, 64, 32, 16)
+                or decoder_attention_type is not None or activation is not None or aux_params is not None):
+            raise NotImplementedError("SegCD on the HIP engine: resnet50 encoder, depth 5, BatchNorm decoder (256,128,64,32,16), "
+                                      "no attention / activation / aux head (the configuration train_pse_cd.py:426 builds)")
+        if not 1 <= in_channels <= 8:
+            raise NotImplementedError("SegCD on the HIP engine: 1..8 input channels")
+        super().__init__(in_channels, classes, dtype)
+        self.encoder = _ResNet50Encoder(in_channels)
+        self.inchannels = in_channels
+        self.encoder_channels = self.encoder.out_channels
+        self.decoder = _UnetDecoder(tuple(decoder_channels))
+        self.segmentation_head = nn.Sequential(nn.Conv2d(decoder_channels[-1], classes, kernel_size=3, padding=1), nn.Identity(), nn.Identity())
+        nn.init.xavier_uniform_(self.segmentation_head[0].weight)      # base/initialization.py:22-27
+        nn.init.constant_(self.segmentation_head[0].bias, 0)
+        self.name = "u-{}".format(encoder_name)
+        self._ctor = dict(encoder_name=encoder_name, in_channels=in_channels, classes=classes)
+        if encoder_weights is not None:
+            self._load_encoder(encoder_weights)
+        self._check_layout()
+
+    def _load_encoder(self, weights: str):
+        if os.path.exists(weights):
+            sd = torch.load(weights, map_location="cpu")
+        elif weights == "imagenet":
+            sd = torch.hub.load_state_dict_from_url(_IMAGENET_URL, map_location="cpu")
+        else:
+            raise KeyError("Wrong pretrained weights `{}` for encoder `resnet50`. Available options are: "
+                           "['imagenet', <path to a state_dict file>]".format(weights))
+        sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
+        if self.inchannels != 3:          # encoders/_utils.py patch_first_conv: 1 channel = sum, otherwise cycle RGB scaled by 3/C
+            w = sd["conv1.weight"]
+            if self.inchannels == 1:
+                w = w.sum(1, keepdim=True)
+            else:
+                w = torch.stack([w[:, i % 3] for i in range(self.inchannels)], 1) * (3.0 / self.inchannels)
+            sd["conv1.weight"] = w
+        self.encoder.load_state_dict(sd)
+
+    def __deepcopy__(self, memo):
+        new = type(self)(dtype=self._engine.dtype, **self._ctor)
+        new.load_state_dict({k: v.detach().clone() for k, v in self.state_dict().items()})
+        new.train(self.training)
+        if self._flat_params is not None:
+            new.to(self._flat_params.device)
+        return new
+
+    def forward(self, A, B):
+        if A.dim() == 4 and (A.shape[2] % 32 or A.shape[3] % 32):
+            raise StcdError(f"SegCD needs H and W divisible by 32, got {tuple(A.shape[2:])} "
+                            "(the reference's torch.cat of the x2 up-sampled maps fails for other sizes)")
+        return super().forward(A, B)
+
+    def _wrap_output(self, out, B):
+        return out[:B], out[B:2 * B], out[2 * B:]
