@@ -31,7 +31,12 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 MFMA_F32_PEAK_TF = 157.3
 # ALGORITHMIC work of one training step per image pair at 256x256 (measured on the reference's
 # modules with forward hooks: 2*MAC of every conv call; (in + out + weights) * 2 B per conv call; train = 3x forward)
-ALG_PER_PAIR_256 = {"diff": (25.37e9, 169e6), "sub": (25.37e9, 169e6), "conc": (28.99e9, 182e6), "snunet": (279.6e9, 1118e6)}
+ALG_PER_PAIR_256 = {"diff": (25.37e9, 169e6), "sub": (25.37e9, 169e6), "conc": (28.99e9, 182e6), "snunet": (279.6e9, 1118e6),
+                    # SegCD(resnet50): same accounting from the layer table (oracle/segcd_ref.py block_specs / decoder_specs), both dates
+                    "segcd": (127.65e9, 912.2e6)}
+
+
+NAMES = {"diff": "SiamUnet_diff", "conc": "SiamUnet_conc", "sub": "SiamUnet_sub", "snunet": "SNUNet_ECAM", "segcd": "SegCD-resnet50"}
 
 
 def parse():
@@ -39,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub", "snunet"])
+    ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub", "snunet", "segcd"])
     ap.add_argument("--batch", type=int, default=16, help="image pairs per GPU per step")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -49,6 +54,34 @@ def parse():
     ap.add_argument("--cpu-pairs", type=int, default=8)      # bounded CPU sample: ~10-20 s of host work in total
     ap.add_argument("--cpu-steps", type=int, default=20)
     return ap.parse_args()
+
+
+def cpu_baseline_segcd(size, pairs, steps):
+    """oracle/segcd_ref.py timed on the host: fwd + BCE/Dice on sigmoid(change) + bwd + Adam, fp32, all host threads
+    (steps capped at 4: one ResNet-50 UNet step on two dates is seconds of CPU work)."""
+    from oracle import fcsiam_ref as R
+    from oracle import segcd_ref as G
+    from stcd_amd import synth
+    steps = min(steps, 4)
+    a, b, lab = synth.make_batch(pairs, size, size, seed=1337)
+    A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab).float().unsqueeze(1)
+    st = G.synth_state(3, 1, seed=1)
+    params = [v.requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
+    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999))
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        _, _, ch = G.forward(st, A, B, training=True)
+        loss = R.cd_loss(torch.sigmoid(ch), L)
+        loss.backward()
+        opt.step()
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(pairs / med, 3), "unit": "image-pairs/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/segcd_ref.py SegCD(resnet50) fp32, {pairs} pairs {size}x{size}, median of {steps} full steps after 1 warm-up "
+                      f"({med * 1e3:.0f} ms/step)"}
 
 
 def cpu_baseline(arch, label, size, pairs, steps):
@@ -61,6 +94,8 @@ def cpu_baseline(arch, label, size, pairs, steps):
     torch.set_num_threads(max(1, min(ncpu, int(os.environ.get("STCD_CPU_THREADS", "16")))))
     a, b, lab = synth.make_batch(pairs, size, size, seed=1337)
     A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab)
+    if arch == "segcd":
+        return cpu_baseline_segcd(size, pairs, steps)
     st = SN.synth_state(3, label, seed=1) if arch == "snunet" else R.synth_state(arch, 3, label, seed=1)
     params = [v.requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
     opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
@@ -121,12 +156,17 @@ def main():
     assert world == args.gpus or world == 1 and args.gpus == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU fallback"
     dev = torch.device("cuda", local_rank)
-    cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub, "snunet": SNUNet_ECAM}[args.model]
-
     torch.manual_seed(1337)
-    model = cls(3, args.label, dtype=args.dtype).to(dev).train()
+    if args.model == "segcd":       # train_pse_cd.py:426-431: SegCD(resnet50), 1 class, Adam(lr 1e-3), BCE+Dice on sigmoid(change)
+        from stcd_amd.segcd import SegCD
+        args.label = 1
+        model = SegCD(encoder_name="resnet50", encoder_weights=None, in_channels=3, classes=1, dtype=args.dtype).to(dev).train()
+    else:
+        cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub, "snunet": SNUNet_ECAM}[args.model]
+        model = cls(3, args.label, dtype=args.dtype).to(dev).train()
     broadcast_parameters(model)
-    opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)     # torch.optim.AdamW semantics, one launch
+    # torch.optim.AdamW semantics, one launch (weight_decay 0 == the Adam the SegCD script uses)
+    opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0 if args.model == "segcd" else 0.01)
     reducer = FlatGradReducer(model)  # noqa: F841  (installs the gradient hook when world > 1)
 
     a, b, lab = synth.make_batch(args.batch, args.size, args.size, seed=1337 + rank)
@@ -136,7 +176,7 @@ def main():
     def step():
         opt.zero_grad(set_to_none=True)
         out = model(A, B)
-        out = out[-1] if isinstance(out, list) else out
+        out = out[-1] if isinstance(out, (list, tuple)) else out      # SiamUnet_sub: [logits]; SegCD: (mask_t1, mask_t2, change)
         loss = cross_entropy(out, L) if args.label == 2 else bce_dice_with_logits(out, Lf)
         loss.backward()
         opt.step()
@@ -171,15 +211,15 @@ def main():
 
     result = {
         "metric": "image-pairs/sec (256x256 bf16 SiamUnet_diff train)" if (args.model, args.size, args.dtype) == ("diff", 256, "bf16")
-        else f"image-pairs/sec ({args.size}x{args.size} {args.dtype} {'SNUNet_ECAM' if args.model == 'snunet' else 'SiamUnet_' + args.model} train)",
+        else f"image-pairs/sec ({args.size}x{args.size} {args.dtype} {NAMES[args.model]} train)",
         "value": round(world * args.batch * args.steps / elapsed, 2),
         "unit": "image-pairs/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{'SNUNet_ECAM' if args.model == 'snunet' else 'SiamUnet_' + args.model}(3,{args.label}) {args.size}x{args.size} full training step "
-                               f"(fwd + {'cross_entropy' if args.label == 2 else 'sigmoid+cd_loss'} + bwd + AdamW), "
+        "config": {"workload": f"{NAMES[args.model]}(3,{args.label}) {args.size}x{args.size} full training step "
+                               f"(fwd + {'cross_entropy' if args.label == 2 else 'sigmoid+cd_loss'} + bwd + {'Adam' if args.model == 'segcd' else 'AdamW'}), "
                                f"{args.batch} pairs/GPU, synthetic LEVIR-CD-shaped pairs resident in HBM",
                    "global_batch": world * args.batch, "image": args.size, "parallelism": f"dp{world}",
                    "last_loss": round(last_loss, 5)},

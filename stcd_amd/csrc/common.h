@@ -170,6 +170,7 @@ int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_mo
 struct WgradMfmaPlan {
     int WCI = 1, NTW = 1, gx = 1, gy = 1, gz = 1;
     int64_t slab_floats = 0;
+    int wi_valid = 0;      // > 0: columns of the input that exist (a strided VIEW passes a virtual width: see configure_segcd)
     bool ok = false;
 };
 WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld);
@@ -191,6 +192,8 @@ struct WgradJob {
     int gx, gy, gz;                        // block grid of this job
     int start;                             // first block of the job inside a grouped launch
     int lds_bytes;
+    int wi_valid;                          // input columns >= wi_valid read as zero (== g.wi for a plain tensor)
+    int pad_;
 };
 WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t in_off, int64_t dout_off, int64_t slab_off,
                         int kpad, int wld);

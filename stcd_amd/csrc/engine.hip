@@ -132,7 +132,7 @@ struct GLayer {
     std::vector<ViewRef> extra_dst;       // decoder concat slices that also receive A
     std::vector<ViewRef> grad_src;        // gradient contributions gathered into dA by the BatchNorm-backward reduction
     bool grad_base = true;                // dA already holds a contribution when the backward of this layer starts
-    ConvOp fwd, dgr[4]; int ndgr = 0; WgradOp wg;
+    ConvOp fwd, dgr[4]; int ndgr = 0; WgradOp wg[4]; int nwg = 0;
     int64_t stat = -1, coef = -1, facc = -1, bacc = -1;
 };
 enum GStepKind { GS_LAYER = 0, GS_MAXPOOL = 1, GS_UPSAMPLE = 2 };
@@ -256,7 +256,15 @@ static void make_specs(ConvW& c, bool need_dgrad) {
     if (c.kind == K_CONV3_S2) {   // Conv2d(k3, s2, p1): forward = stride-2 gather; data gradient = 4 sub-pixel phases (as K_UPCONV's forward)
         PackSpec& f = c.fwd;
         f.ks = 3; f.K = c.cin; f.N = c.cout; f.kpad = c.kin_p; f.wld = c.nout_p; f.ntaps = 9; f.kn_major = 0;
-        for (int k = 0; k < 9; ++k) { f.ky[k] = k / 3; f.kx[k] = k % 3; }
+        {   // taps grouped by the PARITY PLANE of the input pixel they read (row 2m + ky - 1: ky == 1 -> even rows, else odd), planes
+            // (0,0),(0,1),(1,0),(1,1) with 1+2+2+4 taps: the weight gradient runs as four stride-1 launches over plane views
+            int t = 0;
+            for (int py = 0; py < 2; ++py)
+                for (int px = 0; px < 2; ++px)
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int kx = 0; kx < 3; ++kx)
+                            if ((ky != 1) == (py == 1) && (kx != 1) == (px == 1)) { f.ky[t] = ky; f.kx[t] = kx; ++t; }
+        }
         PackSpec& d = c.dgrad;
         d.ks = 3; d.K = c.cout; d.N = c.cin; d.kpad = c.nout_p; d.wld = round8(c.cin); d.ntaps = need_dgrad ? 9 : 0; d.kn_major = 1;
         int t = 0;
@@ -1808,12 +1816,12 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
         }
         e.conv_ops.push_back(&op);
     };
-    auto bind_wgrad = [&](WgradOp& op, const stcd_conv_geom& g, int conv, int64_t in_off, int64_t dout_off) {
+    auto bind_wgrad = [&](WgradOp& op, const stcd_conv_geom& g, int conv, int64_t in_off, int64_t dout_off, int tap0 = 0, int wi_valid = 0) {
         const ConvW& cv = e.convs[conv];
-        op.g = g; op.conv = conv; op.tap0 = 0; op.kreal = cv.cin; op.nreal = cv.cout;
+        op.g = g; op.conv = conv; op.tap0 = tap0; op.kreal = cv.cin; op.nreal = cv.cout;
         op.in_off = in_off; op.dout_off = dout_off; op.grouped = false;
         op.plan = WgradMfmaPlan(); op.slab = -1; op.stage = 0;
-        if (e.dt == BF16) op.plan = wgrad_mfma_plan(g, cv.fwd.kpad, cv.fwd.wld);
+        if (e.dt == BF16) { op.plan = wgrad_mfma_plan(g, cv.fwd.kpad, cv.fwd.wld); op.plan.wi_valid = wi_valid; }
         e.wgrad_ops.push_back(&op);
     };
     for (auto& L : e.g_layers) {
@@ -1828,12 +1836,36 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
             g.n = L.N; g.hi = L.Hi; g.wi = L.Wi; g.ci = L.K; g.ldi = L.in.ld;
             g.hm = L.Ho; g.wm = L.Wo; g.in_stride = 2; g.ho = L.Ho; g.wo = L.Wo; g.out_stride = 1;
             g.co = cv.cout; g.ldo = L.Y.ld;
-            if (L.kind == K_CONV3_S2) { g.ntaps = 9; for (int t = 0; t < 9; ++t) { g.dy[t] = (int8_t)(t / 3 - 1); g.dx[t] = (int8_t)(t % 3 - 1); } }
+            if (L.kind == K_CONV3_S2) { g.ntaps = 9; for (int t = 0; t < 9; ++t) { g.dy[t] = (int8_t)(cv.fwd.ky[t] - 1); g.dx[t] = (int8_t)(cv.fwd.kx[t] - 1); } }
             else { g.ntaps = 1; g.dy[0] = 0; g.dx[0] = 0; }
         }
         bind_conv(L.fwd, g, L.conv, false, 0, cv.cin, cv.cout, L.groups);
-        stcd_conv_geom gw = g; gw.ldo = L.dA.ld;
-        bind_wgrad(L.wg, gw, L.conv, L.in.off, L.dA.off);
+        if (stride == 1) {
+            stcd_conv_geom gw = g; gw.ldo = L.dA.ld;
+            bind_wgrad(L.wg[0], gw, L.conv, L.in.off, L.dA.off);
+            L.nwg = 1;
+        } else {
+            // stride 2: input pixel (2m + ky - 1, 2n + kx - 1) lies in parity plane (py, px) at plane coordinates (m + dy, n + dx),
+            // dy = -1 for ky == 0 and 0 otherwise.  A plane is a VIEW of the NHWC tensor: pixel stride 2*ld, and a virtual row
+            // of Wi pixels (= two real rows), of which the first Wi/2 exist -- one stride-1 weight-gradient launch per plane.
+            static const int start[4] = {0, 1, 3, 5}, cnt[4] = {1, 2, 2, 4};
+            const int nph = L.kind == K_CONV3_S2 ? 4 : 1;
+            for (int ph = 0; ph < nph; ++ph) {
+                const int py = ph >> 1, px = ph & 1;
+                stcd_conv_geom gw;
+                memset(&gw, 0, sizeof(gw));
+                gw.n = L.N; gw.hi = L.Hi / 2; gw.wi = L.Wi; gw.ci = L.K; gw.ldi = 2 * L.in.ld;
+                gw.hm = L.Ho; gw.wm = L.Wo; gw.in_stride = 1; gw.ho = L.Ho; gw.wo = L.Wo; gw.out_stride = 1;
+                gw.co = cv.cout; gw.ldo = L.dA.ld;
+                gw.ntaps = L.kind == K_CONV3_S2 ? cnt[ph] : 1;
+                for (int t = 0; t < gw.ntaps; ++t) {
+                    const int ky = L.kind == K_CONV3_S2 ? cv.fwd.ky[start[ph] + t] : 1, kx = L.kind == K_CONV3_S2 ? cv.fwd.kx[start[ph] + t] : 1;
+                    gw.dy[t] = (int8_t)(ky == 0 ? -1 : 0); gw.dx[t] = (int8_t)(kx == 0 ? -1 : 0);
+                }
+                bind_wgrad(L.wg[ph], gw, L.conv, L.in.off + ((int64_t)py * L.Wi + px) * L.in.ld * T, L.dA.off, start[ph], L.Wi / 2);
+            }
+            L.nwg = nph;
+        }
         if (!L.has_dIn) continue;
         if (stride == 1) {
             stcd_conv_geom gd = L.kind == K_CONV3 ? geom3(L.N, L.Ho, L.Wo, cv.dgrad.kpad, L.dA.ld, cv.cin, L.dIn.ld)
@@ -1948,7 +1980,7 @@ static void glayer_backward(const Ctx& c, GLayer& L) {
         launch_stem_wgrad(e.dt, c.at(L.in.off), c.at(L.dA.off), c.grads + cv.w_off, L.N, L.Hi, L.Wi, cv.cin, cv.cout, c.s);
         return;
     }
-    exec_wgrad(c, L.wg, c.at(L.in.off), c.at(L.dA.off));
+    for (int k = 0; k < L.nwg; ++k) exec_wgrad(c, L.wg[k], c.at(L.wg[k].in_off), c.at(L.dA.off));
     if (!L.has_dIn) return;
     if (L.kind == K_CONV1_S2)
         (void)hipMemsetAsync(c.at(L.dIn.off), 0, (size_t)L.N * L.Hi * L.Wi * L.dIn.ld * dsize(e.dt), c.s);

@@ -519,7 +519,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
                                           mx0_ * a.g.out_stride + a.g.ox0) * a.g.ldo) * 2);                            \
         _Pragma("unroll") for (int p = 0; p < MAXX; ++p) {                                                            \
             if (p < npx) {                                                                                            \
-                const bool ok_ = (unsigned)(my0_ + xa[p]) < (unsigned)a.g.hi && (unsigned)(mx0_ + xb[p]) < (unsigned)a.g.wi; \
+                const bool ok_ = (unsigned)(my0_ + xa[p]) < (unsigned)a.g.hi && (unsigned)(mx0_ + xb[p]) < (unsigned)a.wi_valid; \
                 const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok_ ? (unsigned)xg[p] : 0x80000000u, xs_, 0); \
                 prex[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                     \
             }                                                                                                         \
@@ -785,6 +785,7 @@ WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t
     a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
     a.dout_bytes = (unsigned)((int64_t)g.n * g.ho * g.wo * g.ldo * 2);
     a.gx = p.gx; a.gy = p.gy; a.gz = p.gz; a.start = 0;
+    a.wi_valid = p.wi_valid > 0 ? p.wi_valid : g.wi; a.pad_ = 0;
     const int WK = 4 / p.WCI;
     a.lds_bytes = (int)std::max<size_t>(2 * (size_t)(a.x_bytes + a.y_bytes), (size_t)(WK - 1) * p.WCI * 9 * p.NTW * 4 * 64 * 4);
     return a;
