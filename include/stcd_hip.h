@@ -117,6 +117,23 @@ int stcd_backward(stcd_engine* e, const float* grad_logits, const float* params,
 /* [begin,end) element range of the flat gradient buffer that stage 0 finalises (the rest belongs to stage 1). */
 int stcd_grad_stage_range(const stcd_engine* e, int stage, int64_t* begin, int64_t* end);
 
+/* ---- test introspection: the named activation / gradient tensors of the CURRENT configuration inside the workspace, so a
+ *      parity test can check every layer of a deep network IN PLACE (layer output against a convolution of the layer's own
+ *      stored input, weight gradient against the stored input and output gradient ...) at per-op tolerance, independent of how
+ *      rounding differences grow through the depth.  Filled for STCD_ARCH_SEGCD ("<conv name>.in|.Y|.A|.dY|.dIn"); 0 tensors
+ *      for the other families.  NHWC: element (n, y, x, ch) at offset_bytes + (((n*h + y)*w + x)*ld + ch) * elem_size.
+ *      stcd_set_debug bit 0 (before stcd_configure): every layer writes its input gradient to a buffer of its own (the
+ *      producer gathers it) instead of in place into the producer's gradient tensor, so ".dIn" survives the backward. */
+typedef struct stcd_ws_tensor {
+    char name[96];
+    int64_t offset_bytes;
+    int n, h, w, c, ld;
+    int dtype;
+} stcd_ws_tensor;
+int stcd_set_debug(stcd_engine* e, int flags);
+int stcd_ws_tensor_count(const stcd_engine* e);
+int stcd_ws_tensor_get(const stcd_engine* e, int index, stcd_ws_tensor* out);
+
 /* ---- measurement aid (bench.py): when enabled, every launch of the engine's kernel classes is bracketed by a
  *      hipEvent pair on the caller's stream; stcd_profile_read sums one class (it synchronises those events) and
  *      reports the ALGORITHMIC work of the same launches (each tensor counted once).

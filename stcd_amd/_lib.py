@@ -43,6 +43,11 @@ class ConvGeom(C.Structure):
                 ("dy", C.c_int8 * 9), ("dx", C.c_int8 * 9), ("pad_", C.c_int8 * 2)]
 
 
+class WsTensor(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("offset_bytes", C.c_int64), ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c", C.c_int),
+                ("ld", C.c_int), ("dtype", C.c_int)]
+
+
 class MapGeom(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("groups", C.c_int32)]
 
@@ -68,6 +73,9 @@ _PROTOS = {
     "stcd_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _i, _vp, _vp, _vp]),
     "stcd_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "stcd_grad_stage_range": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "stcd_set_debug": (_i, [_vp, _i]),
+    "stcd_ws_tensor_count": (_i, [_vp]),
+    "stcd_ws_tensor_get": (_i, [_vp, _i, C.POINTER(WsTensor)]),
     "stcd_profile_enable": (_i, [_vp, _i]),
     "stcd_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "stcd_profile_num_kernels": (_i, [_vp]),

@@ -65,6 +65,8 @@ struct WgradOp {
     int stage = 0;
     int64_t in_off = -1, dout_off = -1;  // workspace offsets of X and dY (grouped launch at the end of the stage)
     bool grouped = false;
+    bool own_taps = false;               // filter taps (ky, kx) of this launch given here instead of conv.fwd.ky/kx[tap0 + t]
+    int8_t oky[9] = {0}, okx[9] = {0};   // (the 7x7 stem: 49 taps spread over 7 launches)
 };
 struct WgradGroup {                      // all launches of one kernel variant in one backward stage
     int WCI = 1, NTW = 1; bool t9 = false;
@@ -132,7 +134,7 @@ struct GLayer {
     std::vector<ViewRef> extra_dst;       // decoder concat slices that also receive A
     std::vector<ViewRef> grad_src;        // gradient contributions gathered into dA by the BatchNorm-backward reduction
     bool grad_base = true;                // dA already holds a contribution when the backward of this layer starts
-    ConvOp fwd, dgr[4]; int ndgr = 0; WgradOp wg[4]; int nwg = 0;
+    ConvOp fwd, dgr[4]; int ndgr = 0; WgradOp wg[8]; int nwg = 0;
     int64_t stat = -1, coef = -1, facc = -1, bacc = -1;
 };
 enum GStepKind { GS_LAYER = 0, GS_MAXPOOL = 1, GS_UPSAMPLE = 2 };
@@ -179,6 +181,8 @@ struct stcd_engine_impl {
     std::vector<GLayer> g_layers;                            // every conv + BatchNorm (+ residual) (+ ReLU) layer, forward order
     std::vector<GStep> g_fwd;                                // forward program (the backward walks it in reverse)
     int g_stem = -1, g_head_conv = -1;
+    int debug_flags = 0;
+    std::vector<stcd_ws_tensor> ws_tensors;
     std::vector<std::array<int, 4>> g_blocks;                // (L1, L2, L3, Ld or -1) per bottleneck
     std::vector<std::array<int, 2>> g_dec;                   // (conv1, conv2) per decoder block
     TRef gP0, gdP0, gX3, gdX3, gFuseTmp;
@@ -513,7 +517,10 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
             j.slab_stride = (int64_t)op->g.ntaps * cv.fwd.kpad * cv.fwd.wld;
             j.gx = op->plan.gx; j.ntaps = op->g.ntaps; j.K = cv.cin; j.N = cv.cout; j.kpad = cv.fwd.kpad; j.wld = cv.fwd.wld;
             j.ks = cv.fwd.ks; j.kn_major = cv.fwd.kn_major;
-            for (int t = 0; t < op->g.ntaps; ++t) { j.ky[t] = cv.fwd.ky[op->tap0 + t]; j.kx[t] = cv.fwd.kx[op->tap0 + t]; }
+            for (int t = 0; t < op->g.ntaps; ++t) {
+                j.ky[t] = op->own_taps ? op->oky[t] : cv.fwd.ky[op->tap0 + t];
+                j.kx[t] = op->own_taps ? op->okx[t] : cv.fwd.kx[op->tap0 + t];
+            }
             {   // index space: parts x outputs (padded to whole waves); <= 32 slabs per part
                 const int64_t outs_pad = ((int64_t)j.ntaps * j.K * j.N + 63) & ~(int64_t)63;
                 const int parts = (j.gx + 31) / 32;
@@ -909,7 +916,10 @@ static void exec_wgrad(const Ctx& c, const WgradOp& op, const void* in, const vo
     const ConvW& cv = c.e.convs[op.conv];
     PackSpec sub = cv.fwd;                 // this launch's taps of the filter
     sub.ntaps = op.g.ntaps;
-    for (int t = 0; t < op.g.ntaps; ++t) { sub.ky[t] = cv.fwd.ky[op.tap0 + t]; sub.kx[t] = cv.fwd.kx[op.tap0 + t]; }
+    for (int t = 0; t < op.g.ntaps; ++t) {
+        sub.ky[t] = op.own_taps ? op.oky[t] : cv.fwd.ky[op.tap0 + t];
+        sub.kx[t] = op.own_taps ? op.okx[t] : cv.fwd.kx[op.tap0 + t];
+    }
     double fl, by;
     conv_work(c.e, op.g, op.kreal, op.nreal, &fl, &by);
     if (mfma_on(c.e) && op.plan.ok && op.grouped) return;    // runs in the stage's grouped launch (wgrad_stage)
@@ -923,6 +933,7 @@ static void exec_wgrad(const Ctx& c, const WgradOp& op, const void* in, const vo
         }
         if (rc == 0) return;       // the slabs are summed by the stage's batched reduce launch (reduce_stage)
     }
+    if (op.own_taps) { set_error("internal: no reference fallback for a launch with its own tap table"); return; }
     double* dwe = c.at<double>(cv.dwe) + (int64_t)op.tap0 * sub.kpad * sub.wld;
     if (mfma_on(c.e))   // the bulk memset of the reference path's accumulators is skipped in MFMA mode
         (void)hipMemsetAsync(dwe, 0, (size_t)sub.ntaps * sub.kpad * sub.wld * 8, c.s);
@@ -1738,7 +1749,10 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
             shape(L3, L2.A, L2.C, ho, wo, 1);
             L3.res = blk[3] >= 0 ? e.g_layers[blk[3]].A : cur;
             // gradient wiring: single-consumer tensors are written in place, the block input gets contribution buffers
-            L2.dIn = L1.dA; L3.dIn = L2.dA;
+            if (e.debug_flags & 1) {
+                L2.dIn = plain(N, h, w, L1.C); L1.grad_base = false; L1.grad_src.push_back(view(L2.dIn, 0, L1.C, h, w));
+                L3.dIn = plain(N, ho, wo, L2.C); L2.grad_base = false; L2.grad_src.push_back(view(L3.dIn, 0, L2.C, ho, wo));
+            } else { L2.dIn = L1.dA; L3.dIn = L2.dA; }
             L1.dIn = (prev_out < 0) ? e.gdP0 : plain(N, h, w, curC);
             TRef idc;                                                          // identity-branch contribution to d(cur)
             if (blk[3] >= 0) { GLayer& Ld = e.g_layers[blk[3]]; L3.dRes = Ld.dA; Ld.dIn = plain(N, h, w, curC); idc = Ld.dIn; }
@@ -1773,7 +1787,9 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
         GLayer& D1 = e.g_layers[e.g_dec[i][0]]; GLayer& D2 = e.g_layers[e.g_dec[i][1]];
         shape(D1, cat, Cx + Cs, hh, ww, 1);
         shape(D2, D1.A, D1.C, hh, ww, 1);
-        D1.dIn = dcat; D2.dIn = D1.dA;
+        D1.dIn = dcat;
+        if (e.debug_flags & 1) { D2.dIn = plain(N, hh, ww, D1.C); D1.grad_base = false; D1.grad_src.push_back(view(D2.dIn, 0, D1.C, hh, ww)); }
+        else D2.dIn = D1.dA;
         for (int k : {e.g_dec[i][0], e.g_dec[i][1]}) { GStep st; st.layer = k; e.g_fwd.push_back(st); }
         xl = e.g_dec[i][1];
     }
@@ -1825,7 +1841,45 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
         e.wgrad_ops.push_back(&op);
     };
     for (auto& L : e.g_layers) {
-        if (L.kind == K_STEM7) continue;
+        if (L.kind == K_STEM7) {
+            // 7x7 stride-2 weight gradient on the MFMA path: row 2y + ky - 3 lies in parity plane py = (ky + 1) & 1 at plane row
+            // y + (ky - 3 - py) / 2; per plane 3x3 / 3x4 / 4x3 / 4x4 taps, run as stride-1 launches of <= 9 taps over plane views
+            // (see the stride-2 layers below).  fp32 mode (and any plan that does not fit) keeps the dedicated fp32 kernel.
+            L.nwg = 0;
+            if (!(e.dt == BF16 && e.use_mfma && e.use_wgroup)) continue;
+            const ConvW& cv = e.convs[L.conv];
+            bool all_ok = true;
+            int nops = 0;
+            for (int ph = 0; ph < 4 && all_ok; ++ph) {
+                const int py = ph >> 1, px = ph & 1;
+                std::vector<std::pair<int, int>> taps;
+                for (int ky = 0; ky < 7; ++ky)
+                    for (int kx = 0; kx < 7; ++kx)
+                        if (((ky + 1) & 1) == py && ((kx + 1) & 1) == px) taps.push_back({ky, kx});
+                const int nchunk = ((int)taps.size() + 8) / 9, per = ((int)taps.size() + nchunk - 1) / nchunk;
+                for (int c0 = 0; c0 < (int)taps.size(); c0 += per) {
+                    const int nt = std::min(per, (int)taps.size() - c0);
+                    stcd_conv_geom gw;
+                    memset(&gw, 0, sizeof(gw));
+                    gw.n = L.N; gw.hi = L.Hi / 2; gw.wi = L.Wi; gw.ci = 8; gw.ldi = 2 * L.in.ld;
+                    gw.hm = L.Ho; gw.wm = L.Wo; gw.in_stride = 1; gw.ho = L.Ho; gw.wo = L.Wo; gw.out_stride = 1;
+                    gw.co = cv.cout; gw.ldo = L.dA.ld; gw.ntaps = nt;
+                    WgradOp& op = L.wg[nops];
+                    for (int t = 0; t < nt; ++t) {
+                        const int ky = taps[c0 + t].first, kx = taps[c0 + t].second;
+                        gw.dy[t] = (int8_t)((ky - 3 - py) / 2); gw.dx[t] = (int8_t)((kx - 3 - px) / 2);
+                        op.oky[t] = (int8_t)ky; op.okx[t] = (int8_t)kx;
+                    }
+                    bind_wgrad(op, gw, L.conv, L.in.off + ((int64_t)py * L.Wi + px) * L.in.ld * T, L.dA.off, 0, L.Wi / 2);
+                    op.own_taps = true;
+                    all_ok = all_ok && op.plan.ok;
+                    ++nops;
+                }
+            }
+            if (all_ok) L.nwg = nops;
+            else for (int k = 0; k < nops; ++k) e.wgrad_ops.pop_back();
+            continue;
+        }
         const ConvW& cv = e.convs[L.conv];
         stcd_conv_geom g;
         const int stride = L.Hi / L.Ho;
@@ -1903,6 +1957,23 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
         bind_wgrad(e.g_head_wg, geom3(3 * B, H, W, 16, 16, e.label, 8), e.g_head_conv, e.gX3.off, e.G.off);
         bind_conv(e.g_head_dgr, geom3(3 * B, H, W, cv.dgrad.kpad, 8, 16, 16), e.g_head_conv, true, 0, e.label, 16);
     }
+    e.ws_tensors.clear();
+    for (const auto& L : e.g_layers) {
+        auto rec = [&](const char* sfx, const TRef& t, int n, int h, int w, int c) {
+            if (t.off < 0) return;
+            stcd_ws_tensor r;
+            memset(&r, 0, sizeof(r));
+            snprintf(r.name, sizeof(r.name), "%s.%s", L.name.c_str(), sfx);
+            r.offset_bytes = t.off; r.n = n; r.h = h; r.w = w; r.c = c; r.ld = t.ld; r.dtype = e.dt;
+            e.ws_tensors.push_back(r);
+        };
+        rec("in", L.in, L.N, L.Hi, L.Wi, L.K);
+        rec("Y", L.Y, L.N, L.Ho, L.Wo, L.C);
+        rec("A", L.A, L.N, L.Ho, L.Wo, L.C);
+        rec("dY", L.dA, L.N, L.Ho, L.Wo, L.C);
+        if (L.has_dIn) rec("dIn", L.dIn, L.N, L.Hi, L.Wi, L.K);
+        rec("res", L.res, L.N, L.Ho, L.Wo, L.C);
+    }
     e.slab = ws.take(e.slab_floats * 4);
     e.bias_jobs.clear();
     {
@@ -1974,6 +2045,10 @@ static void glayer_backward(const Ctx& c, GLayer& L) {
         launch_bn_bwd_apply(e.dt, c.at(L.dA.off), L.dA.ld, ppg * L.dA.ld, c.at(L.dA.off), L.dA.ld, c.at(L.Y.off), L.Y.ld, stat,
                             c.at<long long>(L.bacc), c.grads + bn.g_off, c.grads + bn.b_off, nullptr, L.C, L.groups, L.npg, HW, L.relu ? 1 : 0,
                             c.s, res, L.res.ld, L.dRes.off >= 0 ? c.at(L.dRes.off) : nullptr, L.dRes.ld);
+    }
+    if (L.kind == K_STEM7 && L.nwg > 0) {
+        for (int k = 0; k < L.nwg; ++k) exec_wgrad(c, L.wg[k], c.at(L.wg[k].in_off), c.at(L.dA.off));
+        return;
     }
     if (L.kind == K_STEM7) {
         ProfScope ps(c, PC_WGRAD, 2.0 * L.N * HW * 49.0 * cv.cin * cv.cout, 0.0, "k_stem_wgrad");
@@ -2167,6 +2242,20 @@ int stcd_backward(stcd_engine* e, const float* grad_logits, const float* params,
     if (e->arch == STCD_ARCH_SNUNET) return backward_snunet(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
     if (e->arch == STCD_ARCH_SEGCD) return backward_segcd(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
     return backward_fcsiam(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
+}
+
+int stcd_set_debug(stcd_engine* e, int flags) {
+    STCD_CHECK(e != nullptr, "engine is null");
+    e->debug_flags = flags;
+    e->configured = false;      // takes effect at the next stcd_configure
+    return 0;
+}
+int stcd_ws_tensor_count(const stcd_engine* e) { return e ? (int)e->ws_tensors.size() : 0; }
+int stcd_ws_tensor_get(const stcd_engine* e, int index, stcd_ws_tensor* out) {
+    STCD_CHECK(e != nullptr && out != nullptr, "null argument");
+    STCD_CHECK(index >= 0 && index < (int)e->ws_tensors.size(), "tensor index out of range");
+    *out = e->ws_tensors[index];
+    return 0;
 }
 
 int stcd_grad_stage_range(const stcd_engine* e, int stage, int64_t* begin, int64_t* end) {

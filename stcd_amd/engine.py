@@ -129,6 +129,24 @@ class Engine:
         _lib.check(self._l.stcd_backward(self._h, _ptr(grad_logits), _ptr(flat_params), _ptr(flat_grads),
                                          _ptr(self.workspace), stage, _stream()))
 
+    # ------------------------------------------------------------------ test introspection
+    def set_debug(self, flags: int):
+        """bit 0: every layer keeps its input gradient in a buffer of its own (see include/stcd_hip.h)."""
+        _lib.check(self._l.stcd_set_debug(self._h, int(flags)))
+        self.shape = None
+
+    def ws_tensors(self):
+        """-> {name: NHWC view [n, h, w, c] of the live workspace} for the current configuration (SegCD only)."""
+        out = {}
+        wt = _lib.WsTensor()
+        for i in range(self._l.stcd_ws_tensor_count(self._h)):
+            _lib.check(self._l.stcd_ws_tensor_get(self._h, i, C.byref(wt)))
+            dt = torch.bfloat16 if wt.dtype == _lib.DTYPE_IDS["bf16"] else torch.float32
+            es = 2 if dt == torch.bfloat16 else 4
+            flat = self.workspace[wt.offset_bytes:wt.offset_bytes + wt.n * wt.h * wt.w * wt.ld * es].view(dt)
+            out[wt.name.decode()] = flat.view(wt.n, wt.h, wt.w, wt.ld)[..., :wt.c]
+        return out
+
     # ------------------------------------------------------------------ measurement aid (bench.py)
     PROFILE_CLASSES = ("conv", "wgrad", "bn_stats", "bn_act", "bn_bwd_reduce", "bn_bwd_apply", "pool_fuse_bwd", "pack")
 

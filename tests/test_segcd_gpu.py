@@ -102,3 +102,175 @@ def test_segcd_rejects_unsupported_configs_and_sizes():
     m = SegCD(dtype="fp32").to(DEV)
     with pytest.raises(Exception, match="divisible by 32"):
         m(torch.zeros(1, 3, 48, 48, device=DEV), torch.zeros(1, 3, 48, 48, device=DEV))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Layer-local parity INSIDE the network: rounding differences grow through ~110 BatchNorm-ed layers (with the synthetic
+# weights the step's gradient changes by 3e-2 between two fp32 evaluation orders, and bf16 storage decorrelates it), so an
+# end-to-end comparison cannot bound a bf16 kernel.  Instead every layer is checked in place against torch's convolution
+# applied to the layer's OWN stored input / output gradient (stcd_ws_tensor_* introspection): output, weight gradient,
+# input gradient, BatchNorm + ReLU (+ residual), and the concat / up-sampling plumbing -- at per-op tolerance.
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).float().contiguous()
+
+
+def _holders(m):
+    """conv name -> (conv holder, bn holder) for every Conv+BN layer of the plan."""
+    out = {"encoder.conv1": (m.encoder.conv1, m.encoder.bn1)}
+    for li in range(1, 5):
+        for b, blk in enumerate(getattr(m.encoder, f"layer{li}")):
+            pre = f"encoder.layer{li}.{b}"
+            for k in (1, 2, 3):
+                out[f"{pre}.conv{k}"] = (getattr(blk, f"conv{k}"), getattr(blk, f"bn{k}"))
+            if blk.downsample is not None:
+                out[f"{pre}.downsample.0"] = (blk.downsample[0], blk.downsample[1])
+    for i, blk in enumerate(m.decoder.blocks):
+        out[f"decoder.blocks.{i}.conv1.0"] = (blk.conv1[0], blk.conv1[1])
+        out[f"decoder.blocks.{i}.conv2.0"] = (blk.conv2[0], blk.conv2[1])
+    return out
+
+
+@pytest.mark.parametrize("dtype,B,H,W", [("fp32", 2, 64, 64), ("bf16", 2, 64, 96), ("bf16", 3, 128, 128)])
+def test_segcd_every_layer_in_place(dtype, B, H, W):
+    tol = 2e-4 if dtype == "fp32" else 6e-3            # bf16: one rounding of the output (2^-9 relative, ~1.2e-3 rms) + bf16 weights
+    rng = np.random.default_rng(31)
+    x1 = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32)).to(DEV)
+    x2 = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32)).to(DEV)
+    tgt = torch.from_numpy((rng.random((B, 1, H, W)) < 0.2).astype(np.float32)).to(DEV)
+    m = SegCD(dtype=dtype)
+    m.load_state_dict(G.synth_state(3, 1, 11))
+    m._engine.set_debug(1)
+    m.to(DEV).train()
+    o = m(x1, x2)
+    loss = bce_dice_with_logits(o[2], tgt) + bce_dice_with_logits(o[0], tgt) + 0.5 * o[1].mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    ws = m._engine.ws_tensors()
+    hold = _holders(m)
+    assert len(hold) == 63 and all(f"{k}.Y" in ws for k in hold)
+    worst = {}
+
+    def chk(kind, name, got, want, t=tol):
+        r = float((got.float() - want).norm() / want.norm().clamp_min(1e-30))
+        worst[kind] = max(worst.get(kind, (0.0, ""))[0], r), (name if r >= worst.get(kind, (0.0, ""))[0] else worst[kind][1])
+        assert r <= t, (kind, name, r)
+
+    wq = (lambda w: w.detach().to(torch.bfloat16).float()) if dtype == "bf16" else (lambda w: w.detach())
+    for name, (conv, bn) in hold.items():
+        X, Y, A, dY = _nchw(ws[name + ".in"]), _nchw(ws[name + ".Y"]), _nchw(ws[name + ".A"]), _nchw(ws[name + ".dY"])
+        Wt = wq(conv.weight)
+        if name == "encoder.conv1":
+            X = X[:, :3]
+        chk("conv output", name, Y, torch.nn.functional.conv2d(X, Wt, None, conv.stride, conv.padding))
+        # weight gradient from the stored input and output gradient (fp32 accumulation of bf16 products on both sides)
+        want_dw = torch.nn.grad.conv2d_weight(X, conv.weight.shape, dY, conv.stride, conv.padding)
+        chk("weight gradient", name, conv.weight.grad, want_dw, 2e-4 if dtype == "fp32" else 2e-3)
+        if name + ".dIn" in ws:
+            want_dx = torch.nn.grad.conv2d_input(X.shape, Wt, dY, conv.stride, conv.padding)
+            if name == "encoder.layer1.0.conv1":      # the max-pool's gradient buffer: the down-sample branch is accumulated into it
+                dc = hold["encoder.layer1.0.downsample.0"][0]
+                want_dx = want_dx + torch.nn.grad.conv2d_input(X.shape, wq(dc.weight), _nchw(ws["encoder.layer1.0.downsample.0.dY"]), dc.stride, dc.padding)
+            chk("input gradient", name, _nchw(ws[name + ".dIn"]), want_dx)
+        # BatchNorm (per-date batch statistics) + residual + ReLU from the stored conv output
+        res = _nchw(ws[name + ".res"]) if name + ".res" in ws else None
+        outs = []
+        for d in range(2):
+            y = Y[d * B:(d + 1) * B]
+            mu, var = y.mean(dim=(0, 2, 3), keepdim=True), y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+            z = (y - mu) * torch.rsqrt(var + 1e-5) * bn.weight.detach().view(1, -1, 1, 1) + bn.bias.detach().view(1, -1, 1, 1)
+            if res is not None:
+                z = z + res[d * B:(d + 1) * B]
+            outs.append(z if ".downsample." in name else torch.relu(z))
+        chk("bn+relu", name, A, torch.cat(outs), 1e-4 if dtype == "fp32" else 1.2e-2)
+    # plumbing: max-pool, residual wiring, up-sampling + skip concat (exact copies of stored tensors)
+    f1 = _nchw(ws["encoder.conv1.A"])
+    assert torch.equal(_nchw(ws["encoder.layer1.0.conv1.in"]), torch.nn.functional.max_pool2d(f1, 3, 2, 1))
+    assert torch.equal(_nchw(ws["encoder.layer1.1.conv3.res"]), _nchw(ws["encoder.layer1.0.conv3.A"]))
+    assert torch.equal(_nchw(ws["encoder.layer2.0.conv3.res"]), _nchw(ws["encoder.layer2.0.downsample.0.A"]))
+    skips = ["encoder.layer3.5.conv3", "encoder.layer2.3.conv3", "encoder.layer1.2.conv3", "encoder.conv1"]
+    x = _nchw(ws["encoder.layer4.2.conv3.A"])
+    for i in range(5):
+        cat = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
+        if i < 4:
+            cat = torch.cat([cat, _nchw(ws[skips[i] + ".A"])], dim=1)
+        assert torch.equal(_nchw(ws[f"decoder.blocks.{i}.conv1.0.in"]), cat), i
+        x = _nchw(ws[f"decoder.blocks.{i}.conv2.0.A"])
+    # head: logits from the last decoder activation, in torch
+    d1, d2 = x[:B], x[B:]
+    hw, hb = wq(m.segmentation_head[0].weight), m.segmentation_head[0].bias.detach()
+    head = lambda t_: torch.nn.functional.conv2d(t_, hw, hb, padding=1)
+    m1, m2 = head(d1), head(d2)
+    want = (m1, m2, torch.min(head((d1 - d2).abs()), (m1 - m2).abs()))
+    for k in range(3):
+        chk("head", f"output {k}", o[k].detach(), want[k], 1e-4 if dtype == "fp32" else 2e-2)
+    print(f"SegCD {dtype} B={B} {H}x{W} layer-local worst relative l2: " + ", ".join(f"{k} {v[0]:.1e} ({v[1]})" for k, v in worst.items()))
+
+
+def test_segcd_bf16_tracks_reference_vectors(golden):
+    """bf16 storage end to end against the reference's vectors (G10): eval-mode maps at 4e-2 relative l2 (measured 2.1e-2: one
+    bf16 rounding per stored activation over ~110 layers), training loss at 2e-2; gradients: the head's and the last decoder
+    block's (a few layers from the loss) keep their direction, every tensor keeps its magnitude -- deeper directions are
+    not comparable on this synthetic network even between two fp32 evaluation orders (see the layer-local test above, which
+    bounds every kernel instead)."""
+    g = golden("g10_segcd.npz")
+    seed = int(g["seed"])
+    x1, x2 = t(g["x1"]).to(DEV), t(g["x2"]).to(DEV)
+    m = SegCD(dtype="bf16")
+    m.load_state_dict(G.synth_state(3, 1, seed, perturb_running=True))
+    m.to(DEV).eval()
+    with torch.no_grad():
+        o = m(x1, x2)
+    for k, v in zip(("m1", "m2"), o):
+        r, _ = rel_l2_cos(v.cpu().numpy(), g[f"eval/{k}"])
+        assert r <= 4e-2, (k, r)
+    m = SegCD(dtype="bf16")
+    m.load_state_dict(G.synth_state(3, 1, seed))
+    m.to(DEV).train()
+    m1, m2, ch = m(x1, x2)
+    loss = _loss(m1, m2, ch, t(g["seg_target"]).to(DEV), t(g["target"]).to(DEV))
+    assert abs(loss.item() - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
+    loss.backward()
+    from tests._util import gf_index
+    ratios = []
+    for name, p in m.named_parameters():
+        ref = g["gf/" + name]
+        got = p.grad.detach().cpu().numpy().ravel()[gf_index(name, p.numel())]
+        nr = float(np.linalg.norm(ref))
+        if nr < 1e-10:
+            continue
+        ratios.append(float(np.linalg.norm(got)) / nr)
+        if name.startswith("segmentation_head") or name.startswith("decoder.blocks.4.conv2"):
+            r, c = rel_l2_cos(got, ref)
+            assert c >= (0.99 if name.startswith("segmentation_head") else 0.9), (name, r, c)
+    ratios = np.array(ratios)
+    print(f"SegCD bf16 vs reference G10: gradient norm ratios median {np.median(ratios):.3f}, range [{ratios.min():.2f}, {ratios.max():.2f}]")
+    assert 0.8 <= np.median(ratios) <= 1.25 and ratios.min() >= 0.4 and ratios.max() <= 2.5
+
+
+def test_segcd_bf16_training_tracks_fp32():
+    """The same 30 Adam steps on a fixed synthetic set in fp32 and in bf16: both must learn (loss falls by > 25 %) and the
+    bf16 loss curve must stay within 25 % of fp32's over the last 10 steps (two fp32 runs of this loop already end 15 % apart:
+    0.233 vs 0.271 measured -- the fp32 reference kernels accumulate weight gradients with atomics, and 30 Adam steps at lr 1e-3 on
+    a freshly initialised ResNet-50 amplify the last-bit differences)."""
+    from stcd_amd import synth
+    from stcd_amd.optim import FlatAdamW
+    a, b, lab = synth.make_batch(8, 64, 64, seed=3)
+    A, Bt, L = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), torch.from_numpy(lab).to(DEV).float().unsqueeze(1)
+    curves = {}
+    for dt in ("fp32", "bf16"):
+        torch.manual_seed(5)
+        m = SegCD(dtype=dt).to(DEV).train()
+        opt = FlatAdamW(m, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0)
+        losses = []
+        for _ in range(30):
+            opt.zero_grad(set_to_none=True)
+            loss = bce_dice_with_logits(m(A, Bt)[2], L)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        curves[dt] = np.array(losses)
+        assert np.isfinite(curves[dt]).all()
+        assert curves[dt][-5:].mean() < 0.75 * curves[dt][:3].mean(), (dt, curves[dt])
+    tail32, tail16 = curves["fp32"][-10:].mean(), curves["bf16"][-10:].mean()
+    print(f"SegCD 30 steps: fp32 {curves['fp32'][0]:.3f} -> {tail32:.3f}, bf16 {curves['bf16'][0]:.3f} -> {tail16:.3f}")
+    assert abs(tail16 - tail32) <= 0.25 * tail32
