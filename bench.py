@@ -116,25 +116,30 @@ def cpu_baseline(arch, label, size, pairs, steps):
                       f"median of {steps} full steps after 1 warm-up ({med * 1e3:.0f} ms/step)"}
 
 
+def _pmc_files(model):
+    """Committed PMC summaries of THIS model's bench command, newest round first (diff's files carry no model tag)."""
+    import glob
+    files = glob.glob(os.path.join(REPO, "profiles", f"*_{model}_pmc_traffic.txt"))
+    if model == "diff":
+        files += glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc_traffic.txt"))
+    return sorted(files, reverse=True)
+
+
 def pmc_step_traffic(model):
     """Whole-step HBM-side bytes (sum over every kernel of launches x bytes per launch / profiled steps) from the committed
     PMC summary of the same command for this model (tools/collect_profiles.py writes the '# step_total_B' line)."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(REPO, "profiles", f"*_{model}_pmc_traffic.txt")) +
-                       (sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc_traffic.txt"))) if model == "diff" else []),
-                       reverse=True):
+    for path in _pmc_files(model):
         for line in open(path):
             if line.startswith("# step_total_B"):
                 return int(float(line.split()[-1])), os.path.relpath(path, REPO)
     return None, None
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, model):
     """HBM-side bytes per launch of `kernel` from the committed PMC summary of this same command: the counters need
     their own rocprofv3 --pmc passes (tools/profile_round.sh; FETCH_SIZE doubled per the gfx950 correction), so they
-    cannot be read inside the timed run.  None when no summary holds the kernel."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.txt")), reverse=True):
+    cannot be read inside the timed run.  None when no summary of this model holds the kernel."""
+    for path in _pmc_files(model):
         for line in open(path):
             if line.startswith(kernel + " ") or (len(kernel) > 48 and line.startswith(kernel[:48] + " ")):
                 try:
@@ -269,7 +274,7 @@ def main():
         else:
             ach, peak, unit = p["flops"] / secs / 1e12, peak_tf, "TFLOP/s"
         tot_ms = sum(v["ms"] for v in prof.values())
-        traffic, traffic_src = pmc_traffic("stcd::" + dom)
+        traffic, traffic_src = pmc_traffic("stcd::" + dom, args.model)
         result["roofline"] = {
             "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src,
