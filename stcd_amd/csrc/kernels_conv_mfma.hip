@@ -1496,4 +1496,254 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
     return 0;
 }
 
+
+// =====================================================================================================
+// 1x1 convolution = GEMM  out[m][co] = sum_ci X[m][ci] * W[ci][co]  over m = the positions of one BN group.
+//
+// Block tile TM x TN = (32*W) x (32*W) (W = 4: 128x128, W = 2: 64x64), 4 waves as 2 (positions) x 2 (channels), each
+// W x W fragments of 16x16; K walks in 64-channel steps: X rows (128 contiguous bytes each, raw buffer loads with
+// hardware zero-fill past the group's last position) and the weight fragments (already in MFMA order, contiguous
+// 1-KB pieces) are requested into registers before the MFMAs of the current step and parked in the other LDS buffer
+// after them (one barrier per step).  X image: row pitch 128 B, 16-B chunk index XOR-swizzled by (row >> 1) & 7 (the
+// layout of k_conv_res's 64-channel halo).  Weights are the MFMA A operand, so a lane's accumulator is 4 consecutive
+// channels of one position; the finished tile goes through LDS once more and leaves as full 16-B pieces of complete
+// output rows.  A stride (1x1 stride-2 down-sampling convs and their data gradient) only changes the row -> pixel maps.
+struct Gemm1x1Args {
+    stcd_conv_geom g;
+    const bf16* in; const bf16* wf; const float* bias; bf16* out;
+    long long* stat_acc;
+    int groups, cpad, stat_c0;
+    float s1_scale, s2_scale;
+    int NTtot, nchunks;            // n-tiles of the fragment image; Ci / 64
+    int Mg;                        // positions per group
+    int tiles_m, tiles_m8, tiles_n;
+    unsigned in_bytes;
+};
+
+template <int W>
+__global__ void __launch_bounds__(256, W == 2 ? 4 : 2)
+k_gemm1x1(const Gemm1x1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TM = 32 * W, TN = 32 * W, NF = TN / 16;
+    constexpr int XB = TM * 128, WB = 2 * NF * 1024, STAGE = XB + WB;
+    constexpr int XP = TM / 32, WP = (2 * NF * 64) / 256;           // 16-B pieces per thread and stage
+    constexpr int OPITCH = TN * 2 + 16;                             // out-tile row pitch (bytes)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int q = lane >> 4, r = lane & 15;
+    const int wm = wid & 1, wn = wid >> 1;
+    // block -> (group, m tile, n tile): the n tiles of one m tile are 8 blocks apart, i.e. on the same XCD (one L2 fetch of X)
+    const int per_grp = a.tiles_m8 * 8 * a.tiles_n;
+    const int grp = blockIdx.x / per_grp, idx = blockIdx.x - grp * per_grp;
+    const int m8 = idx / (8 * a.tiles_n), rem = idx - m8 * 8 * a.tiles_n;
+    const int nt = rem >> 3, mt = m8 * 8 + (rem & 7);
+    if (mt >= a.tiles_m) return;
+    const int m0 = mt * TM;                                         // first position of the tile inside the group
+    const int nf0 = nt * NF;                                        // first n-fragment
+
+    // ---- staging plan
+    const int ch = tid & 7;
+    unsigned xoff[XP]; int xlds[XP];
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+        const int row = (tid >> 3) + p * 32, m = m0 + row;
+        unsigned off = 0x80000000u;
+        if (m < a.Mg) {
+            const int mm = grp * a.Mg + m;
+            const int x = mm % a.g.wm, t = mm / a.g.wm, y = t % a.g.hm, n = t / a.g.hm;
+            off = (unsigned)(((((int64_t)n * a.g.hi + y * a.g.in_stride) * a.g.wi + x * a.g.in_stride) * a.g.ldi + ch * 8) * 2);
+        }
+        xoff[p] = off;
+        xlds[p] = (row * 8 + (ch ^ ((row >> 1) & 7))) * 16;
+    }
+    unsigned woff[WP]; int wlds[WP];
+#pragma unroll
+    for (int p = 0; p < WP; ++p) {
+        const int i = tid + p * 256, f = (i >> 6) % NF, ks = (i >> 6) / NF;
+        woff[p] = (unsigned)(((ks * a.NTtot + nf0 + f) * 64 + (i & 63)) * 16);          // + chunk * 2 * NTtot * 1024 per step
+        wlds[p] = XB + ((ks * NF + f) * 64 + (i & 63)) * 16;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.in)), (short)0, (int)a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.wf)), (short)0, a.nchunks * 2 * a.NTtot * 1024, 0x00020000);
+    const unsigned wstep = (unsigned)(2 * a.NTtot * 1024);
+    // two register sets: the chunk after next is requested before the MFMAs of the current one, so every load has two
+    // loop iterations to land (one block per CU on the deep layers: nothing else hides the L2 / HBM round trip)
+    uint4 pxa[XP], pwa[WP], pxb[XP], pwb[WP];
+#define GM_FETCH(C_, PX_, PW_)                                                                                         \
+    do {                                                                                                               \
+        const unsigned cs_ = (unsigned)__builtin_amdgcn_readfirstlane(C_);      /* chunk index as a scalar offset */   \
+        _Pragma("unroll") for (int p = 0; p < XP; ++p) {                                                               \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc, xoff[p], cs_ * 128u, 0);                      \
+            PX_[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                           \
+        }                                                                                                              \
+        _Pragma("unroll") for (int p = 0; p < WP; ++p) {                                                               \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[p], cs_ * wstep, 0);                      \
+            PW_[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                           \
+        }                                                                                                              \
+    } while (0)
+#define GM_STASH(BUF_, PX_, PW_)                                                                                       \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int p = 0; p < XP; ++p) *reinterpret_cast<uint4*>(smem + (BUF_) * STAGE + xlds[p]) = PX_[p]; \
+        _Pragma("unroll") for (int p = 0; p < WP; ++p) *reinterpret_cast<uint4*>(smem + (BUF_) * STAGE + wlds[p]) = PW_[p]; \
+    } while (0)
+#define GM_COMPUTE(BUF_)                                                                                               \
+    do {                                                                                                               \
+        const char* sb = smem + (BUF_) * STAGE;                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                             \
+            bf16x8 xf[W], wfr[W];                                                                                      \
+            _Pragma("unroll") for (int m = 0; m < W; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(sb + xr[m][ks]);    \
+            _Pragma("unroll") for (int n = 0; n < W; ++n) wfr[n] = *reinterpret_cast<const bf16x8*>(sb + wr + (ks * NF + n) * 1024); \
+            _Pragma("unroll") for (int m = 0; m < W; ++m)                                                              \
+                _Pragma("unroll") for (int n = 0; n < W; ++n)                                                          \
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[n], xf[m], acc[m][n], 0, 0, 0);            \
+        }                                                                                                              \
+    } while (0)
+
+    f32x4 acc[W][W];
+#pragma unroll
+    for (int m = 0; m < W; ++m)
+#pragma unroll
+        for (int n = 0; n < W; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int xr[W][2];                       // X fragment offsets: row wm*16W + 16m + r, chunk 4ks + q
+#pragma unroll
+    for (int m = 0; m < W; ++m)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = wm * 16 * W + 16 * m + r;
+            xr[m][ks] = (row * 8 + ((ks * 4 + q) ^ ((row >> 1) & 7))) * 16;
+        }
+    const int wr = XB + (wn * W * 64 + lane) * 16;
+
+    // every fetch / stash is unconditional (the chunk index is clamped: the tail re-reads the last chunk into a buffer nobody
+    // reads), so both register sets stay in registers across the loop
+    const int nc = a.nchunks;
+    GM_FETCH(0, pxa, pwa);
+    GM_FETCH(min(1, nc - 1), pxb, pwb);
+    GM_STASH(0, pxa, pwa);
+    __syncthreads();
+    for (int c = 0; c < nc; c += 2) {
+        GM_FETCH(min(c + 2, nc - 1), pxa, pwa);
+        GM_COMPUTE(0);
+        GM_STASH(1, pxb, pwb);
+        barrier_lds();
+        if (c + 1 >= nc) break;
+        GM_FETCH(min(c + 3, nc - 1), pxb, pwb);
+        GM_COMPUTE(1);
+        GM_STASH(0, pxa, pwa);
+        barrier_lds();
+    }
+#undef GM_COMPUTE
+#undef GM_FETCH
+#undef GM_STASH
+
+    // ---- epilogue: bias, rounding, statistics of the rounded values, out tile -> LDS [TM][TN] (pitch OPITCH)
+    char* const ot = smem;                                           // both stage buffers are dead (barrier above)
+    float s1[W][4], s2[W][4];
+#pragma unroll
+    for (int n = 0; n < W; ++n) {
+        const int cb = (nf0 + wn * W + n) * 16 + 4 * q;
+        float bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bv[j] = (a.bias && cb + j < a.g.co) ? a.bias[cb + j] : 0.f; s1[n][j] = s2[n][j] = 0.f; }
+#pragma unroll
+        for (int m = 0; m < W; ++m) {
+            const int row = wm * 16 * W + 16 * m + r;
+            const bool valid = m0 + row < a.Mg;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc[m][n][j] + bv[j];
+                const float rv = round_as<bf16>(v[j]);
+                if (valid) { s1[n][j] += rv; s2[n][j] += rv * rv; }
+            }
+            uint2 pk;
+            pk.x = pack_bf16x2(v[0], v[1]);
+            pk.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(ot + row * OPITCH + ((wn * W + n) * 16 + 4 * q) * 2) = pk;
+        }
+    }
+    float* const red = reinterpret_cast<float*>(smem + TM * OPITCH);  // [2 wm][2 wn][W][4 q][4 j][2]
+    if (a.stat_acc) {
+#pragma unroll
+        for (int n = 0; n < W; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = s1[n][j], y = s2[n][j];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); }
+                if (r == 0) {
+                    red[((((wm * 2 + wn) * W + n) * 4 + q) * 4 + j) * 2] = x;
+                    red[((((wm * 2 + wn) * W + n) * 4 + q) * 4 + j) * 2 + 1] = y;
+                }
+            }
+    }
+    __syncthreads();
+    // ---- complete output rows leave as 16-B pieces (TN / 8 per row)
+    constexpr int OP = (TM * (TN / 8)) / 256;
+#pragma unroll
+    for (int p = 0; p < OP; ++p) {
+        const int i = tid + p * 256, row = i / (TN / 8), c8 = i - row * (TN / 8), m = m0 + row;
+        if (m < a.Mg) {
+            const int mm = grp * a.Mg + m;
+            const int x = mm % a.g.wm, t = mm / a.g.wm, y = t % a.g.hm, n = t / a.g.hm;
+            const int64_t opix = ((int64_t)n * a.g.ho + y * a.g.out_stride + a.g.oy0) * a.g.wo + x * a.g.out_stride + a.g.ox0;
+            *reinterpret_cast<uint4*>(a.out + opix * a.g.ldo + nt * TN + c8 * 8) = *reinterpret_cast<const uint4*>(ot + row * OPITCH + c8 * 16);
+        }
+    }
+    if (a.stat_acc) {
+        for (int i = tid; i < TN * 2; i += 256) {
+            const int which = i / TN, c = i - which * TN;             // channel c of the tile: wn = c / (16W), n, q, j
+            const int wn_ = c / (16 * W), n = (c >> 4) % W, qq = (c >> 2) & 3, j = c & 3;
+            const float v = red[((((0 * 2 + wn_) * W + n) * 4 + qq) * 4 + j) * 2 + which] + red[((((1 * 2 + wn_) * W + n) * 4 + qq) * 4 + j) * 2 + which];
+            const int chn = nt * TN + c - a.stat_c0;
+            if (chn >= 0 && chn < a.cpad) bn_acc_add(a.stat_acc, mt, a.groups, a.cpad, grp, which, chn, v, which ? a.s2_scale : a.s1_scale);
+        }
+    }
+}
+
+Gemm1x1Plan gemm1x1_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups) {
+    Gemm1x1Plan gp;
+    if (!p.ok || p.modeB || p.CiB != 64 || g.ntaps != 1 || g.dy[0] != 0 || g.dx[0] != 0) return gp;
+    if (g.ci % 64 != 0 || g.co % 64 != 0 || g.ldi % 8 != 0 || g.ldo % 8 != 0 || groups < 1 || g.n % groups != 0) return gp;
+    if ((int64_t)g.n * g.hi * g.wi * g.ldi * 2 >= ((int64_t)1 << 31)) return gp;
+    if ((g.hm - 1) * g.in_stride >= g.hi || (g.wm - 1) * g.in_stride >= g.wi) return gp;
+    const int64_t Mg = (int64_t)(g.n / groups) * g.hm * g.wm;
+    if (Mg * groups >= ((int64_t)1 << 31)) return gp;
+    // the 128x128 tile when it still fills the chip (>= 192 blocks), else 64x64
+    int W = 4;
+    if (g.co % 128 != 0 || p.NTtot % 8 != 0 || (int64_t)groups * ((Mg + 127) / 128) * (g.co / 128) < 192) W = 2;
+    if (p.NTtot % (2 * W) != 0) return gp;
+    const int T = 32 * W;
+    gp.W = W;
+    gp.tiles_m = (int)((Mg + T - 1) / T);
+    gp.tiles_n = g.co / T;
+    gp.blocks = groups * ((gp.tiles_m + 7) / 8) * 8 * gp.tiles_n;
+    gp.lds_bytes = std::max(2 * (T * 128 + 2 * (T / 16) * 1024), T * (T * 2 + 16) + 2 * 2 * W * 16 * 2 * 4);
+    gp.ok = true;
+    return gp;
+}
+
+int launch_gemm1x1(const stcd_conv_geom& g, const ConvMfmaPlan& p, const Gemm1x1Plan& gp, const void* in, const void* wf,
+                   const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0,
+                   float s1_scale, float s2_scale) {
+    if (!gp.ok) return 1;
+    Gemm1x1Args a;
+    a.g = g;
+    a.in = (const bf16*)in; a.wf = (const bf16*)wf; a.bias = bias; a.out = (bf16*)out;
+    a.stat_acc = stat_acc; a.groups = groups; a.cpad = cpad; a.stat_c0 = stat_c0; a.s1_scale = s1_scale; a.s2_scale = s2_scale;
+    a.NTtot = p.NTtot; a.nchunks = g.ci / 64;
+    a.Mg = (g.n / groups) * g.hm * g.wm;
+    a.tiles_m = gp.tiles_m; a.tiles_m8 = (gp.tiles_m + 7) / 8; a.tiles_n = gp.tiles_n;
+    a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
+    if (gp.W == 4) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_gemm1x1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        k_gemm1x1<4><<<(unsigned)gp.blocks, 256, (size_t)gp.lds_bytes, s>>>(a);
+    } else {
+        k_gemm1x1<2><<<(unsigned)gp.blocks, 256, (size_t)gp.lds_bytes, s>>>(a);
+    }
+    return 0;
+}
+
 }  // namespace stcd

@@ -351,3 +351,41 @@ def test_pointwise_conv_against_reference_vectors(golden, dt, impl):
     dX = torch.zeros(n, h, w, ci, dtype=tdt, device=DEV)
     _run_conv_dt(dcode, impl, geo, dY, wd, None, dX)
     np.testing.assert_allclose(_nchw(dX, ci), dx_ref, **_tol(dt))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 1x1 convolutions as the tiled GEMM kernel (k_gemm1x1, impl=1 picks it when Ci % 64 == 0 and Co % 64 == 0): SegCD's
+# bottleneck / down-sample shapes, both tile sizes, ragged position counts, stride-2 gather (down-sample forward) and
+# stride-2 scatter (its data gradient), against an fp64 matmul of the same bf16 operands and against the generic kernel.
+GEMM_CASES = [  # n, h, w, ci, co, in_stride, out_stride
+    (4, 32, 32, 64, 64, 1, 1), (2, 32, 32, 256, 64, 1, 1), (8, 32, 32, 64, 256, 1, 1), (2, 16, 16, 512, 128, 1, 1),
+    (2, 8, 8, 2048, 512, 1, 1), (2, 8, 8, 512, 2048, 1, 1), (32, 16, 16, 256, 1024, 1, 1), (3, 6, 4, 128, 192, 1, 1),
+    (1, 5, 7, 64, 128, 1, 1), (4, 32, 32, 256, 512, 2, 1), (3, 12, 20, 64, 128, 2, 1), (4, 16, 16, 512, 256, 1, 2),
+]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,si,so", GEMM_CASES)
+def test_pointwise_gemm_kernel(n, h, w, ci, co, si, so):
+    rng = np.random.default_rng(ci + 3 * co + h)
+    hm, wm = h // si, w // si                       # positions computed
+    ho, wo = hm * so, wm * so
+    x = rnd(rng, n, h, w, ci).to(DEV)
+    wt = rnd(rng, 1, ci, co, scale=1.0 / np.sqrt(ci)).float().to(DEV)
+    bias = torch.from_numpy(rng.standard_normal(co).astype(np.float32)).to(DEV)
+    g = geom(n, h, w, ci, ci, hm, wm, si, ho, wo, so, 0, 0, co, co, [(0, 0)])
+    outs = {}
+    for impl in (1, 2):
+        out = torch.full((n, ho, wo, co), 7.0, dtype=torch.bfloat16, device=DEV)
+        run_conv(impl, g, x, wt, bias, out)
+        outs[impl] = out.float()
+    xs = x[:, ::si, ::si].double()[:, :hm, :wm]
+    want = (xs.reshape(-1, ci) @ wt[0].double() + bias.double()).reshape(n, hm, wm, co)
+    for impl in (1, 2):
+        got = outs[impl][:, ::so, ::so]
+        err = (got.double() - want).abs().max().item()
+        assert err <= 2.0 ** -7 * want.abs().max().item(), (impl, err)          # one bf16 rounding of the output
+        if so == 2:                                                            # positions the scatter must not touch
+            untouched = outs[impl].clone()
+            untouched[:, ::2, ::2] = 7.0
+            assert torch.equal(untouched, torch.full_like(untouched, 7.0))
+    assert (outs[1] - outs[2]).abs().max().item() <= 2.0 ** -7 * want.abs().max().item()
