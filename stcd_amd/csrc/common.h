@@ -161,16 +161,17 @@ ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int gr
 int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvResPlan& rp, const void* in, const void* wf,
                     const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0 = 0,
                     float s1_scale = BN_FS1, float s2_scale = BN_FS2);
-// 1x1 convolutions (any stride) as a tiled GEMM [positions x Ci] . [Ci x Co] with Ci % 64 == 0, Co % 64 == 0: 128x128 or
-// 64x64 block tiles staged through LDS in 64-channel steps, fused bias + BN statistics, LDS-transposed 16-B output stores.
+// Tap-list convolutions with Ci % 64 == 0, Co % 64 == 0 as a tiled GEMM [positions x (taps * Ci)] . [(taps * Ci) x Co]: 128x128
+// or 64x64 block tiles staged through LDS in (64-channel chunk, tap) steps, fused bias + BN statistics, LDS-transposed 16-B
+// output stores.  1x1 convolutions of any stride, and the wide layers the resident-filter kernel cannot take.
 // Uses the mode-A fragment image of conv_mfma_plan (CiB == 64).
-struct Gemm1x1Plan {
+struct ConvGemmPlan {
     int W = 0;             // fragments per wave and side: 4 -> 128x128 block tile, 2 -> 64x64
     int tiles_m = 0, tiles_n = 0, blocks = 0, lds_bytes = 0;
     bool ok = false;
 };
-Gemm1x1Plan gemm1x1_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups);
-int launch_gemm1x1(const stcd_conv_geom& g, const ConvMfmaPlan& p, const Gemm1x1Plan& gp, const void* in, const void* wf,
+ConvGemmPlan conv_gemm_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups);
+int launch_conv_gemm(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvGemmPlan& gp, const void* in, const void* wf,
                    const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0 = 0,
                    float s1_scale = BN_FS1, float s2_scale = BN_FS2);
 // small-channel persistent kernel (filter in registers, double-buffered halo, optional fused BN statistics);

@@ -56,7 +56,7 @@ struct ConvOp {
     ConvMfmaPlan plan; int64_t wf = -1;  // MFMA path: plan + fragment-order weight image (workspace offset)
     bool small = false;                  // eligible for the small-channel persistent kernel
     ConvResPlan res; int res_groups = 1; // resident-filter persistent kernel (3x3 stride 1, Ci % 32 == 0)
-    Gemm1x1Plan gemm;                    // 1x1 convs with Ci % 64 == 0, Co % 64 == 0: tiled GEMM
+    ConvGemmPlan gemm;                    // 1x1 convs with Ci % 64 == 0, Co % 64 == 0: tiled GEMM
 };
 struct WgradOp {
     stcd_conv_geom g{};
@@ -725,7 +725,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             if (op.plan.ok) op.wf = ws.take(op.plan.wf_elems * 2);
             op.small = conv_small_ok(g, op.plan);
             if (e.use_res && !op.small) op.res = conv_res_plan(g, op.plan, groups);
-            op.gemm = e.use_gemm ? gemm1x1_plan(g, op.plan, groups) : Gemm1x1Plan();
+            op.gemm = (e.use_gemm && !op.small && !op.res.ok) ? conv_gemm_plan(g, op.plan, groups) : ConvGemmPlan();
         }
         e.conv_ops.push_back(&op);
     };
@@ -866,7 +866,7 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     const bool small_path = !gemm_path && mfma_on(c.e) && op.small && op.wf >= 0 && c.e.use_small;
     const bool res_path = !gemm_path && !small_path && mfma_on(c.e) && op.res.ok && op.wf >= 0 && !nchw;
     const bool mfma_path = !small_path && !res_path && mfma_on(c.e) && op.plan.ok && op.wf >= 0;
-    if (gemm_path) snprintf(kname, sizeof(kname), "k_gemm1x1<%d>", op.gemm.W);
+    if (gemm_path) snprintf(kname, sizeof(kname), "k_conv_gemm<%d>", op.gemm.W);
     else if (res_path) snprintf(kname, sizeof(kname), "k_conv_res<%d, %d>", op.res.NT, op.res.CW);
     else if (small_path) snprintf(kname, sizeof(kname), "k_conv_small<1, %d>", (op.g.ntaps * op.g.ci + 31) / 32 <= 5 ? 5 : 9);
     else if (mfma_path) snprintf(kname, sizeof(kname), "k_conv_mfma<%d>", op.plan.NT);
@@ -876,7 +876,7 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     if (gemm_path) {
         const bool want = stat_groups > 0 && stat_groups == op.res_groups && stat_acc;
         long long* sp = want ? stat_acc : nullptr;
-        if (launch_gemm1x1(op.g, op.plan, op.gemm, in, c.at(op.wf), bias, out, op.res_groups, sp, want ? sr->C : op.g.co, c.s,
+        if (launch_conv_gemm(op.g, op.plan, op.gemm, in, c.at(op.wf), bias, out, op.res_groups, sp, want ? sr->C : op.g.co, c.s,
                            want ? sr->c0 : 0, want ? sr->s1 : BN_FS1, want ? sr->s2 : BN_FS2) == 0) {
             if (stat_chunks && want) *stat_chunks = 1;
             return;
@@ -1419,7 +1419,7 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
             if (op.plan.ok) op.wf = ws.take(op.plan.wf_elems * 2);
             op.small = conv_small_ok(g, op.plan);
             if (e.use_res && !op.small) op.res = conv_res_plan(g, op.plan, groups);
-            op.gemm = e.use_gemm ? gemm1x1_plan(g, op.plan, groups) : Gemm1x1Plan();
+            op.gemm = (e.use_gemm && !op.small && !op.res.ok) ? conv_gemm_plan(g, op.plan, groups) : ConvGemmPlan();
         }
         e.conv_ops.push_back(&op);
     };
@@ -1843,7 +1843,7 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
             if (op.plan.ok) op.wf = ws.take(op.plan.wf_elems * 2);
             op.small = conv_small_ok(g, op.plan);
             if (e.use_res && !op.small) op.res = conv_res_plan(g, op.plan, groups);
-            op.gemm = e.use_gemm ? gemm1x1_plan(g, op.plan, groups) : Gemm1x1Plan();
+            op.gemm = (e.use_gemm && !op.small && !op.res.ok) ? conv_gemm_plan(g, op.plan, groups) : ConvGemmPlan();
         }
         e.conv_ops.push_back(&op);
     };
@@ -2431,16 +2431,16 @@ int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, c
             STCD_HIP(hipGetLastError());
             return 0;
         }
-        if (impl == 1 && !(getenv("STCD_NO_GEMM_KERNEL") && getenv("STCD_NO_GEMM_KERNEL")[0] == '1')) {
-            const Gemm1x1Plan gp = gemm1x1_plan(*g, p, 1);
-            if (gp.ok && launch_gemm1x1(*g, p, gp, in, scratch, bias, out, 1, nullptr, g->co, (hipStream_t)hip_stream) == 0) {
+        if (impl == 1 && !(getenv("STCD_NO_RES_KERNEL") && getenv("STCD_NO_RES_KERNEL")[0] == '1')) {
+            const ConvResPlan rp = conv_res_plan(*g, p, 1);
+            if (rp.ok && launch_conv_res(*g, p, rp, in, scratch, bias, out, 1, nullptr, g->co, (hipStream_t)hip_stream) == 0) {
                 STCD_HIP(hipGetLastError());
                 return 0;
             }
         }
-        if (impl == 1 && !(getenv("STCD_NO_RES_KERNEL") && getenv("STCD_NO_RES_KERNEL")[0] == '1')) {
-            const ConvResPlan rp = conv_res_plan(*g, p, 1);
-            if (rp.ok && launch_conv_res(*g, p, rp, in, scratch, bias, out, 1, nullptr, g->co, (hipStream_t)hip_stream) == 0) {
+        if (impl == 1 && !(getenv("STCD_NO_GEMM_KERNEL") && getenv("STCD_NO_GEMM_KERNEL")[0] == '1')) {
+            const ConvGemmPlan gp = conv_gemm_plan(*g, p, 1);
+            if (gp.ok && launch_conv_gemm(*g, p, gp, in, scratch, bias, out, 1, nullptr, g->co, (hipStream_t)hip_stream) == 0) {
                 STCD_HIP(hipGetLastError());
                 return 0;
             }

@@ -1498,7 +1498,10 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
 
 
 // =====================================================================================================
-// 1x1 convolution = GEMM  out[m][co] = sum_ci X[m][ci] * W[ci][co]  over m = the positions of one BN group.
+// Tap-list convolution as a GEMM  out[m][co] = sum_{t, ci} X[pixel(m) * stride + tap_t][ci] * W[t][ci][co]  over m = the
+// positions of one BN group: 1x1 convolutions (one tap: a plain GEMM), and every wide (Ci % 64 == 0, Co % 64 == 0) layer the
+// resident-filter kernel cannot take -- 3x3 with a filter slice beyond LDS (UNet decoder 3072 -> 256), stride-2 3x3, the data
+// gradient of 2x2 stride-2 transposed convs -- where K simply walks over (64-channel chunk, tap).
 //
 // Block tile TM x TN = (32*W) x (32*W) (W = 4: 128x128, W = 2: 64x64), 4 waves as 2 (positions) x 2 (channels), each
 // W x W fragments of 16x16; K walks in 64-channel steps: X rows (128 contiguous bytes each, raw buffer loads with
@@ -1508,13 +1511,14 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
 // layout of k_conv_res's 64-channel halo).  Weights are the MFMA A operand, so a lane's accumulator is 4 consecutive
 // channels of one position; the finished tile goes through LDS once more and leaves as full 16-B pieces of complete
 // output rows.  A stride (1x1 stride-2 down-sampling convs and their data gradient) only changes the row -> pixel maps.
-struct Gemm1x1Args {
+struct ConvGemmArgs {
     stcd_conv_geom g;
     const bf16* in; const bf16* wf; const float* bias; bf16* out;
     long long* stat_acc;
     int groups, cpad, stat_c0;
     float s1_scale, s2_scale;
-    int NTtot, nchunks;            // n-tiles of the fragment image; Ci / 64
+    int NTtot, nsteps;             // n-tiles of the fragment image; (Ci / 64) * ntaps
+    unsigned lead;                 // bytes the X descriptor starts before the tensor (most negative tap offset)
     int Mg;                        // positions per group
     int tiles_m, tiles_m8, tiles_n;
     unsigned in_bytes;
@@ -1522,7 +1526,7 @@ struct Gemm1x1Args {
 
 template <int W>
 __global__ void __launch_bounds__(256, W == 2 ? 4 : 2)
-k_gemm1x1(const Gemm1x1Args a) {
+k_conv_gemm(const ConvGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TM = 32 * W, TN = 32 * W, NF = TN / 16;
     constexpr int XB = TM * 128, WB = 2 * NF * 1024, STAGE = XB + WB;
@@ -1542,17 +1546,19 @@ k_gemm1x1(const Gemm1x1Args a) {
 
     // ---- staging plan
     const int ch = tid & 7;
-    unsigned xoff[XP]; int xlds[XP];
+    unsigned xoff[XP]; int xlds[XP], xyx[XP];          // byte offset of the row's centre pixel (+ lead), packed (y, x) of it
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
         const int row = (tid >> 3) + p * 32, m = m0 + row;
         unsigned off = 0x80000000u;
+        int yx = (int)0xC000C000;                      // far outside every image: all taps of a masked row read zeros
         if (m < a.Mg) {
             const int mm = grp * a.Mg + m;
             const int x = mm % a.g.wm, t = mm / a.g.wm, y = t % a.g.hm, n = t / a.g.hm;
-            off = (unsigned)(((((int64_t)n * a.g.hi + y * a.g.in_stride) * a.g.wi + x * a.g.in_stride) * a.g.ldi + ch * 8) * 2);
+            off = (unsigned)(((((int64_t)n * a.g.hi + y * a.g.in_stride) * a.g.wi + x * a.g.in_stride) * a.g.ldi + ch * 8) * 2) + a.lead;
+            yx = ((y * a.g.in_stride) << 16) | (x * a.g.in_stride);
         }
-        xoff[p] = off;
+        xoff[p] = off; xyx[p] = yx;
         xlds[p] = (row * 8 + (ch ^ ((row >> 1) & 7))) * 16;
     }
     unsigned woff[WP]; int wlds[WP];
@@ -1562,23 +1568,30 @@ k_gemm1x1(const Gemm1x1Args a) {
         woff[p] = (unsigned)(((ks * a.NTtot + nf0 + f) * 64 + (i & 63)) * 16);          // + chunk * 2 * NTtot * 1024 per step
         wlds[p] = XB + ((ks * NF + f) * 64 + (i & 63)) * 16;
     }
+    // the X descriptor starts `lead` bytes before the tensor, so a tap's (possibly negative) pixel offset never wraps
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.in)), (short)0, (int)a.in_bytes, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(a.in)) - a.lead, (short)0, (int)(a.in_bytes + a.lead), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.wf)), (short)0, a.nchunks * 2 * a.NTtot * 1024, 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(a.wf)), (short)0, a.nsteps * 2 * a.NTtot * 1024, 0x00020000);
     const unsigned wstep = (unsigned)(2 * a.NTtot * 1024);
+    const int ntaps = a.g.ntaps;
     // two register sets: the chunk after next is requested before the MFMAs of the current one, so every load has two
     // loop iterations to land (one block per CU on the deep layers: nothing else hides the L2 / HBM round trip)
     uint4 pxa[XP], pwa[WP], pxb[XP], pwb[WP];
-#define GM_FETCH(C_, PX_, PW_)                                                                                         \
+    // step s = (chunk, tap), tap fastest -- the order of the fragment image [chunk][tap][ks][n-tile]
+#define GM_FETCH(S_, PX_, PW_)                                                                                         \
     do {                                                                                                               \
-        const unsigned cs_ = (unsigned)__builtin_amdgcn_readfirstlane(C_);      /* chunk index as a scalar offset */   \
+        const int ss_ = __builtin_amdgcn_readfirstlane(S_);                     /* scalar step index */                \
+        const int cc_ = ss_ / ntaps, tt_ = ss_ - cc_ * ntaps;                                                          \
+        const int tdy_ = a.g.dy[tt_], tdx_ = a.g.dx[tt_];                                                              \
+        const int toff_ = (tdy_ * a.g.wi + tdx_) * a.g.ldi * 2;                                                        \
         _Pragma("unroll") for (int p = 0; p < XP; ++p) {                                                               \
-            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc, xoff[p], cs_ * 128u, 0);                      \
+            const bool ok_ = (unsigned)((xyx[p] >> 16) + tdy_) < (unsigned)a.g.hi && (unsigned)((int)(short)(xyx[p] & 0xffff) + tdx_) < (unsigned)a.g.wi; \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok_ ? xoff[p] + (unsigned)toff_ : 0x80000000u, (unsigned)cc_ * 128u, 0); \
             PX_[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                           \
         }                                                                                                              \
         _Pragma("unroll") for (int p = 0; p < WP; ++p) {                                                               \
-            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[p], cs_ * wstep, 0);                      \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[p], (unsigned)ss_ * wstep, 0);            \
             PW_[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                           \
         }                                                                                                              \
     } while (0)
@@ -1617,7 +1630,7 @@ k_gemm1x1(const Gemm1x1Args a) {
 
     // every fetch / stash is unconditional (the chunk index is clamped: the tail re-reads the last chunk into a buffer nobody
     // reads), so both register sets stay in registers across the loop
-    const int nc = a.nchunks;
+    const int nc = a.nsteps;
     GM_FETCH(0, pxa, pwa);
     GM_FETCH(min(1, nc - 1), pxb, pwb);
     GM_STASH(0, pxa, pwa);
@@ -1702,12 +1715,14 @@ k_gemm1x1(const Gemm1x1Args a) {
     }
 }
 
-Gemm1x1Plan gemm1x1_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups) {
-    Gemm1x1Plan gp;
-    if (!p.ok || p.modeB || p.CiB != 64 || g.ntaps != 1 || g.dy[0] != 0 || g.dx[0] != 0) return gp;
+ConvGemmPlan conv_gemm_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups) {
+    ConvGemmPlan gp;
+    if (!p.ok || p.modeB || p.CiB != 64 || g.ntaps < 1) return gp;
+    for (int t = 0; t < g.ntaps; ++t)
+        if (g.dy[t] < -2 || g.dy[t] > 2 || g.dx[t] < -2 || g.dx[t] > 2) return gp;
     if (g.ci % 64 != 0 || g.co % 64 != 0 || g.ldi % 8 != 0 || g.ldo % 8 != 0 || groups < 1 || g.n % groups != 0) return gp;
-    if ((int64_t)g.n * g.hi * g.wi * g.ldi * 2 >= ((int64_t)1 << 31)) return gp;
-    if ((g.hm - 1) * g.in_stride >= g.hi || (g.wm - 1) * g.in_stride >= g.wi) return gp;
+    if (((int64_t)g.n * g.hi + 4) * g.wi * g.ldi * 2 >= ((int64_t)1 << 31) || g.hi >= 16384 || g.wi >= 16384) return gp;
+    if ((g.hm - 1) * g.in_stride >= g.hi + 2 || (g.wm - 1) * g.in_stride >= g.wi + 2) return gp;
     const int64_t Mg = (int64_t)(g.n / groups) * g.hm * g.wm;
     if (Mg * groups >= ((int64_t)1 << 31)) return gp;
     // the 128x128 tile when it still fills the chip (>= 192 blocks), else 64x64
@@ -1724,24 +1739,25 @@ Gemm1x1Plan gemm1x1_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int gro
     return gp;
 }
 
-int launch_gemm1x1(const stcd_conv_geom& g, const ConvMfmaPlan& p, const Gemm1x1Plan& gp, const void* in, const void* wf,
+int launch_conv_gemm(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvGemmPlan& gp, const void* in, const void* wf,
                    const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0,
                    float s1_scale, float s2_scale) {
     if (!gp.ok) return 1;
-    Gemm1x1Args a;
+    ConvGemmArgs a;
     a.g = g;
     a.in = (const bf16*)in; a.wf = (const bf16*)wf; a.bias = bias; a.out = (bf16*)out;
     a.stat_acc = stat_acc; a.groups = groups; a.cpad = cpad; a.stat_c0 = stat_c0; a.s1_scale = s1_scale; a.s2_scale = s2_scale;
-    a.NTtot = p.NTtot; a.nchunks = g.ci / 64;
+    a.NTtot = p.NTtot; a.nsteps = (g.ci / 64) * g.ntaps;
+    a.lead = (unsigned)((2 * g.wi + 2) * g.ldi * 2);
     a.Mg = (g.n / groups) * g.hm * g.wm;
     a.tiles_m = gp.tiles_m; a.tiles_m8 = (gp.tiles_m + 7) / 8; a.tiles_n = gp.tiles_n;
     a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
     if (gp.W == 4) {
         static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_gemm1x1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-        k_gemm1x1<4><<<(unsigned)gp.blocks, 256, (size_t)gp.lds_bytes, s>>>(a);
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_conv_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        k_conv_gemm<4><<<(unsigned)gp.blocks, 256, (size_t)gp.lds_bytes, s>>>(a);
     } else {
-        k_gemm1x1<2><<<(unsigned)gp.blocks, 256, (size_t)gp.lds_bytes, s>>>(a);
+        k_conv_gemm<2><<<(unsigned)gp.blocks, 256, (size_t)gp.lds_bytes, s>>>(a);
     }
     return 0;
 }

@@ -354,7 +354,7 @@ def test_pointwise_conv_against_reference_vectors(golden, dt, impl):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# 1x1 convolutions as the tiled GEMM kernel (k_gemm1x1, impl=1 picks it when Ci % 64 == 0 and Co % 64 == 0): SegCD's
+# 1x1 convolutions as the tiled GEMM kernel (k_conv_gemm, impl=1 picks it when Ci % 64 == 0 and Co % 64 == 0): SegCD's
 # bottleneck / down-sample shapes, both tile sizes, ragged position counts, stride-2 gather (down-sample forward) and
 # stride-2 scatter (its data gradient), against an fp64 matmul of the same bf16 operands and against the generic kernel.
 GEMM_CASES = [  # n, h, w, ci, co, in_stride, out_stride
@@ -389,3 +389,37 @@ def test_pointwise_gemm_kernel(n, h, w, ci, co, si, so):
             untouched[:, ::2, ::2] = 7.0
             assert torch.equal(untouched, torch.full_like(untouched, 7.0))
     assert (outs[1] - outs[2]).abs().max().item() <= 2.0 ** -7 * want.abs().max().item()
+
+
+# the same kernel walking a tap list: 3x3 layers whose filter slice exceeds LDS (impl=1 falls through the resident-filter kernel
+# to it), stride-2 3x3 gathers, and the 2x2-tap stride-2 gather that is the data gradient of ConvTranspose2d(k=2, s=2)
+TAPGEMM_CASES = [  # n, h, w, ci, co, stride, taps
+    (2, 16, 16, 768, 128, 1, TAPS3), (1, 8, 8, 3072, 256, 1, TAPS3), (2, 9, 11, 512, 64, 1, TAPS3),
+    (2, 32, 32, 128, 128, 2, TAPS3), (3, 12, 20, 64, 192, 2, TAPS3), (2, 16, 16, 256, 64, 2, [(0, 0), (0, 1), (1, 0), (1, 1)]),
+]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,stride,taps", TAPGEMM_CASES)
+def test_tap_list_gemm_kernel(n, h, w, ci, co, stride, taps):
+    rng = np.random.default_rng(ci + co + h + len(taps))
+    hm, wm = h // stride, w // stride
+    x = rnd(rng, n, h, w, ci).to(DEV)
+    wt = rnd(rng, len(taps), ci, co, scale=1.0 / np.sqrt(len(taps) * ci)).float().to(DEV)
+    bias = torch.from_numpy(rng.standard_normal(co).astype(np.float32)).to(DEV)
+    g = geom(n, h, w, ci, ci, hm, wm, stride, hm, wm, 1, 0, 0, co, co, taps)
+    outs = {}
+    for impl in (1, 2):
+        out = torch.zeros(n, hm, wm, co, dtype=torch.bfloat16, device=DEV)
+        run_conv(impl, g, x, wt, bias, out)
+        outs[impl] = out.double()
+    want = bias.double().view(1, 1, 1, co).expand(n, hm, wm, co).clone()
+    xd = x.double()
+    for t, (dy, dx) in enumerate(taps):                       # out(y, x) += X(y*s + dy, x*s + dx) . W[t]   (zero outside the image)
+        ys = torch.arange(hm, device=DEV) * stride + dy
+        xs = torch.arange(wm, device=DEV) * stride + dx
+        oky, okx = (ys >= 0) & (ys < h), (xs >= 0) & (xs < w)
+        sub = xd[:, ys.clamp(0, h - 1)][:, :, xs.clamp(0, w - 1)] * (oky.view(1, -1, 1, 1) & okx.view(1, 1, -1, 1))
+        want += (sub.reshape(-1, ci) @ wt[t].double()).reshape(n, hm, wm, co)
+    tol = 2.0 ** -7 * want.abs().max().item()
+    for impl in (1, 2):
+        assert (outs[impl] - want).abs().max().item() <= tol, impl

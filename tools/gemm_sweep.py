@@ -12,8 +12,8 @@ REP = 5
 if len(sys.argv) > 2 and sys.argv[1] == "--parse":
     f = glob.glob(sys.argv[2] + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "k_gemm1x1" in r["Kernel_Name"]]
-    names = [r["Kernel_Name"] for r in rows if "k_gemm1x1" in r["Kernel_Name"]]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "k_conv_gemm" in r["Kernel_Name"]]
+    names = [r["Kernel_Name"] for r in rows if "k_conv_gemm" in r["Kernel_Name"]]
     for i, (n, h, w, ci, co) in enumerate(SHAPES):
         v = sorted(d[i * REP:(i + 1) * REP])
         us = v[len(v) // 2]
