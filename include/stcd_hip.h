@@ -215,11 +215,13 @@ typedef struct stcd_conv_geom {
     int8_t pad_[2];
 } stcd_conv_geom;
 
-/* w: fp32 [ntaps][ci][co]; bias: fp32 [co] or NULL; impl: 0 = reference FMA kernel, 1 = MFMA (bf16 only; the
- * small-channel persistent kernel when the geometry is eligible, else the generic one), 2 = generic MFMA kernel */
+/* w: fp32 [ntaps][ci][co]; bias: fp32 [co] or NULL; impl: 0 = reference FMA kernel, 1 = MFMA, the kernel the engine would
+ * pick (bf16 only: small-channel persistent kernel, resident-filter kernel, tap-list GEMM kernel, else the generic one),
+ * 2 = generic MFMA kernel */
 int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, const float* w, const float* bias,
                  void* out, void* scratch, int64_t scratch_bytes, void* hip_stream);
-/* dw: fp32 [ntaps][ci][co], overwritten */
+/* dw: fp32 [ntaps][ci][co], overwritten; impl: 0 = reference FMA kernel, 1 = MFMA tile kernel, 3 = MFMA position-GEMM kernel
+ * (one tap, Ci >= 64, Co >= 64: what the engine runs for 1x1 convs and the phases of 2x2 stride-2 transposed convs) */
 int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, const void* dout, float* dw,
                   void* scratch, int64_t scratch_bytes, void* hip_stream);
 int64_t stcd_op_scratch_bytes(const stcd_conv_geom* g);

@@ -184,6 +184,7 @@ struct WgradMfmaPlan {
     int WCI = 1, NTW = 1, gx = 1, gy = 1, gz = 1;
     int64_t slab_floats = 0;
     int wi_valid = 0;      // > 0: columns of the input that exist (a strided VIEW passes a virtual width: see configure_segcd)
+    int gemm = 0;          // > 0: one-tap launch on k_wgrad_gemm<gemm> (32*gemm x 32*gemm channel tile), gx = position slices
     bool ok = false;
 };
 WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld);
@@ -208,6 +209,12 @@ struct WgradJob {
     int wi_valid;                          // input columns >= wi_valid read as zero (== g.wi for a plain tensor)
     int pad_;
 };
+// one-tap weight gradients with Ci, Co >= 64 (1x1 convs, the phases of 2x2 stride-2 transposed convs): dW = X^T . dY as a GEMM
+// over positions, 128x128 / 64x64 channel tiles, positions split over gx blocks that each write one fp32 slab
+WgradMfmaPlan wgrad_gemm_plan(const stcd_conv_geom& g, int kpad, int wld);
+WgradJob wgrad_gemm_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t in_off, int64_t dout_off, int64_t slab_off,
+                             int kpad, int wld);
+int launch_wgrad_gemm_group(int W, const WgradJob* jobs_dev, int njobs, int total_blocks, const char* base, hipStream_t s);
 WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t in_off, int64_t dout_off, int64_t slab_off,
                         int kpad, int wld);
 int wgrad_variant_slots(int WCI, int NTW, bool t9, int lds_bytes);   // resident blocks of that kernel variant on the chip

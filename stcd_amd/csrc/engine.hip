@@ -71,6 +71,7 @@ struct WgradOp {
 };
 struct WgradGroup {                      // all launches of one kernel variant in one backward stage
     int WCI = 1, NTW = 1; bool t9 = false;
+    int gemm = 0;                        // > 0: k_wgrad_gemm<gemm> group (one-tap launches; WCI / NTW / t9 unused)
     std::vector<WgradJob> jobs;
     int total_blocks = 0, lds_bytes = 0;
     int64_t table_off = -1;
@@ -447,6 +448,15 @@ static stcd_conv_geom geom_up_phase(const UpConv& U, int py, int px, int ldi, in
 
 static void conv_work(const stcd_engine& e, const stcd_conv_geom& g, int kreal, int nreal, double* flops, double* bytes);
 
+// weight-gradient plan of one launch: the GEMM kernel for one-tap launches with >= 64 channels on both sides, else the tile kernel
+static WgradMfmaPlan pick_wgrad_plan(const stcd_engine& e, const stcd_conv_geom& g, int kpad, int wld) {
+    if (e.use_gemm && e.use_wgroup) {
+        WgradMfmaPlan p = wgrad_gemm_plan(g, kpad, wld);
+        if (p.ok) return p;
+    }
+    return wgrad_mfma_plan(g, kpad, wld);
+}
+
 static void build_pack_jobs(stcd_engine& e, Bump& ws) {
     // ---- per-launch slab regions + the batched reduce job tables (MFMA path only)
     for (int st = 0; st < 2; ++st) { e.rjobs[st].clear(); e.rjobs_total[st] = 0; }
@@ -462,16 +472,17 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                 std::vector<WgradGroup>& gs = e.wgroups[op->stage];
                 size_t gi = 0;
                 for (; gi < gs.size(); ++gi)
-                    if (gs[gi].WCI == op->plan.WCI && gs[gi].NTW == op->plan.NTW && gs[gi].t9 == t9) break;
-                if (gi == gs.size()) { WgradGroup g; g.WCI = op->plan.WCI; g.NTW = op->plan.NTW; g.t9 = t9; gs.push_back(g); }
+                    if (gs[gi].gemm == op->plan.gemm && gs[gi].WCI == op->plan.WCI && gs[gi].NTW == op->plan.NTW && gs[gi].t9 == t9) break;
+                if (gi == gs.size()) { WgradGroup g; g.WCI = op->plan.WCI; g.NTW = op->plan.NTW; g.t9 = t9; g.gemm = op->plan.gemm; gs.push_back(g); }
                 op->grouped = true;
             }
             for (int st = 0; st < 2; ++st)
                 for (WgradGroup& G : e.wgroups[st]) {
+                    if (G.gemm) { G.lds_bytes = 2 * 2 * G.gemm * (64 * 64 + 8 * 32); continue; }     // gx fixed by wgrad_gemm_plan
                     std::vector<WgradOp*> ops;
                     int64_t W = 0;
                     for (WgradOp* op : e.wgrad_ops)
-                        if (op->grouped && op->stage == st && op->plan.WCI == G.WCI && op->plan.NTW == G.NTW && (op->g.ntaps == 9) == G.t9) {
+                        if (op->grouped && op->stage == st && !op->plan.gemm && op->plan.WCI == G.WCI && op->plan.NTW == G.NTW && (op->g.ntaps == 9) == G.t9) {
                             ops.push_back(op);
                             const int64_t ntiles = (int64_t)op->g.n * ((op->g.wm + 15) / 16) * ((op->g.hm + 7) / 8);
                             W += ntiles * op->plan.gy * op->plan.gz;
@@ -503,8 +514,9 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
             if (op->grouped) {
                 const bool t9 = op->g.ntaps == 9;
                 for (WgradGroup& G : e.wgroups[op->stage])
-                    if (G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9) {
-                        WgradJob j = wgrad_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld);
+                    if (G.gemm == op->plan.gemm && G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9) {
+                        WgradJob j = op->plan.gemm ? wgrad_gemm_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
+                                                   : wgrad_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld);
                         j.start = G.total_blocks;
                         G.total_blocks += j.gx * j.gy * j.gz;
                         G.jobs.push_back(j);
@@ -735,7 +747,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         op.in_off = in_off; op.dout_off = dout_off; op.grouped = false;
         op.plan = WgradMfmaPlan(); op.slab = -1;
         op.stage = e.convs[conv].w_off < e.enc_param_end ? 1 : 0;     // encoder filters are finalised by stage 1
-        if (e.dt == BF16) op.plan = wgrad_mfma_plan(g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
+        if (e.dt == BF16) op.plan = pick_wgrad_plan(e, g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
         e.wgrad_ops.push_back(&op);
     };
     auto bind_cbrd = [&](Cbrd& L) {
@@ -984,8 +996,13 @@ static void reduce_stage(const Ctx& c, int stage) {
     stcd_engine& e = c.e;
     for (const WgradGroup& G : e.wgroups[stage]) {
         char kname[64];
-        snprintf(kname, sizeof(kname), "k_wgrad_group<%d, %d, %s>", G.WCI, G.NTW, G.t9 ? "true" : "false");
+        if (G.gemm) snprintf(kname, sizeof(kname), "k_wgrad_gemm<%d>", G.gemm);
+        else snprintf(kname, sizeof(kname), "k_wgrad_group<%d, %d, %s>", G.WCI, G.NTW, G.t9 ? "true" : "false");
         ProfScope prof(c, PC_WGRAD, G.flops, G.bytes, kname);
+        if (G.gemm) {
+            launch_wgrad_gemm_group(G.gemm, c.at<WgradJob>(G.table_off), (int)G.jobs.size(), G.total_blocks, c.ws, c.s);
+            continue;
+        }
         if (launch_wgrad_group(G.WCI, G.NTW, G.t9, c.at<WgradJob>(G.table_off), (int)G.jobs.size(), G.total_blocks, G.lds_bytes,
                                c.ws, c.s) != 0)
             set_error("grouped weight-gradient launch exceeds the LDS budget");
@@ -1428,7 +1445,7 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
         op.g = g; op.conv = conv; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
         op.in_off = in_off; op.dout_off = dout_off; op.grouped = false;
         op.plan = WgradMfmaPlan(); op.slab = -1; op.stage = 0;
-        if (e.dt == BF16) op.plan = wgrad_mfma_plan(g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
+        if (e.dt == BF16) op.plan = pick_wgrad_plan(e, g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
         e.wgrad_ops.push_back(&op);
     };
     for (auto& b : e.sn_blocks) {
@@ -1852,7 +1869,7 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
         op.g = g; op.conv = conv; op.tap0 = tap0; op.kreal = cv.cin; op.nreal = cv.cout;
         op.in_off = in_off; op.dout_off = dout_off; op.grouped = false;
         op.plan = WgradMfmaPlan(); op.slab = -1; op.stage = 0;
-        if (e.dt == BF16) { op.plan = wgrad_mfma_plan(g, cv.fwd.kpad, cv.fwd.wld); op.plan.wi_valid = wi_valid; }
+        if (e.dt == BF16) { op.plan = pick_wgrad_plan(e, g, cv.fwd.kpad, cv.fwd.wld); op.plan.wi_valid = wi_valid; }
         e.wgrad_ops.push_back(&op);
     };
     for (auto& L : e.g_layers) {
@@ -2413,7 +2430,8 @@ int64_t stcd_op_scratch_bytes(const stcd_conv_geom* g) {
     if (!g) return 0;
     ConvMfmaPlan p = conv_mfma_plan(*g);
     WgradMfmaPlan w = wgrad_mfma_plan(*g, g->ci, g->co);
-    return std::max<int64_t>(p.wf_elems * 2, w.slab_floats * 4) + 256;
+    WgradMfmaPlan wg = wgrad_gemm_plan(*g, g->ci, g->co);
+    return std::max<int64_t>(p.wf_elems * 2, std::max(w.slab_floats, wg.ok ? wg.slab_floats : 0) * 4) + 1024;
 }
 int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, const float* w, const float* bias,
                  void* out, void* scratch, int64_t scratch_bytes, void* hip_stream) {
@@ -2468,7 +2486,21 @@ int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, 
         STCD_HIP(hipGetLastError());
         return 0;
     }
-    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA) or 1 (MFMA)");
+    if (impl == 3) {      // one-tap launches on the position-GEMM kernel (the engine's choice for Ci, Co >= 64)
+        STCD_CHECK(dtype == STCD_DTYPE_BF16, "the MFMA implementation is bf16 only");
+        WgradMfmaPlan p = wgrad_gemm_plan(*g, g->ci, g->co);
+        STCD_CHECK(p.ok, "geometry not supported by the GEMM weight-gradient kernel (one tap, Ci >= 64, Co >= 64)");
+        const int64_t table = (p.slab_floats * 4 + 255) & ~(int64_t)255;
+        STCD_CHECK(scratch && scratch_bytes >= table + (int64_t)sizeof(WgradJob), "scratch too small for the partial slabs + job table");
+        WgradJob j = wgrad_gemm_make_job(*g, p, (int64_t)(intptr_t)in, (int64_t)(intptr_t)dout, (int64_t)(intptr_t)scratch, g->ci, g->co);
+        STCD_HIP(hipMemcpyAsync((char*)scratch + table, &j, sizeof(j), hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+        STCD_HIP(hipStreamSynchronize((hipStream_t)hip_stream));       // `j` is a stack object
+        launch_wgrad_gemm_group(p.gemm, (const WgradJob*)((char*)scratch + table), 1, p.gx * p.gy * p.gz, nullptr, (hipStream_t)hip_stream);
+        launch_reduce_dw((const float*)scratch, p.gx, *g, g->ci, g->co, g->ci, g->co, nullptr, dw, (hipStream_t)hip_stream);
+        STCD_HIP(hipGetLastError());
+        return 0;
+    }
+    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA), 1 (MFMA tile kernel) or 3 (MFMA position-GEMM kernel)");
     STCD_HIP(hipMemsetAsync(dw, 0, (size_t)g->ntaps * g->ci * g->co * 4, (hipStream_t)hip_stream));
     launch_wgrad_ref(dtype, *g, in, dout, dw, g->ci, g->co, (hipStream_t)hip_stream);
     STCD_HIP(hipGetLastError());

@@ -1762,4 +1762,198 @@ int launch_conv_gemm(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvG
     return 0;
 }
 
+
+// =====================================================================================================
+// One-tap weight gradient as a GEMM over positions:  dW[ci][co] = sum_m X[pixel_in(m)][ci] * dY[pixel_out(m)][co].
+// Block tile T x T channels (T = 32*W: 128 or 64), 4 waves as 2 (ci) x 2 (co), each W x W accumulators; the positions are
+// cut into gx contiguous slices (one block and one fp32 slab each), walked in 64-position chunks: both operand rows (T
+// channels = 2T contiguous bytes) go global -> registers -> LDS with two chunks in flight, as 32-channel sub-images in the
+// padded layout of k_wgrad_group (pixel p at p*64 + (p>>3)*32), and come back channel-major through ds_read_b64_tr_b16.
+// Any stride / phase is only a row -> pixel map (2x2 stride-2 transposed convs, stride-2 1x1 convs).
+template <int W>
+__global__ void __launch_bounds__(256, 2)
+k_wgrad_gemm(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T = 32 * W, NS = T / 32, SUB = 64 * 64 + 8 * 32, IMG = NS * SUB, STAGE = 2 * IMG;
+    constexpr int PP = (64 * (T / 8)) / 256;                       // 16-B pieces per thread, operand and chunk
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WgradJob& a = jobs[lo];
+    const int lb = blockIdx.x - a.start;
+    // blocks of one position slice (all channel tiles) are 8 ids apart: same XCD, the slice's rows are fetched into its L2 once
+    const int G = a.gy * a.gz, full = (a.gx >> 3) << 3;
+    int bx, r;
+    if (lb < full * G) { const int rem = lb % (8 * G); bx = (lb / (8 * G)) * 8 + (rem & 7); r = rem >> 3; }
+    else { const int l2 = lb - full * G, tail = a.gx - full; bx = full + l2 % tail; r = l2 / tail; }
+    const int by = r % a.gy, bz = r / a.gy;
+    const int ci0 = by * T, co0 = bz * T;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wa = wid & 1, wb = wid >> 1;
+    const int grp = lane >> 4, li = lane & 15, qrow = li >> 2, pcol = li & 3;
+    const int M = a.ntiles;                                         // positions of the job
+    const int nchunks = (M + 63) >> 6;
+    const int cpb = (nchunks + a.gx - 1) / a.gx;
+    const int c0 = bx * cpb, c1 = min(nchunks, c0 + cpb);
+
+    // staging plan: piece i = tid + p*256 -> position i / (T/8) of the chunk, 16-B chunk c8 = i % (T/8)
+    int prow[PP], plds[PP]; unsigned xch[PP], ych[PP];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+        const int i = tid + p * 256, row = i / (T / 8), c8 = i - row * (T / 8);
+        prow[p] = row;
+        plds[p] = (c8 >> 2) * SUB + row * 64 + (row >> 3) * 32 + (c8 & 3) * 16;
+        xch[p] = (ci0 + c8 * 8 < a.g.ci) ? (unsigned)((ci0 + c8 * 8) * 2) : 0x80000000u;
+        ych[p] = (co0 + c8 * 8 < a.co_valid) ? (unsigned)((co0 + c8 * 8) * 2) : 0x80000000u;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(base + a.in_off), (short)0, (int)a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(base + a.dout_off), (short)0, (int)a.dout_bytes, 0x00020000);
+    const int tdy = a.g.dy[0], tdx = a.g.dx[0];
+    uint4 xa[PP], ya[PP], xb[PP], yb[PP];
+#define WGG_FETCH(C_, PX_, PY_)                                                                                        \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                                               \
+            const int m_ = (C_) * 64 + prow[p];                                                                        \
+            const int x_ = m_ % a.g.wm, t_ = m_ / a.g.wm, y_ = t_ % a.g.hm, n_ = t_ / a.g.hm;                          \
+            const int iy_ = y_ * a.g.in_stride + tdy, ix_ = x_ * a.g.in_stride + tdx;                                  \
+            const bool okx_ = m_ < M && (unsigned)iy_ < (unsigned)a.g.hi && (unsigned)ix_ < (unsigned)a.wi_valid;      \
+            const unsigned xo_ = (unsigned)((((n_ * a.g.hi + iy_) * a.g.wi + ix_) * a.g.ldi) * 2);                     \
+            const unsigned yo_ = (unsigned)((((n_ * a.g.ho + y_ * a.g.out_stride + a.g.oy0) * a.g.wo + x_ * a.g.out_stride + a.g.ox0) * a.g.ldo) * 2); \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, okx_ ? xo_ + xch[p] : 0x80000000u, 0, 0);      \
+            const u32x4 w_ = __builtin_amdgcn_raw_buffer_load_b128(yrs, m_ < M ? yo_ + ych[p] : 0x80000000u, 0, 0);    \
+            PX_[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                           \
+            PY_[p] = make_uint4(w_[0], w_[1], w_[2], w_[3]);                                                           \
+        }                                                                                                              \
+    } while (0)
+#define WGG_STASH(BUF_, PX_, PY_)                                                                                      \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                                               \
+            *reinterpret_cast<uint4*>(smem + (BUF_) * STAGE + plds[p]) = PX_[p];                                       \
+            *reinterpret_cast<uint4*>(smem + (BUF_) * STAGE + IMG + plds[p]) = PY_[p];                                 \
+        }                                                                                                              \
+    } while (0)
+
+    f32x4 acc[W][W];
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment offsets inside an image: k-step ks (32 positions), half h: position 32ks + 16(grp>>1) + 8(grp&1) + 4h + qrow
+    int fo[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pp = 32 * ks + 16 * (grp >> 1) + 8 * (grp & 1) + 4 * h + qrow;
+            fo[ks][h] = pp * 64 + (pp >> 3) * 32 + 8 * pcol;
+        }
+#define WGG_COMPUTE(BUF_)                                                                                              \
+    do {                                                                                                               \
+        const char* xs_ = smem + (BUF_) * STAGE;                                                                       \
+        const char* ys_ = xs_ + IMG;                                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                             \
+            bf16x8 af[W], bfr[W];                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < W; ++i) {                                                            \
+                const int t_ = wa * W + i;                                                                             \
+                af[i] = tr_frag(xs_ + (t_ >> 1) * SUB + (t_ & 1) * 32 + fo[ks][0], xs_ + (t_ >> 1) * SUB + (t_ & 1) * 32 + fo[ks][1]); \
+            }                                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < W; ++j) {                                                            \
+                const int t_ = wb * W + j;                                                                             \
+                bfr[j] = tr_frag(ys_ + (t_ >> 1) * SUB + (t_ & 1) * 32 + fo[ks][0], ys_ + (t_ >> 1) * SUB + (t_ & 1) * 32 + fo[ks][1]); \
+            }                                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < W; ++i)                                                              \
+                _Pragma("unroll") for (int j = 0; j < W; ++j)                                                          \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);            \
+        }                                                                                                              \
+    } while (0)
+
+    if (c0 < c1) {
+        const int last = c1 - 1;
+        WGG_FETCH(c0, xa, ya);
+        WGG_FETCH(min(c0 + 1, last), xb, yb);
+        WGG_STASH(0, xa, ya);
+        __syncthreads();
+        for (int c = c0; c < c1; c += 2) {
+            WGG_FETCH(min(c + 2, last), xa, ya);
+            WGG_COMPUTE(0);
+            WGG_STASH(1, xb, yb);
+            barrier_lds();
+            if (c + 1 >= c1) break;
+            WGG_FETCH(min(c + 3, last), xb, yb);
+            WGG_COMPUTE(1);
+            WGG_STASH(0, xa, ya);
+            barrier_lds();
+        }
+    }
+#undef WGG_FETCH
+#undef WGG_STASH
+#undef WGG_COMPUTE
+    // ---- slab[bx][ci][co]: lane holds D[ci_local = 4*grp + j][co_local = li] of every accumulator
+    float* slab = reinterpret_cast<float*>(const_cast<char*>(base) + a.slab_off) + (int64_t)bx * a.kpad * a.wld;
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ci = ci0 + (wa * W + i) * 16 + 4 * grp + e, co = co0 + (wb * W + j) * 16 + li;
+                if (ci < a.kpad && co < a.wld) slab[(int64_t)ci * a.wld + co] = acc[i][j][e];
+            }
+}
+
+WgradMfmaPlan wgrad_gemm_plan(const stcd_conv_geom& g, int kpad, int wld) {
+    WgradMfmaPlan p;
+    if (g.ntaps != 1 || g.ci < 64 || g.co < 64 || g.ci % 8 != 0 || g.ldi % 8 != 0 || g.ldo % 8 != 0) return p;
+    if (((int64_t)g.n * g.hi + 4) * g.wi * g.ldi * 2 >= ((int64_t)1 << 31) || (int64_t)g.n * g.ho * g.wo * g.ldo * 2 >= ((int64_t)1 << 31)) return p;
+    const int64_t M = (int64_t)g.n * g.hm * g.wm;
+    if (M >= ((int64_t)1 << 30)) return p;
+    const int W = (g.ci >= 128 && g.co >= 128) ? 4 : 2, T = 32 * W;
+    p.gemm = W; p.WCI = 0; p.NTW = 0;
+    p.gy = (g.ci + T - 1) / T; p.gz = (g.co + T - 1) / T;
+    const int64_t nchunks = (M + 63) / 64;
+    // about 1024 blocks per launch (two rounds of two blocks per CU), at least 4 chunks per block, slabs <= 16 MB per layer
+    int64_t gx = std::max<int64_t>(1, 1024 / ((int64_t)p.gy * p.gz));
+    gx = std::min<int64_t>(gx, std::max<int64_t>(1, nchunks / 4));
+    gx = std::min<int64_t>(gx, std::max<int64_t>(1, ((int64_t)16 << 20) / ((int64_t)kpad * wld * 4)));
+    p.gx = (int)gx;
+    p.slab_floats = gx * (int64_t)kpad * wld;
+    p.ok = true;
+    return p;
+}
+
+WgradJob wgrad_gemm_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t in_off, int64_t dout_off, int64_t slab_off,
+                             int kpad, int wld) {
+    WgradJob a;
+    memset(&a, 0, sizeof(a));
+    a.g = g;
+    a.in_off = in_off; a.dout_off = dout_off; a.slab_off = slab_off; a.kpad = kpad; a.wld = wld;
+    a.ntiles = g.n * g.hm * g.wm;                 // positions
+    a.co_valid = (g.co + 7) & ~7;
+    a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
+    a.dout_bytes = (unsigned)((int64_t)g.n * g.ho * g.wo * g.ldo * 2);
+    a.gx = p.gx; a.gy = p.gy; a.gz = p.gz; a.start = 0;
+    a.wi_valid = p.wi_valid > 0 ? p.wi_valid : g.wi;
+    const int T = 32 * p.gemm;
+    a.lds_bytes = 2 * 2 * (T / 32) * (64 * 64 + 8 * 32);
+    return a;
+}
+
+int launch_wgrad_gemm_group(int W, const WgradJob* jobs_dev, int njobs, int total_blocks, const char* base, hipStream_t s) {
+    if (njobs <= 0 || total_blocks <= 0) return 0;
+    const int T = 32 * W;
+    const size_t lds = (size_t)2 * 2 * (T / 32) * (64 * 64 + 8 * 32);
+    if (W == 4) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_wgrad_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        k_wgrad_gemm<4><<<(unsigned)total_blocks, 256, lds, s>>>(jobs_dev, njobs, base);
+    } else {
+        k_wgrad_gemm<2><<<(unsigned)total_blocks, 256, lds, s>>>(jobs_dev, njobs, base);
+    }
+    return 0;
+}
+
 }  // namespace stcd

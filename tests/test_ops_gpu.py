@@ -423,3 +423,31 @@ def test_tap_list_gemm_kernel(n, h, w, ci, co, stride, taps):
     tol = 2.0 ** -7 * want.abs().max().item()
     for impl in (1, 2):
         assert (outs[impl] - want).abs().max().item() <= tol, impl
+
+
+# one-tap weight gradients on the position-GEMM kernel (impl=3): 1x1 convs, stride-2 1x1 (in_stride 2), the phases of a 2x2
+# stride-2 transposed conv (dY read at stride 2 from phase (py, px)), ragged position counts and channel counts that are not
+# multiples of the 64 / 128 tile -- against an fp64 matmul of the same bf16 operands and the reference kernel (impl=0)
+WGEMM_CASES = [  # n, h, w, ci, co, in_stride, out_stride, oy0, ox0
+    (4, 32, 32, 64, 64, 1, 1, 0, 0), (2, 16, 16, 256, 128, 1, 1, 0, 0), (2, 8, 8, 2048, 512, 1, 1, 0, 0), (3, 5, 7, 192, 320, 1, 1, 0, 0),
+    (8, 16, 16, 64, 256, 1, 1, 0, 0), (2, 16, 16, 128, 256, 2, 1, 0, 0), (2, 8, 8, 128, 128, 1, 2, 1, 0), (2, 8, 8, 64, 64, 1, 2, 1, 1),
+    (32, 16, 16, 1024, 256, 1, 1, 0, 0),
+]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,si,so,oy0,ox0", WGEMM_CASES)
+def test_weight_gradient_gemm_kernel(n, h, w, ci, co, si, so, oy0, ox0):
+    rng = np.random.default_rng(ci + co + h + so)
+    hm, wm = h // si, w // si
+    ho, wo = hm * so, wm * so
+    x = rnd(rng, n, h, w, ci).to(DEV)
+    dout = rnd(rng, n, ho, wo, co).to(DEV)
+    g = geom(n, h, w, ci, ci, hm, wm, si, ho, wo, so, oy0, ox0, co, co, [(0, 0)])
+    got = run_wgrad(3, g, x, dout)[0].double()
+    ref = run_wgrad(0, g, x, dout)[0].double()
+    xs = x[:, ::si, ::si][:, :hm, :wm].double().reshape(-1, ci)
+    ys = dout[:, oy0::so, ox0::so][:, :hm, :wm].double().reshape(-1, co)
+    want = xs.T @ ys
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-5 * scale + 1e-6       # fp32 accumulation order only
+    assert (ref - want).abs().max().item() <= 2e-5 * scale + 1e-6
