@@ -1916,8 +1916,10 @@ WgradMfmaPlan wgrad_gemm_plan(const stcd_conv_geom& g, int kpad, int wld) {
     p.gy = (g.ci + T - 1) / T; p.gz = (g.co + T - 1) / T;
     const int64_t nchunks = (M + 63) / 64;
     // about 1024 blocks per launch (two rounds of two blocks per CU), at least 4 chunks per block, slabs <= 16 MB per layer
-    int64_t gx = std::max<int64_t>(1, 1024 / ((int64_t)p.gy * p.gz));
-    gx = std::min<int64_t>(gx, std::max<int64_t>(1, nchunks / 4));
+    static const int target_blocks = [] { const char* e = getenv("STCD_WGEMM_BLOCKS"); return e ? atoi(e) : 512; }();
+    static const int min_chunks = [] { const char* e = getenv("STCD_WGEMM_MIN_CHUNKS"); return e ? atoi(e) : 16; }();
+    int64_t gx = std::max<int64_t>(1, target_blocks / ((int64_t)p.gy * p.gz));
+    gx = std::min<int64_t>(gx, std::max<int64_t>(1, nchunks / min_chunks));
     gx = std::min<int64_t>(gx, std::max<int64_t>(1, ((int64_t)16 << 20) / ((int64_t)kpad * wld * 4)));
     p.gx = (int)gx;
     p.slab_floats = gx * (int64_t)kpad * wld;

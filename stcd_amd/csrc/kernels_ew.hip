@@ -40,6 +40,8 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // grid of the kernels that build a per-block BatchNorm table in their prologue: capped at ~2 resident rounds of the
 // chip so the table (one dependent round trip + a few double operations per channel) is built <= 2048 times per launch
 static inline int ew_grid(int64_t total_threads) { return (int)std::min<int64_t>(cdiv(total_threads, 256), 2048); }
+// channel slabs of the BatchNorm consumer kernels: 64 channels per block from 128 channels up (a pixel's slab is one 128-B line)
+static inline int bn_slabs(int C) { return (C >= 128 && C % 64 == 0) ? C / 64 : 1; }
 
 // grouped view: element (g, n_in_group, pix, c) at p + g*goff + (n_in_group*HW + pix)*ld + c
 struct GV {
@@ -290,8 +292,12 @@ void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t p
 __device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __restrict__ facc, const float* __restrict__ gamma,
                                              const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                              float* __restrict__ stat, int C, int groups, int64_t ppg, float momentum, float eps,
-                                             bool publish) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+                                             bool publish, int cbase = 0, int CS = 0) {
+    // channels [cbase, cbase + CS) only (CS == 0: all): wide layers give every block one 64-channel slab, so its prologue reads
+    // 64 channels' accumulators instead of up to 2048
+    if (CS == 0) CS = C;
+    for (int cl = threadIdx.x; cl < CS; cl += blockDim.x) {
+        const int c = cbase + cl;
         if (facc) {
             const float gam = gamma[c], bet = beta[c];
             float rm = (publish && rmean) ? rmean[c] : 0.f, rv = (publish && rvar) ? rvar[c] : 0.f;
@@ -302,8 +308,8 @@ __device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __rest
                 if (var < 0.0) var = 0.0;
                 const double invstd = 1.0 / sqrt(var + (double)eps);
                 const float sc = (float)(gam * invstd), sh = (float)(bet - mean * gam * invstd);
-                tab[(g * 2 + 0) * C + c] = sc;
-                tab[(g * 2 + 1) * C + c] = sh;
+                tab[(g * 2 + 0) * CS + cl] = sc;
+                tab[(g * 2 + 1) * CS + cl] = sh;
                 if (publish) {
                     float* st = stat + (int64_t)g * 4 * C;
                     st[c] = (float)mean; st[C + c] = (float)invstd; st[2 * C + c] = sc; st[3 * C + c] = sh;
@@ -316,8 +322,8 @@ __device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __rest
             if (publish && rvar) rvar[c] = rv;
         } else {
             for (int g = 0; g < groups; ++g) {
-                tab[(g * 2 + 0) * C + c] = stat[(int64_t)g * 4 * C + 2 * C + c];
-                tab[(g * 2 + 1) * C + c] = stat[(int64_t)g * 4 * C + 3 * C + c];
+                tab[(g * 2 + 0) * CS + cl] = stat[(int64_t)g * 4 * C + 2 * C + c];
+                tab[(g * 2 + 1) * CS + cl] = stat[(int64_t)g * 4 * C + 3 * C + c];
             }
         }
     }
@@ -325,20 +331,22 @@ __device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __rest
 // tab: [groups][5][C] = (scale, shift, b, mean, c) of dY = scale*dz + b*(y - mean) + c  (see k_bn_bwd_apply)
 __device__ __forceinline__ void bn_bwd_table(float* tab, const long long* __restrict__ bacc, const float* __restrict__ stat,
                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int groups, int64_t ppg,
-                                             bool publish) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+                                             bool publish, int cbase = 0, int CS = 0) {
+    if (CS == 0) CS = C;                         // channel slab [cbase, cbase + CS), see bn_fwd_table
+    for (int cl = threadIdx.x; cl < CS; cl += blockDim.x) {
+        const int c = cbase + cl;
         double tg = 0.0, tb = 0.0;
         for (int g = 0; g < groups; ++g) {
             const double s1 = bn_acc_get(bacc, groups, C, g, 0, c, BN_BS), s2 = bn_acc_get(bacc, groups, C, g, 1, c, BN_BS);
             const float* st = stat + (int64_t)g * 4 * C;
             const double mean = st[c], invstd = st[C + c], scale = st[2 * C + c];
             const double k1 = s1 / (double)ppg, k2 = s2 / (double)ppg;
-            float* bw = tab + (int64_t)g * 5 * C;
-            bw[c] = (float)scale;
-            bw[C + c] = st[3 * C + c];
-            bw[2 * C + c] = (float)(-scale * k2 * invstd);
-            bw[3 * C + c] = (float)mean;
-            bw[4 * C + c] = (float)(-scale * k1);
+            float* bw = tab + (int64_t)g * 5 * CS;
+            bw[cl] = (float)scale;
+            bw[CS + cl] = st[3 * C + c];
+            bw[2 * CS + cl] = (float)(-scale * k2 * invstd);
+            bw[3 * CS + cl] = (float)mean;
+            bw[4 * CS + cl] = (float)(-scale * k1);
             tb += s1; tg += s2;
         }
         if (publish && dgamma) { dgamma[c] = (float)tg; dbeta[c] = (float)tb; }
@@ -373,16 +381,18 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
          float* __restrict__ stat, const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg,
          int H, int W, int relu, int64_t total, const long long* __restrict__ facc, const float* __restrict__ gamma,
          const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, int groups, float momentum, float eps,
-         const SliceViews xd) {
-    extern __shared__ float bn_tab[];           // [groups][2][C]
-    bn_fwd_table(bn_tab, facc, gamma, beta, rmean, rvar, stat, C, groups, (int64_t)npg * H * W, momentum, eps, blockIdx.x == 0);
+         const SliceViews xd, int nslab) {
+    extern __shared__ float bn_tab[];           // [groups][2][CS]
+    // block -> (channel slab, block inside the slab): the slab's blocks walk its (quad, 8-channel chunk) items grid-stride
+    const int CS = C / nslab, slab = blockIdx.x % nslab, bi = blockIdx.x / nslab, bps = gridDim.x / nslab, cbase = slab * CS;
+    bn_fwd_table(bn_tab, facc, gamma, beta, rmean, rvar, stat, C, groups, (int64_t)npg * H * W, momentum, eps, bi == 0, cbase, CS);
     __syncthreads();
-    // grid-stride walk: the table above is built once per block, the grid is capped (see the launcher)
-    for (int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i64 < total; i64 += (int64_t)gridDim.x * blockDim.x) {
-    const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
+    const int64_t total_s = total / nslab;
+    for (int64_t i64 = (int64_t)bi * blockDim.x + threadIdx.x; i64 < total_s; i64 += (int64_t)bps * blockDim.x) {
+    const int cb = CS >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
     // 32-bit index arithmetic (the launcher guarantees total < 2^31)
     uint32_t r = (uint32_t)i64;
-    const int c0 = (int)(r % (uint32_t)cb) * 8; r /= (uint32_t)cb;
+    const int c0l = (int)(r % (uint32_t)cb) * 8, c0 = cbase + c0l; r /= (uint32_t)cb;
     const int xc = (int)(r % (uint32_t)Wc); r /= (uint32_t)Wc;
     const int yc = (int)(r % (uint32_t)Hc);
     const int n = (int)(r / (uint32_t)Hc);
@@ -390,7 +400,7 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
     float sc[8], sh[8], mk[8];
     {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = bn_tab[(g * 2 + 0) * C + c0 + j]; sh[j] = bn_tab[(g * 2 + 1) * C + c0 + j]; }
+        for (int j = 0; j < 8; ++j) { sc[j] = bn_tab[(g * 2 + 0) * CS + c0l + j]; sh[j] = bn_tab[(g * 2 + 1) * CS + c0l + j]; }
         if (mask) {
             const float4* mp = reinterpret_cast<const float4*>(mask + (int64_t)n * C + c0);
             const float4 m0 = mp[0], m1 = mp[1];
@@ -535,17 +545,18 @@ void launch_bn_act_pair(int dt, const BnActArgs& a, void* F, int ldf, int fmode,
 void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s) {
     int64_t total = (int64_t)a.groups * a.npg * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.C / 8);
     GV av{a.lda, a.a_group_off};
-    const size_t lds = (size_t)a.groups * 2 * a.C * 4;
-    const int grid = ew_grid(total);
+    const int nslab = bn_slabs(a.C);
+    const size_t lds = (size_t)a.groups * 2 * (a.C / nslab) * 4;
+    const int grid = std::max(1, ew_grid(total) / nslab) * nslab;
     if (dt == BF16)
         k_bn_act<bf16><<<grid, 256, lds, s>>>((const bf16*)a.Y, a.ldy, (bf16*)a.A, av, (bf16*)a.P, a.ldp, a.stat,
                                                           a.mask, (const bf16*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total, a.facc,
-                                                          a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps, a.extra);
+                                                          a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps, a.extra, nslab);
     else
         k_bn_act<float><<<grid, 256, lds, s>>>((const float*)a.Y, a.ldy, (float*)a.A, av, (float*)a.P, a.ldp,
                                                            a.stat, a.mask, (const float*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total,
                                                            a.facc, a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps,
-                                                           a.extra);
+                                                           a.extra, nslab);
 }
 
 template <typename T>
@@ -807,22 +818,24 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
                const float* __restrict__ stat, const long long* __restrict__ bacc, float* __restrict__ dgamma, float* __restrict__ dbeta,
                int groups, const float* __restrict__ mask, const T* __restrict__ res, int ldres,
                T* __restrict__ dZout, int lddz, const T* __restrict__ extra, int ldex, int C, int npg, int64_t HW, int relu,
-               int64_t total) {
-    extern __shared__ float bw_tab[];           // [groups][5][C]
-    bn_bwd_table(bw_tab, bacc, stat, dgamma, dbeta, C, groups, (int64_t)npg * HW, blockIdx.x == 0);
+               int64_t total, int nslab) {
+    extern __shared__ float bw_tab[];           // [groups][5][CS]
+    const int CS = C / nslab, slab = blockIdx.x % nslab, bi = blockIdx.x / nslab, bps = gridDim.x / nslab, cbase = slab * CS;
+    bn_bwd_table(bw_tab, bacc, stat, dgamma, dbeta, C, groups, (int64_t)npg * HW, bi == 0, cbase, CS);
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cb = C >> 3;
+    const int64_t total_s = total / nslab;
+    for (int64_t i = (int64_t)bi * blockDim.x + threadIdx.x; i < total_s; i += (int64_t)bps * blockDim.x) {
+    const int cb = CS >> 3;
     const uint32_t iu = (uint32_t)i;               // launcher guarantees total < 2^31
-    const int c0 = (int)(iu % (uint32_t)cb) * 8;
+    const int c0l = (int)(iu % (uint32_t)cb) * 8, c0 = cbase + c0l;
     const int64_t p0 = (int64_t)(iu / (uint32_t)cb) * PX;  // first of PX pixels (PX > 1 only when HW % PX == 0: same image)
     const int n = (int)((uint32_t)p0 / (uint32_t)HW);
     const int g = n / npg;
     const int64_t pig0 = p0 - (int64_t)g * npg * HW;
     float sc[8], sh[8], kb[8], mu[8], kc[8], mk[8];
-    const float* w = bw_tab + (int64_t)g * 5 * C + c0;
+    const float* w = bw_tab + (int64_t)g * 5 * CS + c0l;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = w[j]; sh[j] = w[C + j]; kb[j] = w[2 * C + j]; mu[j] = w[3 * C + j]; kc[j] = w[4 * C + j]; }
+    for (int j = 0; j < 8; ++j) { sc[j] = w[j]; sh[j] = w[CS + j]; kb[j] = w[2 * CS + j]; mu[j] = w[3 * CS + j]; kc[j] = w[4 * CS + j]; }
     if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
     // all loads of the PX pixels first (dY may alias dA: every thread reads its own elements before it writes them)
     float y[PX][8], d[PX][8], rs[PX][8], ex[PX][8];
@@ -1300,10 +1313,12 @@ void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void
                          int npg, int64_t HW, int relu, hipStream_t s, const void* res, int ldres, void* dZout, int lddz,
                          const void* extra, int ldex) {
     GV dav{ldda, da_goff};
-    const size_t lds = (size_t)groups * 5 * C * 4;
+    const int nslab = bn_slabs(C);
+    const size_t lds = (size_t)groups * 5 * (C / nslab) * 4;
     const int px = (HW % 4 == 0) ? 4 : 1;        // odd-sized maps (ReplicationPad2d branch): one pixel per thread
     int64_t total = (int64_t)groups * npg * HW / px * (C / 8);
-#define BWD_APPLY(T_, PX_) k_bn_bwd_apply<T_, PX_><<<ew_grid(total), 256, lds, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, stat, bacc, dgamma, dbeta, groups, mask, (const T_*)res, ldres, (T_*)dZout, lddz, (const T_*)extra, ldex, C, npg, HW, relu, total)
+    const int grid = std::max(1, ew_grid(total) / nslab) * nslab;
+#define BWD_APPLY(T_, PX_) k_bn_bwd_apply<T_, PX_><<<grid, 256, lds, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, stat, bacc, dgamma, dbeta, groups, mask, (const T_*)res, ldres, (T_*)dZout, lddz, (const T_*)extra, ldex, C, npg, HW, relu, total, nslab)
     if (dt == BF16) { if (px == 4) BWD_APPLY(bf16, 4); else BWD_APPLY(bf16, 1); }
     else { if (px == 4) BWD_APPLY(float, 4); else BWD_APPLY(float, 1); }
 #undef BWD_APPLY

@@ -179,7 +179,7 @@ def oracle_bn_act_bwd(x, ga, gamma, beta, mask, relu, groups, means, invstds):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("n,c,h,w,groups", [(4, 16, 12, 10, 2), (2, 32, 7, 5, 1), (6, 8, 9, 16, 2), (2, 128, 4, 6, 1), (4, 64, 16, 16, 2)])
+@pytest.mark.parametrize("n,c,h,w,groups", [(4, 16, 12, 10, 2), (2, 32, 7, 5, 1), (6, 8, 9, 16, 2), (2, 128, 4, 6, 1), (4, 64, 16, 16, 2), (2, 512, 6, 6, 2), (4, 2048, 4, 4, 2), (2, 256, 8, 12, 1)])
 def test_bn_relu_dropout_pool_vs_oracle(dtype, n, c, h, w, groups):
     """BatchNorm2d(train) + ReLU + Dropout2d mask + 2x2 max-pool and its backward: odd sizes, two groups (the shared encoder
     BN sees date 0 then date 1: running statistics updated twice), masks with zeros."""
