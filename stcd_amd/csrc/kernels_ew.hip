@@ -165,12 +165,17 @@ template <typename T, int MODE, int NS = 0>
 __global__ void __launch_bounds__(256)
 k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, const float* __restrict__ stat,
             const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg, int64_t HW, int relu,
-            int64_t ppg, int nchunk, long long* __restrict__ acc, const SliceViews xs, int base_valid, T* __restrict__ dA_sum) {
+            int64_t ppg, int nchunk, long long* __restrict__ acc, const SliceViews xs, int base_valid, T* __restrict__ dA_sum,
+            int nslab) {
     __shared__ float red[256 * 16];
-    const int g = blockIdx.y, chunk = blockIdx.x;
-    const int cb = C >> 3;                   // channel blocks (power of two, <= 256)
+    // block -> (channel slab, pixel chunk): wide layers give a block 64 channels (one 128-B line per pixel) of many pixels, so
+    // it ends with 128 atomic adds instead of 2*C
+    const int CS = C / nslab, slab = blockIdx.x % nslab, cbase = slab * CS;
+    const int g = blockIdx.y, chunk = blockIdx.x / nslab;
+    const int cb = CS >> 3;                  // channel blocks of the slab (power of two, <= 256)
     const int lanes = 256 / cb;
     const int mycb = threadIdx.x % cb, lane = threadIdx.x / cb;
+    const int cofs = cbase + mycb * 8;       // first channel of this thread
     const int64_t per = (ppg + nchunk - 1) / nchunk;
     const int64_t p0 = (int64_t)chunk * per, p1 = min(ppg, p0 + per);
     float s1[8], s2[8];
@@ -178,13 +183,13 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
     float mean[8], invstd[8], scale[8], shift[8];
     if (MODE == 1) {
-        const float* st = stat + (int64_t)g * 4 * C + mycb * 8;
+        const float* st = stat + (int64_t)g * 4 * C + cofs;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             mean[j] = st[j]; invstd[j] = st[C + j]; scale[j] = st[2 * C + j]; shift[j] = st[3 * C + j];
         }
     }
-    const T* yb = Y + ((int64_t)g * ppg) * ldy + mycb * 8;
+    const T* yb = Y + ((int64_t)g * ppg) * ldy + cofs;
     // 4 pixels per trip, every load of the trip issued before the arithmetic (a block owns only ~8 pixels per thread:
     // one load in flight at a time made the small maps pure latency)
     constexpr int U = NS > 0 ? 2 : 4;
@@ -199,9 +204,9 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
             const int64_t pc = ok[u] ? pu : p;
             load8<T>(yb + pc * ldy, y[u]);
             if (MODE == 1) {
-                if constexpr (NS == 0) load8<T>(dA + g * dav.goff + pc * dav.ld + mycb * 8, d[u]);
+                if constexpr (NS == 0) load8<T>(dA + g * dav.goff + pc * dav.ld + cofs, d[u]);
                 else {
-                    if (base_valid) load8<T>(dA + g * dav.goff + pc * dav.ld + mycb * 8, d[u]);
+                    if (base_valid) load8<T>(dA + g * dav.goff + pc * dav.ld + cofs, d[u]);
                     else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) d[u][j] = 0.f;
@@ -212,13 +217,13 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
                     for (int k = 0; k < NS; ++k) {
                         const bool on = k < xs.n && ((xs.gmask[k] >> g) & 1);
                         const int kk = on ? k : 0;                       // an inactive slot re-reads view 0 (valid address), x 0
-                        load8<T>(reinterpret_cast<const T*>(xs.p[kk]) + (xs.gmask[kk] == 3 ? g * xs.goff[kk] : 0) + pc * xs.ld[kk] + mycb * 8, ex[u][k]);
+                        load8<T>(reinterpret_cast<const T*>(xs.p[kk]) + (xs.gmask[kk] == 3 ? g * xs.goff[kk] : 0) + pc * xs.ld[kk] + cofs, ex[u][k]);
                     }
                 }
-                if (res) load8<T>(res + ((int64_t)g * ppg + pc) * ldres + mycb * 8, rs[u]);
+                if (res) load8<T>(res + ((int64_t)g * ppg + pc) * ldres + cofs, rs[u]);
                 if (mask) {
                     const int nig = (int)((uint32_t)pc / (uint32_t)HW);
-                    const float4* mp = reinterpret_cast<const float4*>(mask + ((int64_t)(g * npg + nig)) * C + mycb * 8);
+                    const float4* mp = reinterpret_cast<const float4*>(mask + ((int64_t)(g * npg + nig)) * C + cofs);
                     const float4 m0 = mp[0], m1 = mp[1];
                     mk[u][0] = m0.x; mk[u][1] = m0.y; mk[u][2] = m0.z; mk[u][3] = m0.w;
                     mk[u][4] = m1.x; mk[u][5] = m1.y; mk[u][6] = m1.z; mk[u][7] = m1.w;
@@ -238,7 +243,7 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
                 for (int j = 0; j < 8; ++j) d[u][j] = round_as<T>(d[u][j]);
                 if (ok[u]) {
                     const int64_t pu = p + (int64_t)u * lanes;
-                    store8<T>(dA_sum + g * dav.goff + pu * dav.ld + mycb * 8, d[u]);
+                    store8<T>(dA_sum + g * dav.goff + pu * dav.ld + cofs, d[u]);
                 }
             }
         }
@@ -264,22 +269,23 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s1[j]; red[threadIdx.x * 16 + 8 + j] = s2[j]; }
     __syncthreads();
-    for (int o = threadIdx.x; o < 2 * C; o += 256) {
-        int which = o / C, c = o - which * C;
+    for (int o = threadIdx.x; o < 2 * CS; o += 256) {
+        int which = o / CS, c = o - which * CS;
         float a_ = 0.f;
         for (int l = 0; l < lanes; ++l) a_ += red[(l * cb + (c >> 3)) * 16 + which * 8 + (c & 7)];
-        bn_acc_add(acc, chunk, gridDim.y, C, g, which, c, a_, MODE == 0 ? (which ? BN_FS2 : BN_FS1) : BN_BS);
+        bn_acc_add(acc, chunk, gridDim.y, C, g, which, cbase + c, a_, MODE == 0 ? (which ? BN_FS2 : BN_FS1) : BN_BS);
     }
 }
 
 void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t ppg, long long* acc, hipStream_t s) {
-    int nchunk = bn_stats_chunks(ppg, C);
-    dim3 grid(nchunk, groups);
+    const int nslab = bn_slabs(C);
+    int nchunk = bn_stats_chunks(ppg, C / nslab);
+    dim3 grid(nchunk * nslab, groups);
     GV z{0, 0};
     if (dt == BF16)
-        k_bn_reduce<bf16, 0><<<grid, 256, 0, s>>>((const bf16*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, acc, SliceViews(), 1, nullptr);
+        k_bn_reduce<bf16, 0><<<grid, 256, 0, s>>>((const bf16*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, acc, SliceViews(), 1, nullptr, nslab);
     else
-        k_bn_reduce<float, 0><<<grid, 256, 0, s>>>((const float*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, acc, SliceViews(), 1, nullptr);
+        k_bn_reduce<float, 0><<<grid, 256, 0, s>>>((const float*)Y, ld, nullptr, z, nullptr, nullptr, nullptr, 0, C, 0, 1, 0, ppg, nchunk, acc, SliceViews(), 1, nullptr, nslab);
 }
 
 
@@ -1290,22 +1296,23 @@ void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, con
                           const float* mask, int C, int groups, int npg, int64_t HW, int relu, long long* bacc,
                           hipStream_t s, const void* res, int ldres, const SliceViews* extra_src, int base_valid, void* dA_sum) {
     const SliceViews xs = extra_src ? *extra_src : SliceViews();
+    const int nslab = bn_slabs(C);
     if (xs.n > 0) {
         const int ns = xs.n <= 2 ? 2 : xs.n <= 4 ? 4 : MAX_VIEWS;
-#define RED_NS(T_, N_) k_bn_reduce<T_, 1, N_><<<dim3(bn_stats_chunks((int64_t)npg * HW, C), groups), 256, 0, s>>>((const T_*)Y, ldy, (const T_*)dA, GV{ldda, da_goff}, stat, mask, (const T_*)res, ldres, C, npg, HW, relu, (int64_t)npg * HW, bn_stats_chunks((int64_t)npg * HW, C), bacc, xs, base_valid, (T_*)dA_sum)
+#define RED_NS(T_, N_) k_bn_reduce<T_, 1, N_><<<dim3(bn_stats_chunks((int64_t)npg * HW, C / nslab) * nslab, groups), 256, 0, s>>>((const T_*)Y, ldy, (const T_*)dA, GV{ldda, da_goff}, stat, mask, (const T_*)res, ldres, C, npg, HW, relu, (int64_t)npg * HW, bn_stats_chunks((int64_t)npg * HW, C / nslab), bacc, xs, base_valid, (T_*)dA_sum, nslab)
         if (dt == BF16) { if (ns == 2) RED_NS(bf16, 2); else if (ns == 4) RED_NS(bf16, 4); else RED_NS(bf16, MAX_VIEWS); }
         else { if (ns == 2) RED_NS(float, 2); else if (ns == 4) RED_NS(float, 4); else RED_NS(float, MAX_VIEWS); }
 #undef RED_NS
         return;
     }
     int64_t ppg = (int64_t)npg * HW;
-    int nchunk = bn_stats_chunks(ppg, C);
-    dim3 grid(nchunk, groups);
+    int nchunk = bn_stats_chunks(ppg, C / nslab);
+    dim3 grid(nchunk * nslab, groups);
     GV dav{ldda, da_goff};
     if (dt == BF16)
-        k_bn_reduce<bf16, 1><<<grid, 256, 0, s>>>((const bf16*)Y, ldy, (const bf16*)dA, dav, stat, mask, (const bf16*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc, xs, base_valid, (bf16*)dA_sum);
+        k_bn_reduce<bf16, 1><<<grid, 256, 0, s>>>((const bf16*)Y, ldy, (const bf16*)dA, dav, stat, mask, (const bf16*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc, xs, base_valid, (bf16*)dA_sum, nslab);
     else
-        k_bn_reduce<float, 1><<<grid, 256, 0, s>>>((const float*)Y, ldy, (const float*)dA, dav, stat, mask, (const float*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc, xs, base_valid, (float*)dA_sum);
+        k_bn_reduce<float, 1><<<grid, 256, 0, s>>>((const float*)Y, ldy, (const float*)dA, dav, stat, mask, (const float*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc, xs, base_valid, (float*)dA_sum, nslab);
 }
 
 void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
