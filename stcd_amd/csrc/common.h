@@ -168,6 +168,7 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
 struct ConvGemmPlan {
     int W = 0;             // fragments per wave and side: 4 -> 128x128 block tile, 2 -> 64x64
     int tiles_m = 0, tiles_n = 0, blocks = 0, lds_bytes = 0;
+    int pix_chunks = 0;    // 1: the 64 "channels" of a row are 8 consecutive PIXELS of 8 channels (the 7x7 stem): bounds per pixel
     bool ok = false;
 };
 ConvGemmPlan conv_gemm_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups);
@@ -258,6 +259,7 @@ struct PackJob {
     int kind;
     PackSpec ps;              // reference index map restricted to the launch's taps
     int Ci, Co, CiB, nchunks, KS, NTtot, modeB;   // fragment-image parameters (kind 1)
+    int aux;                  // kind 2 (7x7 stem as a 7-tap GEMM over 8-pixel rows): real input channels
 };
 void launch_pack_jobs(const PackJob* jobs_dev, int njobs, int64_t total, const float* params, char* ws, hipStream_t s);
 

@@ -577,6 +577,12 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                 j.ps.ntaps = op->g.ntaps;
                 for (int t = 0; t < op->g.ntaps; ++t) { j.ps.ky[t] = full.ky[op->tap0 + t]; j.ps.kx[t] = full.kx[op->tap0 + t]; }
                 j.src_off = cv.w_off;
+                if (cv.kind == K_STEM7) {          // the stem's forward as a 7-tap GEMM over 8-pixel rows (configure_segcd)
+                    j.kind = 2; j.dst_off = op->wf; j.count = op->plan.wf_elems;
+                    j.Co = cv.cout; j.NTtot = op->plan.NTtot; j.aux = cv.cin;
+                    push(j);
+                    continue;
+                }
                 if (op->plan.ok && op->wf >= 0) {
                     j.kind = 1; j.dst_off = op->wf; j.count = op->plan.wf_elems;
                     j.Ci = op->g.ci; j.Co = op->g.co; j.CiB = op->plan.CiB; j.nchunks = op->plan.nchunks; j.KS = op->plan.KS;
@@ -1878,6 +1884,23 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
             // y + (ky - 3 - py) / 2; per plane 3x3 / 3x4 / 4x3 / 4x4 taps, run as stride-1 launches of <= 9 taps over plane views
             // (see the stride-2 layers below).  fp32 mode (and any plan that does not fit) keeps the dedicated fp32 kernel.
             L.nwg = 0;
+            L.fwd = ConvOp();
+            if (e.dt == BF16 && e.use_mfma && e.use_gemm) {
+                // forward on the tap-list GEMM kernel: tap = filter row ky, and the 7 filter columns x 8 (padded) channels of a
+                // row are 112 contiguous bytes of the NHWC8 input -- one 64-"channel" row of 8 pixels starting 3 pixels to the left
+                stcd_conv_geom gs;
+                memset(&gs, 0, sizeof(gs));
+                gs.n = L.N; gs.hi = L.Hi; gs.wi = L.Wi; gs.ci = 64; gs.ldi = L.in.ld;
+                gs.hm = L.Ho; gs.wm = L.Wo; gs.in_stride = 2; gs.ho = L.Ho; gs.wo = L.Wo; gs.out_stride = 1;
+                gs.co = e.convs[L.conv].cout; gs.ldo = L.Y.ld; gs.ntaps = 7;
+                for (int t = 0; t < 7; ++t) { gs.dy[t] = (int8_t)(t - 3); gs.dx[t] = -3; }
+                ConvOp& op = L.fwd;
+                op.g = gs; op.conv = L.conv; op.dgrad = false; op.tap0 = 0; op.kreal = e.convs[L.conv].cin; op.nreal = gs.co;
+                op.plan = conv_mfma_plan(gs); op.res_groups = L.groups;
+                op.gemm = (L.in.ld == 8 && gs.co % 64 == 0) ? conv_gemm_plan(gs, op.plan, L.groups) : ConvGemmPlan();
+                op.gemm.pix_chunks = 1;
+                if (op.gemm.ok) { op.wf = ws.take(op.plan.wf_elems * 2); e.conv_ops.push_back(&op); }
+            }
             if (!(e.dt == BF16 && e.use_mfma && e.use_wgroup)) continue;
             const ConvW& cv = e.convs[L.conv];
             bool all_ok = true;
@@ -2033,7 +2056,12 @@ static void glayer_forward(const Ctx& c, GLayer& L, float* bn_running, bool trai
     const int64_t ppg = (int64_t)L.npg * L.Ho * L.Wo;
     float* stat = c.at<float>(L.stat);
     int fused = 0;
-    if (L.kind == K_STEM7) {
+    if (L.kind == K_STEM7 && mfma_on(e) && L.fwd.gemm.ok && L.fwd.wf >= 0) {
+        ProfScope ps(c, PC_CONV, 2.0 * L.N * L.Ho * L.Wo * 49.0 * cv.cin * cv.cout, 0.0, "k_conv_gemm<stem>");
+        long long* sp = training ? c.at<long long>(L.facc) : nullptr;
+        if (launch_conv_gemm(L.fwd.g, L.fwd.plan, L.fwd.gemm, c.at(L.in.off), c.at(L.fwd.wf), nullptr, c.at(L.Y.off), L.groups, sp, L.C, c.s) == 0)
+            fused = sp ? 1 : 0;
+    } else if (L.kind == K_STEM7) {
         ProfScope ps(c, PC_CONV, 2.0 * L.N * L.Ho * L.Wo * 49.0 * cv.cin * cv.cout, 0.0, "k_stem_fwd");
         launch_stem_fwd(e.dt, c.at(L.in.off), c.params + cv.w_off, c.at(L.Y.off), L.N, L.Hi, L.Wi, cv.cin, cv.cout, c.s);
     } else {

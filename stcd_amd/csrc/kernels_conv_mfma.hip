@@ -311,6 +311,18 @@ k_pack_jobs(const PackJob* __restrict__ jobs, int njobs, int64_t total, const fl
         const int k = (int)((e / jb.ps.wld) % jb.ps.kpad);
         const int t = (int)(e / ((int64_t)jb.ps.wld * jb.ps.kpad));
         reinterpret_cast<float*>(ws + jb.dst_off)[e] = ref_weight(jb.ps, src, t, k, n);
+    } else if (jb.kind == 2) {
+        // 7x7 stride-2 stem as a 7-tap GEMM: tap = ky, "channel" k = kx*8 + c over a row of 8 pixels x 8 channels (kx == 7 and
+        // c >= cin are zero); source layout [co][cin][7][7]
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        int64_t f = e >> 9;
+        const int nt = (int)(f % jb.NTtot); f /= jb.NTtot;
+        const int ks = (int)(f % 2); f /= 2;
+        const int ky = (int)f, co = nt * 16 + (lane & 15);
+        const int k = ks * 32 + 8 * (lane >> 4) + j, kx = k >> 3, c = k & 7;
+        float v = 0.f;
+        if (ky < 7 && kx < 7 && c < jb.aux && co < jb.Co) v = src[(((int64_t)co * jb.aux + c) * 7 + ky) * 7 + kx];
+        reinterpret_cast<bf16*>(ws + jb.dst_off)[e] = (bf16)v;
     } else {
         const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
         int64_t f = e >> 9;
@@ -1519,6 +1531,7 @@ struct ConvGemmArgs {
     float s1_scale, s2_scale;
     int NTtot, nsteps;             // n-tiles of the fragment image; (Ci / 64) * ntaps
     unsigned lead;                 // bytes the X descriptor starts before the tensor (most negative tap offset)
+    int pix_chunks;                // 1: 16-B chunk ch of a row is the pixel ch to the right (stem), bounds checked per chunk
     int Mg;                        // positions per group
     int tiles_m, tiles_m8, tiles_n;
     unsigned in_bytes;
@@ -1575,6 +1588,7 @@ k_conv_gemm(const ConvGemmArgs a) {
         const_cast<char*>(reinterpret_cast<const char*>(a.wf)), (short)0, a.nsteps * 2 * a.NTtot * 1024, 0x00020000);
     const unsigned wstep = (unsigned)(2 * a.NTtot * 1024);
     const int ntaps = a.g.ntaps;
+    const int chx = a.pix_chunks ? ch : 0;
     // two register sets: the chunk after next is requested before the MFMAs of the current one, so every load has two
     // loop iterations to land (one block per CU on the deep layers: nothing else hides the L2 / HBM round trip)
     uint4 pxa[XP], pwa[WP], pxb[XP], pwb[WP];
@@ -1586,7 +1600,7 @@ k_conv_gemm(const ConvGemmArgs a) {
         const int tdy_ = a.g.dy[tt_], tdx_ = a.g.dx[tt_];                                                              \
         const int toff_ = (tdy_ * a.g.wi + tdx_) * a.g.ldi * 2;                                                        \
         _Pragma("unroll") for (int p = 0; p < XP; ++p) {                                                               \
-            const bool ok_ = (unsigned)((xyx[p] >> 16) + tdy_) < (unsigned)a.g.hi && (unsigned)((int)(short)(xyx[p] & 0xffff) + tdx_) < (unsigned)a.g.wi; \
+            const bool ok_ = (unsigned)((xyx[p] >> 16) + tdy_) < (unsigned)a.g.hi && (unsigned)((int)(short)(xyx[p] & 0xffff) + tdx_ + chx) < (unsigned)a.g.wi; \
             const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok_ ? xoff[p] + (unsigned)toff_ : 0x80000000u, (unsigned)cc_ * 128u, 0); \
             PX_[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                           \
         }                                                                                                              \
@@ -1719,9 +1733,9 @@ ConvGemmPlan conv_gemm_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int 
     ConvGemmPlan gp;
     if (!p.ok || p.modeB || p.CiB != 64 || g.ntaps < 1) return gp;
     for (int t = 0; t < g.ntaps; ++t)
-        if (g.dy[t] < -2 || g.dy[t] > 2 || g.dx[t] < -2 || g.dx[t] > 2) return gp;
+        if (g.dy[t] < -3 || g.dy[t] > 3 || g.dx[t] < -3 || g.dx[t] > 3) return gp;
     if (g.ci % 64 != 0 || g.co % 64 != 0 || g.ldi % 8 != 0 || g.ldo % 8 != 0 || groups < 1 || g.n % groups != 0) return gp;
-    if (((int64_t)g.n * g.hi + 4) * g.wi * g.ldi * 2 >= ((int64_t)1 << 31) || g.hi >= 16384 || g.wi >= 16384) return gp;
+    if (((int64_t)g.n * g.hi + 8) * g.wi * g.ldi * 2 >= ((int64_t)1 << 31) || g.hi >= 16384 || g.wi >= 16384) return gp;
     if ((g.hm - 1) * g.in_stride >= g.hi + 2 || (g.wm - 1) * g.in_stride >= g.wi + 2) return gp;
     const int64_t Mg = (int64_t)(g.n / groups) * g.hm * g.wm;
     if (Mg * groups >= ((int64_t)1 << 31)) return gp;
@@ -1748,7 +1762,8 @@ int launch_conv_gemm(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvG
     a.in = (const bf16*)in; a.wf = (const bf16*)wf; a.bias = bias; a.out = (bf16*)out;
     a.stat_acc = stat_acc; a.groups = groups; a.cpad = cpad; a.stat_c0 = stat_c0; a.s1_scale = s1_scale; a.s2_scale = s2_scale;
     a.NTtot = p.NTtot; a.nsteps = (g.ci / 64) * g.ntaps;
-    a.lead = (unsigned)((2 * g.wi + 2) * g.ldi * 2);
+    a.lead = (unsigned)((3 * g.wi + 3) * g.ldi * 2);
+    a.pix_chunks = gp.pix_chunks;
     a.Mg = (g.n / groups) * g.hm * g.wm;
     a.tiles_m = gp.tiles_m; a.tiles_m8 = (gp.tiles_m + 7) / 8; a.tiles_n = gp.tiles_n;
     a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
