@@ -448,6 +448,17 @@ static stcd_conv_geom geom_up_phase(const UpConv& U, int py, int px, int ldi, in
 
 static void conv_work(const stcd_engine& e, const stcd_conv_geom& g, int kreal, int nreal, double* flops, double* bytes);
 
+// the tap-list GEMM kernel takes what the resident-filter kernel cannot, and (STCD_GEMM_OVER_RES: 0 never, 1 [default] when the
+// resident kernel would run 16-channel output slices, i.e. re-read X once per 16 output channels, 2 always)
+static void pick_gemm_or_res(const stcd_engine& e, ConvOp& op, const stcd_conv_geom& g, int groups) {
+    op.gemm = ConvGemmPlan();
+    if (!e.use_gemm || op.small) return;
+    static const int mode = [] { const char* v = getenv("STCD_GEMM_OVER_RES"); return v ? atoi(v) : 0; }();
+    if (op.res.ok && !(mode == 2 || (mode == 1 && op.res.NT == 1))) return;
+    op.gemm = conv_gemm_plan(g, op.plan, groups);
+    if (op.gemm.ok) op.res = ConvResPlan();
+}
+
 // weight-gradient plan of one launch: the GEMM kernel for one-tap launches with >= 64 channels on both sides, else the tile kernel
 static WgradMfmaPlan pick_wgrad_plan(const stcd_engine& e, const stcd_conv_geom& g, int kpad, int wld) {
     if (e.use_gemm && e.use_wgroup) {
@@ -743,7 +754,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             if (op.plan.ok) op.wf = ws.take(op.plan.wf_elems * 2);
             op.small = conv_small_ok(g, op.plan);
             if (e.use_res && !op.small) op.res = conv_res_plan(g, op.plan, groups);
-            op.gemm = (e.use_gemm && !op.small && !op.res.ok) ? conv_gemm_plan(g, op.plan, groups) : ConvGemmPlan();
+            pick_gemm_or_res(e, op, g, groups);
         }
         e.conv_ops.push_back(&op);
     };
@@ -1442,7 +1453,7 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
             if (op.plan.ok) op.wf = ws.take(op.plan.wf_elems * 2);
             op.small = conv_small_ok(g, op.plan);
             if (e.use_res && !op.small) op.res = conv_res_plan(g, op.plan, groups);
-            op.gemm = (e.use_gemm && !op.small && !op.res.ok) ? conv_gemm_plan(g, op.plan, groups) : ConvGemmPlan();
+            pick_gemm_or_res(e, op, g, groups);
         }
         e.conv_ops.push_back(&op);
     };
@@ -1866,7 +1877,7 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
             if (op.plan.ok) op.wf = ws.take(op.plan.wf_elems * 2);
             op.small = conv_small_ok(g, op.plan);
             if (e.use_res && !op.small) op.res = conv_res_plan(g, op.plan, groups);
-            op.gemm = (e.use_gemm && !op.small && !op.res.ok) ? conv_gemm_plan(g, op.plan, groups) : ConvGemmPlan();
+            pick_gemm_or_res(e, op, g, groups);
         }
         e.conv_ops.push_back(&op);
     };
