@@ -461,7 +461,9 @@ static void pick_gemm_or_res(const stcd_engine& e, ConvOp& op, const stcd_conv_g
 
 // weight-gradient plan of one launch: the GEMM kernel for one-tap launches with >= 64 channels on both sides, else the tile kernel
 static WgradMfmaPlan pick_wgrad_plan(const stcd_engine& e, const stcd_conv_geom& g, int kpad, int wld) {
-    if (e.use_gemm && e.use_wgroup) {
+    // (a GEMM group is one more launch of the stage: only layers with >= 0.8 GFLOP go there -- FC-Siam's two one-tap up-conv
+    //  phases, 0.54 GFLOP each, stay in the tile kernel's grid: measured +2 % on the diff step otherwise)
+    if (e.use_gemm && e.use_wgroup && 2.0 * g.n * g.hm * g.wm * (double)g.ci * g.co >= 0.8e9) {
         WgradMfmaPlan p = wgrad_gemm_plan(g, kpad, wld);
         if (p.ok) return p;
     }

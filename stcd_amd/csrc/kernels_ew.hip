@@ -7,6 +7,8 @@
 //   F.max_pool2d(2,2)                /root/reference/models/SiamUnet_diff.py:101
 //   |T1-T2| / T2-T1 skip fusion      SiamUnet_diff.py:150 / SiamUnet_sub.py:150
 //   ReplicationPad2d                 SiamUnet_diff.py:149
+#include <cstdlib>
+
 #include "common.h"
 
 namespace stcd {
@@ -41,7 +43,10 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // chip so the table (one dependent round trip + a few double operations per channel) is built <= 2048 times per launch
 static inline int ew_grid(int64_t total_threads) { return (int)std::min<int64_t>(cdiv(total_threads, 256), 2048); }
 // channel slabs of the BatchNorm consumer kernels: 64 channels per block from 128 channels up (a pixel's slab is one 128-B line)
-static inline int bn_slabs(int C) { return (C >= 128 && C % 64 == 0) ? C / 64 : 1; }
+static inline int bn_slabs(int C) {
+    static const int min_c = [] { const char* e = getenv("STCD_BN_SLAB_MIN_C"); return e ? atoi(e) : 128; }();
+    return (C >= min_c && C % 64 == 0) ? C / 64 : 1;
+}
 
 // grouped view: element (g, n_in_group, pix, c) at p + g*goff + (n_in_group*HW + pix)*ld + c
 struct GV {
