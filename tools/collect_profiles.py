@@ -16,7 +16,8 @@ os.makedirs(dst, exist_ok=True)
 line = [l for l in open(f"{src}/bench.json") if l.startswith("{")][-1]
 json.loads(line)
 open(f"{dst}/{tag}_bench.json", "w").write(line)
-stats = glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True)[0]
+newest = lambda pattern: max(glob.glob(pattern, recursive=True), key=os.path.getmtime)   # re-runs leave older files behind
+stats = newest(f"{src}/stats/**/*kernel_stats.csv")
 shutil.copy(stats, f"{dst}/{tag}_kernel_stats.csv")
 
 
@@ -28,7 +29,7 @@ def short(n):
 
 def per_kernel(path, counter):
     agg = collections.defaultdict(list)
-    for f in glob.glob(f"{path}/**/*counter_collection.csv", recursive=True):
+    for f in [newest(f"{path}/**/*counter_collection.csv")]:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
@@ -52,3 +53,18 @@ with open(f"{dst}/{tag}_pmc_traffic.txt", "w") as o:
     for tot, k, n, fb, wb in rows:
         o.write(f"{k[:48]:48s} {n:8d} {fb:14.0f} {wb:14.0f} {tot:14.0f}\n")
 print(open(f"{dst}/{tag}_pmc_traffic.txt").read()[:3000])
+
+# the bench line was printed before the counter passes of the same command ran: fill its traffic fields from THIS summary
+d = json.loads(line)
+r = d.get("roofline", {})
+dom = r.get("kernel")
+step_total = sum(t * n for t, _, n, _, _ in rows) / STEPS
+for tot, k, n, fb, wb in rows:
+    if dom and (k == dom or (len(dom) > 48 and k[:48] == dom[:48]) or k.startswith(dom.split("<")[0] + "<") and k.replace(" ", "") == dom.replace(" ", "")):
+        r["traffic"] = int(tot); r["traffic_source"] = f"profiles/{tag}_pmc_traffic.txt"
+        break
+r["traffic_step"] = int(step_total); r["traffic_step_source"] = f"profiles/{tag}_pmc_traffic.txt"
+if "step" in r and r["step"].get("alg_bytes"):
+    r["traffic_step_over_algorithmic"] = round(step_total / r["step"]["alg_bytes"], 3)
+open(f"{dst}/{tag}_bench.json", "w").write(json.dumps(d) + "\n")
+print("bench line:", {k: r.get(k) for k in ("kernel", "traffic", "traffic_step", "traffic_step_over_algorithmic")})
