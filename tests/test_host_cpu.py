@@ -140,5 +140,11 @@ def test_bench_reads_pmc_traffic_from_profiles(tmp_path, monkeypatch):
     (tmp_path / "profiles" / "r09_pmc_traffic.txt").write_text(
         "# header\nkernel   launches read_B write_B total_B\nstcd::k_conv_res<2, 32>   56   100   50   150\n")
     monkeypatch.setattr(b, "REPO", str(tmp_path))
-    assert b.pmc_traffic("stcd::k_conv_res<2, 32>") == (150, os.path.join("profiles", "r09_pmc_traffic.txt"))
-    assert b.pmc_traffic("stcd::k_other") == (None, None)
+    (tmp_path / "profiles" / "r09_snunet_pmc_traffic.txt").write_text(
+        "# step_total_B (sum): 9000\nkernel   launches read_B write_B total_B\nstcd::k_conv_res<2, 32>   56   100   70   170\n")
+    assert b.pmc_traffic("stcd::k_conv_res<2, 32>", "diff") == (150, os.path.join("profiles", "r09_pmc_traffic.txt"))
+    assert b.pmc_traffic("stcd::k_other", "diff") == (None, None)
+    # every family reads ITS OWN summary (same kernel name, different launches)
+    assert b.pmc_traffic("stcd::k_conv_res<2, 32>", "snunet") == (170, os.path.join("profiles", "r09_snunet_pmc_traffic.txt"))
+    assert b.pmc_traffic("stcd::k_conv_res<2, 32>", "segcd") == (None, None)
+    assert b.pmc_step_traffic("snunet") == (9000, os.path.join("profiles", "r09_snunet_pmc_traffic.txt"))
