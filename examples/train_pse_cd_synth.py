@@ -39,6 +39,10 @@ parser.add_argument("--load_path", type=str, default="")
 parser.add_argument("--train_tiles", type=int, default=64)
 parser.add_argument("--val_tiles", type=int, default=16)
 parser.add_argument("--change_fraction", type=float, default=0.75, help="share of tiles that are in the change list")
+parser.add_argument("--net", type=str, default="SiamUnet_diff", choices=["SiamUnet_diff", "SegCD"],
+                    help="SegCD = smp.SegCD(encoder_name='resnet50'), the model train_pse_cd.py:426 builds (its third output, the change "
+                         "map, feeds the loss as at :224-228); --encoder_weights as in smp (None | path | imagenet)")
+parser.add_argument("--encoder_weights", type=str, default=None)
 
 
 class DevicePairs:
@@ -68,7 +72,11 @@ def main():
     args = parser.parse_args()
     assert torch.cuda.is_available(), "the engine needs a GPU (no CPU fallback)"
     device = "cuda:0"
-    model = SiamUnet_diff(3, 1).to(device)                            # train_pse_cd.py:424
+    if args.net == "SegCD":                                           # train_pse_cd.py:426
+        from stcd_amd.segcd import SegCD
+        model = SegCD(encoder_name="resnet50", encoder_weights=args.encoder_weights).to(device)
+    else:
+        model = SiamUnet_diff(3, 1).to(device)                        # train_pse_cd.py:424
     if args.load_path:
         model.load_state_dict(torch.load(args.load_path, map_location="cpu"), strict=False)
     optimizer = FlatAdam(model, lr=0.001, betas=(0.9, 0.999))          # train_pse_cd.py:431, one fused launch per step

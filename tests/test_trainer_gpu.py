@@ -141,15 +141,17 @@ def test_f1_and_loss_parity_with_cpu_oracle_training():
     assert abs(f1b - f1o) * 100 < 1.5
 
 
-def test_example_script_runs_and_learns(monkeypatch):
-    """examples/train_pse_cd_synth.py: the reference script's CLI on device-synthesised pseudo-change pairs."""
+@pytest.mark.parametrize("net", ["SiamUnet_diff", "SegCD"])
+def test_example_script_runs_and_learns(monkeypatch, net):
+    """examples/train_pse_cd_synth.py: the reference script's CLI on device-synthesised pseudo-change pairs, with the script's own
+    model (SiamUnet_diff(3,1), train_pse_cd.py:424) and with the one it trains by default (smp.SegCD resnet50, :426)."""
     import importlib.util
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("train_pse_cd_synth", os.path.join(repo, "examples", "train_pse_cd_synth.py"))
     mod = importlib.util.module_from_spec(spec)
     monkeypatch.setattr(sys, "argv", ["train_pse_cd_synth.py", "--n_epochs", "3", "--batch_size", "4", "--img_height", "64",
-                                      "--img_width", "64", "--train_tiles", "16", "--val_tiles", "8"])
+                                      "--img_width", "64", "--train_tiles", "16", "--val_tiles", "8", "--net", net])
     spec.loader.exec_module(mod)
     hist = mod.main()
     assert len(hist) == 3 and all(np.isfinite(h["cd_loss"]) for h in hist)
