@@ -330,7 +330,8 @@ void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, con
 void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
                          const float* stat, const long long* bacc, float* dgamma, float* dbeta, const float* mask, int C, int groups,
                          int npg, int64_t HW, int relu, hipStream_t s, const void* res = nullptr, int ldres = 0,
-                         void* dZout = nullptr, int lddz = 0, const void* extra = nullptr, int ldex = 0);
+                         void* dZout = nullptr, int lddz = 0, const void* extra = nullptr, int ldex = 0,
+                         float* dbeta_copy = nullptr);      // dbeta_copy: a second destination of d(beta) (SNUNet: conv1's bias gradient)
 // dst[.., 0:C] (ld ldd) = or += src[.., 0:C] (ld lds): dense concatenation by copy, and its gradient scatter
 void launch_slice(int dt, void* dst, int ldd, const void* src, int lds, int64_t pixels, int C, int accumulate, hipStream_t s);
 // ECAM head of SNUNet (SNUNet.py:46-59,144-149); scratch layouts documented at the kernels (kernels_ew.hip)

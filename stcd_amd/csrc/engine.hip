@@ -1606,7 +1606,8 @@ static void sn_block_backward(const Ctx& c, const NBlock& b) {
         ProfScope ps(c, PC_BN_BWD_APPLY, 0.0, 5.0 * act_bytes);
         launch_bn_bwd_apply(e.dt, c.at(b.dOut.off), b.dOut.ld, goff_out, c.at(b.dOut.off), b.dOut.ld, c.at(b.Y2.off), b.Y2.ld,
                             c.at<float>(b.stat2), c.at<long long>(b.bacc2), c.grads + bn2.g_off, c.grads + bn2.b_off, nullptr, b.C,
-                            b.groups, b.npg, HW, 1, c.s, c.at(b.Y1.off), b.Y1.ld, c.at(b.dZ2.off), b.dZ2.ld, nullptr, 0);
+                            b.groups, b.npg, HW, 1, c.s, c.at(b.Y1.off), b.Y1.ld, c.at(b.dZ2.off), b.dZ2.ld, nullptr, 0,
+                            c.grads + e.convs[b.c1].b_off);
     }
     exec_wgrad(c, b.w2, c.at(b.A1.off), c.at(b.dOut.off));                   // dOut now holds dY2
     exec_conv(c, b.d2, c.at(b.dOut.off), nullptr, c.at(b.dA1.off), false);
@@ -1622,8 +1623,8 @@ static void sn_block_backward(const Ctx& c, const NBlock& b) {
                             b.groups, b.npg, HW, 1, c.s, nullptr, 0, nullptr, 0, c.at(b.dZ2.off), b.dZ2.ld);
     }
     // conv1's bias reaches the loss only through the identity branch (its BN path has zero gradient): db1 = sum dZ2,
-    // and dZ2 is exactly the gated gradient whose per-channel sum bn2's backward already formed as d(beta2)
-    (void)hipMemcpyAsync(c.grads + e.convs[b.c1].b_off, c.grads + bn2.b_off, (size_t)b.C * 4, hipMemcpyDeviceToDevice, c.s);
+    // and dZ2 is exactly the gated gradient whose per-channel sum bn2's backward already formed as d(beta2): bn2's apply
+    // kernel wrote it to both places (a 128-byte hipMemcpyAsync cost three copy kernels per block, 44 launches per step)
     exec_wgrad(c, b.w1, c.at(b.in.off), c.at(b.dA1.off));                   // dA1 now holds dY1
     if (b.dIn.off >= 0) {
         StatReq sr;

@@ -342,7 +342,7 @@ __device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __rest
 // tab: [groups][5][C] = (scale, shift, b, mean, c) of dY = scale*dz + b*(y - mean) + c  (see k_bn_bwd_apply)
 __device__ __forceinline__ void bn_bwd_table(float* tab, const long long* __restrict__ bacc, const float* __restrict__ stat,
                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int groups, int64_t ppg,
-                                             bool publish, int cbase = 0, int CS = 0) {
+                                             bool publish, int cbase = 0, int CS = 0, float* __restrict__ dbeta_copy = nullptr) {
     if (CS == 0) CS = C;                         // channel slab [cbase, cbase + CS), see bn_fwd_table
     for (int cl = threadIdx.x; cl < CS; cl += blockDim.x) {
         const int c = cbase + cl;
@@ -360,7 +360,7 @@ __device__ __forceinline__ void bn_bwd_table(float* tab, const long long* __rest
             bw[4 * CS + cl] = (float)(-scale * k1);
             tb += s1; tg += s2;
         }
-        if (publish && dgamma) { dgamma[c] = (float)tg; dbeta[c] = (float)tb; }
+        if (publish && dgamma) { dgamma[c] = (float)tg; dbeta[c] = (float)tb; if (dbeta_copy) dbeta_copy[c] = (float)tb; }
     }
 }
 
@@ -829,10 +829,10 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
                const float* __restrict__ stat, const long long* __restrict__ bacc, float* __restrict__ dgamma, float* __restrict__ dbeta,
                int groups, const float* __restrict__ mask, const T* __restrict__ res, int ldres,
                T* __restrict__ dZout, int lddz, const T* __restrict__ extra, int ldex, int C, int npg, int64_t HW, int relu,
-               int64_t total, int nslab) {
+               int64_t total, int nslab, float* __restrict__ dbeta_copy) {
     extern __shared__ float bw_tab[];           // [groups][5][CS]
     const int CS = C / nslab, slab = blockIdx.x % nslab, bi = blockIdx.x / nslab, bps = gridDim.x / nslab, cbase = slab * CS;
-    bn_bwd_table(bw_tab, bacc, stat, dgamma, dbeta, C, groups, (int64_t)npg * HW, bi == 0, cbase, CS);
+    bn_bwd_table(bw_tab, bacc, stat, dgamma, dbeta, C, groups, (int64_t)npg * HW, bi == 0, cbase, CS, dbeta_copy);
     __syncthreads();
     const int64_t total_s = total / nslab;
     for (int64_t i = (int64_t)bi * blockDim.x + threadIdx.x; i < total_s; i += (int64_t)bps * blockDim.x) {
@@ -1323,14 +1323,14 @@ void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, con
 void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
                          const float* stat, const long long* bacc, float* dgamma, float* dbeta, const float* mask, int C, int groups,
                          int npg, int64_t HW, int relu, hipStream_t s, const void* res, int ldres, void* dZout, int lddz,
-                         const void* extra, int ldex) {
+                         const void* extra, int ldex, float* dbeta_copy) {
     GV dav{ldda, da_goff};
     const int nslab = bn_slabs(C);
     const size_t lds = (size_t)groups * 5 * (C / nslab) * 4;
     const int px = (HW % 4 == 0) ? 4 : 1;        // odd-sized maps (ReplicationPad2d branch): one pixel per thread
     int64_t total = (int64_t)groups * npg * HW / px * (C / 8);
     const int grid = std::max(1, ew_grid(total) / nslab) * nslab;
-#define BWD_APPLY(T_, PX_) k_bn_bwd_apply<T_, PX_><<<grid, 256, lds, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, stat, bacc, dgamma, dbeta, groups, mask, (const T_*)res, ldres, (T_*)dZout, lddz, (const T_*)extra, ldex, C, npg, HW, relu, total, nslab)
+#define BWD_APPLY(T_, PX_) k_bn_bwd_apply<T_, PX_><<<grid, 256, lds, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, stat, bacc, dgamma, dbeta, groups, mask, (const T_*)res, ldres, (T_*)dZout, lddz, (const T_*)extra, ldex, C, npg, HW, relu, total, nslab, dbeta_copy)
     if (dt == BF16) { if (px == 4) BWD_APPLY(bf16, 4); else BWD_APPLY(bf16, 1); }
     else { if (px == 4) BWD_APPLY(float, 4); else BWD_APPLY(float, 1); }
 #undef BWD_APPLY
