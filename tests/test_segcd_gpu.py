@@ -51,18 +51,18 @@ def test_segcd_fp32_matches_reference_vectors(golden):
         np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), g[k], rtol=1e-4, atol=5e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("B,H,W", [(1, 128, 160), (3, 96, 64)])
-def test_segcd_fp32_matches_oracle_on_other_shapes(B, H, W):
+@pytest.mark.parametrize("B,H,W,cin", [(1, 128, 160, 3), (3, 96, 64, 3), (3, 96, 96, 5)])
+def test_segcd_fp32_matches_oracle_on_other_shapes(B, H, W, cin):
     """Odd batch, non-square sizes, 2 classes against the CPU oracle run in fp64 (gradients of the whole step).  Sizes keep >= 18
     samples per BatchNorm at the deepest stage (H/32 x W/32 x B): below that the normalisation amplifies fp32 rounding beyond any
     meaningful bound (3 samples at 1x32x96 move the outputs by 9e-2)."""
     seed = 77 + B
     rng = np.random.default_rng(seed)
-    x1 = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32))
-    x2 = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32))
+    x1 = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    x2 = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32))
     w1, w2, w3 = (torch.from_numpy(rng.standard_normal((B, 2, H, W)).astype(np.float32)) for _ in range(3))
-    st = G.synth_state(3, 2, seed)
-    m = SegCD(classes=2, dtype="fp32")
+    st = G.synth_state(cin, 2, seed)
+    m = SegCD(in_channels=cin, classes=2, dtype="fp32")
     m.load_state_dict(st)
     m.to(DEV).train()
     o = m(x1.to(DEV), x2.to(DEV))
@@ -88,7 +88,7 @@ def test_segcd_fp32_matches_oracle_on_other_shapes(B, H, W):
         worst = (max(worst[0], r), min(worst[1], c))
     print(f"worst tensor: {worst_name}")
     assert worst[0] <= SEG_REL and worst[1] >= SEG_COS, (worst_name, worst)
-    print(f"SegCD fp32 vs fp64 oracle B={B} {H}x{W}: worst rel-l2 {worst[0]:.2e}, worst cos {worst[1]:.6f}")
+    print(f"SegCD fp32 vs fp64 oracle B={B} {H}x{W} cin={cin}: worst rel-l2 {worst[0]:.2e}, worst cos {worst[1]:.6f}")
     sd = m.state_dict()
     for k in ("encoder.bn1", "encoder.layer2.0.downsample.1", "decoder.blocks.3.conv2.1"):
         np.testing.assert_allclose(sd[k + ".running_mean"].cpu().numpy(), st64[k + ".running_mean"].float().numpy(), rtol=1e-4, atol=1e-5)
@@ -130,15 +130,15 @@ def _holders(m):
     return out
 
 
-@pytest.mark.parametrize("dtype,B,H,W", [("fp32", 2, 64, 64), ("bf16", 2, 64, 96), ("bf16", 3, 128, 128)])
-def test_segcd_every_layer_in_place(dtype, B, H, W):
+@pytest.mark.parametrize("dtype,B,H,W,cin", [("fp32", 2, 64, 64, 3), ("bf16", 2, 64, 96, 3), ("bf16", 3, 128, 128, 3), ("bf16", 2, 96, 64, 6)])
+def test_segcd_every_layer_in_place(dtype, B, H, W, cin):
     tol = 2e-4 if dtype == "fp32" else 6e-3            # bf16: one rounding of the output (2^-9 relative, ~1.2e-3 rms) + bf16 weights
     rng = np.random.default_rng(31)
-    x1 = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32)).to(DEV)
-    x2 = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32)).to(DEV)
+    x1 = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32)).to(DEV)
+    x2 = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32)).to(DEV)
     tgt = torch.from_numpy((rng.random((B, 1, H, W)) < 0.2).astype(np.float32)).to(DEV)
-    m = SegCD(dtype=dtype)
-    m.load_state_dict(G.synth_state(3, 1, 11))
+    m = SegCD(in_channels=cin, dtype=dtype)
+    m.load_state_dict(G.synth_state(cin, 1, 11))
     m._engine.set_debug(1)
     m.to(DEV).train()
     o = m(x1, x2)
@@ -160,7 +160,7 @@ def test_segcd_every_layer_in_place(dtype, B, H, W):
         X, Y, A, dY = _nchw(ws[name + ".in"]), _nchw(ws[name + ".Y"]), _nchw(ws[name + ".A"]), _nchw(ws[name + ".dY"])
         Wt = wq(conv.weight)
         if name == "encoder.conv1":
-            X = X[:, :3]
+            X = X[:, :cin]
         chk("conv output", name, Y, torch.nn.functional.conv2d(X, Wt, None, conv.stride, conv.padding))
         # weight gradient from the stored input and output gradient (fp32 accumulation of bf16 products on both sides)
         want_dw = torch.nn.grad.conv2d_weight(X, conv.weight.shape, dY, conv.stride, conv.padding)
