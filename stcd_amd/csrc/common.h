@@ -188,7 +188,7 @@ struct WgradMfmaPlan {
     int gemm = 0;          // > 0: one-tap launch on k_wgrad_gemm<gemm> (32*gemm x 32*gemm channel tile), gx = position slices
     bool ok = false;
 };
-WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld);
+WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld, bool allow_wide = false);   // allow_wide: 64 x 32 tile for ci >= 64
 int launch_wgrad_mfma(const stcd_conv_geom& g, const WgradMfmaPlan& p, const void* in, const void* dout, float* slab,
                       int kpad, int wld, hipStream_t s);
 // One weight-gradient launch as the kernel sees it.  A backward stage runs ALL its launches of one kernel variant as a

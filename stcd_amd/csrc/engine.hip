@@ -467,7 +467,7 @@ static WgradMfmaPlan pick_wgrad_plan(const stcd_engine& e, const stcd_conv_geom&
         WgradMfmaPlan p = wgrad_gemm_plan(g, kpad, wld);
         if (p.ok) return p;
     }
-    return wgrad_mfma_plan(g, kpad, wld);
+    return wgrad_mfma_plan(g, kpad, wld, e.arch == STCD_ARCH_SNUNET);
 }
 
 static void build_pack_jobs(stcd_engine& e, Bump& ws) {
@@ -2471,9 +2471,9 @@ static int check_geom(const stcd_conv_geom* g) {
 int64_t stcd_op_scratch_bytes(const stcd_conv_geom* g) {
     if (!g) return 0;
     ConvMfmaPlan p = conv_mfma_plan(*g);
-    WgradMfmaPlan w = wgrad_mfma_plan(*g, g->ci, g->co);
+    WgradMfmaPlan w = wgrad_mfma_plan(*g, g->ci, g->co), ww = wgrad_mfma_plan(*g, g->ci, g->co, true);
     WgradMfmaPlan wg = wgrad_gemm_plan(*g, g->ci, g->co);
-    return std::max<int64_t>(p.wf_elems * 2, std::max(w.slab_floats, wg.ok ? wg.slab_floats : 0) * 4) + 1024;
+    return std::max<int64_t>(p.wf_elems * 2, std::max(std::max(w.slab_floats, ww.slab_floats), wg.ok ? wg.slab_floats : 0) * 4) + 1024;
 }
 int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, const float* w, const float* bias,
                  void* out, void* scratch, int64_t scratch_bytes, void* hip_stream) {
@@ -2518,9 +2518,9 @@ int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, 
                   int64_t scratch_bytes, void* hip_stream) {
     if (check_geom(g)) return 1;
     STCD_CHECK(in && dout && dw, "null pointer argument");
-    if (impl == 1) {
+    if (impl == 1 || impl == 4) {      // 4: the tile kernel with its 64 x 32-channel tile allowed (the SNUNet engine's choice)
         STCD_CHECK(dtype == STCD_DTYPE_BF16, "the MFMA implementation is bf16 only");
-        WgradMfmaPlan p = wgrad_mfma_plan(*g, g->ci, g->co);
+        WgradMfmaPlan p = wgrad_mfma_plan(*g, g->ci, g->co, impl == 4);
         STCD_CHECK(p.ok, "geometry not supported by the MFMA kernel");
         STCD_CHECK(scratch && scratch_bytes >= p.slab_floats * 4, "scratch too small for the partial slabs");
         STCD_CHECK(launch_wgrad_mfma(*g, p, in, dout, (float*)scratch, g->ci, g->co, (hipStream_t)hip_stream) == 0, "LDS budget exceeded");
@@ -2542,7 +2542,7 @@ int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, 
         STCD_HIP(hipGetLastError());
         return 0;
     }
-    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA), 1 (MFMA tile kernel) or 3 (MFMA position-GEMM kernel)");
+    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA), 1 / 4 (MFMA tile kernel, 4: wide tile allowed) or 3 (MFMA position-GEMM kernel)");
     STCD_HIP(hipMemsetAsync(dw, 0, (size_t)g->ntaps * g->ci * g->co * 4, (hipStream_t)hip_stream));
     launch_wgrad_ref(dtype, *g, in, dout, dw, g->ci, g->co, (hipStream_t)hip_stream);
     STCD_HIP(hipGetLastError());

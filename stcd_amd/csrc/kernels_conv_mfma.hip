@@ -465,6 +465,10 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
     float* a_slab = reinterpret_cast<float*>(const_cast<char*>(base) + a.slab_off);
     constexpr int WK = 4 / WCI, CIB = WCI * 16, COB = NTW * 16;
     constexpr int XCH = CIB / 8, YCH = COB / 8;
+    // WCI == 4: a 64-channel X tile as TWO 32-channel sub-images (the padded layout is conflict-free up to 32 channels per
+    // pixel); each wave then owns one 16-channel ci tile for ALL k-steps (WK == 1: no cross-wave exchange at the end)
+    constexpr int SCX = CIB > 32 ? 32 : CIB, NSX = CIB / SCX;
+    const int xsub = a.x_bytes / NSX;
     constexpr int YROW = 16 * 2 * COB + 2 * (COB == 16 ? 128 : 32);       // bytes of one 16-position dY row
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wci = wid % WCI, wk = wid / WCI;
@@ -485,7 +489,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
     //      out-of-range piece reads the tile origin and is zeroed by a select), so the loop body has no divergent
     //      branches and all loads of a tile are in flight together.
     const int nx = a.HH * HWp * XCH;
-    constexpr int MAXX = 3;
+    constexpr int MAXX = WCI == 4 ? 6 : 3;
     int xg[MAXX], xl[MAXX], xa[MAXX], xb[MAXX];       // global element offset, LDS byte offset, bound coords
 #pragma unroll
     for (int p = 0; p < MAXX; ++p) {
@@ -493,7 +497,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
         const int ch = i % XCH, pix = i / XCH, hx = pix % HWp, hy = pix / HWp;
         xa[p] = hy + a.dymin; xb[p] = hx + a.dxmin;
         xg[p] = ((hy * a.g.wi + hx) * a.g.ldi + ci0 + ch * 8) * 2;  // bytes past the tile's halo corner
-        xl[p] = hy * a.xrow_bytes + px_off<CIB>(hx) + ch * 16;
+        xl[p] = (ch / (SCX / 8)) * xsub + hy * a.xrow_bytes + px_off<SCX>(hx) + (ch % (SCX / 8)) * 16;
         if (ci0 + ch * 8 >= a.g.ci) xa[p] = 1 << 28;                 // channels beyond Ci: zero
     }
     int yg[NTW], yl[NTW], ya[NTW], yb[NTW];
@@ -558,8 +562,9 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int tdy = t < ntaps ? a.g.dy[t] - a.dymin : 0, tdx = t < ntaps ? a.g.dx[t] - a.dxmin : 0;
-        xoff0[t] = (tdy + frow) * a.xrow_bytes + px_off<CIB>(fx0 + tdx) + wci * 32 + 8 * pcol;
-        xoff1[t] = (tdy + frow) * a.xrow_bytes + px_off<CIB>(fx1 + tdx) + wci * 32 + 8 * pcol;
+        const int csub = (wci * 16 / SCX) * xsub + (wci * 16 % SCX) * 2;      // this wave's ci tile: sub-image + byte offset inside a pixel
+        xoff0[t] = (tdy + frow) * a.xrow_bytes + px_off<SCX>(fx0 + tdx) + csub + 8 * pcol;
+        xoff1[t] = (tdy + frow) * a.xrow_bytes + px_off<SCX>(fx1 + tdx) + csub + 8 * pcol;
     }
 
     int buf = 0;
@@ -656,7 +661,7 @@ k_wgrad_mfma(const WgradJob a) {
 }
 
 template <int WCI, int NTW, bool T9>
-__global__ void __launch_bounds__(256, (WCI == 2 && NTW == 2) ? 3 : 2)
+__global__ void __launch_bounds__(256, (WCI == 2 && NTW == 2) ? 3 : 2)      // <4,2>: 72 accumulators + 6 X pieces in flight: 2
 k_wgrad_group(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
     int lo = 0, hi = njobs - 1;            // last job with start <= blockIdx.x (uniform: scalar loads)
     while (lo < hi) {
@@ -749,16 +754,26 @@ void launch_reduce_jobs(const ReduceJob* jobs_dev, int njobs, int64_t total, con
     if (njobs > 0 && total > 0) k_reduce_jobs<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(jobs_dev, njobs, total, ws, grads);
 }
 
-WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld) {
+WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld, bool allow_wide) {
     WgradMfmaPlan p;
-    // block tile <= 32 ci x 32 co: 72 accumulator registers, >= 3 waves per SIMD, and enough (ci,co) groups that wide
-    // layers fill the chip without a deep K split (the fp32 slab per K slice is ntaps*Ci*Co*4 bytes)
-    p.WCI = g.ci >= 32 ? 2 : 1;
-    p.NTW = g.co >= 32 ? 2 : 1;
-    p.gy = (g.ci + p.WCI * 16 - 1) / (p.WCI * 16);
-    p.gz = (g.co + p.NTW * 16 - 1) / (p.NTW * 16);
+    int dymin, dymax, dxmin, dxmax;
+    taps_extent(g, &dymin, &dymax, &dxmin, &dxmax);
+    const int HH = 7 * g.in_stride + (dymax - dymin) + 1, HWp = 15 * g.in_stride + (dxmax - dxmin) + 1;
+    // block tile: 16 / 32 / 64 input channels x 16 / 32 output channels.  <= 32 x 32: 72 accumulator registers, >= 3 waves per
+    // SIMD, the k-steps of a tile split over the waves; 64 x 32 (wide layers): every wave owns one 16-channel ci tile for all
+    // k-steps, dY is re-read once per 64 input channels instead of 32, twice the MFMAs per staged tile.
+    static const int wide_env = [] { const char* e = getenv("STCD_WGRAD_CI64"); return e ? atoi(e) : -1; }();     // -1: the caller decides
+    const bool wide_ok = wide_env < 0 ? allow_wide : wide_env != 0;
     const int tiles_x = (g.wm + 15) / 16, tiles_y = (g.hm + 7) / 8;
     const int64_t ntiles = (int64_t)g.n * tiles_x * tiles_y;
+    p.NTW = g.co >= 32 ? 2 : 1;
+    // (allow_wide is the ENGINE's per-family choice: all qualifying layers of a stage must move together -- two grouped launches
+    //  overlap worse than one.  Measured: SNUNet (hundreds of concatenated input channels on 128^2 / 256^2 maps) 2.50 -> 2.12 ms;
+    //  SegCD +0.11 ms, SiamUnet_diff +0.07 ms: on their small deep maps halving the (ci, co) groups costs more parallelism and
+    //  slab traffic than the wider tile saves.)
+    p.WCI = (wide_ok && g.ci >= 64 && p.NTW == 2 && HH * HWp * 8 <= 6 * 256) ? 4 : g.ci >= 32 ? 2 : 1;
+    p.gy = (g.ci + p.WCI * 16 - 1) / (p.WCI * 16);
+    p.gz = (g.co + p.NTW * 16 - 1) / (p.NTW * 16);
     const int64_t slab_bytes = (int64_t)g.ntaps * kpad * wld * 4;
     static const int target_blocks = [] { const char* e = getenv("STCD_WGRAD_BLOCKS"); return e ? atoi(e) : 1536; }();
     int64_t gx = std::max<int64_t>(1, target_blocks / (p.gy * p.gz));
@@ -766,11 +781,8 @@ WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld) {
     gx = std::min<int64_t>(gx, ntiles);
     p.gx = (int)gx;
     p.slab_floats = (int64_t)p.gx * g.ntaps * kpad * wld;
-    int dymin, dymax, dxmin, dxmax;
-    taps_extent(g, &dymin, &dymax, &dxmin, &dxmax);
-    const int HH = 7 * g.in_stride + (dymax - dymin) + 1, HWp = 15 * g.in_stride + (dxmax - dxmin) + 1;
     const int xpieces = HH * HWp * (p.WCI * 2);
-    p.ok = g.ci % 8 == 0 && g.ldi % 8 == 0 && g.ldo % 8 == 0 && g.in_stride == 1 && xpieces <= 3 * 256 && g.hm <= g.hi && g.wm <= g.wi &&
+    p.ok = g.ci % 8 == 0 && g.ldi % 8 == 0 && g.ldo % 8 == 0 && g.in_stride == 1 && xpieces <= (p.WCI == 4 ? 6 : 3) * 256 && g.hm <= g.hi && g.wm <= g.wi &&
            ((int64_t)g.n * g.hi + 4) * g.wi * g.ldi * 2 < ((int64_t)1 << 31) && (int64_t)g.n * g.ho * g.wo * g.ldo * 2 < ((int64_t)1 << 31);
     return p;
 }
@@ -789,9 +801,10 @@ WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t
     a.tiles_y = (g.hm + 7) / 8;
     a.ntiles = g.n * a.tiles_x * a.tiles_y;
     const int CIB = p.WCI * 16, COB = p.NTW * 16;
-    const int xpad = CIB == 16 ? 128 : 32, ypad = COB == 16 ? 128 : 32;
-    a.xrow_bytes = (a.HWp * 2 * CIB + ((a.HWp + 7) / 8) * xpad + 15) & ~15;
-    a.x_bytes = (a.HH * a.xrow_bytes + 255) & ~255;
+    const int SCX = CIB > 32 ? 32 : CIB, NSX = CIB / SCX;          // X tile as NSX sub-images of SCX channels (wgrad_body)
+    const int xpad = SCX == 16 ? 128 : 32, ypad = COB == 16 ? 128 : 32;
+    a.xrow_bytes = (a.HWp * 2 * SCX + ((a.HWp + 7) / 8) * xpad + 15) & ~15;
+    a.x_bytes = NSX * ((a.HH * a.xrow_bytes + 255) & ~255);
     a.y_bytes = (8 * (16 * 2 * COB + 2 * ypad) + 255) & ~255;
     a.co_valid = (g.co + 7) & ~7;
     a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
@@ -805,7 +818,8 @@ WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t
 
 #define WG_DISPATCH(W_, N_, T_, WHAT)                                       \
     do {                                                                    \
-        if ((W_) == 1 && (N_) == 1) { if (T_) { WHAT(1, 1, true); } else { WHAT(1, 1, false); } }   \
+        if ((W_) == 4) { if (T_) { WHAT(4, 2, true); } else { WHAT(4, 2, false); } }                \
+        else if ((W_) == 1 && (N_) == 1) { if (T_) { WHAT(1, 1, true); } else { WHAT(1, 1, false); } }   \
         else if ((W_) == 1) { if (T_) { WHAT(1, 2, true); } else { WHAT(1, 2, false); } }           \
         else if ((N_) == 1) { if (T_) { WHAT(2, 1, true); } else { WHAT(2, 1, false); } }           \
         else { if (T_) { WHAT(2, 2, true); } else { WHAT(2, 2, false); } }                          \
@@ -827,7 +841,15 @@ int wgrad_variant_slots(int WCI, int NTW, bool t9, int lds_bytes) {
 int launch_wgrad_group(int WCI, int NTW, bool t9, const WgradJob* jobs_dev, int njobs, int total_blocks, int lds_bytes,
                        const char* base, hipStream_t s) {
     if (njobs <= 0 || total_blocks <= 0) return 0;
-    if (lds_bytes > 64 * 1024) return 1;
+    if (lds_bytes > 80 * 1024) return 1;
+    if (lds_bytes > 64 * 1024) {      // the 64-channel tile: two 34-KB buffers
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_wgrad_group<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_wgrad_group<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+    }
 #define WG_GROUP(W_, N_, T_) k_wgrad_group<W_, N_, T_><<<(unsigned)total_blocks, 256, (size_t)lds_bytes, s>>>(jobs_dev, njobs, base)
     WG_DISPATCH(WCI, NTW, t9, WG_GROUP);
 #undef WG_GROUP
@@ -838,7 +860,15 @@ int launch_wgrad_mfma(const stcd_conv_geom& g, const WgradMfmaPlan& p, const voi
                       int kpad, int wld, hipStream_t s) {
     if (!p.ok) return 1;
     const WgradJob a = wgrad_make_job(g, p, (int64_t)(intptr_t)in, (int64_t)(intptr_t)dout, (int64_t)(intptr_t)slab, kpad, wld);
-    if (a.lds_bytes > 64 * 1024) return 1;
+    if (a.lds_bytes > 80 * 1024) return 1;
+    if (a.lds_bytes > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_wgrad_mfma<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_wgrad_mfma<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+    }
     dim3 grid((unsigned)p.gx, (unsigned)p.gy, (unsigned)p.gz);
     const bool t9 = g.ntaps == 9;
 #define WG_ONE(W_, N_, T_) k_wgrad_mfma<W_, N_, T_><<<grid, 256, (size_t)a.lds_bytes, s>>>(a)

@@ -87,7 +87,7 @@ def test_conv3x3_mfma_vs_ref_vs_oracle(n, h, w, ci, co):
     np.testing.assert_allclose(outs[1].numpy(), outs[0].numpy(), rtol=2 ** -7, atol=2e-3)
 
 
-WGRAD_CASES = [(2, 16, 16, 8, 16), (2, 16, 32, 16, 16), (1, 24, 16, 16, 32), (2, 16, 16, 32, 32), (2, 8, 16, 64, 64),
+WGRAD_CASES = [(2, 40, 24, 192, 96), (1, 16, 16, 320, 32), (2, 16, 16, 8, 16), (2, 16, 32, 16, 16), (1, 24, 16, 16, 32), (2, 16, 16, 32, 32), (2, 8, 16, 64, 64),
                (1, 16, 16, 64, 128), (1, 8, 16, 128, 128), (1, 8, 16, 256, 128), (1, 16, 16, 48, 16), (1, 16, 16, 96, 32),
                (2, 16, 16, 16, 2), (1, 20, 18, 16, 16), (1, 9, 11, 64, 64), (4, 32, 32, 16, 16)]
 
@@ -107,6 +107,8 @@ def test_wgrad_mfma_vs_ref_vs_oracle(n, h, w, ci, co):
     scale = np.abs(ref).max()
     np.testing.assert_allclose(dw0 / scale, ref / scale, atol=2e-4, err_msg="ref-kernel")
     np.testing.assert_allclose(dw1 / scale, ref / scale, atol=2e-4, err_msg="mfma")
+    if ci >= 64:          # the 64 x 32-channel tile (two 32-channel LDS sub-images, no k-split across waves)
+        np.testing.assert_allclose(run_wgrad(4, g, x, dout).cpu().numpy() / scale, ref / scale, atol=2e-4, err_msg="mfma, wide tile")
 
 
 def up_phase_taps(py, px):
@@ -190,8 +192,9 @@ def test_full_size_conv_properties(n, h, w, ci, co):
     np.testing.assert_allclose(o1.float().cpu().numpy(), o0.float().cpu().numpy(), rtol=2 ** -7, atol=2e-3)
 
 
-@pytest.mark.parametrize("n,h,w,ci,co", [(32, 256, 256, 16, 16), (32, 128, 128, 32, 32), (32, 32, 32, 128, 128), (16, 256, 256, 32, 16)])
-def test_full_size_wgrad_properties(n, h, w, ci, co):
+@pytest.mark.parametrize("n,h,w,ci,co,impl", [(32, 256, 256, 16, 16, 1), (32, 128, 128, 32, 32, 1), (32, 32, 32, 128, 128, 1), (16, 256, 256, 32, 16, 1),
+                                               (32, 32, 32, 128, 128, 4), (16, 128, 128, 192, 64, 4)])
+def test_full_size_wgrad_properties(n, h, w, ci, co, impl):
     """Bench-sized weight gradients: (a) exactly linear in dY for a power-of-two factor (fp32 slabs, fixed fold order);
     (b) invariant under a permutation of the batch up to fp32 summation order; (c) the sum over a batch equals the sum of
     the two half-batches' gradients (the K split over blocks must not lose or double-count positions)."""
@@ -199,17 +202,17 @@ def test_full_size_wgrad_properties(n, h, w, ci, co):
     x = rnd(rng, n, h, w, ci).to(DEV)
     dout = rnd(rng, n, h, w, co).to(DEV)
     g = geom(n, h, w, ci, ci, h, w, 1, h, w, 1, 0, 0, co, co, TAPS3)
-    dw = run_wgrad(1, g, x, dout)
+    dw = run_wgrad(impl, g, x, dout)
     assert torch.isfinite(dw).all()
-    dw2 = run_wgrad(1, g, x, (dout.float() * 2).bfloat16())
+    dw2 = run_wgrad(impl, g, x, (dout.float() * 2).bfloat16())
     assert torch.equal(dw2, 2 * dw)
     perm = torch.from_numpy(rng.permutation(n)).to(DEV)
-    dwp = run_wgrad(1, g, x[perm].contiguous(), dout[perm].contiguous())
+    dwp = run_wgrad(impl, g, x[perm].contiguous(), dout[perm].contiguous())
     scale = dw.abs().max().item()
     assert (dwp - dw).abs().max().item() < 2e-5 * scale
     gh = geom(n // 2, h, w, ci, ci, h, w, 1, h, w, 1, 0, 0, co, co, TAPS3)
-    halves = run_wgrad(1, gh, x[:n // 2].contiguous(), dout[:n // 2].contiguous()) + \
-             run_wgrad(1, gh, x[n // 2:].contiguous(), dout[n // 2:].contiguous())
+    halves = run_wgrad(impl, gh, x[:n // 2].contiguous(), dout[:n // 2].contiguous()) + \
+             run_wgrad(impl, gh, x[n // 2:].contiguous(), dout[n // 2:].contiguous())
     assert (halves - dw).abs().max().item() < 2e-5 * scale
 
 
