@@ -256,6 +256,10 @@ int stcd_op_maxpool(int dtype, const stcd_map_geom* g, const void* a, int lda, v
 int stcd_op_maxpool_bwd(int dtype, const stcd_map_geom* g, const void* a, int lda, const void* dpool, int ldp, void* da, int ldda,
                         int accumulate, void* hip_stream);
 /* skip fusion of the two dates (groups == 2): d[n/2 images] = |a1 - a2| (mode 0) or a2 - a1 (mode 1), and its gradient */
+/* F.max_pool2d(x, 3, 2, 1) of the ResNet stem (models/resnet.py:176) and its gradient (SegCD): g describes the INPUT map (h, w even);
+ * pool / dpool are [n, h/2, w/2, c]; idx (n*(h/2)*(w/2)*c bytes) receives / provides the winning window position of every element */
+int stcd_op_maxpool3(int dtype, const stcd_map_geom* g, const void* a, int lda, void* pool, int ldp, void* idx, void* hip_stream);
+int stcd_op_maxpool3_bwd(int dtype, const stcd_map_geom* g, const void* idx, const void* dpool, int ldp, void* da, int ldda, void* hip_stream);
 int stcd_op_fuse(int dtype, int mode, const stcd_map_geom* g, const void* a, int lda, void* d, int ldd, void* hip_stream);
 int stcd_op_fuse_bwd(int dtype, int mode, const stcd_map_geom* g, const void* a, int lda, const void* dd, int ldd, void* da, int ldda,
                      void* hip_stream);

@@ -360,8 +360,9 @@ void launch_fill(float* p, int64_t n, float v, hipStream_t s);
 // ---- ResNet-50 UNet (SegCD) specific kernels (kernels_ew.hip)
 void launch_stem_fwd(int dt, const void* X, const float* w, void* Y, int N, int H, int W, int cin, int Co, hipStream_t s);
 void launch_stem_wgrad(int dt, const void* X, const void* dY, float* dW, int N, int H, int W, int cin, int Co, hipStream_t s);
-void launch_maxpool3(int dt, const void* A, int lda, void* P, int ldp, int N, int H, int W, int C, hipStream_t s);
-void launch_maxpool3_bwd(int dt, const void* A, int lda, const void* dP, int ldp, void* dA, int ldda, int N, int H, int W, int C,
+// idx: [N, H/2, W/2, C] bytes, the winning window position 0..8 of every pooled element (nullable in the forward: inference)
+void launch_maxpool3(int dt, const void* A, int lda, void* P, int ldp, int N, int H, int W, int C, hipStream_t s, unsigned char* idx = nullptr);
+void launch_maxpool3_bwd(int dt, const unsigned char* idx, const void* dP, int ldp, void* dA, int ldda, int N, int H, int W, int C,
                          hipStream_t s);
 void launch_upsample2(int dt, const void* X, int ldx, void* D, int ldd, int N, int h, int w, int C, hipStream_t s);
 void launch_upsample2_bwd(int dt, const void* dD, int ldd, void* dX, int ldx, int N, int h, int w, int C, hipStream_t s);

@@ -188,6 +188,7 @@ struct stcd_engine_impl {
     std::vector<std::array<int, 4>> g_blocks;                // (L1, L2, L3, Ld or -1) per bottleneck
     std::vector<std::array<int, 2>> g_dec;                   // (conv1, conv2) per decoder block
     TRef gP0, gdP0, gX3, gdX3, gFuseTmp;
+    int64_t g_pool_idx = -1;                                  // winners of the stem's 3x3 max-pool (bytes)
     int64_t g_raw3 = -1, g_draw3 = -1;
     ConvOp g_head_fwd, g_head_dgr; WgradOp g_head_wg;
     int arch = 0, in_ch = 3, label = 2, dt = F32;
@@ -1784,6 +1785,7 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
     S.has_dIn = false;
     { GStep st; st.kind = GS_LAYER; st.layer = e.g_stem; e.g_fwd.push_back(st); }
     e.gP0 = plain(N, H / 4, W / 4, 64); e.gdP0 = plain(N, H / 4, W / 4, 64);
+    e.g_pool_idx = ws.take((int64_t)N * (H / 4) * (W / 4) * 64);
     { GStep st; st.kind = GS_MAXPOOL; st.src = S.A; st.dst = e.gP0; st.dsrc = S.dA; st.ddst = e.gdP0; st.N = N; st.h = H / 2; st.w = W / 2; st.C = 64; e.g_fwd.push_back(st); }
     TRef cur = e.gP0; int curC = 64, h = H / 4, w = W / 4, prev_out = -1;      // prev_out: layer whose A is `cur` (-1: the max-pool)
     std::vector<int> stage_out;                                               // L3 of the last block of layer1..4
@@ -2151,7 +2153,8 @@ static int forward_segcd(stcd_engine& e, const float* x1, const float* x2, const
     launch_in_pack(dt, x1, x2, c.at(e.X0.off), B, e.in_ch, e.H, e.W, s);
     for (const GStep& st : e.g_fwd) {
         if (st.kind == GS_LAYER) glayer_forward(c, e.g_layers[st.layer], bn_running, training != 0);
-        else if (st.kind == GS_MAXPOOL) launch_maxpool3(dt, c.at(st.src.off), st.src.ld, c.at(st.dst.off), st.dst.ld, st.N, st.h, st.w, st.C, s);
+        else if (st.kind == GS_MAXPOOL) launch_maxpool3(dt, c.at(st.src.off), st.src.ld, c.at(st.dst.off), st.dst.ld, st.N, st.h, st.w, st.C, s,
+                                                        training ? c.at<unsigned char>(e.g_pool_idx) : nullptr);
         else launch_upsample2(dt, c.at(st.src.off), st.src.ld, c.at(st.dst.off), st.dst.ld, st.N, st.h, st.w, st.C, s);
     }
     // head: X3[2B:3B] = |d1 - d2| ; raw = conv(X3) = [m1; m2; diffea] ; logits = [m1; m2; min(diffea, |m1 - m2|)]
@@ -2185,7 +2188,7 @@ static int backward_segcd(stcd_engine& e, const float* grad_logits, const float*
         else {      // max-pool: d(P0) = conv1 contribution (written in place) + down-sample branch contribution of layer1.0
             const GLayer& Ld = e.g_layers[e.g_blocks[0][3]];
             launch_slice(dt, c.at(st.ddst.off), st.ddst.ld, c.at(Ld.dIn.off), Ld.dIn.ld, (int64_t)st.N * (st.h / 2) * (st.w / 2), st.C, 1, s);
-            launch_maxpool3_bwd(dt, c.at(st.src.off), st.src.ld, c.at(st.ddst.off), st.ddst.ld, c.at(st.dsrc.off), st.dsrc.ld, st.N, st.h, st.w, st.C, s);
+            launch_maxpool3_bwd(dt, c.at<unsigned char>(e.g_pool_idx), c.at(st.ddst.off), st.ddst.ld, c.at(st.dsrc.off), st.dsrc.ld, st.N, st.h, st.w, st.C, s);
         }
     }
     reduce_stage(c, 0);

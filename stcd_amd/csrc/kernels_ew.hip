@@ -1486,9 +1486,13 @@ void launch_stem_wgrad(int dt, const void* X, const void* dY, float* dW, int N, 
     else k_stem_wgrad<float><<<grid, 256, 0, s>>>((const float*)X, (const float*)dY, dW, N, H, W, cin, Ho, Wo, Co);
 }
 
-// ---- 3x3 stride-2 padding-1 max-pool (H, W even) and its gradient (first maximum in scan order, as torch)
+// ---- 3x3 stride-2 padding-1 max-pool (H, W even) and its gradient (first maximum in scan order, as torch).
+// The forward also records WHICH of the 9 window positions won (one byte per pooled element, idx [N,Ho,Wo,C]): the
+// backward then reads (index, dP) of the <= 4 windows an input pixel belongs to instead of re-scanning their 9 inputs each
+// (the scan version read ~20 pieces per pixel: 369 us on the 32 x 128 x 128 x 64 stem map; this one ~6).
 template <typename T>
-__global__ void k_maxpool3(const T* __restrict__ A, int lda, T* __restrict__ P, int ldp, int H, int W, int C, int64_t total) {
+__global__ void k_maxpool3(const T* __restrict__ A, int lda, T* __restrict__ P, int ldp, unsigned char* __restrict__ idx, int H, int W, int C,
+                           int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int cb = C >> 3, Ho = H / 2, Wo = W / 2;
@@ -1498,8 +1502,9 @@ __global__ void k_maxpool3(const T* __restrict__ A, int lda, T* __restrict__ P, 
     const int oy = (int)(r % Ho);
     const int n = (int)(r / Ho);
     float best[8];
+    unsigned char arg[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) best[j] = -INFINITY;
+    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; arg[j] = 255; }
     for (int ky = 0; ky < 3; ++ky) {
         const int y = 2 * oy - 1 + ky;
         if (y < 0 || y >= H) continue;
@@ -1509,19 +1514,26 @@ __global__ void k_maxpool3(const T* __restrict__ A, int lda, T* __restrict__ P, 
             float v[8];
             load8<T>(A + (((int64_t)n * H + y) * W + x) * lda + c0, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], v[j]);
+            for (int j = 0; j < 8; ++j)
+                if (v[j] > best[j] || arg[j] == 255) { best[j] = v[j]; arg[j] = (unsigned char)(ky * 3 + kx); }     // strict >: the FIRST maximum
         }
     }
     store8<T>(P + (((int64_t)n * Ho + oy) * Wo + ox) * ldp + c0, best);
+    if (idx) {
+        uint2 pk;
+        pk.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24);
+        pk.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24);
+        *reinterpret_cast<uint2*>(idx + (((int64_t)n * Ho + oy) * Wo + ox) * C + c0) = pk;
+    }
 }
-void launch_maxpool3(int dt, const void* A, int lda, void* P, int ldp, int N, int H, int W, int C, hipStream_t s) {
+void launch_maxpool3(int dt, const void* A, int lda, void* P, int ldp, int N, int H, int W, int C, hipStream_t s, unsigned char* idx) {
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
-    if (dt == BF16) k_maxpool3<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)A, lda, (bf16*)P, ldp, H, W, C, total);
-    else k_maxpool3<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)A, lda, (float*)P, ldp, H, W, C, total);
+    if (dt == BF16) k_maxpool3<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)A, lda, (bf16*)P, ldp, idx, H, W, C, total);
+    else k_maxpool3<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)A, lda, (float*)P, ldp, idx, H, W, C, total);
 }
-// dA(y,x) = sum over the (up to 4) windows that contain (y,x) of dP(window) * [(y,x) is the window's FIRST maximum]
+// dA(y,x) = sum over the (up to 4) windows that contain (y,x) of dP(window) * [window's recorded winner is (y,x)]
 template <typename T>
-__global__ void k_maxpool3_bwd(const T* __restrict__ A, int lda, const T* __restrict__ dP, int ldp, T* __restrict__ dA, int ldda, int H,
+__global__ void k_maxpool3_bwd(const unsigned char* __restrict__ idx, const T* __restrict__ dP, int ldp, T* __restrict__ dA, int ldda, int H,
                                int W, int C, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -1531,45 +1543,39 @@ __global__ void k_maxpool3_bwd(const T* __restrict__ A, int lda, const T* __rest
     const int x = (int)(r % W); r /= W;
     const int y = (int)(r % H);
     const int n = (int)(r / H);
-    float me[8], out[8];
-    load8<T>(A + (((int64_t)n * H + y) * W + x) * lda + c0, me);
+    float out[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[j] = 0.f;
-    // windows oy with 2*oy-1 <= y <= 2*oy+1
-    for (int oy = (y + 1) / 2 - ((y & 1) ? 0 : 0); oy >= 0 && 2 * oy + 1 >= y; --oy) {
-        if (oy >= Ho || 2 * oy - 1 > y) continue;
-        for (int ox = (x + 1) / 2; ox >= 0 && 2 * ox + 1 >= x; --ox) {
-            if (ox >= Wo || 2 * ox - 1 > x) continue;
-            // is (y,x) the first maximum of window (oy,ox) ?
-            bool first[8];
+    // rows: an even y lies in window oy = y/2 only (as its middle row), an odd y in windows (y-1)/2 (bottom row) and (y+1)/2 (top row)
+    const int oy0 = y >> 1, noy = (y & 1) ? 2 : 1, ox0 = x >> 1, nox = (x & 1) ? 2 : 1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) first[j] = true;
-            for (int ky = 0; ky < 3; ++ky) {
-                const int yy = 2 * oy - 1 + ky;
-                if (yy < 0 || yy >= H) continue;
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int xx = 2 * ox - 1 + kx;
-                    if (xx < 0 || xx >= W || (yy == y && xx == x)) continue;
-                    float v[8];
-                    load8<T>(A + (((int64_t)n * H + yy) * W + xx) * lda + c0, v);
-                    const bool before = yy < y || (yy == y && xx < x);
+    for (int a = 0; a < 2; ++a) {
+        const int oy = oy0 + a;
+        if (a >= noy || oy >= Ho) continue;
+        const int ky = y - (2 * oy - 1);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) first[j] = first[j] && (before ? v[j] < me[j] : v[j] <= me[j]);
-                }
-            }
+        for (int b = 0; b < 2; ++b) {
+            const int ox = ox0 + b;
+            if (b >= nox || ox >= Wo) continue;
+            const int k = ky * 3 + (x - (2 * ox - 1));
+            const int64_t pp = ((int64_t)n * Ho + oy) * Wo + ox;
+            const uint2 pk = *reinterpret_cast<const uint2*>(idx + pp * C + c0);
             float g[8];
-            load8<T>(dP + (((int64_t)n * Ho + oy) * Wo + ox) * ldp + c0, g);
+            load8<T>(dP + pp * ldp + c0, g);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) out[j] += first[j] ? g[j] : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const unsigned w = j < 4 ? pk.x : pk.y;
+                out[j] += (int)((w >> (8 * (j & 3))) & 255u) == k ? g[j] : 0.f;
+            }
         }
     }
     store8<T>(dA + (((int64_t)n * H + y) * W + x) * ldda + c0, out);
 }
-void launch_maxpool3_bwd(int dt, const void* A, int lda, const void* dP, int ldp, void* dA, int ldda, int N, int H, int W, int C,
+void launch_maxpool3_bwd(int dt, const unsigned char* idx, const void* dP, int ldp, void* dA, int ldda, int N, int H, int W, int C,
                          hipStream_t s) {
     const int64_t total = (int64_t)N * H * W * (C / 8);
-    if (dt == BF16) k_maxpool3_bwd<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)A, lda, (const bf16*)dP, ldp, (bf16*)dA, ldda, H, W, C, total);
-    else k_maxpool3_bwd<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)A, lda, (const float*)dP, ldp, (float*)dA, ldda, H, W, C, total);
+    if (dt == BF16) k_maxpool3_bwd<bf16><<<cdiv(total, 256), 256, 0, s>>>(idx, (const bf16*)dP, ldp, (bf16*)dA, ldda, H, W, C, total);
+    else k_maxpool3_bwd<float><<<cdiv(total, 256), 256, 0, s>>>(idx, (const float*)dP, ldp, (float*)dA, ldda, H, W, C, total);
 }
 
 // ---- nearest x2 up-sampling into a channel slice of the decoder's concat buffer, and its gradient (sum of the 2x2 block)

@@ -127,6 +127,23 @@ int stcd_op_maxpool_bwd(int dtype, const stcd_map_geom* g, const void* a, int ld
     return 0;
 }
 
+/* 3x3 stride-2 padding-1 max-pool of the ResNet stem (F.max_pool2d(x, 3, 2, 1), models/resnet.py:176) and its gradient through the
+ * recorded winners.  g: the INPUT map (h, w even); pool / dpool: [n, h/2, w/2, c]; idx: n*(h/2)*(w/2)*c bytes. */
+int stcd_op_maxpool3(int dtype, const stcd_map_geom* g, const void* a, int lda, void* pool, int ldp, void* idx, void* hip_stream) {
+    if (check_map(g)) return 1;
+    STCD_CHECK(a && pool && g->h % 2 == 0 && g->w % 2 == 0, "null pointer argument or odd size");
+    launch_maxpool3(dtype, a, lda, pool, ldp, g->n, g->h, g->w, g->c, (hipStream_t)hip_stream, (unsigned char*)idx);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+int stcd_op_maxpool3_bwd(int dtype, const stcd_map_geom* g, const void* idx, const void* dpool, int ldp, void* da, int ldda, void* hip_stream) {
+    if (check_map(g)) return 1;
+    STCD_CHECK(idx && dpool && da && g->h % 2 == 0 && g->w % 2 == 0, "null pointer argument or odd size");
+    launch_maxpool3_bwd(dtype, (const unsigned char*)idx, dpool, ldp, da, ldda, g->n, g->h, g->w, g->c, (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
 int stcd_op_fuse(int dtype, int mode, const stcd_map_geom* g, const void* a, int lda, void* d, int ldd, void* hip_stream) {
     if (check_map(g)) return 1;
     STCD_CHECK(g->groups == 2 && (mode == 0 || mode == 1) && a && d, "bad argument (groups must be 2, mode 0 or 1)");

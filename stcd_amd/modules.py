@@ -45,15 +45,34 @@ class _EngineFn(torch.autograd.Function):
         logits = model._run_forward(x1, x2, True)
         ctx.model = model
         ctx.ticket = model._engine.ticket
-        return logits
+        n = model.OUT_MAPS
+        if n == 1:
+            return logits
+        # several maps per pair (SegCD): one autograd output each, so an unused map costs nothing in the backward (slicing ONE
+        # output tensor outside made autograd zero-fill and copy through ~45 small kernels per step)
+        ctx.set_materialize_grads(False)
+        ctx.out_shape = logits.shape
+        b = logits.shape[0] // n
+        return tuple(logits[k * b:(k + 1) * b] for k in range(n))
 
     @staticmethod
-    def backward(ctx, grad_logits):
+    def backward(ctx, *grads):
         model = ctx.model
         if ctx.ticket != model._engine.ticket:
             raise StcdError("backward() for a forward pass whose saved activations were overwritten by a later "
                             "forward of the same module (the engine keeps one step of activations)")
-        model._run_backward(grad_logits.contiguous())
+        if len(grads) == 1:
+            g = grads[0].contiguous()
+        else:
+            live = [gk for gk in grads if gk is not None]
+            g = torch.empty(ctx.out_shape, dtype=torch.float32, device=live[0].device)
+            b = ctx.out_shape[0] // len(grads)
+            for k, gk in enumerate(grads):
+                if gk is None:
+                    g[k * b:(k + 1) * b].zero_()
+                else:
+                    g[k * b:(k + 1) * b].copy_(gk)
+        model._run_backward(g)
         return None, None, None, None
 
 

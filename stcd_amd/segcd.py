@@ -169,4 +169,6 @@ class SegCD(HipChangeDetector):
         return super().forward(A, B)
 
     def _wrap_output(self, out, B):
+        if isinstance(out, tuple):          # training: the autograd node already returns the three maps
+            return out
         return out[:B], out[B:2 * B], out[2 * B:]

@@ -368,3 +368,31 @@ def test_encoder_skip_layer_forward_and_backward_vs_oracle(dtype, mode, b, c, h,
     scale = max(1.0, float(np.abs(dg_ref).max()))
     np.testing.assert_allclose(dg.cpu().numpy()[:c] / scale, dg_ref / scale, **SUM_TOL[dtype])
     np.testing.assert_allclose(db.cpu().numpy()[:c] / scale, db_ref / scale, **SUM_TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 32, 32), (3, 8, 6, 10), (1, 128, 16, 8)])
+def test_stem_maxpool3_and_gradient_vs_torch(dtype, n, c, h, w):
+    """F.max_pool2d(x, 3, 2, 1) (ResNet stem, models/resnet.py:176) and its gradient through the recorded winners, on ReLU-ed
+    inputs (most windows hold several equal zeros: torch routes the gradient to the FIRST maximum in scan order) -- against
+    torch's own max_pool2d / autograd on the same stored values."""
+    rng = np.random.default_rng(n + c + h)
+    x = np.maximum(rng.standard_normal((n, c, h, w)).astype(np.float32), 0.0)
+    x[:, :, ::3, ::2] = np.maximum(x[:, :, ::3, ::2], 0.5)                 # and some equal positive values
+    xq = rq(x, dtype)
+    X = nhwc(xq, dtype)
+    g = mg(n, h, w, cpad(c))
+    ld = cpad(c)
+    Pl = torch.zeros(n, h // 2, w // 2, ld, dtype=DT[dtype][1], device=DEV)
+    idx = torch.zeros(n * (h // 2) * (w // 2) * ld, dtype=torch.uint8, device=DEV)
+    l = _lib.lib()
+    _lib.check(l.stcd_op_maxpool3(DT[dtype][0], C.byref(g), P(X), ld, P(Pl), ld, P(idx), stream()))
+    xt = torch.from_numpy(xq).to(DEV).requires_grad_(True)
+    pt = torch.nn.functional.max_pool2d(xt, 3, 2, 1)
+    np.testing.assert_array_equal(nchw(Pl, c), pt.detach().cpu().numpy())
+    gp = rq(rng.standard_normal(pt.shape).astype(np.float32), dtype)
+    pt.backward(torch.from_numpy(gp).to(DEV))
+    dA = torch.full((n, h, w, ld), 7.0, dtype=DT[dtype][1], device=DEV)
+    _lib.check(l.stcd_op_maxpool3_bwd(DT[dtype][0], C.byref(g), P(idx), P(nhwc(gp, dtype)), ld, P(dA), ld, stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(nchw(dA, c), rq(xt.grad.cpu().numpy(), dtype), **SUM_TOL[dtype])   # up to 4 windows summed per pixel
