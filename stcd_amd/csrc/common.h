@@ -232,6 +232,7 @@ struct ReduceJob {
     int gx, ntaps, K, N, kpad, wld;
     int ks, kn_major;          // reference index map of the launch's taps (as PackSpec)
     int8_t ky[9], kx[9];
+    int8_t tiled, pad_[5];     // 1: block = (32 co x TK ci x taps tile, part), LDS-transposed stores; 0: thread = (output, part)
 };
 void launch_reduce_jobs(const ReduceJob* jobs_dev, int njobs, int64_t total, const char* ws, float* grads, hipStream_t s);
 // out = sum of the gx slabs; ps == nullptr: engine layout [tap][kpad][wld], else scattered into the reference layout

