@@ -274,3 +274,48 @@ def test_segcd_bf16_training_tracks_fp32():
     tail32, tail16 = curves["fp32"][-10:].mean(), curves["bf16"][-10:].mean()
     print(f"SegCD 30 steps: fp32 {curves['fp32'][0]:.3f} -> {tail32:.3f}, bf16 {curves['bf16'][0]:.3f} -> {tail16:.3f}")
     assert 0.5 * tail32 <= tail16 <= 2.0 * tail32
+
+
+def test_semi_supervised_step_of_train_stcd_vs_oracle():
+    """The step of the semi-supervised script (/root/reference/train_stcd.py:421-447): labelled and pseudo-change pairs
+    concatenated into ONE forward of SegCD, loss = BCE+Dice(sigmoid(mask_t1)[:B], seg label) + BCE+Dice(sigmoid(change), labels)
+    + contrastive_loss(sigmoid(change), cd_label, pseudo_label) -- every piece through the engine's C ABI (fp32 mode), against
+    the fp64 oracle (network, losses, and autograd through them)."""
+    from oracle import fcsiam_ref as R
+    from stcd_amd.losses import cd_loss, contrastive_loss
+    B, H, W = 2, 64, 64
+    rng = np.random.default_rng(91)
+    f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    image_A, image_B, CA, CB = f(B, 3, H, W), f(B, 3, H, W), f(B, 3, H, W), f(B, 3, H, W)
+    lab = lambda p: torch.from_numpy((rng.random((B, 1, H, W)) < p).astype(np.float32))
+    s_label_A, cd_label, CL = lab(0.3), lab(0.2), lab(0.25)
+    st = G.synth_state(3, 1, 17)
+    m = SegCD(dtype="fp32")
+    m.load_state_dict(st)
+    m.to(DEV).train()
+    dA, dB, dl = torch.cat((image_A, CA)).to(DEV), torch.cat((image_B, CB)).to(DEV), torch.cat((cd_label, CL)).to(DEV)
+    seg_A, seg_B, diff = m(dA, dB)
+    cp = torch.sigmoid(diff)
+    parts = (cd_loss(torch.sigmoid(seg_A)[:B], s_label_A.to(DEV)), cd_loss(cp, dl), contrastive_loss(cp, cd_label.to(DEV), CL.to(DEV)))
+    (parts[0] + parts[1] + parts[2]).backward()
+
+    st64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in st.items()}
+    params = [k for k, v in st64.items() if v.dtype.is_floating_point and "running" not in k]
+    for k in params:
+        st64[k].requires_grad_(True)
+    r1, r2, rd = G.forward(st64, torch.cat((image_A, CA)).double(), torch.cat((image_B, CB)).double(), training=True)
+    rcp = torch.sigmoid(rd)
+    rparts = (R.cd_loss(torch.sigmoid(r1)[:B], s_label_A.double()), R.cd_loss(rcp, torch.cat((cd_label, CL)).double()),
+              R.contrastive_loss(rcp, cd_label.double(), CL.double()))
+    (rparts[0] + rparts[1] + rparts[2]).backward()
+    for got, want, name in zip(parts, rparts, ("seg", "cd", "contrastive")):
+        assert abs(got.item() - want.item()) <= 2e-3 * max(1.0, abs(want.item())), (name, got.item(), want.item())
+    worst = (0.0, 1.0)
+    for name, p in m.named_parameters():
+        ref = st64[name].grad
+        if ref is None or float(ref.abs().max()) < 1e-12:
+            continue
+        r, c = rel_l2_cos(p.grad.cpu().double().numpy(), ref.numpy())
+        worst = (max(worst[0], r), min(worst[1], c))
+    print(f"train_stcd step, fp32 engine vs fp64 oracle: losses {[round(p.item(), 5) for p in parts]}, worst gradient rel-l2 {worst[0]:.2e} / cos {worst[1]:.6f}")
+    assert worst[0] <= SEG_REL and worst[1] >= SEG_COS, worst
