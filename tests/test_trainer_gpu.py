@@ -227,3 +227,19 @@ def test_f1_parity_at_survey_size_vs_reference_run(golden, dtype):
     np.testing.assert_allclose(em, rm, atol=0.02 if dtype == "fp32" else 0.03)
     assert ref[tail].mean() - F1_TOL_BELOW <= f1[tail].mean() <= ref[tail].mean() + F1_TOL_ABS, (f1[tail], ref[tail])
     assert ref[tail].min() - F1_TOL_BELOW <= f1[-1] <= ref[tail].max() + F1_TOL_ABS, (f1[tail], ref[tail])
+
+
+def test_semi_supervised_example_runs_and_learns(monkeypatch):
+    """examples/train_stcd_synth.py: the loop of train_stcd.py (SegCD, seg + cd + contrastive losses, device-side pair synthesis and
+    augmentation) for three short epochs: finite, and the change loss falls."""
+    import importlib.util
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_stcd_synth", os.path.join(repo, "examples", "train_stcd_synth.py"))
+    mod = importlib.util.module_from_spec(spec)
+    monkeypatch.setattr(sys, "argv", ["train_stcd_synth.py", "--n_epochs", "3", "--batch_size", "2", "--img_height", "64", "--img_width", "64",
+                                      "--train_tiles", "8"])
+    spec.loader.exec_module(mod)
+    hist = mod.main()
+    assert len(hist) == 3 and all(np.isfinite([h["seg_loss"], h["cd_loss"], h["ct_loss"]]).all() for h in hist)
+    assert hist[-1]["cd_loss"] < hist[0]["cd_loss"]
