@@ -114,6 +114,11 @@ int stcd_forward(stcd_engine* e, const float* x1, const float* x2, const float* 
  */
 int stcd_backward(stcd_engine* e, const float* grad_logits, const float* params, float* grads,
                   void* workspace, int stage, void* hip_stream);
+/* Inference loops: every stcd_forward repacks the filters from `params` into the workspace (the optimizer rewrites them each
+ * training step).  A caller that KNOWS the parameters are unchanged declares it with a non-zero tag: while the tag, the workspace
+ * and the parameter pointer stay the same the repack is skipped (0.3 ms of a 3.5 ms SegCD eval forward).  tag 0 (default): always
+ * repack.  Changing the parameters without changing the tag is the caller's error. */
+int stcd_set_weights_tag(stcd_engine* e, uint64_t tag);
 /* [begin,end) element range of the flat gradient buffer that stage 0 finalises (the rest belongs to stage 1). */
 int stcd_grad_stage_range(const stcd_engine* e, int stage, int64_t* begin, int64_t* end);
 

@@ -73,6 +73,7 @@ _PROTOS = {
     "stcd_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _i, _vp, _vp, _vp]),
     "stcd_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "stcd_grad_stage_range": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "stcd_set_weights_tag": (_i, [_vp, C.c_uint64]),
     "stcd_set_debug": (_i, [_vp, _i]),
     "stcd_ws_tensor_count": (_i, [_vp]),
     "stcd_ws_tensor_get": (_i, [_vp, _i, C.POINTER(WsTensor)]),

@@ -218,6 +218,8 @@ struct stcd_engine_impl {
     std::vector<PackJob> jobs[2];
     int64_t jobs_total[2] = {0, 0}, jobs_off[2] = {-1, -1};
     const void* jobs_uploaded_ws = nullptr;
+    uint64_t weights_tag = 0, packed_tag = 0;      // stcd_set_weights_tag: skip the repack while the caller vouches for the weights
+    const void* packed_ws = nullptr; const void* packed_params = nullptr; int packed_level = -1;
     TRef X0, G, finalIn, dFinalIn;
     int Hs[5] = {0}, Ws[5] = {0};
     TRef D[4], dD[4], P[4], dP[4];
@@ -1016,8 +1018,14 @@ static int pack_all_weights(const Ctx& c, bool with_dgrad) {
         e.jobs_uploaded_ws = c.ws;
     }
     const int k = with_dgrad ? 1 : 0;
+    // the caller declared the weights constant under this tag (stcd_set_weights_tag): the images packed into THIS workspace from
+    // THIS parameter buffer under the same tag are still valid (the forward-only image set is a subset of the training one)
+    // Training forwards always repack and never vouch for the next call (an optimizer step follows them).
+    if (k == 0 && e.weights_tag != 0 && e.weights_tag == e.packed_tag && e.packed_ws == (const void*)c.ws && e.packed_params == (const void*)c.params)
+        return 0;
     ProfScope prof(c, PC_PACK, 0.0, 0.0);
     launch_pack_jobs(c.at<PackJob>(e.jobs_off[k]), (int)e.jobs[k].size(), e.jobs_total[k], c.params, c.ws, c.s);
+    e.packed_tag = k == 0 ? e.weights_tag : 0; e.packed_ws = c.ws; e.packed_params = c.params; e.packed_level = k;
     return 0;
 }
 
@@ -2273,6 +2281,7 @@ int stcd_configure(stcd_engine* e, int batch, int height, int width) {
     STCD_CHECK(height >= 16 && width >= 16, "height and width must be >= 16 (four 2x2 pools)");
     STCD_CHECK((int64_t)2 * batch * height * width * 16 < ((int64_t)1 << 31), "tensor too large for 32-bit pixel indexing");
     e->configured = false;
+    e->packed_tag = 0; e->packed_ws = nullptr; e->packed_level = -1;
     e->B = batch; e->H = height; e->W = width;
     if (e->arch == STCD_ARCH_SNUNET) {
         STCD_CHECK(height % 16 == 0 && width % 16 == 0, "SNUNet needs height and width divisible by 16 (the reference's cat of up-sampled maps fails otherwise)");
@@ -2332,6 +2341,11 @@ int stcd_backward(stcd_engine* e, const float* grad_logits, const float* params,
     return backward_fcsiam(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
 }
 
+int stcd_set_weights_tag(stcd_engine* e, uint64_t tag) {
+    STCD_CHECK(e != nullptr, "engine is null");
+    e->weights_tag = tag;
+    return 0;
+}
 int stcd_set_debug(stcd_engine* e, int flags) {
     STCD_CHECK(e != nullptr, "engine is null");
     e->debug_flags = flags;

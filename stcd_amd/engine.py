@@ -129,6 +129,10 @@ class Engine:
         _lib.check(self._l.stcd_backward(self._h, _ptr(grad_logits), _ptr(flat_params), _ptr(flat_grads),
                                          _ptr(self.workspace), stage, _stream()))
 
+    def set_weights_tag(self, tag: int):
+        """Non-zero: the caller vouches that the parameters do not change under this tag (the filter repack is skipped)."""
+        _lib.check(self._l.stcd_set_weights_tag(self._h, C.c_uint64(tag & (2 ** 64 - 1))))
+
     # ------------------------------------------------------------------ test introspection
     def set_debug(self, flags: int):
         """bit 0: every layer keeps its input gradient in a buffer of its own (see include/stcd_hip.h)."""

@@ -90,6 +90,13 @@ class _NoEvalGradFn(torch.autograd.Function):
                         "(call .train(), or wrap inference in torch.no_grad()); see INTEGRATION.md, limits")
 
 
+def frozen_weights(model):
+    """``model.frozen_weights()`` for an engine module (also behind ``nn.DataParallel``), a no-op context for anything else."""
+    import contextlib
+    m = getattr(model, "module", model)
+    return m.frozen_weights() if isinstance(m, HipChangeDetector) else contextlib.nullcontext(model)
+
+
 class HipChangeDetector(nn.Module):
     """Common machinery: flat parameter / gradient / BN buffers shared with the engine."""
 
@@ -177,6 +184,29 @@ class HipChangeDetector(nn.Module):
         if self._flat_params is not None:
             new.to(self._flat_params.device)
         return new
+
+    # ------------------------------------------------------------------ inference loops
+    def frozen_weights(self):
+        """Context manager for inference loops: inside it the caller vouches that the parameters do not change, so the engine
+        packs its filter images once instead of on every forward (they are re-packed on every call otherwise, because an optimizer
+        may have rewritten them -- through ``.data`` or a fused kernel, which nothing here could notice)::
+
+            model.eval()
+            with torch.no_grad(), model.frozen_weights():
+                for a, b in loader:
+                    out = model(a, b)
+        """
+        import contextlib
+
+        @contextlib.contextmanager
+        def _ctx():
+            self._freeze_count = getattr(self, "_freeze_count", 0) + 1
+            self._engine.set_weights_tag(self._freeze_count)
+            try:
+                yield self
+            finally:
+                self._engine.set_weights_tag(0)
+        return _ctx()
 
     # ------------------------------------------------------------------ knobs
     def _engine_dropout_p(self, p: float):

@@ -12,6 +12,7 @@ from copy import deepcopy
 import torch
 
 from .losses import bce_dice_with_logits
+from .modules import frozen_weights
 from .metrics import SegmentationMetric
 
 
@@ -79,7 +80,7 @@ def train_cd_epoch(model, trainloader, valloader, optimizer, args, device="cuda:
         rec = {"epoch": epoch, "cd_loss": (total / max(n_it, 1)).item(),
                "train_f1": float(train_acc.F1score()[1]), "train_iou": float(train_acc.IntersectionOverUnion()[1])}
         model.eval()
-        with torch.no_grad():
+        with torch.no_grad(), frozen_weights(model):      # the validation loop does not touch the weights: pack the filters once
             cd_acc = SegmentationMetric(numClass=2, device=device)
             vtot, vn = torch.zeros((), device=device), 0
             for batch in valloader:

@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 import torch.optim as optim
 
+from .modules import frozen_weights
 from .optim import FlatAdam, FlatAdamW
 
 from . import losses
@@ -336,10 +337,11 @@ class CDTrainer:
             self._clear_cache()
             self.is_training = False
             self.net_G.eval()
-            for self.batch_id, batch in enumerate(self.dataloaders["val"], 0):
-                with torch.no_grad():
-                    self._forward_pass(batch)
-                self._collect_running_batch_states()
+            with frozen_weights(self.net_G):       # nothing updates the weights during validation: the filters are packed once
+                for self.batch_id, batch in enumerate(self.dataloaders["val"], 0):
+                    with torch.no_grad():
+                        self._forward_pass(batch)
+                    self._collect_running_batch_states()
             self._collect_epoch_states()
             self._update_val_acc_curve()
             self._update_checkpoints()

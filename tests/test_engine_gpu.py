@@ -513,3 +513,36 @@ def test_train_step_128_tracks_reference_vectors(golden, arch, dtype):
     cos_min, rel_max = BF16_GRAD[arch]
     assert worst[1] >= cos_min and worst[0] <= rel_max, (worst_name[0], worst[0], worst[1])
     assert worst[3] >= cos_min and worst[2] <= rel_max, (worst_name[1], worst[2], worst[3])
+
+
+def test_frozen_weights_context_packs_once_and_is_exact():
+    """Inference loops may vouch for constant weights (model.frozen_weights()): identical outputs to the plain path; a weight change
+    INSIDE the context is by contract not seen until it ends; training-mode forwards always repack."""
+    rng = np.random.default_rng(5)
+    x1 = torch.from_numpy(rng.standard_normal((2, 3, 32, 32)).astype(np.float32)).to(DEV)
+    x2 = torch.from_numpy(rng.standard_normal((2, 3, 32, 32)).astype(np.float32)).to(DEV)
+    m = SiamUnet_diff(3, 2, dtype="bf16")
+    m.load_state_dict(R.synth_state("diff", 3, 2, 3, perturb_running=True))
+    m.to(DEV).eval()
+    with torch.no_grad():
+        plain = m(x1, x2).clone()
+        with m.frozen_weights():
+            a = m(x1, x2).clone()
+            b = m(x2, x1).clone()
+            assert torch.equal(a, plain)
+            m.conv11.weight.mul_(2.0)                       # not noticed while frozen (documented)
+            assert torch.equal(m(x1, x2), plain)
+        changed = m(x1, x2).clone()                         # context over: repacked
+        assert not torch.equal(changed, plain)
+        with m.frozen_weights():                            # a new context packs the current weights
+            assert torch.equal(m(x1, x2), changed)
+            assert torch.equal(m(x2, x1), m(x2, x1))
+    m.train()
+    with m.frozen_weights():                                # training forwards ignore the vouching
+        m.set_dropout_masks(R.synth_masks("diff", 2, 9))
+        l1 = m(x1, x2).sum()
+        with torch.no_grad():
+            m.conv11.weight.mul_(0.5)
+        m.set_dropout_masks(R.synth_masks("diff", 2, 9))
+        l2 = m(x1, x2).sum()
+        assert l1.item() != l2.item()
