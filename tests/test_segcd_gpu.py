@@ -319,3 +319,39 @@ def test_semi_supervised_step_of_train_stcd_vs_oracle():
         worst = (max(worst[0], r), min(worst[1], c))
     print(f"train_stcd step, fp32 engine vs fp64 oracle: losses {[round(p.item(), 5) for p in parts]}, worst gradient rel-l2 {worst[0]:.2e} / cos {worst[1]:.6f}")
     assert worst[0] <= SEG_REL and worst[1] >= SEG_COS, worst
+
+
+def test_segcd_full_size_properties_bf16():
+    """SegCD at the bench's size (16 pairs of 256x256, bf16), where the CPU oracle would take minutes, through size-independent
+    properties: (a) eval mode treats pairs independently -- the 16-pair batch equals its two 8-pair halves bit for bit for all
+    three maps (every GEMM / conv tile walk, the stem, the decoder's concat slices); (b) the backward is linear in the output
+    gradients: doubling them doubles every parameter gradient (up to the order of the atomically folded slab sums); (c) the
+    `change` map obeys its definition min(., |mask_t1 - mask_t2|) <= |mask_t1 - mask_t2|; (d) everything finite, every parameter
+    receives a gradient."""
+    from stcd_amd import synth
+    a, b, _ = synth.make_batch(16, 256, 256, seed=79)
+    A, Bt = t(a).to(DEV), t(b).to(DEV)
+    torch.manual_seed(8)
+    m = SegCD(dtype="bf16").to(DEV)
+    m.eval()
+    with torch.no_grad():
+        full = [o.clone() for o in m(A, Bt)]
+        h0 = [o.clone() for o in m(A[:8], Bt[:8])]
+        h1 = [o.clone() for o in m(A[8:], Bt[8:])]
+    for k in range(3):
+        assert torch.isfinite(full[k]).all()
+        assert torch.equal(full[k], torch.cat([h0[k], h1[k]])), k
+    assert (full[2] <= (full[0] - full[1]).abs() + 1e-6).all()
+    m.train()
+    grads = []
+    for scale in (1.0, 2.0):
+        m.zero_grad(set_to_none=True)
+        o = m(A, Bt)
+        torch.autograd.backward(o, [torch.ones_like(x) * 1e-3 * scale * w for x, w in zip(o, (1.0, -0.5, 2.0))])
+        grads.append(torch.cat([p.grad.flatten() for p in m.parameters()]).clone())
+        if scale == 1.0:
+            for name, p in m.named_parameters():
+                assert torch.isfinite(p.grad).all(), name
+                assert p.grad.abs().max().item() > 0, name
+    rel = ((grads[1] - 2.0 * grads[0]).abs().max() / grads[1].abs().max()).item()
+    assert rel < 5e-5, rel
