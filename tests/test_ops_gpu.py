@@ -454,3 +454,29 @@ def test_weight_gradient_gemm_kernel(n, h, w, ci, co, si, so, oy0, ox0):
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() <= 2e-5 * scale + 1e-6       # fp32 accumulation order only
     assert (ref - want).abs().max().item() <= 2e-5 * scale + 1e-6
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,stride,taps", [(32, 64, 64, 64, 256, 1, [(0, 0)]), (32, 64, 64, 256, 64, 1, [(0, 0)]), (32, 8, 8, 2048, 512, 1, [(0, 0)]),
+                                                     (32, 32, 32, 512, 1024, 2, [(0, 0)]), (32, 16, 16, 3072, 256, 1, TAPS3), (32, 64, 64, 128, 128, 2, TAPS3)])
+def test_full_size_gemm_conv_properties(n, h, w, ci, co, stride, taps):
+    """SegCD's bench-sized layers on the tap-list GEMM kernel (ResNet-50 bottleneck 1x1s, the stride-2 down-sample, the decoder's
+    3072 -> 256 3x3, a stride-2 3x3): (a) batch independence, bit for bit -- image k of the 32-image batch equals the same image
+    convolved alone (different tile walk, different position groups); (b) agreement with the plain-FMA reference kernel on that
+    image to the rounding of the bf16 output."""
+    rng = np.random.default_rng(h + ci + len(taps))
+    hm, wm = h // stride, w // stride
+    x = rnd(rng, n, h, w, ci).to(DEV)
+    wt = rnd(rng, len(taps), ci, co, scale=1.0 / np.sqrt(len(taps) * ci)).float().to(DEV)
+    bias = torch.from_numpy(rng.standard_normal(co).astype(np.float32)).to(DEV)
+    g = geom(n, h, w, ci, ci, hm, wm, stride, hm, wm, 1, 0, 0, co, co, taps)
+    out = torch.zeros(n, hm, wm, co, dtype=torch.bfloat16, device=DEV)
+    run_conv(1, g, x, wt, bias, out)
+    assert torch.isfinite(out.float()).all()
+    k = n // 2 + 1
+    g1 = geom(1, h, w, ci, ci, hm, wm, stride, hm, wm, 1, 0, 0, co, co, taps)
+    o1 = torch.zeros(1, hm, wm, co, dtype=torch.bfloat16, device=DEV)
+    run_conv(1, g1, x[k:k + 1].contiguous(), wt, bias, o1)
+    assert torch.equal(o1[0], out[k])
+    o0 = torch.zeros(1, hm, wm, co, dtype=torch.bfloat16, device=DEV)
+    run_conv(0, g1, x[k:k + 1].contiguous(), wt, bias, o0)
+    np.testing.assert_allclose(o1.float().cpu().numpy(), o0.float().cpu().numpy(), rtol=2 ** -7, atol=2e-3)
