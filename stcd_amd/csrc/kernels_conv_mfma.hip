@@ -1891,33 +1891,64 @@ k_wgrad_gemm(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
     const int cpb = (nchunks + a.gx - 1) / a.gx;
     const int c0 = bx * cpb, c1 = min(nchunks, c0 + cpb);
 
-    // staging plan: piece i = tid + p*256 -> position i / (T/8) of the chunk, 16-B chunk c8 = i % (T/8)
-    int prow[PP], plds[PP]; unsigned xch[PP], ych[PP];
-#pragma unroll
-    for (int p = 0; p < PP; ++p) {
-        const int i = tid + p * 256, row = i / (T / 8), c8 = i - row * (T / 8);
-        prow[p] = row;
-        plds[p] = (c8 >> 2) * SUB + row * 64 + (row >> 3) * 32 + (c8 & 3) * 16;
-        xch[p] = (ci0 + c8 * 8 < a.g.ci) ? (unsigned)((ci0 + c8 * 8) * 2) : 0x80000000u;
-        ych[p] = (co0 + c8 * 8 < a.co_valid) ? (unsigned)((co0 + c8 * 8) * 2) : 0x80000000u;
-    }
+    // staging plan: piece i = tid + p*256 -> position i / (T/8) of the chunk, 16-B chunk c8 = i % (T/8).  256 is a multiple of
+    // T/8, so c8 is the same for all of a thread's pieces and its rows are RP = 256/(T/8) apart: scalars, not arrays
+    constexpr int RP = 256 / (T / 8), LSTEP = RP * 64 + (RP / 8) * 32;
+    const int prow0 = tid / (T / 8), c8 = tid % (T / 8);
+    const int plds0 = (c8 >> 2) * SUB + prow0 * 64 + (prow0 >> 3) * 32 + (c8 & 3) * 16;
+    const unsigned xch = (ci0 + c8 * 8 < a.g.ci) ? (unsigned)((ci0 + c8 * 8) * 2) : 0x80000000u;
+    const unsigned ych = (co0 + c8 * 8 < a.co_valid) ? (unsigned)((co0 + c8 * 8) * 2) : 0x80000000u;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(base + a.in_off), (short)0, (int)a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(base + a.dout_off), (short)0, (int)a.dout_bytes, 0x00020000);
     const int tdy = a.g.dy[0], tdx = a.g.dx[0];
     uint4 xa[PP], ya[PP], xb[PP], yb[PP];
+    // plain layout (the common 1x1 case): position m IS the pixel index of both tensors -- no (n, y, x) decomposition per piece
+    // (two integer divisions per piece and chunk made the loader, not the MFMAs, the bottleneck: ~200 VALU beside 32 MFMAs).
+    // Strided / phase maps keep a running (n, y, x) per piece, advanced by 64 positions per chunk with carries.
+    const bool plain = a.g.in_stride == 1 && a.g.out_stride == 1 && a.g.hm == a.g.hi && a.g.wm == a.g.wi && a.g.ho == a.g.hm && a.g.wo == a.g.wm &&
+                       a.g.oy0 == 0 && a.g.ox0 == 0 && tdy == 0 && tdx == 0 && a.wi_valid == a.g.wi;
+    constexpr bool INCR = W == 2;                       // (W == 4 has no registers to spare for the state: it divides per chunk)
+    int px_[PP], py_[PP], pn_[PP];                      // (x, y, n) of piece p's position in chunk `pos_chunk`
+    int pos_chunk = c0;
+    const int adv_x = 64 % a.g.wm, adv_t = 64 / a.g.wm, adv_y = adv_t % a.g.hm, adv_n = adv_t / a.g.hm;
+    if (INCR && !plain) {
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            const int m_ = c0 * 64 + prow0 + p * RP;
+            px_[p] = m_ % a.g.wm; const int t_ = m_ / a.g.wm; py_[p] = t_ % a.g.hm; pn_[p] = t_ / a.g.hm;
+        }
+    }
 #define WGG_FETCH(C_, PX_, PY_)                                                                                        \
     do {                                                                                                               \
+        const int cc_ = (C_);                                                                                          \
+        if (INCR && !plain) {                                                                                          \
+            while (pos_chunk < cc_) {                       /* uniform: chunks are requested in non-decreasing order */ \
+                _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                                       \
+                    px_[p] += adv_x; py_[p] += adv_y; pn_[p] += adv_n;                                                 \
+                    if (px_[p] >= a.g.wm) { px_[p] -= a.g.wm; ++py_[p]; }                                              \
+                    if (py_[p] >= a.g.hm) { py_[p] -= a.g.hm; ++pn_[p]; }                                              \
+                }                                                                                                      \
+                ++pos_chunk;                                                                                           \
+            }                                                                                                          \
+        }                                                                                                              \
         _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                                               \
-            const int m_ = (C_) * 64 + prow[p];                                                                        \
-            const int x_ = m_ % a.g.wm, t_ = m_ / a.g.wm, y_ = t_ % a.g.hm, n_ = t_ / a.g.hm;                          \
-            const int iy_ = y_ * a.g.in_stride + tdy, ix_ = x_ * a.g.in_stride + tdx;                                  \
-            const bool okx_ = m_ < M && (unsigned)iy_ < (unsigned)a.g.hi && (unsigned)ix_ < (unsigned)a.wi_valid;      \
-            const unsigned xo_ = (unsigned)((((n_ * a.g.hi + iy_) * a.g.wi + ix_) * a.g.ldi) * 2);                     \
-            const unsigned yo_ = (unsigned)((((n_ * a.g.ho + y_ * a.g.out_stride + a.g.oy0) * a.g.wo + x_ * a.g.out_stride + a.g.ox0) * a.g.ldo) * 2); \
-            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, okx_ ? xo_ + xch[p] : 0x80000000u, 0, 0);      \
-            const u32x4 w_ = __builtin_amdgcn_raw_buffer_load_b128(yrs, m_ < M ? yo_ + ych[p] : 0x80000000u, 0, 0);    \
+            const int m_ = cc_ * 64 + prow0 + p * RP;                                                                  \
+            bool okx_; unsigned xo_, yo_;                                                                              \
+            if (plain) {                                                                                               \
+                okx_ = m_ < M; xo_ = (unsigned)(m_ * a.g.ldi * 2); yo_ = (unsigned)(m_ * a.g.ldo * 2);                 \
+            } else {                                                                                                   \
+                int x_, y_, n_;                                                                                        \
+                if (INCR) { x_ = px_[p]; y_ = py_[p]; n_ = pn_[p]; }                                                   \
+                else { x_ = m_ % a.g.wm; const int t_ = m_ / a.g.wm; y_ = t_ % a.g.hm; n_ = t_ / a.g.hm; }            \
+                const int iy_ = y_ * a.g.in_stride + tdy, ix_ = x_ * a.g.in_stride + tdx;                              \
+                okx_ = m_ < M && (unsigned)iy_ < (unsigned)a.g.hi && (unsigned)ix_ < (unsigned)a.wi_valid;             \
+                xo_ = (unsigned)((((n_ * a.g.hi + iy_) * a.g.wi + ix_) * a.g.ldi) * 2);                                \
+                yo_ = (unsigned)((((n_ * a.g.ho + y_ * a.g.out_stride + a.g.oy0) * a.g.wo + x_ * a.g.out_stride + a.g.ox0) * a.g.ldo) * 2); \
+            }                                                                                                          \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, okx_ ? xo_ + xch : 0x80000000u, 0, 0);         \
+            const u32x4 w_ = __builtin_amdgcn_raw_buffer_load_b128(yrs, m_ < M ? yo_ + ych : 0x80000000u, 0, 0);       \
             PX_[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                           \
             PY_[p] = make_uint4(w_[0], w_[1], w_[2], w_[3]);                                                           \
         }                                                                                                              \
@@ -1925,8 +1956,8 @@ k_wgrad_gemm(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
 #define WGG_STASH(BUF_, PX_, PY_)                                                                                      \
     do {                                                                                                               \
         _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                                               \
-            *reinterpret_cast<uint4*>(smem + (BUF_) * STAGE + plds[p]) = PX_[p];                                       \
-            *reinterpret_cast<uint4*>(smem + (BUF_) * STAGE + IMG + plds[p]) = PY_[p];                                 \
+            *reinterpret_cast<uint4*>(smem + (BUF_) * STAGE + plds0 + p * LSTEP) = PX_[p];                             \
+            *reinterpret_cast<uint4*>(smem + (BUF_) * STAGE + IMG + plds0 + p * LSTEP) = PY_[p];                       \
         }                                                                                                              \
     } while (0)
 
