@@ -1637,6 +1637,8 @@ k_conv_gemm(const ConvGemmArgs a) {
 
     // ---- staging plan
     const int ch = tid & 7;
+    const bool plain_in = a.g.ntaps == 1 && a.g.dy[0] == 0 && a.g.dx[0] == 0 && a.g.in_stride == 1 && a.g.hm == a.g.hi && a.g.wm == a.g.wi && !a.pix_chunks;
+    const bool plain_out = a.g.out_stride == 1 && a.g.ho == a.g.hm && a.g.wo == a.g.wm && a.g.oy0 == 0 && a.g.ox0 == 0;
     unsigned xoff[XP]; int xlds[XP], xyx[XP];          // byte offset of the row's centre pixel (+ lead), packed (y, x) of it
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
@@ -1645,9 +1647,14 @@ k_conv_gemm(const ConvGemmArgs a) {
         int yx = (int)0xC000C000;                      // far outside every image: all taps of a masked row read zeros
         if (m < a.Mg) {
             const int mm = grp * a.Mg + m;
-            const int x = mm % a.g.wm, t = mm / a.g.wm, y = t % a.g.hm, n = t / a.g.hm;
-            off = (unsigned)(((((int64_t)n * a.g.hi + y * a.g.in_stride) * a.g.wi + x * a.g.in_stride) * a.g.ldi + ch * 8) * 2) + a.lead;
-            yx = ((y * a.g.in_stride) << 16) | (x * a.g.in_stride);
+            if (plain_in) {          // 1x1, stride 1: the position IS the pixel (no integer divisions in the prologue of a 1-4 step block)
+                off = (unsigned)(((int64_t)mm * a.g.ldi + ch * 8) * 2) + a.lead;
+                yx = 0;
+            } else {
+                const int x = mm % a.g.wm, t = mm / a.g.wm, y = t % a.g.hm, n = t / a.g.hm;
+                off = (unsigned)(((((int64_t)n * a.g.hi + y * a.g.in_stride) * a.g.wi + x * a.g.in_stride) * a.g.ldi + ch * 8) * 2) + a.lead;
+                yx = ((y * a.g.in_stride) << 16) | (x * a.g.in_stride);
+            }
         }
         xoff[p] = off; xyx[p] = yx;
         xlds[p] = (row * 8 + (ch ^ ((row >> 1) & 7))) * 16;
@@ -1791,8 +1798,11 @@ k_conv_gemm(const ConvGemmArgs a) {
         const int i = tid + p * 256, row = i / (TN / 8), c8 = i - row * (TN / 8), m = m0 + row;
         if (m < a.Mg) {
             const int mm = grp * a.Mg + m;
-            const int x = mm % a.g.wm, t = mm / a.g.wm, y = t % a.g.hm, n = t / a.g.hm;
-            const int64_t opix = ((int64_t)n * a.g.ho + y * a.g.out_stride + a.g.oy0) * a.g.wo + x * a.g.out_stride + a.g.ox0;
+            int64_t opix = mm;
+            if (!plain_out) {
+                const int x = mm % a.g.wm, t = mm / a.g.wm, y = t % a.g.hm, n = t / a.g.hm;
+                opix = ((int64_t)n * a.g.ho + y * a.g.out_stride + a.g.oy0) * a.g.wo + x * a.g.out_stride + a.g.ox0;
+            }
             *reinterpret_cast<uint4*>(a.out + opix * a.g.ldo + nt * TN + c8 * 8) = *reinterpret_cast<const uint4*>(ot + row * OPITCH + c8 * 16);
         }
     }
