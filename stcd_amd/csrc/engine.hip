@@ -609,7 +609,8 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                     continue;
                 }
                 if (op->plan.ok && op->wf >= 0) {
-                    j.kind = 1; j.dst_off = op->wf; j.count = op->plan.wf_elems;
+                    j.kind = 1; j.dst_off = op->wf;
+                    j.count = op->plan.modeB ? op->plan.wf_elems : op->plan.wf_elems / op->g.ntaps;      // mode A: one thread per (ci, co), all taps
                     j.Ci = op->g.ci; j.Co = op->g.co; j.CiB = op->plan.CiB; j.nchunks = op->plan.nchunks; j.KS = op->plan.KS;
                     j.NTtot = op->plan.NTtot; j.modeB = op->plan.modeB;
                 } else {   // no MFMA plan for this launch: it runs on the reference kernel and needs the fp32 image

@@ -323,6 +323,20 @@ k_pack_jobs(const PackJob* __restrict__ jobs, int njobs, int64_t total, const fl
         float v = 0.f;
         if (ky < 7 && kx < 7 && c < jb.aux && co < jb.Co) v = src[(((int64_t)co * jb.aux + c) * 7 + ky) * 7 + kx];
         reinterpret_cast<bf16*>(ws + jb.dst_off)[e] = (bf16)v;
+    } else if (!jb.modeB) {
+        // fragment image [chunk][tap][ks][n-tile][lane][8]: one thread = one (ci, co) pair for ALL taps of the launch -- its taps
+        // are adjacent in the reference tensor ([..][..][k][k]), so a wave reads whole lines (8 consecutive ci x k*k floats) and
+        // writes one full 128-B segment per tap (thread-per-element read one float per line: ~0.8 TB/s on SegCD's 32.5 M weights)
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        int64_t f = e >> 9;
+        const int nt = (int)(f % jb.NTtot); f /= jb.NTtot;
+        const int ks = (int)(f % jb.KS);
+        const int cc = (int)(f / jb.KS);
+        const int co = nt * 16 + (lane & 15), ci = cc * jb.CiB + ks * 32 + 8 * (lane >> 4) + j;
+        const bool in = ci < jb.Ci && co < jb.Co;
+        bf16* dst = reinterpret_cast<bf16*>(ws + jb.dst_off) + (((int64_t)cc * jb.ps.ntaps * jb.KS + ks) * jb.NTtot + nt) * 512 + (e & 511);
+        const int64_t tstride = (int64_t)jb.KS * jb.NTtot * 512;
+        for (int t = 0; t < jb.ps.ntaps; ++t) dst[t * tstride] = (bf16)(in ? ref_weight(jb.ps, src, t, ci, co) : 0.f);
     } else {
         const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
         int64_t f = e >> 9;
