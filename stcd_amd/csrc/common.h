@@ -155,6 +155,7 @@ int launch_conv_mfma_x4(const stcd_conv_geom g[4], const ConvMfmaPlan p[4], cons
 struct ConvResPlan {
     int NT = 0, CW = 32, nslices = 0, P = 0, blocks = 0;
     int filt_bytes = 0, lds_bytes = 0;
+    int single_halo = 0;       // one halo buffer (two barriers per step): a wider output-channel slice where LDS allows one block per CU anyway
     bool ok = false;
 };
 ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups);

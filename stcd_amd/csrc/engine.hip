@@ -911,7 +911,7 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     const bool res_path = !gemm_path && !small_path && mfma_on(c.e) && op.res.ok && op.wf >= 0 && !nchw;
     const bool mfma_path = !small_path && !res_path && mfma_on(c.e) && op.plan.ok && op.wf >= 0;
     if (gemm_path) snprintf(kname, sizeof(kname), "k_conv_gemm<%d>", op.gemm.W);
-    else if (res_path) snprintf(kname, sizeof(kname), "k_conv_res<%d, %d>", op.res.NT, op.res.CW);
+    else if (res_path) snprintf(kname, sizeof(kname), "k_conv_res<%d, %d, %s>", op.res.NT, op.res.CW, op.res.single_halo ? "true" : "false");
     else if (small_path) snprintf(kname, sizeof(kname), "k_conv_small<1, %d>", (op.g.ntaps * op.g.ci + 31) / 32 <= 5 ? 5 : 9);
     else if (mfma_path) snprintf(kname, sizeof(kname), "k_conv_mfma<%d>", op.plan.NT);
     else snprintf(kname, sizeof(kname), "k_conv_ref");

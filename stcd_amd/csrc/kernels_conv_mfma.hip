@@ -1259,7 +1259,7 @@ constexpr int RES_HW = 18;     // halo edge of the 16 x 16 output tile
 
 // CW = channels per pipeline step (32: 64-B pixel rows; 64: full 128-B lines and half as many steps -- used whenever
 // Ci % 64 == 0, where the wider co slice it leaves room for also halves the re-reads of X through L2).
-template <int NT, int CW>
+template <int NT, int CW, bool SH = false>
 __global__ void __launch_bounds__(256, (CW == 64 && NT == 4) ? 1 : 2)
 k_conv_res(const ConvResArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1401,7 +1401,7 @@ k_conv_res(const ConvResArgs a) {
     while (cur.tile < tile_end) {
         const bool have_next = nxt.tile < tile_end;
         if (have_next) RES_FETCH(nxt);
-        const char* hb = halo0 + buf * HALO_BYTES;
+        const char* hb = halo0 + (SH ? 0 : buf) * HALO_BYTES;
 #pragma unroll
         for (int ks = 0; ks < KSC; ++ks) {
             const char* fb = filt + (int64_t)(cur.c * KSC + ks) * (ntaps * NT * 1024) + lane * 16;
@@ -1424,7 +1424,8 @@ k_conv_res(const ConvResArgs a) {
                 }
             }
         }
-        if (have_next) RES_STASH(buf ^ 1);
+        if constexpr (SH) barrier_lds();                  // one halo buffer: every wave is done reading it before it is refilled
+        if (have_next) RES_STASH(SH ? 0 : (buf ^ 1));
         if (cur.c == nsteps - 1) {
             // ---- epilogue of this tile: lane (q, r) holds channels 4q..4q+3 of n-tile t2 at row 4*wid + m, column r
             const int mx = cur.x * 16 + r;
@@ -1544,11 +1545,21 @@ ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int gr
         for (int nt = ntmax; nt >= 1 && !NT; nt >>= 1)
             if (fits(nt, 1)) NT = nt;
         if (!NT) return rp;
+        // Layers whose filter slice leaves ONE block per CU either way (SNUNet's 160 ... 224 concatenated input channels -> 32 on
+        // 256^2 maps): with a single halo buffer (the refill waits for a second barrier) the slice can be twice as wide, so the
+        // 0.3 - 0.5 GB input is read once instead of once per 16 output channels.
+        static const int sh_mode = [] { const char* e = getenv("STCD_CONV_RES_SH"); return e ? atoi(e) : 1; }();
+        const int64_t tiles = (int64_t)g.n * ((g.wm + 15) / 16) * ((g.hm + 15) / 16);
+        if (sh_mode && tiles >= 2048 && !fits(NT, 2)) {
+            const int halo1 = RES_HW * RES_HW * 64;
+            for (int nt = ntmax; nt > NT; nt >>= 1)
+                if (p.NTtot % nt == 0 && nchunks * 9 * nt * 1024 + halo1 <= cap) { NT = nt; rp.single_halo = 1; break; }
+        }
     }
     if (p.NTtot % NT != 0) return rp;
     rp.NT = NT; rp.CW = CW; rp.nslices = p.NTtot / NT;
     rp.filt_bytes = nchunks * 9 * NT * 1024;
-    rp.lds_bytes = rp.filt_bytes + 2 * RES_HW * RES_HW * CW * 2;
+    rp.lds_bytes = rp.filt_bytes + (rp.single_halo ? 1 : 2) * RES_HW * RES_HW * CW * 2;
     const int64_t tiles_x = (g.wm + 15) / 16, tiles_y = (g.hm + 15) / 16, ntiles = (int64_t)g.n * tiles_x * tiles_y;
     const int64_t tpg = ntiles / groups;
     const int per_cu = std::max(1, std::min(4, (160 * 1024) / (rp.lds_bytes + 256)));
@@ -1583,7 +1594,18 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
         }                                                                                                         \
         k_conv_res<N_, W_><<<(unsigned)rp.blocks, 256, (size_t)rp.lds_bytes, s>>>(a);                             \
     } while (0)
-    if (rp.CW == 64) {
+#define LAUNCH_RES_SH(N_)                                                                                         \
+    do {                                                                                                          \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute((const void*)k_conv_res<N_, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        k_conv_res<N_, 32, true><<<(unsigned)rp.blocks, 256, (size_t)rp.lds_bytes, s>>>(a);                       \
+    } while (0)
+    if (rp.single_halo) {
+        if (rp.NT == 2) LAUNCH_RES_SH(2); else LAUNCH_RES_SH(4);
+    } else if (rp.CW == 64) {
         switch (rp.NT) {
             case 1: LAUNCH_RES(1, 64); break;
             case 2: LAUNCH_RES(2, 64); break;
@@ -1597,6 +1619,7 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
         }
     }
 #undef LAUNCH_RES
+#undef LAUNCH_RES_SH
     return 0;
 }
 
