@@ -1066,9 +1066,6 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
             ProfScope ps(c, PC_BN_STATS, 0.0, act_bytes);
             launch_bn_stats(e.dt, c.at(L.Y.off), L.Y.ld, C, L.groups, ppg, c.at<long long>(L.facc), c.s);
         }
-    } else {
-        launch_bn_eval_prepare(C, L.groups, c.params + bn.g_off, c.params + bn.b_off, bn_running + bn.run_off,
-                               bn_running + bn.run_off + C, stat, 1e-5f, c.s);
     }
     BnActArgs a;
     a.Y = c.at(L.Y.off); a.ldy = L.Y.ld;
@@ -1077,10 +1074,11 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     a.stat = stat;
     a.mask = (training && e.drop_p > 0.f) ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
     a.C = C; a.groups = L.groups; a.npg = L.npg; a.H = L.H; a.W = L.W; a.relu = 1;
-    if (training) {     // the activation kernel derives scale / shift from the accumulators itself (no finalize launch)
-        a.facc = c.at<long long>(L.facc); a.gamma = c.params + bn.g_off; a.beta = c.params + bn.b_off;
-        a.running_mean = bn_running + bn.run_off; a.running_var = bn_running + bn.run_off + C;
-    }
+    // the activation kernel derives scale / shift itself: from the accumulators in training mode, from the running statistics in
+    // eval mode (no finalize / prepare launch either way)
+    a.facc = training ? c.at<long long>(L.facc) : nullptr;
+    a.gamma = c.params + bn.g_off; a.beta = c.params + bn.b_off;
+    a.running_mean = bn_running + bn.run_off; a.running_var = bn_running + bn.run_off + C;
     if (L.fuse_dst.off >= 0 && e.use_act_fuse && L.groups == 2) {
         ProfScope ps(c, PC_BN_ACT, 0.0, act_bytes * 2.75, "k_bn_act_pair");
         launch_bn_act_pair(e.dt, a, c.at(L.fuse_dst.off), L.fuse_dst.ld, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.s);
@@ -1572,10 +1570,9 @@ static void sn_block_forward(const Ctx& c, const NBlock& b, float* bn_running, b
             }
             a.facc = c.at<long long>(facc_off); a.gamma = c.params + bn.g_off; a.beta = c.params + bn.b_off;
             a.running_mean = bn_running + bn.run_off; a.running_var = bn_running + bn.run_off + b.C;
-        } else {
-            launch_bn_eval_prepare(b.C, b.groups, c.params + bn.g_off, c.params + bn.b_off, bn_running + bn.run_off,
-                                   bn_running + bn.run_off + b.C, stat, 1e-5f, c.s);
-            a.facc = nullptr;
+        } else {      // eval: the activation kernel reads the running statistics itself
+            a.facc = nullptr; a.gamma = c.params + bn.g_off; a.beta = c.params + bn.b_off;
+            a.running_mean = bn_running + bn.run_off; a.running_var = bn_running + bn.run_off + b.C;
         }
     };
     bn_stage(b.f1, c.at(b.in.off), b.c1, b.bn1, b.Y1, b.stat1, b.facc1);
@@ -2107,9 +2104,9 @@ static void glayer_forward(const Ctx& c, GLayer& L, float* bn_running, bool trai
         if (!fused) launch_bn_stats(e.dt, c.at(L.Y.off), L.Y.ld, L.C, L.groups, ppg, c.at<long long>(L.facc), c.s);
         a.facc = c.at<long long>(L.facc); a.gamma = c.params + bn.g_off; a.beta = c.params + bn.b_off;
         a.running_mean = bn_running + bn.run_off; a.running_var = bn_running + bn.run_off + L.C;
-    } else {
-        launch_bn_eval_prepare(L.C, L.groups, c.params + bn.g_off, c.params + bn.b_off, bn_running + bn.run_off,
-                               bn_running + bn.run_off + L.C, stat, 1e-5f, c.s);
+    } else {      // eval: the activation kernel reads the running statistics itself
+        a.gamma = c.params + bn.g_off; a.beta = c.params + bn.b_off;
+        a.running_mean = bn_running + bn.run_off; a.running_var = bn_running + bn.run_off + L.C;
     }
     a.Y = c.at(L.Y.off); a.ldy = L.Y.ld; a.A = c.at(L.A.off); a.lda = L.A.ld; a.a_group_off = ppg * L.A.ld;
     a.P = nullptr; a.ldp = 0; a.stat = stat; a.mask = nullptr;

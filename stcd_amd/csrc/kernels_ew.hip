@@ -331,6 +331,13 @@ __device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __rest
             }
             if (publish && rmean) rmean[c] = rm;
             if (publish && rvar) rvar[c] = rv;
+        } else if (gamma) {      // eval mode: the running statistics (read-only), the arithmetic of k_bn_eval_prepare -- no launch for it
+            const float invstd = 1.f / sqrtf(rvar[c] + eps);
+            const float sc = gamma[c] * invstd, sh = beta[c] - rmean[c] * gamma[c] * invstd;
+            for (int g = 0; g < groups; ++g) {
+                tab[(g * 2 + 0) * CS + cl] = sc;
+                tab[(g * 2 + 1) * CS + cl] = sh;
+            }
         } else {
             for (int g = 0; g < groups; ++g) {
                 tab[(g * 2 + 0) * CS + cl] = stat[(int64_t)g * 4 * C + 2 * C + c];
