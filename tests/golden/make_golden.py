@@ -485,28 +485,27 @@ def _reference_segcd(classes=1):
     return RefSegCD()
 
 
-def g10_segcd():
+def _segcd_fixture(fname, tag, seed, classes, B, H, W):
     from oracle import segcd_ref
-    print("G10 SegCD (ResNet-50 UNet)")
-    seed = 1000
+    print(tag)
     d = {"seed": seed}
-    m = _reference_segcd(1)
+    m = _reference_segcd(classes)
     names = [k for k in m.state_dict().keys()]
-    assert names == [n for n, _, _ in segcd_ref.param_specs(3, 1)], "state_dict order differs from oracle.segcd_ref.param_specs"
-    x1, x2 = rand_pair(seed + 1, 2, 64, 64)
+    assert names == [n for n, _, _ in segcd_ref.param_specs(3, classes)], "state_dict order differs from oracle.segcd_ref.param_specs"
+    x1, x2 = rand_pair(seed + 1, B, H, W)
     d["x1"], d["x2"] = t2n(x1), t2n(x2)
-    m.load_state_dict(segcd_ref.synth_state(3, 1, seed, perturb_running=True))
+    m.load_state_dict(segcd_ref.synth_state(3, classes, seed, perturb_running=True))
     m.eval()
     with torch.no_grad():
         o = m(x1, x2)
     d["eval/m1"], d["eval/m2"], d["eval/change"] = (t2n(t) for t in o)
-    m = _reference_segcd(1)
-    m.load_state_dict(segcd_ref.synth_state(3, 1, seed))
+    m = _reference_segcd(classes)
+    m.load_state_dict(segcd_ref.synth_state(3, classes, seed))
     m.train()
     m1, m2, ch = m(x1, x2)
     rng = np.random.default_rng(seed + 4)
-    tgt = torch.from_numpy((rng.random((2, 1, 64, 64)) < 0.2).astype(np.float32))
-    seg = torch.from_numpy((rng.random((2, 1, 64, 64)) < 0.3).astype(np.float32))
+    tgt = torch.from_numpy((rng.random((B, classes, H, W)) < 0.2).astype(np.float32))
+    seg = torch.from_numpy((rng.random((B, classes, H, W)) < 0.3).astype(np.float32))
     d["target"], d["seg_target"] = t2n(tgt), t2n(seg)
     # the semi-supervised stage's sum (train_stcd.py:427-445 without the contrastive term): seg loss on mask_t1 + cd loss
     loss = ref_losses.cd_loss(torch.sigmoid(m1), seg) + ref_losses.cd_loss(torch.sigmoid(ch), tgt) + 0.5 * m2.mean()
@@ -517,12 +516,22 @@ def g10_segcd():
     for k in ("encoder.bn1", "encoder.layer1.0.downsample.1", "encoder.layer4.2.bn3", "decoder.blocks.0.conv1.1", "decoder.blocks.4.conv2.1"):
         d[f"rs/{k}.running_mean"], d[f"rs/{k}.running_var"] = t2n(sd[f"{k}.running_mean"]), t2n(sd[f"{k}.running_var"])
         d[f"rs/{k}.num_batches_tracked"] = t2n(sd[f"{k}.num_batches_tracked"])
-    save("g10_segcd.npz", **d)
+    save(fname, **d)
+
+
+def g10_segcd():
+    _segcd_fixture("g10_segcd.npz", "G10 SegCD (ResNet-50 UNet)", 1000, 1, 2, 64, 64)
+
+
+def g11_segcd():
+    """A second SegCD fixture: two classes (the 3x3 head with two output channels, the per-channel min), a non-square 96 x 64 map,
+    batch 3 (18 samples per BatchNorm at the deepest stage)."""
+    _segcd_fixture("g11_segcd_2cls.npz", "G11 SegCD, 2 classes, 3 x 96 x 64", 1100, 2, 3, 96, 64)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11"]
     fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd,
-          "g7": g7_train128, "g8": g8_contrastive, "g10": g10_segcd}
+          "g7": g7_train128, "g8": g8_contrastive, "g10": g10_segcd, "g11": g11_segcd}
     for w in which:
         fn[w]()

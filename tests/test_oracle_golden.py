@@ -190,21 +190,22 @@ def test_contrastive_loss_against_reference_vectors(golden):
         np.testing.assert_allclose(pred.grad.numpy(), g[f"{tag}/dpred"], rtol=1e-5, atol=1e-8)
 
 
-def test_segcd_eval_and_train_step_against_reference_vectors(golden):
+@pytest.mark.parametrize("fixture,classes", [("g10_segcd.npz", 1), ("g11_segcd_2cls.npz", 2)])
+def test_segcd_eval_and_train_step_against_reference_vectors(golden, fixture, classes):
     """G10: the ResNet-50 UNet change detector the reference's scripts train (smp.SegCD), assembled from the reference's own
     ResNet / UnetDecoder / SegmentationHead: the three outputs in eval and train mode, the loss, every parameter's
     (sampled) gradient and BatchNorm running statistics (each BatchNorm sees date A, then date B)."""
     from oracle import segcd_ref as G
     from tests._util import check_grad
-    g = golden("g10_segcd.npz")
+    g = golden(fixture)        # G10: 1 class, 2 x 64 x 64; G11: 2 classes, 3 x 96 x 64
     seed = int(g["seed"])
     x1, x2 = _t(g["x1"]), _t(g["x2"])
-    st = G.synth_state(3, 1, seed, perturb_running=True)
+    st = G.synth_state(3, classes, seed, perturb_running=True)
     with torch.no_grad():
         o = G.forward(st, x1, x2)
     for k, v in zip(("m1", "m2", "change"), o):
         np.testing.assert_allclose(v.numpy(), g[f"eval/{k}"], rtol=2e-4, atol=2e-4)
-    st = G.synth_state(3, 1, seed)
+    st = G.synth_state(3, classes, seed)
     params = [k for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
     for k in params:
         st[k].requires_grad_(True)

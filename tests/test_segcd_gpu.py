@@ -21,20 +21,21 @@ def _loss(m1, m2, ch, seg, tgt):
     return bce_dice_with_logits(m1, seg) + bce_dice_with_logits(ch, tgt) + 0.5 * m2.mean()
 
 
-def test_segcd_fp32_matches_reference_vectors(golden):
-    g = golden("g10_segcd.npz")
+@pytest.mark.parametrize("fixture,classes", [("g10_segcd.npz", 1), ("g11_segcd_2cls.npz", 2)])
+def test_segcd_fp32_matches_reference_vectors(golden, fixture, classes):
+    g = golden(fixture)        # G10: 1 class, 2 x 64 x 64; G11: 2 classes, 3 x 96 x 64 -- both from the reference's own classes
     seed = int(g["seed"])
     x1, x2 = t(g["x1"]).to(DEV), t(g["x2"]).to(DEV)
-    m = SegCD(dtype="fp32")
-    m.load_state_dict(G.synth_state(3, 1, seed, perturb_running=True))
+    m = SegCD(classes=classes, dtype="fp32")
+    m.load_state_dict(G.synth_state(3, classes, seed, perturb_running=True))
     m.to(DEV).eval()
     with torch.no_grad():
         o = m(x1, x2)
     for k, v in zip(("m1", "m2", "change"), o):
         np.testing.assert_allclose(v.cpu().numpy(), g[f"eval/{k}"], rtol=1e-3, atol=1e-3, err_msg=k)
 
-    m = SegCD(dtype="fp32")
-    m.load_state_dict(G.synth_state(3, 1, seed))
+    m = SegCD(classes=classes, dtype="fp32")
+    m.load_state_dict(G.synth_state(3, classes, seed))
     m.to(DEV).train()
     m1, m2, ch = m(x1, x2)
     for k, v in zip(("m1", "m2", "change"), (m1, m2, ch)):
@@ -45,7 +46,7 @@ def test_segcd_fp32_matches_reference_vectors(golden):
     for name, p in m.named_parameters():
         if float(np.abs(g["gs/" + name][1])) < 1e-12:
             continue
-        check_grad(name, p.grad, g, rel_max=SEG_REL, cos_min=SEG_COS, tag="fp32 SegCD vs reference G10")
+        check_grad(name, p.grad, g, rel_max=SEG_REL, cos_min=SEG_COS, tag=f"fp32 SegCD vs reference {fixture[:3].upper()}")
     sd = m.state_dict()
     for k in [k for k in g if k.startswith("rs/")]:     # layer4's inputs already differ by ~1e-3 relative between two fp32 evaluation orders
         np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), g[k], rtol=1e-4, atol=5e-5, err_msg=k)
