@@ -438,7 +438,7 @@ def test_full_size_properties_other_configs_bf16(arch):
 # 3e-5..2e-3).  Gradients: the network is piecewise linear (ReLU gates, max-pool arg-max, |a1-a2| sign) and at this
 # random-init state extremely flip-sensitive (tests/_util.py): rounding the FORWARD tensors of the CPU oracle to bf16 --
 # fp32 arithmetic everywhere, gradients untouched -- already moves its gradients to a median cosine of 0.90 (diff) / 0.94
-# (conc) against its own fp32 run, worst tensor 0.82 / 0.86 (tools/bf16_emulation.py; rounding the BACKWARD tensors
+# (conc) against its own fp32 run, worst tensor 0.82 / 0.86 (tests/tools_bf16_emulation.py; rounding the BACKWARD tensors
 # changes nothing: cosine 1.0000).  The engine measures median 0.88 / 0.91, worst 0.76 / 0.76; SNUNet (residual blocks, no
 # |a-b| fusion) median 0.987, worst 0.952.  The bounds sit just under the measured values: what they catch is a wrong
 # term, not rounding (the exact-arithmetic checks of the same kernels are the fp32 runs above and the per-op tests).

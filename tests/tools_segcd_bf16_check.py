@@ -1,5 +1,5 @@
 """bf16 SegCD against the fp32 engine on the same inputs (forward error, per-tensor gradient rel-l2 / cosine) under several
-kernel-selection switches.  Run on the GPU box: python tools/segcd_bf16_check.py"""
+kernel-selection switches.  Run on the GPU box: python tests/tools_segcd_bf16_check.py"""
 import sys, os, subprocess, pickle
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
