@@ -148,3 +148,35 @@ def test_bench_reads_pmc_traffic_from_profiles(tmp_path, monkeypatch):
     assert b.pmc_traffic("stcd::k_conv_res<2, 32>", "snunet") == (170, os.path.join("profiles", "r09_snunet_pmc_traffic.txt"))
     assert b.pmc_traffic("stcd::k_conv_res<2, 32>", "segcd") == (None, None)
     assert b.pmc_step_traffic("snunet") == (9000, os.path.join("profiles", "r09_snunet_pmc_traffic.txt"))
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: the package, the tools and the examples must not import it (only tests/, smoke() and the
+    cpu_baseline leg of bench.py may), and bench.py may only do so inside its cpu_baseline functions."""
+    import ast
+    import glob
+    import os
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                hits.append(node.lineno)
+            if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                hits.append(node.lineno)
+        return hits
+
+    for pat in ("stcd_amd/*.py", "tools/*.py", "examples/*.py"):
+        for f in glob.glob(os.path.join(repo, pat)):
+            assert oracle_imports(f) == [], f
+    # bench.py: only inside cpu_baseline* functions
+    src = open(os.path.join(repo, "bench.py")).read()
+    tree = ast.parse(src)
+    allowed = set()
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name.startswith("cpu_baseline"):
+            allowed.update(range(node.lineno, node.end_lineno + 1))
+    assert all(l in allowed for l in oracle_imports(os.path.join(repo, "bench.py")))
