@@ -131,7 +131,7 @@ def _holders(m):
     return out
 
 
-@pytest.mark.parametrize("dtype,B,H,W,cin", [("fp32", 2, 64, 64, 3), ("bf16", 2, 64, 96, 3), ("bf16", 3, 128, 128, 3), ("bf16", 2, 96, 64, 6)])
+@pytest.mark.parametrize("dtype,B,H,W,cin", [("fp32", 2, 64, 64, 3), ("bf16", 2, 64, 96, 3), ("bf16", 3, 128, 128, 3), ("bf16", 2, 96, 64, 6), ("bf16", 1, 32, 64, 3), ("fp32", 5, 32, 32, 1)])
 def test_segcd_every_layer_in_place(dtype, B, H, W, cin):
     tol = 2e-4 if dtype == "fp32" else 6e-3            # bf16: one rounding of the output (2^-9 relative, ~1.2e-3 rms) + bf16 weights
     rng = np.random.default_rng(31)
