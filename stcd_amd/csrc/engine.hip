@@ -846,6 +846,31 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         e.bias_jobs_off = ws.take((int64_t)e.bias_jobs.size() * sizeof(BiasJob) + 16);
     }
 
+    // test introspection (stcd_ws_tensor_*): input, conv output, activation (per date: the two halves may sit in different
+    // buffers) and output gradient of every conv + BN layer, as they stand after a forward / backward
+    e.ws_tensors.clear();
+    auto rec_layer = [&](const Cbrd& L) {
+        const ConvW& cv = e.convs[L.conv];
+        auto rec = [&](const char* sfx, int64_t off, int ld, int n, int ch) {
+            if (off < 0) return;
+            stcd_ws_tensor r;
+            memset(&r, 0, sizeof(r));
+            snprintf(r.name, sizeof(r.name), "%s.%s", cv.name.c_str(), sfx);
+            r.offset_bytes = off; r.n = n; r.h = L.H; r.w = L.W; r.c = ch; r.ld = ld; r.dtype = e.dt;
+            e.ws_tensors.push_back(r);
+        };
+        rec("in", L.in.off, L.in.ld, L.N, L.K);
+        rec("Y", L.Y.off, L.Y.ld, L.N, cv.cout);
+        for (int g = 0; g < L.groups; ++g) {
+            char sfx[8];
+            snprintf(sfx, sizeof(sfx), "A.g%d", g);
+            rec(sfx, L.A.off + g * L.A.goff * T, L.A.ld, L.npg, cv.cout);
+        }
+        rec("dY", L.dY.off, L.dY.ld, L.N, cv.cout);
+    };
+    for (const Cbrd& L : e.enc) rec_layer(L);
+    for (const Cbrd& L : e.dec) rec_layer(L);
+
     build_pack_jobs(e, ws);
     e.jobs_uploaded_ws = nullptr;
     e.ws_bytes = ws.cur;

@@ -546,3 +546,65 @@ def test_frozen_weights_context_packs_once_and_is_exact():
         m.set_dropout_masks(R.synth_masks("diff", 2, 9))
         l2 = m(x1, x2).sum()
         assert l1.item() != l2.item()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Layer-local parity inside the running FC-Siam networks (stcd_ws_tensor_* introspection): bf16 end-to-end gradients can only be
+# bounded statistically (see BF16_GRAD above), so every Conv(Transpose)2d + BatchNorm + ReLU layer is checked IN PLACE against
+# torch's own layer applied to the layer's stored input / output gradient: conv output (one bf16 rounding), weight and bias
+# gradient (fp32 accumulation on both sides), BatchNorm + ReLU per date.  Dropout is switched off (p = 0) so the activation is a
+# function of the stored conv output alone.
+@pytest.mark.parametrize("arch,dtype,B,H,W", [("diff", "bf16", 2, 64, 64), ("conc", "bf16", 3, 48, 80), ("sub", "bf16", 2, 32, 32), ("diff", "fp32", 2, 32, 48)])
+def test_fcsiam_every_layer_in_place(arch, dtype, B, H, W):
+    rng = np.random.default_rng(41)
+    x1 = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32)).to(DEV)
+    x2 = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32)).to(DEV)
+    tgt = torch.from_numpy((rng.random((B, H, W)) < 0.2).astype(np.int64)).to(DEV)
+    m = CLS[arch](3, 2, dtype=dtype)
+    m.load_state_dict(R.synth_state(arch, 3, 2, 21))
+    m.set_dropout_p(0.0)
+    m.to(DEV).train()
+    loss = torch.nn.functional.cross_entropy(unwrap(m(x1, x2)), tgt)
+    loss.backward()
+    torch.cuda.synchronize()
+    ws = m._engine.ws_tensors()
+    names = sorted({k.split(".")[0] for k in ws})
+    assert len(names) == 19, names              # 10 encoder + 9 decoder conv+BN layers (conv11d has no BatchNorm: checked end to end)
+    tol = 5e-6 if dtype == "fp32" else 3e-3      # bf16: the stored Y is rounded to bf16 (2^-9 per element)
+    wq = (lambda w: w.detach().to(torch.bfloat16).float()) if dtype == "bf16" else (lambda w: w.detach())
+    nchw = lambda t_: t_.permute(0, 3, 1, 2).float().contiguous()
+    worst = {}
+
+    def chk(kind, name, got, want, t_=tol):
+        r = float((got.float() - want).norm() / want.norm().clamp_min(1e-30))
+        if r >= worst.get(kind, (0.0, ""))[0]:
+            worst[kind] = (r, name)
+        assert r <= t_, (kind, name, r)
+
+    for name in names:
+        conv, bn = getattr(m, name), getattr(m, "bn" + name[4:])
+        X, Y, dY = nchw(ws[name + ".in"])[:, :conv.in_channels], nchw(ws[name + ".Y"]), nchw(ws[name + ".dY"])      # conv11: 3 of 8 padded channels
+        Wv = wq(conv.weight).requires_grad_(True)
+        bv = conv.bias.detach().clone().requires_grad_(True)
+        if isinstance(conv, torch.nn.ConvTranspose2d):
+            Yt = torch.nn.functional.conv_transpose2d(X, Wv, bv, stride=1, padding=1)
+        else:
+            Yt = torch.nn.functional.conv2d(X, Wv, bv, padding=1)
+        chk("conv output", name, Y, Yt.detach())
+        Yt.backward(dY)
+        chk("weight gradient", name, conv.weight.grad, Wv.grad, 5e-6)      # fp32 accumulation of the same bf16 products on both sides
+        # a bias in front of a training-mode BatchNorm has a mathematically zero gradient (the per-date sums of dY vanish): both
+        # sides are rounding noise, so bound them against the natural scale sum|dY| instead of against each other
+        scale = float(dY.abs().sum(dim=(0, 2, 3)).max())
+        for side, gb in (("engine", conv.bias.grad), ("torch", bv.grad)):
+            r = float(gb.abs().max()) / scale
+            worst["bias gradient / sum|dY|"] = max(worst.get("bias gradient / sum|dY|", (0.0, "")), (r, name + ":" + side))
+            assert r <= (1e-5 if dtype == "fp32" else 4e-3), (name, side, r)
+        groups = [k for k in ws if k.startswith(name + ".A.g")]
+        npg = Y.shape[0] // len(groups)
+        for gi in range(len(groups)):
+            y = Y[gi * npg:(gi + 1) * npg]
+            mu, var = y.mean(dim=(0, 2, 3), keepdim=True), y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+            a = torch.relu((y - mu) * torch.rsqrt(var + 1e-5) * bn.weight.detach().view(1, -1, 1, 1) + bn.bias.detach().view(1, -1, 1, 1))
+            chk("bn+relu", name, nchw(ws[f"{name}.A.g{gi}"]), a, 5e-6 if dtype == "fp32" else 4e-3)
+    print(f"SiamUnet_{arch} {dtype} B={B} {H}x{W} layer-local worst relative l2: " + ", ".join(f"{k} {v[0]:.1e} ({v[1]})" for k, v in worst.items()))
