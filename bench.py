@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--label", type=int, default=2)
+    ap.add_argument("--pseudo", action="store_true",
+                    help="BASELINE.json configs[3]: every step first builds its pairs on the device from resident uint8 tiles "
+                         "(stcd_pseudo_pair: blend + normalise + labels), then trains on them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)      # bounded CPU sample: ~10-20 s of host work in total
@@ -177,9 +180,25 @@ def main():
     a, b, lab = synth.make_batch(args.batch, args.size, args.size, seed=1337 + rank)
     A, B, L = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(lab).to(dev)
     Lf = L.float().unsqueeze(1)
+    if args.pseudo:      # train_pse_cd.py's data path on the device: uint8 HWC tiles -> normalised pair + change label, per step
+        from stcd_amd.pseudo import pseudo_change_pairs
+        ta, td, tl = synth.make_pairs_u8(args.batch, args.size, args.size, seed=1337 + rank)
+        TA, TD, TM = torch.from_numpy(ta).to(dev), torch.from_numpy(td).to(dev), torch.from_numpy((tl * 255).astype("uint8")).to(dev)
+        CH = torch.ones(args.batch, dtype=torch.uint8, device=dev)
+        CH[1::4] = 0                                                   # a quarter of the tiles take the no-change branch
+        step_no = [0]
 
     def step():
         opt.zero_grad(set_to_none=True)
+        if args.pseudo:
+            step_no[0] += 1
+            x1, x2, lab_, _, _ = pseudo_change_pairs(TA, TD, TM, CH, seed=step_no[0])
+            out = model(x1, x2)
+            out = out[-1] if isinstance(out, (list, tuple)) else out
+            loss = cross_entropy(out, lab_) if args.label == 2 else bce_dice_with_logits(out, lab_.float().unsqueeze(1))
+            loss.backward()
+            opt.step()
+            return loss
         out = model(A, B)
         out = out[-1] if isinstance(out, (list, tuple)) else out      # SiamUnet_sub: [logits]; SegCD: (mask_t1, mask_t2, change)
         loss = cross_entropy(out, L) if args.label == 2 else bce_dice_with_logits(out, Lf)
@@ -225,7 +244,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{NAMES[args.model]}(3,{args.label}) {args.size}x{args.size} full training step "
                                f"(fwd + {'cross_entropy' if args.label == 2 else 'sigmoid+cd_loss'} + bwd + {'Adam' if args.model == 'segcd' else 'AdamW'}), "
-                               f"{args.batch} pairs/GPU, synthetic LEVIR-CD-shaped pairs resident in HBM",
+                               f"{args.batch} pairs/GPU, " + ("pairs built every step by the on-device pseudo-change generator from uint8 tiles resident in HBM"
+                                                             if args.pseudo else "synthetic LEVIR-CD-shaped pairs resident in HBM"),
                    "global_batch": world * args.batch, "image": args.size, "parallelism": f"dp{world}",
                    "last_loss": round(last_loss, 5)},
         "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
