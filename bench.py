@@ -36,6 +36,38 @@ ALG_PER_PAIR_256 = {"diff": (25.37e9, 169e6), "sub": (25.37e9, 169e6), "conc": (
                     "segcd": (127.65e9, 912.2e6)}
 
 
+SEGCD_ENCODERS = {"resnet18": (1, (2, 2, 2, 2)), "resnet34": (1, (3, 4, 6, 3)), "resnet50": (4, (3, 4, 6, 3)),
+                  "resnet101": (4, (3, 4, 23, 3)), "resnet152": (4, (3, 8, 36, 3))}       # encoders/resnet.py:126-171
+
+
+def segcd_alg(encoder, classes=1, H=256, W=256):
+    """SURVEY 8d's accounting over SegCD's layer table: per conv call 2 MACs and (input + output + weights) x 2 B, both dates,
+    the head on 3 maps, x 3 for fwd + dgrad + wgrad.  resnet50: (127.65e9, 912.2e6) per pair at 256 x 256."""
+    X, layers = SEGCD_ENCODERS[encoder]
+    convs = [(3, 64, 7, H, W, 2)]                       # (cin, cout, k, h_in, w_in, stride)
+    h, w, inpl = H // 4, W // 4, 64
+    for li, (nb, pl) in enumerate(zip(layers, (64, 128, 256, 512))):
+        for b in range(nb):
+            s = 2 if (b == 0 and li > 0) else 1
+            if X == 4:
+                convs += [(inpl, pl, 1, h, w, 1), (pl, pl, 3, h, w, s), (pl, 4 * pl, 1, h // s, w // s, 1)]
+            else:
+                convs += [(inpl, pl, 3, h, w, s), (pl, pl, 3, h // s, w // s, 1)]
+            if b == 0 and (s != 1 or inpl != pl * X):
+                convs.append((inpl, pl * X, 1, h, w, s))
+            h, w, inpl = h // s, w // s, pl * X
+    enc, dec, cin = [512 * X, 256 * X, 128 * X, 64 * X, 64], [256, 128, 64, 32, 16], 512 * X
+    for i in range(5):
+        h, w = 2 * h, 2 * w
+        convs += [(cin + (enc[i + 1] if i < 4 else 0), dec[i], 3, h, w, 1), (dec[i], dec[i], 3, h, w, 1)]
+        cin = dec[i]
+    fl = sum(2 * (hi // s) * (wi // s) * k * k * ci * co for ci, co, k, hi, wi, s in convs) * 2
+    by = sum((hi * wi * ci + (hi // s) * (wi // s) * co + k * k * ci * co) * 2 for ci, co, k, hi, wi, s in convs) * 2
+    fl += 2 * H * W * 9 * 16 * classes * 3
+    by += (H * W * 16 + H * W * classes + 9 * 16 * classes) * 2 * 3
+    return 3.0 * fl, 3.0 * by
+
+
 NAMES = {"diff": "SiamUnet_diff", "conc": "SiamUnet_conc", "sub": "SiamUnet_sub", "snunet": "SNUNet_ECAM", "segcd": "SegCD-resnet50"}
 
 
@@ -45,6 +77,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub", "snunet", "segcd"])
+    ap.add_argument("--encoder", default="resnet50", choices=sorted(SEGCD_ENCODERS), help="--model segcd: the ResNet encoder")
     ap.add_argument("--batch", type=int, default=16, help="image pairs per GPU per step")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -59,7 +92,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline_segcd(size, pairs, steps):
+def cpu_baseline_segcd(size, pairs, steps, encoder="resnet50"):
     """oracle/segcd_ref.py timed on the host: fwd + BCE/Dice on sigmoid(change) + bwd + Adam, fp32, all host threads
     (steps capped at 4: one ResNet-50 UNet step on two dates is seconds of CPU work)."""
     from oracle import fcsiam_ref as R
@@ -68,7 +101,7 @@ def cpu_baseline_segcd(size, pairs, steps):
     steps = min(steps, 4)
     a, b, lab = synth.make_batch(pairs, size, size, seed=1337)
     A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab).float().unsqueeze(1)
-    st = G.synth_state(3, 1, seed=1)
+    st = G.synth_state(3, 1, seed=1, encoder=encoder)
     params = [v.requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
     opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999))
     times = []
@@ -83,11 +116,11 @@ def cpu_baseline_segcd(size, pairs, steps):
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     return {"value": round(pairs / med, 3), "unit": "image-pairs/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/segcd_ref.py SegCD(resnet50) fp32, {pairs} pairs {size}x{size}, median of {steps} full steps after 1 warm-up "
+            "sample": f"oracle/segcd_ref.py SegCD({encoder}) fp32, {pairs} pairs {size}x{size}, median of {steps} full steps after 1 warm-up "
                       f"({med * 1e3:.0f} ms/step)"}
 
 
-def cpu_baseline(arch, label, size, pairs, steps):
+def cpu_baseline(arch, label, size, pairs, steps, encoder="resnet50"):
     """The oracle timed on the host: same step (fwd + CE + bwd + AdamW), fp32, all host threads."""
     from oracle import fcsiam_ref as R
     from oracle import snunet_ref as SN
@@ -98,7 +131,7 @@ def cpu_baseline(arch, label, size, pairs, steps):
     a, b, lab = synth.make_batch(pairs, size, size, seed=1337)
     A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab)
     if arch == "segcd":
-        return cpu_baseline_segcd(size, pairs, steps)
+        return cpu_baseline_segcd(size, pairs, steps, encoder)
     st = SN.synth_state(3, label, seed=1) if arch == "snunet" else R.synth_state(arch, 3, label, seed=1)
     params = [v.requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
     opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
@@ -168,7 +201,8 @@ def main():
     if args.model == "segcd":       # train_pse_cd.py:426-431: SegCD(resnet50), 1 class, Adam(lr 1e-3), BCE+Dice on sigmoid(change)
         from stcd_amd.segcd import SegCD
         args.label = 1
-        model = SegCD(encoder_name="resnet50", encoder_weights=None, in_channels=3, classes=1, dtype=args.dtype).to(dev).train()
+        model = SegCD(encoder_name=args.encoder, encoder_weights=None, in_channels=3, classes=1, dtype=args.dtype).to(dev).train()
+        NAMES["segcd"] = "SegCD-" + args.encoder
     else:
         cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub, "snunet": SNUNet_ECAM}[args.model]
         model = cls(3, args.label, dtype=args.dtype).to(dev).train()
@@ -253,7 +287,8 @@ def main():
         "pairs_per_sec_per_rank": [round(v, 2) for v in rank_rates],
     }
     # whole-step roofline: SURVEY 8d's algorithmic figures per pair x pairs per step / measured step time (all ranks)
-    fl_pp, by_pp = ALG_PER_PAIR_256[args.model]
+    fl_pp, by_pp = segcd_alg(args.encoder) if args.model == "segcd" else ALG_PER_PAIR_256[args.model]
+    pmc_key = args.model if (args.model != "segcd" or args.encoder == "resnet50") else "segcd_" + args.encoder
     sc = (args.size / 256.0) ** 2
     step_s = elapsed / args.steps
     peak_tf_ = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
@@ -294,7 +329,7 @@ def main():
         else:
             ach, peak, unit = p["flops"] / secs / 1e12, peak_tf, "TFLOP/s"
         tot_ms = sum(v["ms"] for v in prof.values())
-        traffic, traffic_src = pmc_traffic("stcd::" + dom, args.model)
+        traffic, traffic_src = pmc_traffic("stcd::" + dom, pmc_key)
         result["roofline"] = {
             "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src,
@@ -310,7 +345,7 @@ def main():
             "launches_per_step_all_kernels": sum(v["launches"] for v in kern.values()) // nprof,
             "step": step_roof,
         }
-        ts, ts_src = pmc_step_traffic(args.model)
+        ts, ts_src = pmc_step_traffic(pmc_key)
         result["roofline"]["traffic_step"] = ts
         result["roofline"]["traffic_step_source"] = ts_src
         if ts:
@@ -318,7 +353,7 @@ def main():
     elif rank == 0:
         result["roofline"] = {"step": step_roof}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.model, args.label, args.size, args.cpu_pairs, args.cpu_steps)
+        result["cpu_baseline"] = cpu_baseline(args.model, args.label, args.size, args.cpu_pairs, args.cpu_steps, args.encoder)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -40,6 +40,12 @@ extern "C" {
                             * segmentation_models_pytorch/decoders/unet/model.py:267-332).  Its forward returns THREE maps
                             * (mask_t1, mask_t2, change): `logits` / `grad_logits` of stcd_forward / stcd_backward hold
                             * [3*batch, label_ch, H, W] floats in that order; H and W must be divisible by 32. */
+/* the same class over the other plain ResNet encoders of the reference's registry
+ * (segmentation_models_pytorch/encoders/resnet.py:126-171; blocks: models/resnet.py:37-75 BasicBlock, :78-124 Bottleneck) */
+#define STCD_ARCH_SEGCD_R18 5  /* encoder_name="resnet18":  BasicBlock  [2, 2, 2, 2]  */
+#define STCD_ARCH_SEGCD_R34 6  /* encoder_name="resnet34":  BasicBlock  [3, 4, 6, 3]  */
+#define STCD_ARCH_SEGCD_R101 7 /* encoder_name="resnet101": Bottleneck  [3, 4, 23, 3] */
+#define STCD_ARCH_SEGCD_R152 8 /* encoder_name="resnet152": Bottleneck  [3, 8, 36, 3] */
 
 /* arithmetic / storage type of activations. Parameters, gradients, BN statistics, logits: always fp32. */
 #define STCD_DTYPE_F32 0  /* parity mode: fp32 storage, fp32 FMA */
@@ -125,7 +131,7 @@ int stcd_grad_stage_range(const stcd_engine* e, int stage, int64_t* begin, int64
 /* ---- test introspection: the named activation / gradient tensors of the CURRENT configuration inside the workspace, so a
  *      parity test can check every layer of a deep network IN PLACE (layer output against a convolution of the layer's own
  *      stored input, weight gradient against the stored input and output gradient ...) at per-op tolerance, independent of how
- *      rounding differences grow through the depth.  Filled for STCD_ARCH_SEGCD ("<conv name>.in|.Y|.A|.dY|.dIn"); 0 tensors
+ *      rounding differences grow through the depth.  Filled for the STCD_ARCH_SEGCD* families ("<conv name>.in|.Y|.A|.dY|.dIn"); 0 tensors
  *      for the other families.  NHWC: element (n, y, x, ch) at offset_bytes + (((n*h + y)*w + x)*ld + ch) * elem_size.
  *      stcd_set_debug bit 0 (before stcd_configure): every layer writes its input gradient to a buffer of its own (the
  *      producer gathers it) instead of in place into the producer's gradient tensor, so ".dIn" survives the backward. */

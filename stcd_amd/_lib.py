@@ -16,8 +16,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstcd_hip.so")
 
 ARCH_DIFF, ARCH_CONC, ARCH_SUB, ARCH_SNUNET, ARCH_SEGCD = 0, 1, 2, 3, 4
+ARCH_SEGCD_R18, ARCH_SEGCD_R34, ARCH_SEGCD_R101, ARCH_SEGCD_R152 = 5, 6, 7, 8
 DTYPE_F32, DTYPE_BF16 = 0, 1
-ARCH_IDS = {"diff": ARCH_DIFF, "conc": ARCH_CONC, "sub": ARCH_SUB, "snunet": ARCH_SNUNET, "segcd": ARCH_SEGCD}
+ARCH_IDS = {"diff": ARCH_DIFF, "conc": ARCH_CONC, "sub": ARCH_SUB, "snunet": ARCH_SNUNET, "segcd": ARCH_SEGCD,
+            "segcd_resnet50": ARCH_SEGCD, "segcd_resnet18": ARCH_SEGCD_R18, "segcd_resnet34": ARCH_SEGCD_R34,
+            "segcd_resnet101": ARCH_SEGCD_R101, "segcd_resnet152": ARCH_SEGCD_R152}
 DTYPE_IDS = {"fp32": DTYPE_F32, "f32": DTYPE_F32, "bf16": DTYPE_BF16}
 
 

@@ -185,7 +185,9 @@ struct stcd_engine_impl {
     int g_stem = -1, g_head_conv = -1;
     int debug_flags = 0;
     std::vector<stcd_ws_tensor> ws_tensors;
-    std::vector<std::array<int, 4>> g_blocks;                // (L1, L2, L3, Ld or -1) per bottleneck
+    std::vector<std::array<int, 4>> g_blocks;                // per residual block: (L1, L2, L3, Ld or -1) bottleneck; (L1, -1, L2, Ld or -1) basic
+    int seg_x = 4, seg_layers[4] = {3, 4, 6, 3};             // block expansion (4: Bottleneck, 1: BasicBlock) and blocks per stage
+    TRef g_pool_idc;                                         // identity-branch contribution of layer1.0 to d(max-pool output)
     std::vector<std::array<int, 2>> g_dec;                   // (conv1, conv2) per decoder block
     TRef gP0, gdP0, gX3, gdX3, gFuseTmp;
     int64_t g_pool_idx = -1;                                  // winners of the stem's 3x3 max-pool (bytes)
@@ -1756,7 +1758,9 @@ static int backward_snunet(stcd_engine& e, const float* grad_logits, const float
 // the modules are called once per date); only the head combines them.  Gradients of tensors with several consumers
 // (identity branches, decoder skips) are never accumulated by extra kernels: every consumer writes its own contribution
 // buffer and the producer's BatchNorm-backward reduction gathers them (SliceViews).
-static const int RS_LAYERS[4] = {3, 4, 6, 3}, RS_PLANES[4] = {64, 128, 256, 512};
+static const int RS_PLANES[4] = {64, 128, 256, 512};
+static bool is_segcd(int arch) { return arch >= STCD_ARCH_SEGCD && arch <= STCD_ARCH_SEGCD_R152; }
+
 static const int SEG_DEC[5] = {256, 128, 64, 32, 16};
 
 static int add_glayer(stcd_engine& e, const std::string& conv_name, const std::string& bn_name, int kind, int cin, int cout, bool relu,
@@ -1769,23 +1773,48 @@ static int add_glayer(stcd_engine& e, const std::string& conv_name, const std::s
     return (int)e.g_layers.size() - 1;
 }
 
+// encoders/resnet.py:126-171: block type and depths of the plain ResNet registry entries
+static void segcd_encoder_cfg(stcd_engine& e) {
+    static const int L18[4] = {2, 2, 2, 2}, L34[4] = {3, 4, 6, 3}, L101[4] = {3, 4, 23, 3}, L152[4] = {3, 8, 36, 3};
+    const int* l = L34;
+    e.seg_x = 4;
+    switch (e.arch) {
+        case STCD_ARCH_SEGCD_R18: e.seg_x = 1; l = L18; break;
+        case STCD_ARCH_SEGCD_R34: e.seg_x = 1; l = L34; break;
+        case STCD_ARCH_SEGCD_R101: l = L101; break;
+        case STCD_ARCH_SEGCD_R152: l = L152; break;
+        default: break;                                                // resnet50: Bottleneck, [3, 4, 6, 3]
+    }
+    for (int i = 0; i < 4; ++i) e.seg_layers[i] = l[i];
+}
+
 static void build_segcd_tables(stcd_engine& e) {
+    segcd_encoder_cfg(e);
+    const int X = e.seg_x;
     e.g_layers.clear(); e.g_blocks.clear(); e.g_dec.clear();
     e.g_stem = add_glayer(e, "encoder.conv1", "encoder.bn1", K_STEM7, e.in_ch, 64, true, false);
     int inpl = 64;
     for (int li = 0; li < 4; ++li)
-        for (int b = 0; b < RS_LAYERS[li]; ++b) {
+        for (int b = 0; b < e.seg_layers[li]; ++b) {
             const int w = RS_PLANES[li], stride = (b == 0 && li > 0) ? 2 : 1;
             const std::string pre = "encoder.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            // ResNet._make_layer (models/resnet.py:165-187): a down-sample where the stride or the width changes
+            const bool down = b == 0 && (stride != 1 || inpl != w * X);
             std::array<int, 4> blk;
-            blk[0] = add_glayer(e, pre + ".conv1", pre + ".bn1", K_CONV1, inpl, w, true, true);
-            blk[1] = add_glayer(e, pre + ".conv2", pre + ".bn2", stride == 2 ? K_CONV3_S2 : K_CONV3, w, w, true, true);
-            blk[2] = add_glayer(e, pre + ".conv3", pre + ".bn3", K_CONV1, w, 4 * w, true, true);
-            blk[3] = b == 0 ? add_glayer(e, pre + ".downsample.0", pre + ".downsample.1", stride == 2 ? K_CONV1_S2 : K_CONV1, inpl, 4 * w, false, true) : -1;
+            if (X == 4) {      // Bottleneck (models/resnet.py:78-124): 1x1, 3x3 (carries the stride), 1x1
+                blk[0] = add_glayer(e, pre + ".conv1", pre + ".bn1", K_CONV1, inpl, w, true, true);
+                blk[1] = add_glayer(e, pre + ".conv2", pre + ".bn2", stride == 2 ? K_CONV3_S2 : K_CONV3, w, w, true, true);
+                blk[2] = add_glayer(e, pre + ".conv3", pre + ".bn3", K_CONV1, w, 4 * w, true, true);
+            } else {           // BasicBlock (models/resnet.py:37-75): 3x3 (carries the stride), 3x3
+                blk[0] = add_glayer(e, pre + ".conv1", pre + ".bn1", stride == 2 ? K_CONV3_S2 : K_CONV3, inpl, w, true, true);
+                blk[1] = -1;
+                blk[2] = add_glayer(e, pre + ".conv2", pre + ".bn2", K_CONV3, w, w, true, true);
+            }
+            blk[3] = down ? add_glayer(e, pre + ".downsample.0", pre + ".downsample.1", stride == 2 ? K_CONV1_S2 : K_CONV1, inpl, X * w, false, true) : -1;
             e.g_blocks.push_back(blk);
-            inpl = 4 * w;
+            inpl = X * w;
         }
-    static const int ENC_OUT[5] = {2048, 1024, 512, 256, 64};
+    const int ENC_OUT[5] = {512 * X, 256 * X, 128 * X, 64 * X, 64};
     int cin = ENC_OUT[0];
     for (int i = 0; i < 5; ++i) {
         const int cskip = i < 4 ? ENC_OUT[i + 1] : 0, cout = SEG_DEC[i];
@@ -1831,21 +1860,27 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
     std::vector<int> stage_out;                                               // L3 of the last block of layer1..4
     size_t bi = 0;
     for (int li = 0; li < 4; ++li)
-        for (int b = 0; b < RS_LAYERS[li]; ++b, ++bi) {
+        for (int b = 0; b < e.seg_layers[li]; ++b, ++bi) {
             const std::array<int, 4>& blk = e.g_blocks[bi];
             const int stride = (b == 0 && li > 0) ? 2 : 1;
-            GLayer& L1 = e.g_layers[blk[0]]; GLayer& L2 = e.g_layers[blk[1]]; GLayer& L3 = e.g_layers[blk[2]];
-            shape(L1, cur, curC, h, w, 1);
-            shape(L2, L1.A, L1.C, h, w, stride);
             const int ho = h / stride, wo = w / stride;
+            GLayer& L1 = e.g_layers[blk[0]]; GLayer& L3 = e.g_layers[blk[2]];
+            GLayer* L2 = blk[1] >= 0 ? &e.g_layers[blk[1]] : nullptr;
+            if (L2) {          // Bottleneck: the 3x3 in the middle carries the stride
+                shape(L1, cur, curC, h, w, 1);
+                shape(*L2, L1.A, L1.C, h, w, stride);
+            } else {           // BasicBlock: the first 3x3 carries it
+                shape(L1, cur, curC, h, w, stride);
+            }
             if (blk[3] >= 0) { GLayer& Ld = e.g_layers[blk[3]]; shape(Ld, cur, curC, h, w, stride); }
-            shape(L3, L2.A, L2.C, ho, wo, 1);
+            GLayer& Lm = L2 ? *L2 : L1;                                        // producer of the last conv's input
+            shape(L3, Lm.A, Lm.C, ho, wo, 1);
             L3.res = blk[3] >= 0 ? e.g_layers[blk[3]].A : cur;
             // gradient wiring: single-consumer tensors are written in place, the block input gets contribution buffers
             if (e.debug_flags & 1) {
-                L2.dIn = plain(N, h, w, L1.C); L1.grad_base = false; L1.grad_src.push_back(view(L2.dIn, 0, L1.C, h, w));
-                L3.dIn = plain(N, ho, wo, L2.C); L2.grad_base = false; L2.grad_src.push_back(view(L3.dIn, 0, L2.C, ho, wo));
-            } else { L2.dIn = L1.dA; L3.dIn = L2.dA; }
+                if (L2) { L2->dIn = plain(N, h, w, L1.C); L1.grad_base = false; L1.grad_src.push_back(view(L2->dIn, 0, L1.C, h, w)); }
+                L3.dIn = plain(N, ho, wo, Lm.C); Lm.grad_base = false; Lm.grad_src.push_back(view(L3.dIn, 0, Lm.C, ho, wo));
+            } else { if (L2) L2->dIn = L1.dA; L3.dIn = Lm.dA; }
             L1.dIn = (prev_out < 0) ? e.gdP0 : plain(N, h, w, curC);
             TRef idc;                                                          // identity-branch contribution to d(cur)
             if (blk[3] >= 0) { GLayer& Ld = e.g_layers[blk[3]]; L3.dRes = Ld.dA; Ld.dIn = plain(N, h, w, curC); idc = Ld.dIn; }
@@ -1855,12 +1890,13 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
                 Pv.grad_base = false;
                 Pv.grad_src.push_back(view(L1.dIn, 0, curC, h, w));
                 Pv.grad_src.push_back(view(idc, 0, curC, h, w));
-            }
-            for (int k : {blk[0], blk[1]}) { GStep st; st.layer = k; e.g_fwd.push_back(st); }
+            } else e.g_pool_idc = idc;
+            { GStep st; st.layer = blk[0]; e.g_fwd.push_back(st); }
+            if (L2) { GStep st; st.layer = blk[1]; e.g_fwd.push_back(st); }
             if (blk[3] >= 0) { GStep st; st.layer = blk[3]; e.g_fwd.push_back(st); }
             { GStep st; st.layer = blk[2]; e.g_fwd.push_back(st); }
             cur = L3.A; curC = L3.C; h = ho; w = wo; prev_out = blk[2];
-            if (b == RS_LAYERS[li] - 1) stage_out.push_back(blk[2]);
+            if (b == e.seg_layers[li] - 1) stage_out.push_back(blk[2]);
         }
     // ---- decoder: x = f5; block i: nearest x2 into cat_i[:, :Cx], skip (written by its encoder producer) in cat_i[:, Cx:]
     const int skip_layer[4] = {stage_out[2], stage_out[1], stage_out[0], e.g_stem};          // f4, f3, f2, f1
@@ -2225,9 +2261,9 @@ static int backward_segcd(stcd_engine& e, const float* grad_logits, const float*
         if (st.kind == GS_LAYER) glayer_backward(c, e.g_layers[st.layer]);
         else if (st.kind == GS_UPSAMPLE)
             launch_upsample2_bwd(dt, c.at(st.ddst.off), st.ddst.ld, c.at(st.dsrc.off), st.dsrc.ld, st.N, st.h, st.w, st.C, s);
-        else {      // max-pool: d(P0) = conv1 contribution (written in place) + down-sample branch contribution of layer1.0
-            const GLayer& Ld = e.g_layers[e.g_blocks[0][3]];
-            launch_slice(dt, c.at(st.ddst.off), st.ddst.ld, c.at(Ld.dIn.off), Ld.dIn.ld, (int64_t)st.N * (st.h / 2) * (st.w / 2), st.C, 1, s);
+        else {      // max-pool: d(P0) = conv1 contribution (written in place) + identity-branch contribution of layer1.0 (its
+                    // down-sample's data gradient for Bottleneck encoders, the gated residual gradient itself for BasicBlock ones)
+            launch_slice(dt, c.at(st.ddst.off), st.ddst.ld, c.at(e.g_pool_idc.off), e.g_pool_idc.ld, (int64_t)st.N * (st.h / 2) * (st.w / 2), st.C, 1, s);
             launch_maxpool3_bwd(dt, c.at<unsigned char>(e.g_pool_idx), c.at(st.ddst.off), st.ddst.ld, c.at(st.dsrc.off), st.dsrc.ld, st.N, st.h, st.w, st.C, s);
         }
     }
@@ -2247,7 +2283,7 @@ int stcd_abi_version(void) { return STCD_ABI_VERSION; }
 
 int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out) {
     STCD_CHECK(out != nullptr, "out is null");
-    STCD_CHECK(arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD, "unknown arch");
+    STCD_CHECK(arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD_R152, "unknown arch");
     STCD_CHECK(in_ch >= 1 && in_ch <= 8, "in_ch must be in [1,8]");
     STCD_CHECK(label_ch >= 1 && label_ch <= 8, "label_ch must be in [1,8]");
     STCD_CHECK(dtype == STCD_DTYPE_F32 || dtype == STCD_DTYPE_BF16, "unknown dtype");
@@ -2272,7 +2308,7 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
     env = getenv("STCD_WGRAD_MIN_TILES");
     if (env && atoi(env) > 0) e->wgroup_min_tiles = atoi(env);
     if (arch == STCD_ARCH_SNUNET) build_snunet_tables(*e);
-    else if (arch == STCD_ARCH_SEGCD) build_segcd_tables(*e);
+    else if (is_segcd(arch)) build_segcd_tables(*e);
     else build_fcsiam_tables(*e);
     *out = e.release();
     return 0;
@@ -2309,7 +2345,7 @@ int stcd_configure(stcd_engine* e, int batch, int height, int width) {
     if (e->arch == STCD_ARCH_SNUNET) {
         STCD_CHECK(height % 16 == 0 && width % 16 == 0, "SNUNet needs height and width divisible by 16 (the reference's cat of up-sampled maps fails otherwise)");
         if (configure_snunet(*e, batch, height, width)) return 1;
-    } else if (e->arch == STCD_ARCH_SEGCD) {
+    } else if (is_segcd(e->arch)) {
         STCD_CHECK(height % 32 == 0 && width % 32 == 0, "SegCD needs height and width divisible by 32 (five stride-2 stages; the reference's cat of the x2 up-sampled maps fails otherwise)");
         STCD_CHECK((int64_t)3 * batch * height * width * 16 < ((int64_t)1 << 31), "tensor too large for 32-bit pixel indexing");
         if (configure_segcd(*e, batch, height, width)) return 1;
@@ -2345,7 +2381,7 @@ int stcd_forward(stcd_engine* e, const float* x1, const float* x2, const float* 
     e->fwd_training = false;
     int rc = e->arch == STCD_ARCH_SNUNET
                  ? forward_snunet(*e, x1, x2, params, bn_running, training, logits, workspace, (hipStream_t)hip_stream)
-                 : e->arch == STCD_ARCH_SEGCD
+                 : is_segcd(e->arch)
                        ? forward_segcd(*e, x1, x2, params, bn_running, training, logits, workspace, (hipStream_t)hip_stream)
                        : forward_fcsiam(*e, x1, x2, params, bn_running, dropout_masks, dropout_seed, training, logits, workspace,
                                         (hipStream_t)hip_stream);
@@ -2360,7 +2396,7 @@ int stcd_backward(stcd_engine* e, const float* grad_logits, const float* params,
     STCD_CHECK(grad_logits && params && grads && workspace, "null pointer argument");
     STCD_CHECK(stage >= -1 && stage <= 1, "stage must be -1, 0 or 1");
     if (e->arch == STCD_ARCH_SNUNET) return backward_snunet(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
-    if (e->arch == STCD_ARCH_SEGCD) return backward_segcd(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
+    if (is_segcd(e->arch)) return backward_segcd(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
     return backward_fcsiam(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
 }
 

@@ -1,6 +1,8 @@
 """``SegCD``: the ResNet-50 UNet change detector the reference's scripts train
 (``smp.SegCD(encoder_name="resnet50", encoder_weights="imagenet")``, /root/reference/train_pse_cd.py:419-427,
-train_stcd.py:631-638), as a drop-in module over the HIP engine.
+train_stcd.py:631-638), as a drop-in module over the HIP engine -- and the same class over the other plain ResNet encoders of
+the reference's registry (encoders/resnet.py:126-171): resnet18 / resnet34 (BasicBlock, models/resnet.py:37-75), resnet101 /
+resnet152 (Bottleneck, :78-124).
 
 Same constructor arguments, ``forward(A, B) -> (mask_t1, mask_t2, change)`` contract and ``state_dict`` keys / shapes as
 /root/reference/segmentation_models_pytorch/decoders/unet/model.py:267-332 (encoder: encoders/resnet.py:37-70 over
@@ -20,10 +22,18 @@ import torch.nn as nn
 from ._lib import StcdError
 from .modules import HipChangeDetector
 
-_LAYERS = (3, 4, 6, 3)
 _PLANES = (64, 128, 256, 512)
-_ENC_OUT = (3, 64, 256, 512, 1024, 2048)
-_IMAGENET_URL = "https://download.pytorch.org/models/resnet50-19c8e357.pth"      # what `encoder_weights="imagenet"` names
+# encoders/resnet.py:126-171 ("params" of each registry entry): name -> (block expansion, blocks per stage), and the file
+# `encoder_weights="imagenet"` names for it (pretrainedmodels' torchvision URLs)
+_ENCODERS = {"resnet18": (1, (2, 2, 2, 2), "resnet18-5c106cde.pth"), "resnet34": (1, (3, 4, 6, 3), "resnet34-333f7ec4.pth"),
+             "resnet50": (4, (3, 4, 6, 3), "resnet50-19c8e357.pth"), "resnet101": (4, (3, 4, 23, 3), "resnet101-5d3b4d8f.pth"),
+             "resnet152": (4, (3, 8, 36, 3), "resnet152-b121ed2d.pth")}
+_URL_ROOT = "https://download.pytorch.org/models/"
+
+
+def _enc_out(name):
+    x = _ENCODERS[name][0]
+    return (3, 64, 64 * x, 128 * x, 256 * x, 512 * x)
 
 
 class _Bottleneck(nn.Module):
@@ -43,27 +53,43 @@ class _Bottleneck(nn.Module):
         self.stride = stride
 
 
-class _ResNet50Encoder(nn.Module):
-    """ResNetEncoder(resnet50) holders (encoders/resnet.py:37-70)."""
+class _BasicBlock(nn.Module):
+    """BasicBlock holders (models/resnet.py:37-75): two 3x3 convs, the stride on the first."""
+    expansion = 1
 
-    def __init__(self, in_channels):
+    def __init__(self, inplanes, planes, stride, downsample):
         super().__init__()
-        self.out_channels = (in_channels,) + _ENC_OUT[1:]
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class _ResNetEncoder(nn.Module):
+    """ResNetEncoder holders (encoders/resnet.py:37-70) for one registry entry."""
+
+    def __init__(self, name, in_channels):
+        super().__init__()
+        x, layers, _ = _ENCODERS[name]
+        self.out_channels = (in_channels,) + _enc_out(name)[1:]
         self._depth, self._in_channels = 5, in_channels
         self.conv1 = nn.Conv2d(in_channels, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         inpl = 64
-        for li, (nb, pl) in enumerate(zip(_LAYERS, _PLANES)):
+        for li, (nb, pl) in enumerate(zip(layers, _PLANES)):
             blocks = []
             for b in range(nb):
                 stride = 2 if (b == 0 and li > 0) else 1
                 down = None
-                if b == 0:
-                    down = nn.Sequential(nn.Conv2d(inpl, pl * 4, kernel_size=1, stride=stride, bias=False), nn.BatchNorm2d(pl * 4))
-                blocks.append(_Bottleneck(inpl, pl, stride, down))
-                inpl = pl * 4
+                if b == 0 and (stride != 1 or inpl != pl * x):           # ResNet._make_layer (models/resnet.py:165-187)
+                    down = nn.Sequential(nn.Conv2d(inpl, pl * x, kernel_size=1, stride=stride, bias=False), nn.BatchNorm2d(pl * x))
+                blocks.append((_Bottleneck if x == 4 else _BasicBlock)(inpl, pl, stride, down))
+                inpl = pl * x
             setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
         for m in self.modules():                      # models/resnet.py:157-163
             if isinstance(m, nn.Conv2d):
@@ -85,9 +111,9 @@ class _DecoderBlock(nn.Module):
 
 
 class _UnetDecoder(nn.Module):
-    def __init__(self, decoder_channels):
+    def __init__(self, encoder_channels, decoder_channels):
         super().__init__()
-        enc = list(_ENC_OUT[1:])[::-1]
+        enc = list(encoder_channels[1:])[::-1]
         ins = [enc[0]] + list(decoder_channels[:-1])
         skips = enc[1:] + [0]
         self.center = nn.Identity()
@@ -104,10 +130,11 @@ class SegCD(HipChangeDetector):
     """``SegCD(encoder_name="resnet50", encoder_weights=..., in_channels=3, classes=1).forward(A, B)`` ->
     ``(mask_t1, mask_t2, change)`` with ``change = min(head(|d1 - d2|), |mask_t1 - mask_t2|)`` (model.py:316-332).
 
-    Supported configuration = the one the scripts use: ResNet-50 encoder, depth 5, BatchNorm decoder (256,128,64,32,16), no
-    attention, no activation, no aux head; anything else raises NotImplementedError.  ``encoder_weights``: None (the
-    encoder's own random init), a path to a ResNet-50 ``state_dict`` file, or "imagenet" (fetched through torch.hub like the
-    reference does: needs the file in the hub cache when there is no network).  H and W must be multiples of 32."""
+    Supported configurations: the one the scripts use (resnet50) and the other plain ResNet encoders of the registry
+    (resnet18 / 34 / 101 / 152); depth 5, BatchNorm decoder (256,128,64,32,16), no attention, no activation, no aux head;
+    anything else raises NotImplementedError.  ``encoder_weights``: None (the encoder's own random init), a path to that
+    ResNet's ``state_dict`` file, or "imagenet" (fetched through torch.hub like the reference does: needs the file in the hub
+    cache when there is no network).  H and W must be multiples of 32."""
 
     ARCH = "segcd"
     OUT_MAPS = 3
@@ -116,17 +143,18 @@ class SegCD(HipChangeDetector):
                  decoder_use_batchnorm: bool = True, decoder_channels: List[int] = (256, 128, 64, 32, 16),
                  decoder_attention_type: Optional[str] = None, in_channels: int = 3, classes: int = 1, activation=None,
                  aux_params: Optional[dict] = None, dtype: Optional[str] = None):
-        if (encoder_name != "resnet50" or encoder_depth != 5 or decoder_use_batchnorm is not True or tuple(decoder_channels) != (256, 128, 64, 32, 16)
+        if (encoder_name not in _ENCODERS or encoder_depth != 5 or decoder_use_batchnorm is not True or tuple(decoder_channels) != (256, 128, 64, 32, 16)
                 or decoder_attention_type is not None or activation is not None or aux_params is not None):
-            raise NotImplementedError("SegCD on the HIP engine: resnet50 encoder, depth 5, BatchNorm decoder (256,128,64,32,16), "
-                                      "no attention / activation / aux head (the configuration train_pse_cd.py:426 builds)")
+            raise NotImplementedError("SegCD on the HIP engine: resnet18 / 34 / 50 / 101 / 152 encoder, depth 5, BatchNorm decoder "
+                                      "(256,128,64,32,16), no attention / activation / aux head (train_pse_cd.py:426 builds resnet50)")
         if not 1 <= in_channels <= 8:
             raise NotImplementedError("SegCD on the HIP engine: 1..8 input channels")
+        self.ARCH = "segcd_" + encoder_name
         super().__init__(in_channels, classes, dtype)
-        self.encoder = _ResNet50Encoder(in_channels)
+        self.encoder = _ResNetEncoder(encoder_name, in_channels)
         self.inchannels = in_channels
         self.encoder_channels = self.encoder.out_channels
-        self.decoder = _UnetDecoder(tuple(decoder_channels))
+        self.decoder = _UnetDecoder(self.encoder.out_channels, tuple(decoder_channels))
         self.segmentation_head = nn.Sequential(nn.Conv2d(decoder_channels[-1], classes, kernel_size=3, padding=1), nn.Identity(), nn.Identity())
         nn.init.xavier_uniform_(self.segmentation_head[0].weight)      # base/initialization.py:22-27
         nn.init.constant_(self.segmentation_head[0].bias, 0)
@@ -140,10 +168,10 @@ class SegCD(HipChangeDetector):
         if os.path.exists(weights):
             sd = torch.load(weights, map_location="cpu")
         elif weights == "imagenet":
-            sd = torch.hub.load_state_dict_from_url(_IMAGENET_URL, map_location="cpu")
+            sd = torch.hub.load_state_dict_from_url(_URL_ROOT + _ENCODERS[self._ctor["encoder_name"]][2], map_location="cpu")
         else:
-            raise KeyError("Wrong pretrained weights `{}` for encoder `resnet50`. Available options are: "
-                           "['imagenet', <path to a state_dict file>]".format(weights))
+            raise KeyError("Wrong pretrained weights `{}` for encoder `{}`. Available options are: "
+                           "['imagenet', <path to a state_dict file>]".format(weights, self._ctor["encoder_name"]))
         sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
         if self.inchannels != 3:          # encoders/_utils.py patch_first_conv: 1 channel = sum, otherwise cycle RGB scaled by 3/C
             w = sd["conv1.weight"]

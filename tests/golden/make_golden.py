@@ -435,7 +435,7 @@ def g8_contrastive():
 
 
 # ------------------------------------------------------------------------------ G10
-def _reference_segcd(classes=1):
+def _reference_segcd(classes=1, encoder="resnet50"):
     """The reference's own pieces, assembled exactly as SegCD.__init__ / forward state (decoders/unet/model.py:267-332).
     The package `segmentation_models_pytorch` cannot be imported (its __init__ pulls timm; encoders/resnet.py pulls
     torchvision), so: the ResNet is the reference's models/resnet.py (the torchvision code ResNetEncoder subclasses), and
@@ -443,7 +443,9 @@ def _reference_segcd(classes=1):
     package object -- no stand-in for any missing library is written."""
     import importlib.util
     import types
-    from models.resnet import ResNet, Bottleneck
+    from models.resnet import ResNet, Bottleneck, BasicBlock
+    from oracle import segcd_ref
+    expansion, layers = segcd_ref.ENCODERS[encoder]          # encoders/resnet.py:126-171 "params" of each registry entry
     root = "/root/reference/segmentation_models_pytorch"
     if "segmentation_models_pytorch" not in sys.modules:
         pkg = types.ModuleType("segmentation_models_pytorch")
@@ -457,9 +459,9 @@ def _reference_segcd(classes=1):
     class RefSegCD(nn.Module):
         def __init__(self):
             super().__init__()
-            self.encoder = ResNet(Bottleneck, [3, 4, 6, 3])            # resnet50 (encoders/resnet.py:"resnet50" params)
+            self.encoder = ResNet(Bottleneck if expansion == 4 else BasicBlock, list(layers))
             del self.encoder.fc, self.encoder.avgpool                   # ResNetEncoder.__init__ (encoders/resnet.py:44-45)
-            self.decoder = dec_mod.UnetDecoder(encoder_channels=(3, 64, 256, 512, 1024, 2048), decoder_channels=(256, 128, 64, 32, 16),
+            self.decoder = dec_mod.UnetDecoder(encoder_channels=segcd_ref.enc_out(encoder), decoder_channels=(256, 128, 64, 32, 16),
                                                n_blocks=5, use_batchnorm=True, center=False, attention_type=None)
             self.segmentation_head = SegmentationHead(in_channels=16, out_channels=classes, activation=None, kernel_size=3)
 
@@ -485,22 +487,22 @@ def _reference_segcd(classes=1):
     return RefSegCD()
 
 
-def _segcd_fixture(fname, tag, seed, classes, B, H, W):
+def _segcd_fixture(fname, tag, seed, classes, B, H, W, encoder="resnet50", full_for=None):
     from oracle import segcd_ref
     print(tag)
     d = {"seed": seed}
-    m = _reference_segcd(classes)
+    m = _reference_segcd(classes, encoder)
     names = [k for k in m.state_dict().keys()]
-    assert names == [n for n, _, _ in segcd_ref.param_specs(3, classes)], "state_dict order differs from oracle.segcd_ref.param_specs"
+    assert names == [n for n, _, _ in segcd_ref.param_specs(3, classes, encoder)], "state_dict order differs from oracle.segcd_ref.param_specs"
     x1, x2 = rand_pair(seed + 1, B, H, W)
     d["x1"], d["x2"] = t2n(x1), t2n(x2)
-    m.load_state_dict(segcd_ref.synth_state(3, classes, seed, perturb_running=True))
+    m.load_state_dict(segcd_ref.synth_state(3, classes, seed, perturb_running=True, encoder=encoder))
     m.eval()
     with torch.no_grad():
         o = m(x1, x2)
     d["eval/m1"], d["eval/m2"], d["eval/change"] = (t2n(t) for t in o)
-    m = _reference_segcd(classes)
-    m.load_state_dict(segcd_ref.synth_state(3, classes, seed))
+    m = _reference_segcd(classes, encoder)
+    m.load_state_dict(segcd_ref.synth_state(3, classes, seed, encoder=encoder))
     m.train()
     m1, m2, ch = m(x1, x2)
     rng = np.random.default_rng(seed + 4)
@@ -513,7 +515,9 @@ def _segcd_fixture(fname, tag, seed, classes, B, H, W):
     d["train/m1"], d["train/m2"], d["train/change"], d["loss"] = t2n(m1), t2n(m2), t2n(ch), loss.item()
     d.update(grad_summary(m))
     sd = m.state_dict()
-    for k in ("encoder.bn1", "encoder.layer1.0.downsample.1", "encoder.layer4.2.bn3", "decoder.blocks.0.conv1.1", "decoder.blocks.4.conv2.1"):
+    last = f"encoder.layer4.{segcd_ref.ENCODERS[encoder][1][3] - 1}.bn{3 if segcd_ref.ENCODERS[encoder][0] == 4 else 2}"
+    for k in ("encoder.bn1", "encoder.layer2.0.downsample.1" if encoder != "resnet50" else "encoder.layer1.0.downsample.1", last,
+              "decoder.blocks.0.conv1.1", "decoder.blocks.4.conv2.1"):
         d[f"rs/{k}.running_mean"], d[f"rs/{k}.running_var"] = t2n(sd[f"{k}.running_mean"]), t2n(sd[f"{k}.running_var"])
         d[f"rs/{k}.num_batches_tracked"] = t2n(sd[f"{k}.num_batches_tracked"])
     save(fname, **d)
@@ -529,9 +533,25 @@ def g11_segcd():
     _segcd_fixture("g11_segcd_2cls.npz", "G11 SegCD, 2 classes, 3 x 96 x 64", 1100, 2, 3, 96, 64)
 
 
+def g12_segcd_r18():
+    """SegCD over the BasicBlock encoders of the registry (encoders/resnet.py:126-144): resnet18 ..."""
+    _segcd_fixture("g12_segcd_r18.npz", "G12 SegCD resnet18", 1200, 1, 2, 64, 64, encoder="resnet18")
+
+
+def g13_segcd_r34():
+    """... resnet34 (two classes, 3 x 64 x 96) ..."""
+    _segcd_fixture("g13_segcd_r34.npz", "G13 SegCD resnet34, 2 classes, 3 x 64 x 96", 1300, 2, 3, 64, 96, encoder="resnet34")
+
+
+def g14_segcd_r101():
+    """... and the deeper Bottleneck encoder resnet101 ([3, 4, 23, 3]); resnet152 differs from it by depths only."""
+    _segcd_fixture("g14_segcd_r101.npz", "G14 SegCD resnet101, 2 x 128 x 128", 1400, 1, 2, 128, 128, encoder="resnet101")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14"]
     fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd,
-          "g7": g7_train128, "g8": g8_contrastive, "g10": g10_segcd, "g11": g11_segcd}
+          "g7": g7_train128, "g8": g8_contrastive, "g10": g10_segcd, "g11": g11_segcd, "g12": g12_segcd_r18, "g13": g13_segcd_r34,
+          "g14": g14_segcd_r101}
     for w in which:
         fn[w]()

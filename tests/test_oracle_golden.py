@@ -190,28 +190,32 @@ def test_contrastive_loss_against_reference_vectors(golden):
         np.testing.assert_allclose(pred.grad.numpy(), g[f"{tag}/dpred"], rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("fixture,classes", [("g10_segcd.npz", 1), ("g11_segcd_2cls.npz", 2)])
-def test_segcd_eval_and_train_step_against_reference_vectors(golden, fixture, classes):
+@pytest.mark.parametrize("fixture,classes,encoder", [("g10_segcd.npz", 1, "resnet50"), ("g11_segcd_2cls.npz", 2, "resnet50"),
+                                                     ("g12_segcd_r18.npz", 1, "resnet18"), ("g13_segcd_r34.npz", 2, "resnet34"),
+                                                     ("g14_segcd_r101.npz", 1, "resnet101")])
+def test_segcd_eval_and_train_step_against_reference_vectors(golden, fixture, classes, encoder):
     """G10: the ResNet-50 UNet change detector the reference's scripts train (smp.SegCD), assembled from the reference's own
     ResNet / UnetDecoder / SegmentationHead: the three outputs in eval and train mode, the loss, every parameter's
     (sampled) gradient and BatchNorm running statistics (each BatchNorm sees date A, then date B)."""
     from oracle import segcd_ref as G
     from tests._util import check_grad
-    g = golden(fixture)        # G10: 1 class, 2 x 64 x 64; G11: 2 classes, 3 x 96 x 64
+    g = golden(fixture)        # G10: 1 class, 2 x 64 x 64; G11: 2 classes, 3 x 96 x 64; G12-G14: the BasicBlock / deeper encoders
     seed = int(g["seed"])
     x1, x2 = _t(g["x1"]), _t(g["x2"])
-    st = G.synth_state(3, classes, seed, perturb_running=True)
+    st = G.synth_state(3, classes, seed, perturb_running=True, encoder=encoder)
     with torch.no_grad():
         o = G.forward(st, x1, x2)
     for k, v in zip(("m1", "m2", "change"), o):
-        np.testing.assert_allclose(v.numpy(), g[f"eval/{k}"], rtol=2e-4, atol=2e-4)
-    st = G.synth_state(3, classes, seed)
+        # fp32 evaluation-order noise, relative to the map's scale: with synthetic running statistics the eval-mode activations of
+        # the 33-block resnet101 grow to ~4e3 (worst seen: 3.2e-4 absolute on resnet34's O(1) maps, 4e-6 of the scale on resnet101)
+        np.testing.assert_allclose(v.numpy(), g[f"eval/{k}"], rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(g[f"eval/{k}"]).max())))
+    st = G.synth_state(3, classes, seed, encoder=encoder)
     params = [k for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
     for k in params:
         st[k].requires_grad_(True)
     m1, m2, ch = G.forward(st, x1, x2, training=True)
     for k, v in zip(("m1", "m2", "change"), (m1, m2, ch)):
-        np.testing.assert_allclose(v.detach().numpy(), g[f"train/{k}"], rtol=5e-4, atol=5e-4)
+        np.testing.assert_allclose(v.detach().numpy(), g[f"train/{k}"], rtol=1e-3, atol=1e-3)       # worst seen 6.2e-4 (resnet101, 2 of 32768)
     loss = R.cd_loss(torch.sigmoid(m1), _t(g["seg_target"])) + R.cd_loss(torch.sigmoid(ch), _t(g["target"])) + 0.5 * m2.mean()
     assert abs(loss.item() - float(g["loss"])) < 1e-4
     loss.backward()
@@ -222,9 +226,11 @@ def test_segcd_eval_and_train_step_against_reference_vectors(golden, fixture, cl
         # ~110 piecewise-linear layers (ReLU gates, a 3x3 max-pool, |a-b|, min) with BatchNorms over as few as 2*2*2 samples at
         # this fixture's size: two fp32 evaluation orders of the same arithmetic (torch's fused batch_norm vs the explicit
         # formula here) already differ by 2e-2 at the stem -- the bound is 5e-2 / 0.998 for this network
-        r = check_grad(k, st[k].grad, g, rel_max=5e-2, cos_min=0.998)
+        # (resnet101's 33 blocks widen it: two fp32 evaluation orders differ by up to 5.4e-2 there -> 8e-2 / 0.996)
+        deep = encoder in ("resnet101", "resnet152")
+        r = check_grad(k, st[k].grad, g, rel_max=8e-2 if deep else 5e-2, cos_min=0.996 if deep else 0.998)
         if r:
             worst = (max(worst[0], r[0]), min(worst[1], r[1]))
     print(f"SegCD oracle vs reference: worst relative l2 {worst[0]:.2e}, worst cosine {worst[1]:.6f}")
     for k in [k for k in g if k.startswith("rs/")]:
-        np.testing.assert_allclose(st[k[3:]].detach().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(st[k[3:]].detach().numpy(), g[k], rtol=1e-4, atol=5e-5, err_msg=k)      # worst seen 1.9e-5 (resnet101 decoder mean)

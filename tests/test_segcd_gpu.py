@@ -21,21 +21,28 @@ def _loss(m1, m2, ch, seg, tgt):
     return bce_dice_with_logits(m1, seg) + bce_dice_with_logits(ch, tgt) + 0.5 * m2.mean()
 
 
-@pytest.mark.parametrize("fixture,classes", [("g10_segcd.npz", 1), ("g11_segcd_2cls.npz", 2)])
-def test_segcd_fp32_matches_reference_vectors(golden, fixture, classes):
-    g = golden(fixture)        # G10: 1 class, 2 x 64 x 64; G11: 2 classes, 3 x 96 x 64 -- both from the reference's own classes
+FIXTURES = [("g10_segcd.npz", 1, "resnet50"), ("g11_segcd_2cls.npz", 2, "resnet50"), ("g12_segcd_r18.npz", 1, "resnet18"),
+            ("g13_segcd_r34.npz", 2, "resnet34"), ("g14_segcd_r101.npz", 1, "resnet101")]
+
+
+@pytest.mark.parametrize("fixture,classes,encoder", FIXTURES)
+def test_segcd_fp32_matches_reference_vectors(golden, fixture, classes, encoder):
+    # G10: 1 class, 2 x 64 x 64; G11: 2 classes, 3 x 96 x 64; G12 / G13: the BasicBlock encoders; G14: resnet101, 2 x 128 x 128
+    # -- all from the reference's own classes
+    g = golden(fixture)
     seed = int(g["seed"])
+    deep = encoder in ("resnet101", "resnet152")          # tests/test_oracle_golden.py: two fp32 orders differ by 6e-2 at this depth
     x1, x2 = t(g["x1"]).to(DEV), t(g["x2"]).to(DEV)
-    m = SegCD(classes=classes, dtype="fp32")
-    m.load_state_dict(G.synth_state(3, classes, seed, perturb_running=True))
+    m = SegCD(encoder_name=encoder, classes=classes, dtype="fp32")
+    m.load_state_dict(G.synth_state(3, classes, seed, perturb_running=True, encoder=encoder))
     m.to(DEV).eval()
     with torch.no_grad():
         o = m(x1, x2)
-    for k, v in zip(("m1", "m2", "change"), o):
-        np.testing.assert_allclose(v.cpu().numpy(), g[f"eval/{k}"], rtol=1e-3, atol=1e-3, err_msg=k)
+    for k, v in zip(("m1", "m2", "change"), o):       # relative to the map's scale (resnet101's eval maps reach 4e3 with the synthetic statistics)
+        np.testing.assert_allclose(v.cpu().numpy(), g[f"eval/{k}"], rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(g[f"eval/{k}"]).max())), err_msg=k)
 
-    m = SegCD(classes=classes, dtype="fp32")
-    m.load_state_dict(G.synth_state(3, classes, seed))
+    m = SegCD(encoder_name=encoder, classes=classes, dtype="fp32")
+    m.load_state_dict(G.synth_state(3, classes, seed, encoder=encoder))
     m.to(DEV).train()
     m1, m2, ch = m(x1, x2)
     for k, v in zip(("m1", "m2", "change"), (m1, m2, ch)):
@@ -46,7 +53,7 @@ def test_segcd_fp32_matches_reference_vectors(golden, fixture, classes):
     for name, p in m.named_parameters():
         if float(np.abs(g["gs/" + name][1])) < 1e-12:
             continue
-        check_grad(name, p.grad, g, rel_max=SEG_REL, cos_min=SEG_COS, tag=f"fp32 SegCD vs reference {fixture[:3].upper()}")
+        check_grad(name, p.grad, g, rel_max=1.2e-1 if deep else SEG_REL, cos_min=0.992 if deep else SEG_COS, tag=f"fp32 SegCD vs reference {fixture[:3].upper()}")      # deep: worst seen 8.2e-2 / 0.9967 (oracle vs reference: 6.0e-2)
     sd = m.state_dict()
     for k in [k for k in g if k.startswith("rs/")]:     # layer4's inputs already differ by ~1e-3 relative between two fp32 evaluation orders
         np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), g[k], rtol=1e-4, atol=5e-5, err_msg=k)
@@ -99,7 +106,9 @@ def test_segcd_fp32_matches_oracle_on_other_shapes(B, H, W, cin):
 
 def test_segcd_rejects_unsupported_configs_and_sizes():
     with pytest.raises(NotImplementedError):
-        SegCD(encoder_name="resnet34")
+        SegCD(encoder_name="resnext50_32x4d")
+    with pytest.raises(NotImplementedError):
+        SegCD(encoder_name="resnet34", decoder_attention_type="scse")
     m = SegCD(dtype="fp32").to(DEV)
     with pytest.raises(Exception, match="divisible by 32"):
         m(torch.zeros(1, 3, 48, 48, device=DEV), torch.zeros(1, 3, 48, 48, device=DEV))
@@ -121,7 +130,7 @@ def _holders(m):
     for li in range(1, 5):
         for b, blk in enumerate(getattr(m.encoder, f"layer{li}")):
             pre = f"encoder.layer{li}.{b}"
-            for k in (1, 2, 3):
+            for k in (1, 2, 3) if hasattr(blk, "conv3") else (1, 2):
                 out[f"{pre}.conv{k}"] = (getattr(blk, f"conv{k}"), getattr(blk, f"bn{k}"))
             if blk.downsample is not None:
                 out[f"{pre}.downsample.0"] = (blk.downsample[0], blk.downsample[1])
@@ -131,15 +140,18 @@ def _holders(m):
     return out
 
 
-@pytest.mark.parametrize("dtype,B,H,W,cin", [("fp32", 2, 64, 64, 3), ("bf16", 2, 64, 96, 3), ("bf16", 3, 128, 128, 3), ("bf16", 2, 96, 64, 6), ("bf16", 1, 32, 64, 3), ("fp32", 5, 32, 32, 1)])
-def test_segcd_every_layer_in_place(dtype, B, H, W, cin):
+@pytest.mark.parametrize("dtype,B,H,W,cin,encoder", [("fp32", 2, 64, 64, 3, "resnet50"), ("bf16", 2, 64, 96, 3, "resnet50"), ("bf16", 3, 128, 128, 3, "resnet50"),
+                                                      ("bf16", 2, 96, 64, 6, "resnet50"), ("bf16", 1, 32, 64, 3, "resnet50"), ("fp32", 5, 32, 32, 1, "resnet50"),
+                                                      ("fp32", 2, 64, 64, 3, "resnet18"), ("bf16", 3, 96, 128, 3, "resnet18"), ("bf16", 2, 64, 64, 4, "resnet34"),
+                                                      ("bf16", 2, 64, 96, 3, "resnet101"), ("bf16", 1, 64, 64, 3, "resnet152")])
+def test_segcd_every_layer_in_place(dtype, B, H, W, cin, encoder):
     tol = 2e-4 if dtype == "fp32" else 6e-3            # bf16: one rounding of the output (2^-9 relative, ~1.2e-3 rms) + bf16 weights
     rng = np.random.default_rng(31)
     x1 = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32)).to(DEV)
     x2 = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32)).to(DEV)
     tgt = torch.from_numpy((rng.random((B, 1, H, W)) < 0.2).astype(np.float32)).to(DEV)
-    m = SegCD(in_channels=cin, dtype=dtype)
-    m.load_state_dict(G.synth_state(cin, 1, 11))
+    m = SegCD(encoder_name=encoder, in_channels=cin, dtype=dtype)
+    m.load_state_dict(G.synth_state(cin, 1, 11, encoder=encoder))
     m._engine.set_debug(1)
     m.to(DEV).train()
     o = m(x1, x2)
@@ -148,7 +160,10 @@ def test_segcd_every_layer_in_place(dtype, B, H, W, cin):
     torch.cuda.synchronize()
     ws = m._engine.ws_tensors()
     hold = _holders(m)
-    assert len(hold) == 63 and all(f"{k}.Y" in ws for k in hold)
+    basic = G.ENCODERS[encoder][0] == 1
+    nblk = sum(G.ENCODERS[encoder][1])
+    assert len(hold) == 1 + (2 if basic else 3) * nblk + (3 if basic else 4) + 10 and all(f"{k}.Y" in ws for k in hold)      # resnet50: 63
+    last = {li: f"encoder.layer{li}.{G.ENCODERS[encoder][1][li - 1] - 1}.conv{2 if basic else 3}" for li in (1, 2, 3, 4)}
     worst = {}
 
     def chk(kind, name, got, want, t=tol):
@@ -168,10 +183,13 @@ def test_segcd_every_layer_in_place(dtype, B, H, W, cin):
         chk("weight gradient", name, conv.weight.grad, want_dw, 2e-4 if dtype == "fp32" else 2e-3)
         if name + ".dIn" in ws:
             want_dx = torch.nn.grad.conv2d_input(X.shape, Wt, dY, conv.stride, conv.padding)
-            if name == "encoder.layer1.0.conv1":      # the max-pool's gradient buffer: the down-sample branch is accumulated into it
+            if name == "encoder.layer1.0.conv1" and not basic:      # the max-pool's gradient buffer: the down-sample branch is accumulated into it
                 dc = hold["encoder.layer1.0.downsample.0"][0]
                 want_dx = want_dx + torch.nn.grad.conv2d_input(X.shape, wq(dc.weight), _nchw(ws["encoder.layer1.0.downsample.0.dY"]), dc.stride, dc.padding)
-            chk("input gradient", name, _nchw(ws[name + ".dIn"]), want_dx)
+            # BasicBlock layer1.0 has no down-sample: the max-pool's gradient buffer also holds the gated residual gradient of
+            # conv2's BatchNorm, which is dY(conv2) / scale ... not a stored tensor -- its input gradient is covered end to end
+            if not (name == "encoder.layer1.0.conv1" and basic):
+                chk("input gradient", name, _nchw(ws[name + ".dIn"]), want_dx)
         # BatchNorm (per-date batch statistics) + residual + ReLU from the stored conv output
         res = _nchw(ws[name + ".res"]) if name + ".res" in ws else None
         outs = []
@@ -186,10 +204,13 @@ def test_segcd_every_layer_in_place(dtype, B, H, W, cin):
     # plumbing: max-pool, residual wiring, up-sampling + skip concat (exact copies of stored tensors)
     f1 = _nchw(ws["encoder.conv1.A"])
     assert torch.equal(_nchw(ws["encoder.layer1.0.conv1.in"]), torch.nn.functional.max_pool2d(f1, 3, 2, 1))
-    assert torch.equal(_nchw(ws["encoder.layer1.1.conv3.res"]), _nchw(ws["encoder.layer1.0.conv3.A"]))
-    assert torch.equal(_nchw(ws["encoder.layer2.0.conv3.res"]), _nchw(ws["encoder.layer2.0.downsample.0.A"]))
-    skips = ["encoder.layer3.5.conv3", "encoder.layer2.3.conv3", "encoder.layer1.2.conv3", "encoder.conv1"]
-    x = _nchw(ws["encoder.layer4.2.conv3.A"])
+    cl = "conv2" if basic else "conv3"
+    assert torch.equal(_nchw(ws[f"encoder.layer1.1.{cl}.res"]), _nchw(ws[f"encoder.layer1.0.{cl}.A"]))
+    assert torch.equal(_nchw(ws[f"encoder.layer2.0.{cl}.res"]), _nchw(ws["encoder.layer2.0.downsample.0.A"]))
+    if basic:       # layer1.0 has no down-sample: its residual is the max-pool's output
+        assert torch.equal(_nchw(ws["encoder.layer1.0.conv2.res"]), _nchw(ws["encoder.layer1.0.conv1.in"]))
+    skips = [last[3], last[2], last[1], "encoder.conv1"]
+    x = _nchw(ws[last[4] + ".A"])
     for i in range(5):
         cat = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
         if i < 4:
@@ -204,11 +225,11 @@ def test_segcd_every_layer_in_place(dtype, B, H, W, cin):
     want = (m1, m2, torch.min(head((d1 - d2).abs()), (m1 - m2).abs()))
     for k in range(3):
         chk("head", f"output {k}", o[k].detach(), want[k], 1e-4 if dtype == "fp32" else 2e-2)
-    print(f"SegCD {dtype} B={B} {H}x{W} layer-local worst relative l2: " + ", ".join(f"{k} {v[0]:.1e} ({v[1]})" for k, v in worst.items()))
+    print(f"SegCD-{encoder} {dtype} B={B} {H}x{W} layer-local worst relative l2: " + ", ".join(f"{k} {v[0]:.1e} ({v[1]})" for k, v in worst.items()))
 
 
-@pytest.mark.parametrize("fixture,classes", [("g10_segcd.npz", 1), ("g11_segcd_2cls.npz", 2)])
-def test_segcd_bf16_tracks_reference_vectors(golden, fixture, classes):
+@pytest.mark.parametrize("fixture,classes,encoder", FIXTURES[:4])
+def test_segcd_bf16_tracks_reference_vectors(golden, fixture, classes, encoder):
     """bf16 storage end to end against the reference's vectors (G10): eval-mode maps at 4e-2 relative l2 (measured 2.1e-2: one
     bf16 rounding per stored activation over ~110 layers), training loss at 2e-2; gradients: the head's and the last decoder
     block's (a few layers from the loss) keep their direction, every tensor keeps its magnitude -- deeper directions are
@@ -217,16 +238,16 @@ def test_segcd_bf16_tracks_reference_vectors(golden, fixture, classes):
     g = golden(fixture)
     seed = int(g["seed"])
     x1, x2 = t(g["x1"]).to(DEV), t(g["x2"]).to(DEV)
-    m = SegCD(classes=classes, dtype="bf16")
-    m.load_state_dict(G.synth_state(3, classes, seed, perturb_running=True))
+    m = SegCD(encoder_name=encoder, classes=classes, dtype="bf16")
+    m.load_state_dict(G.synth_state(3, classes, seed, perturb_running=True, encoder=encoder))
     m.to(DEV).eval()
     with torch.no_grad():
         o = m(x1, x2)
     for k, v in zip(("m1", "m2"), o):
         r, _ = rel_l2_cos(v.cpu().numpy(), g[f"eval/{k}"])
         assert r <= 4e-2, (k, r)
-    m = SegCD(classes=classes, dtype="bf16")
-    m.load_state_dict(G.synth_state(3, classes, seed))
+    m = SegCD(encoder_name=encoder, classes=classes, dtype="bf16")
+    m.load_state_dict(G.synth_state(3, classes, seed, encoder=encoder))
     m.to(DEV).train()
     m1, m2, ch = m(x1, x2)
     loss = _loss(m1, m2, ch, t(g["seg_target"]).to(DEV), t(g["target"]).to(DEV))
