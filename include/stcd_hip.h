@@ -131,8 +131,8 @@ int stcd_grad_stage_range(const stcd_engine* e, int stage, int64_t* begin, int64
 /* ---- test introspection: the named activation / gradient tensors of the CURRENT configuration inside the workspace, so a
  *      parity test can check every layer of a deep network IN PLACE (layer output against a convolution of the layer's own
  *      stored input, weight gradient against the stored input and output gradient ...) at per-op tolerance, independent of how
- *      rounding differences grow through the depth.  Filled for the STCD_ARCH_SEGCD* families ("<conv name>.in|.Y|.A|.dY|.dIn"); 0 tensors
- *      for the other families.  NHWC: element (n, y, x, ch) at offset_bytes + (((n*h + y)*w + x)*ld + ch) * elem_size.
+ *      rounding differences grow through the depth.  Filled for the STCD_ARCH_SEGCD* families ("<conv name>.in|.Y|.A|.dY|.dIn|.res")
+ *      and the FC-Siam families ("<conv name>.in|.Y|.A.g0|.A.g1|.dY"; the activation per date); 0 tensors for SNUNet.  NHWC: element (n, y, x, ch) at offset_bytes + (((n*h + y)*w + x)*ld + ch) * elem_size.
  *      stcd_set_debug bit 0 (before stcd_configure): every layer writes its input gradient to a buffer of its own (the
  *      producer gathers it) instead of in place into the producer's gradient tensor, so ".dIn" survives the backward. */
 typedef struct stcd_ws_tensor {
