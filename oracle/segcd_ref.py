@@ -16,7 +16,8 @@ Restated from text (the ``segmentation_models_pytorch`` package cannot be import
   UnetDecoder / DecoderBlock /root/reference/segmentation_models_pytorch/decoders/unet/decoder.py:8-123
   Conv2dReLU                 /root/reference/segmentation_models_pytorch/base/modules.py:10-47 (bias-free conv + BN + ReLU)
   SegmentationHead           /root/reference/segmentation_models_pytorch/base/heads.py:5-11 (3x3 conv with bias)
-PINNED by tests/golden/g10_segcd.npz, g11_segcd_2cls.npz (resnet50), g12_segcd_r18.npz, g13_segcd_r34.npz, g14_segcd_r101.npz:
+PINNED by tests/golden/g10_segcd.npz, g11_segcd_2cls.npz (resnet50), g12_segcd_r18.npz, g13_segcd_r34.npz, g14_segcd_r101.npz
+and g15_unetseg.npz (UnetSeg, model.py:109-171: the single-image twin train_sup.py:303 trains):
 the reference's own ResNet (models/resnet.py), UnetDecoder (decoder.py, loaded as a file) and SegmentationHead assembled
 exactly as SegCD.__init__ / forward state (tests/golden/make_golden.py:_segcd_fixture).
 """
@@ -189,3 +190,9 @@ def forward(st, A, B, training=False):
     diffea = head(torch.abs(d1 - d2))
     diffseg = torch.abs(m1 - m2)
     return m1, m2, torch.min(diffea, diffseg)
+
+
+def unetseg_forward(st, x, training=False):
+    """UnetSeg.forward (model.py:165-171): masks = head(decoder(*encoder(x))) -- one image batch, one BatchNorm call per layer."""
+    d = decoder(st, encoder(st, x, training), training)
+    return F.conv2d(d, st["segmentation_head.0.weight"], st["segmentation_head.0.bias"], padding=1)

@@ -5,13 +5,13 @@ host-side mirror of the reference's Python interface for the path (model classes
 ``CDTrainer``).  Importing the package does not touch the GPU or load the library; the first model
 construction does, and raises if the library has not been built.
 """
-__all__ = ["SiamUnet_diff", "SiamUnet_conc", "SiamUnet_sub", "SNUNet_ECAM", "SegCD"]
+__all__ = ["SiamUnet_diff", "SiamUnet_conc", "SiamUnet_sub", "SNUNet_ECAM", "SegCD", "UnetSeg"]
 
 
 def __getattr__(name):
-    if name == "SegCD":
+    if name in ("SegCD", "UnetSeg"):
         from . import segcd
-        return segcd.SegCD
+        return getattr(segcd, name)
     if name in __all__:
         from . import modules
         return getattr(modules, name)

@@ -120,7 +120,7 @@ __device__ __forceinline__ double bn_acc_get(const long long* __restrict__ acc, 
 // All tensors NHWC with an explicit pixel stride ("ld", in elements); channel counts are multiples of 8.
 
 // x1,x2 fp32 NCHW [B,cin,H,W] -> X [2B,H,W,8] (channels >= cin zero)
-void launch_in_pack(int dt, const float* x1, const float* x2, void* X, int B, int cin, int H, int W, hipStream_t s);
+void launch_in_pack(int dt, const float* x1, const float* x2, void* X, int B, int cin, int H, int W, hipStream_t s, int dates = 2);
 // g fp32 NCHW [B,L,H,W] -> G [B,H,W,8]; optional bias_acc (int64 [BN_REP][1][2][8], scale BN_BS): per-channel sums of g
 void launch_gout_pack(int dt, const float* g, void* G, int B, int L, int H, int W, hipStream_t s, long long* bias_acc = nullptr);
 // bias gradients that conv / pack kernels accumulated as integer sums -> fp32 gradient entries (one launch per stage)

@@ -187,6 +187,7 @@ struct stcd_engine_impl {
     std::vector<stcd_ws_tensor> ws_tensors;
     std::vector<std::array<int, 4>> g_blocks;                // per residual block: (L1, L2, L3, Ld or -1) bottleneck; (L1, -1, L2, Ld or -1) basic
     int seg_x = 4, seg_layers[4] = {3, 4, 6, 3};             // block expansion (4: Bottleneck, 1: BasicBlock) and blocks per stage
+    int seg_dates = 2;                                       // 2: SegCD (both dates batched, per-date BatchNorm groups); 1: UnetSeg
     TRef g_pool_idc;                                         // identity-branch contribution of layer1.0 to d(max-pool output)
     std::vector<std::array<int, 2>> g_dec;                   // (conv1, conv2) per decoder block
     TRef gP0, gdP0, gX3, gdX3, gFuseTmp;
@@ -1759,7 +1760,8 @@ static int backward_snunet(stcd_engine& e, const float* grad_logits, const float
 // (identity branches, decoder skips) are never accumulated by extra kernels: every consumer writes its own contribution
 // buffer and the producer's BatchNorm-backward reduction gathers them (SliceViews).
 static const int RS_PLANES[4] = {64, 128, 256, 512};
-static bool is_segcd(int arch) { return arch >= STCD_ARCH_SEGCD && arch <= STCD_ARCH_SEGCD_R152; }
+static bool is_unetseg(int arch) { return arch >= STCD_ARCH_UNETSEG && arch <= STCD_ARCH_UNETSEG + 4; }
+static bool is_segcd(int arch) { return (arch >= STCD_ARCH_SEGCD && arch <= STCD_ARCH_SEGCD_R152) || is_unetseg(arch); }
 
 static const int SEG_DEC[5] = {256, 128, 64, 32, 16};
 
@@ -1768,7 +1770,7 @@ static int add_glayer(stcd_engine& e, const std::string& conv_name, const std::s
     GLayer L;
     L.name = conv_name; L.kind = kind; L.relu = relu; L.has_dIn = need_dgrad;
     L.conv = add_conv(e, conv_name, kind, cin, cout, need_dgrad, false);
-    L.bn = add_bn(e, bn_name, cout, 2);
+    L.bn = add_bn(e, bn_name, cout, e.seg_dates);
     e.g_layers.push_back(L);
     return (int)e.g_layers.size() - 1;
 }
@@ -1778,7 +1780,8 @@ static void segcd_encoder_cfg(stcd_engine& e) {
     static const int L18[4] = {2, 2, 2, 2}, L34[4] = {3, 4, 6, 3}, L101[4] = {3, 4, 23, 3}, L152[4] = {3, 8, 36, 3};
     const int* l = L34;
     e.seg_x = 4;
-    switch (e.arch) {
+    e.seg_dates = is_unetseg(e.arch) ? 1 : 2;
+    switch (is_unetseg(e.arch) ? e.arch - STCD_ARCH_UNETSEG + STCD_ARCH_SEGCD : e.arch) {       // same encoder order in both id ranges
         case STCD_ARCH_SEGCD_R18: e.seg_x = 1; l = L18; break;
         case STCD_ARCH_SEGCD_R34: e.seg_x = 1; l = L34; break;
         case STCD_ARCH_SEGCD_R101: l = L101; break;
@@ -1831,21 +1834,21 @@ static void build_segcd_tables(stcd_engine& e) {
 
 static int configure_segcd(stcd_engine& e, int B, int H, int W) {
     const int64_t T = (int64_t)dsize(e.dt);
-    const int N = 2 * B;
+    const int D = e.seg_dates, N = D * B;
     e.drops.clear(); e.drop_floats = 0;
     e.conv_ops.clear(); e.wgrad_ops.clear(); e.slab_floats = 0;
     e.g_fwd.clear();
     Bump ws;
     auto plain = [&](int n, int h, int w, int C) { TRef t; t.off = ws.take((int64_t)n * h * w * C * T); t.ld = C; return t; };
     auto view = [&](const TRef& t, int coff, int ld, int h, int w) {       // both dates of a plain [2B,h,w,ld] tensor, channel offset coff
-        ViewRef v; v.off = t.off + (int64_t)coff * T; v.ld = ld; v.goff = (int64_t)B * h * w * ld; v.gmask = 3; return v;
+        ViewRef v; v.off = t.off + (int64_t)coff * T; v.ld = ld; v.goff = D == 2 ? (int64_t)B * h * w * ld : 0; v.gmask = D == 2 ? 3 : 1; return v;
     };
     for (auto& L : e.g_layers) { L.extra_dst.clear(); L.grad_src.clear(); L.grad_base = true; L.res = TRef(); L.dRes = TRef(); L.ndgr = 0; }
     e.X0 = plain(N, H, W, 8);
     // ---- shapes + activation buffers, forward order
     auto shape = [&](GLayer& L, const TRef& in, int K, int hi, int wi, int stride) {
         const ConvW& cv = e.convs[L.conv];
-        L.N = N; L.groups = 2; L.npg = B; L.in = in; L.K = K; L.Hi = hi; L.Wi = wi; L.Ho = hi / stride; L.Wo = wi / stride; L.C = cv.cout;
+        L.N = N; L.groups = D; L.npg = B; L.in = in; L.K = K; L.Hi = hi; L.Wi = wi; L.Ho = hi / stride; L.Wo = wi / stride; L.C = cv.cout;
         L.Y = plain(N, L.Ho, L.Wo, L.C); L.A = plain(N, L.Ho, L.Wo, L.C); L.dA = plain(N, L.Ho, L.Wo, L.C);
         L.stat = ws.take((int64_t)2 * 4 * L.C * 4); L.coef = ws.take((int64_t)2 * 5 * L.C * 4);
     };
@@ -1923,13 +1926,18 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
         xl = e.g_dec[i][1];
     }
     // ---- head: X3 = [d1; d2; |d1 - d2|] (3B images), one conv launch; the last decoder layer writes d1, d2 straight into X3
+    //      (UnetSeg: X3 = d, B images, the head's output is the network's)
     GLayer& DL = e.g_layers[xl];
-    e.gX3 = plain(3 * B, H, W, 16); e.gdX3 = plain(3 * B, H, W, 16); e.gFuseTmp = plain(N, H, W, 16);
+    const int nhead = D == 2 ? 3 * B : B;
+    e.gX3 = plain(nhead, H, W, 16); e.gdX3 = plain(nhead, H, W, 16);
     DL.A = e.gX3; DL.dA = e.gdX3;
     DL.grad_base = true;
-    DL.grad_src.push_back(view(e.gFuseTmp, 0, 16, H, W));
-    e.g_raw3 = ws.take((int64_t)3 * B * e.label * H * W * 4); e.g_draw3 = ws.take((int64_t)3 * B * e.label * H * W * 4);
-    e.G = plain(3 * B, H, W, 8);
+    if (D == 2) {
+        e.gFuseTmp = plain(N, H, W, 16);
+        DL.grad_src.push_back(view(e.gFuseTmp, 0, 16, H, W));
+        e.g_raw3 = ws.take((int64_t)3 * B * e.label * H * W * 4); e.g_draw3 = ws.take((int64_t)3 * B * e.label * H * W * 4);
+    }
+    e.G = plain(nhead, H, W, 8);
     for (auto& L : e.g_layers)
         if ((int)L.extra_dst.size() > MAX_VIEWS || (int)L.grad_src.size() > MAX_VIEWS) { set_error("internal: too many views"); return 1; }
     // ---- zero arena: accumulators, tickets-free (consumer-side tables), bias accumulator of the head
@@ -2100,9 +2108,10 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
     }
     {
         const ConvW& cv = e.convs[e.g_head_conv];
-        bind_conv(e.g_head_fwd, geom3(3 * B, H, W, 16, 16, e.label, e.label), e.g_head_conv, false, 0, 16, e.label);
-        bind_wgrad(e.g_head_wg, geom3(3 * B, H, W, 16, 16, e.label, 8), e.g_head_conv, e.gX3.off, e.G.off);
-        bind_conv(e.g_head_dgr, geom3(3 * B, H, W, cv.dgrad.kpad, 8, 16, 16), e.g_head_conv, true, 0, e.label, 16);
+        const int nhead = D == 2 ? 3 * B : B;
+        bind_conv(e.g_head_fwd, geom3(nhead, H, W, 16, 16, e.label, e.label), e.g_head_conv, false, 0, 16, e.label);
+        bind_wgrad(e.g_head_wg, geom3(nhead, H, W, 16, 16, e.label, 8), e.g_head_conv, e.gX3.off, e.G.off);
+        bind_conv(e.g_head_dgr, geom3(nhead, H, W, cv.dgrad.kpad, 8, 16, 16), e.g_head_conv, true, 0, e.label, 16);
     }
     e.ws_tensors.clear();
     for (const auto& L : e.g_layers) {
@@ -2226,12 +2235,17 @@ static int forward_segcd(stcd_engine& e, const float* x1, const float* x2, const
     const int64_t T = (int64_t)dsize(dt), HW = (int64_t)e.H * e.W;
     if (pack_all_weights(c, training != 0)) return 1;
     if (training) STCD_HIP(hipMemsetAsync(c.at(e.zero_begin), 0, e.zero_end - e.zero_begin, s));
-    launch_in_pack(dt, x1, x2, c.at(e.X0.off), B, e.in_ch, e.H, e.W, s);
+    launch_in_pack(dt, x1, x2, c.at(e.X0.off), B, e.in_ch, e.H, e.W, s, e.seg_dates);
     for (const GStep& st : e.g_fwd) {
         if (st.kind == GS_LAYER) glayer_forward(c, e.g_layers[st.layer], bn_running, training != 0);
         else if (st.kind == GS_MAXPOOL) launch_maxpool3(dt, c.at(st.src.off), st.src.ld, c.at(st.dst.off), st.dst.ld, st.N, st.h, st.w, st.C, s,
                                                         training ? c.at<unsigned char>(e.g_pool_idx) : nullptr);
         else launch_upsample2(dt, c.at(st.src.off), st.src.ld, c.at(st.dst.off), st.dst.ld, st.N, st.h, st.w, st.C, s);
+    }
+    if (e.seg_dates == 1) {      // UnetSeg: masks = head(decoder output)
+        exec_conv(c, e.g_head_fwd, c.at(e.gX3.off), params + e.convs[e.g_head_conv].b_off, logits, true);
+        STCD_HIP(hipGetLastError());
+        return 0;
     }
     // head: X3[2B:3B] = |d1 - d2| ; raw = conv(X3) = [m1; m2; diffea] ; logits = [m1; m2; min(diffea, |m1 - m2|)]
     launch_fuse(dt, 0, c.at(e.gX3.off), 16, (int64_t)B * HW * 16, c.at<char>(e.gX3.off) + (int64_t)2 * B * HW * 16 * T, 16, B, HW, 16, s);
@@ -2249,13 +2263,19 @@ static int backward_segcd(stcd_engine& e, const float* grad_logits, const float*
     const int64_t T = (int64_t)dsize(dt), HW = (int64_t)e.H * e.W;
     STCD_HIP(hipMemsetAsync(grads, 0, e.param_floats * 4, s));
     if (!mfma_on(e)) STCD_HIP(hipMemsetAsync(c.at(e.dwe_begin), 0, e.dwe_end - e.dwe_begin, s));
-    launch_segcd_combine_bwd(c.at<float>(e.g_raw3), grad_logits, c.at<float>(e.g_draw3), (int64_t)B * e.label * HW, s);
-    launch_gout_pack(dt, c.at<float>(e.g_draw3), c.at(e.G.off), 3 * B, e.label, e.H, e.W, s, c.at<long long>(e.final_bias_acc));
-    exec_wgrad(c, e.g_head_wg, c.at(e.gX3.off), c.at(e.G.off));
-    exec_conv(c, e.g_head_dgr, c.at(e.G.off), nullptr, c.at(e.gdX3.off), false);
-    // d(d1), d(d2) += -/+ sign(d1 - d2) * d|d1 - d2| : written to a contribution buffer the last decoder layer gathers
-    launch_fuse_bwd(dt, 0, c.at(e.gX3.off), 16, (int64_t)B * HW * 16, c.at<char>(e.gdX3.off) + (int64_t)2 * B * HW * 16 * T, 16,
-                    c.at(e.gFuseTmp.off), 16, (int64_t)B * HW * 16, B, HW, 16, s);
+    if (e.seg_dates == 1) {
+        launch_gout_pack(dt, grad_logits, c.at(e.G.off), B, e.label, e.H, e.W, s, c.at<long long>(e.final_bias_acc));
+        exec_wgrad(c, e.g_head_wg, c.at(e.gX3.off), c.at(e.G.off));
+        exec_conv(c, e.g_head_dgr, c.at(e.G.off), nullptr, c.at(e.gdX3.off), false);
+    } else {
+        launch_segcd_combine_bwd(c.at<float>(e.g_raw3), grad_logits, c.at<float>(e.g_draw3), (int64_t)B * e.label * HW, s);
+        launch_gout_pack(dt, c.at<float>(e.g_draw3), c.at(e.G.off), 3 * B, e.label, e.H, e.W, s, c.at<long long>(e.final_bias_acc));
+        exec_wgrad(c, e.g_head_wg, c.at(e.gX3.off), c.at(e.G.off));
+        exec_conv(c, e.g_head_dgr, c.at(e.G.off), nullptr, c.at(e.gdX3.off), false);
+        // d(d1), d(d2) += -/+ sign(d1 - d2) * d|d1 - d2| : written to a contribution buffer the last decoder layer gathers
+        launch_fuse_bwd(dt, 0, c.at(e.gX3.off), 16, (int64_t)B * HW * 16, c.at<char>(e.gdX3.off) + (int64_t)2 * B * HW * 16 * T, 16,
+                        c.at(e.gFuseTmp.off), 16, (int64_t)B * HW * 16, B, HW, 16, s);
+    }
     for (int k = (int)e.g_fwd.size() - 1; k >= 0; --k) {
         const GStep& st = e.g_fwd[k];
         if (st.kind == GS_LAYER) glayer_backward(c, e.g_layers[st.layer]);
@@ -2283,7 +2303,7 @@ int stcd_abi_version(void) { return STCD_ABI_VERSION; }
 
 int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out) {
     STCD_CHECK(out != nullptr, "out is null");
-    STCD_CHECK(arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD_R152, "unknown arch");
+    STCD_CHECK((arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD_R152) || is_unetseg(arch), "unknown arch");
     STCD_CHECK(in_ch >= 1 && in_ch <= 8, "in_ch must be in [1,8]");
     STCD_CHECK(label_ch >= 1 && label_ch <= 8, "label_ch must be in [1,8]");
     STCD_CHECK(dtype == STCD_DTYPE_F32 || dtype == STCD_DTYPE_BF16, "unknown dtype");

@@ -57,9 +57,9 @@ struct GV {
 // ------------------------------------------------------------------ pack / unpack at the NCHW fp32 boundary
 template <typename T>
 __global__ void k_in_pack(const float* __restrict__ x1, const float* __restrict__ x2, T* __restrict__ X, int B, int cin,
-                          int64_t HW) {
+                          int64_t HW, int64_t total) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * (int64_t)B * HW) return;
+    if (i >= total) return;
     int n = (int)(i / HW);
     int64_t p = i - (int64_t)n * HW;
     const float* src = (n < B ? x1 + (int64_t)n * cin * HW : x2 + (int64_t)(n - B) * cin * HW) + p;
@@ -69,10 +69,11 @@ __global__ void k_in_pack(const float* __restrict__ x1, const float* __restrict_
     store8<T>(X + i * 8, v);
 }
 
-void launch_in_pack(int dt, const float* x1, const float* x2, void* X, int B, int cin, int H, int W, hipStream_t s) {
-    int64_t HW = (int64_t)H * W, n = 2 * (int64_t)B * HW;
-    if (dt == BF16) k_in_pack<bf16><<<cdiv(n, 256), 256, 0, s>>>(x1, x2, (bf16*)X, B, cin, HW);
-    else k_in_pack<float><<<cdiv(n, 256), 256, 0, s>>>(x1, x2, (float*)X, B, cin, HW);
+// dates = 2: images [x1; x2] (2B of them); dates = 1: x1 alone (single-image networks: x2 is not read)
+void launch_in_pack(int dt, const float* x1, const float* x2, void* X, int B, int cin, int H, int W, hipStream_t s, int dates) {
+    int64_t HW = (int64_t)H * W, n = (int64_t)dates * B * HW;
+    if (dt == BF16) k_in_pack<bf16><<<cdiv(n, 256), 256, 0, s>>>(x1, x2, (bf16*)X, B, cin, HW, n);
+    else k_in_pack<float><<<cdiv(n, 256), 256, 0, s>>>(x1, x2, (float*)X, B, cin, HW, n);
 }
 
 template <typename T>

@@ -137,6 +137,7 @@ class SegCD(HipChangeDetector):
     cache when there is no network).  H and W must be multiples of 32."""
 
     ARCH = "segcd"
+    FAMILY = "segcd"
     OUT_MAPS = 3
 
     def __init__(self, encoder_name: str = "resnet50", encoder_depth: int = 5, encoder_weights: Optional[str] = None,
@@ -149,7 +150,7 @@ class SegCD(HipChangeDetector):
                                       "(256,128,64,32,16), no attention / activation / aux head (train_pse_cd.py:426 builds resnet50)")
         if not 1 <= in_channels <= 8:
             raise NotImplementedError("SegCD on the HIP engine: 1..8 input channels")
-        self.ARCH = "segcd_" + encoder_name
+        self.ARCH = self.FAMILY + "_" + encoder_name
         super().__init__(in_channels, classes, dtype)
         self.encoder = _ResNetEncoder(encoder_name, in_channels)
         self.inchannels = in_channels
@@ -200,3 +201,27 @@ class SegCD(HipChangeDetector):
         if isinstance(out, tuple):          # training: the autograd node already returns the three maps
             return out
         return out[:B], out[B:2 * B], out[2 * B:]
+
+
+
+class UnetSeg(SegCD):
+    """``UnetSeg(encoder_name=..., in_channels=3, classes=1).forward(x)`` -> masks: the single-image ResNet UNet
+    ``train_sup.py:303`` trains (``smp.UnetSeg(encoder_name="resnet50", encoder_weights="imagenet")``;
+    /root/reference/segmentation_models_pytorch/decoders/unet/model.py:109-171) -- SegCD's encoder / decoder / head (same
+    ``state_dict``, so a supervised checkpoint loads into SegCD and back) on ONE image batch, BatchNorm over the whole batch."""
+
+    FAMILY = "unetseg"
+    OUT_MAPS = 1
+
+    def __init__(self, encoder_name: str = "resnet34", encoder_depth: int = 5, encoder_weights: Optional[str] = None,
+                 decoder_use_batchnorm: bool = True, decoder_channels: List[int] = (256, 128, 64, 32, 16),
+                 decoder_attention_type: Optional[str] = None, in_channels: int = 3, classes: int = 1, activation=None,
+                 aux_params: Optional[dict] = None, dtype: Optional[str] = None):
+        super().__init__(encoder_name, encoder_depth, encoder_weights, decoder_use_batchnorm, decoder_channels, decoder_attention_type,
+                         in_channels, classes, activation, aux_params, dtype)
+
+    def forward(self, x):
+        return super().forward(x, x)           # the engine reads the first input only (STCD_ARCH_UNETSEG)
+
+    def _wrap_output(self, out, B):
+        return out

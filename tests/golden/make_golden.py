@@ -533,6 +533,39 @@ def g11_segcd():
     _segcd_fixture("g11_segcd_2cls.npz", "G11 SegCD, 2 classes, 3 x 96 x 64", 1100, 2, 3, 96, 64)
 
 
+def g15_unetseg():
+    """UnetSeg (decoders/unet/model.py:109-171), the model train_sup.py:303 trains: the reference's ResNet / UnetDecoder /
+    SegmentationHead on one image batch; the step of train_sup.py:131-137 (sigmoid + criterion = cd_loss)."""
+    from oracle import segcd_ref
+    print("G15 UnetSeg")
+    d = {}
+    for tag, encoder, seed, classes, B, H, W in (("r50", "resnet50", 1500, 1, 4, 96, 96), ("r34", "resnet34", 1510, 2, 3, 96, 64)):
+        x, _ = rand_pair(seed + 1, B, H, W)
+        d[f"{tag}/x"], d[f"{tag}/seed"] = t2n(x), seed
+        ref = _reference_segcd(classes, encoder)
+        unet = lambda m, t_: m.segmentation_head(m.decoder(*m.features(t_)))            # UnetSeg.forward (model.py:165-171)
+        ref.load_state_dict(segcd_ref.synth_state(3, classes, seed, perturb_running=True, encoder=encoder))
+        ref.eval()
+        with torch.no_grad():
+            d[f"{tag}/eval"] = t2n(unet(ref, x))
+        ref = _reference_segcd(classes, encoder)
+        ref.load_state_dict(segcd_ref.synth_state(3, classes, seed, encoder=encoder))
+        ref.train()
+        out = unet(ref, x)
+        rng = np.random.default_rng(seed + 4)
+        tgt = torch.from_numpy((rng.random((B, classes, H, W)) < 0.3).astype(np.float32))
+        loss = ref_losses.cd_loss(torch.sigmoid(out), tgt)
+        loss.backward()
+        d[f"{tag}/target"], d[f"{tag}/train"], d[f"{tag}/loss"] = t2n(tgt), t2n(out), loss.item()
+        for k, v in grad_summary(ref).items():
+            d[f"{tag}/{k}"] = v
+        sd = ref.state_dict()
+        for k in ("encoder.bn1", "decoder.blocks.0.conv1.1", "decoder.blocks.4.conv2.1"):
+            d[f"{tag}/rs/{k}.running_mean"], d[f"{tag}/rs/{k}.running_var"] = t2n(sd[f"{k}.running_mean"]), t2n(sd[f"{k}.running_var"])
+            d[f"{tag}/rs/{k}.num_batches_tracked"] = t2n(sd[f"{k}.num_batches_tracked"])
+    save("g15_unetseg.npz", **d)
+
+
 def g12_segcd_r18():
     """SegCD over the BasicBlock encoders of the registry (encoders/resnet.py:126-144): resnet18 ..."""
     _segcd_fixture("g12_segcd_r18.npz", "G12 SegCD resnet18", 1200, 1, 2, 64, 64, encoder="resnet18")
@@ -549,9 +582,9 @@ def g14_segcd_r101():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15"]
     fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd,
           "g7": g7_train128, "g8": g8_contrastive, "g10": g10_segcd, "g11": g11_segcd, "g12": g12_segcd_r18, "g13": g13_segcd_r34,
-          "g14": g14_segcd_r101}
+          "g14": g14_segcd_r101, "g15": g15_unetseg}
     for w in which:
         fn[w]()

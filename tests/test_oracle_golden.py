@@ -234,3 +234,41 @@ def test_segcd_eval_and_train_step_against_reference_vectors(golden, fixture, cl
     print(f"SegCD oracle vs reference: worst relative l2 {worst[0]:.2e}, worst cosine {worst[1]:.6f}")
     for k in [k for k in g if k.startswith("rs/")]:
         np.testing.assert_allclose(st[k[3:]].detach().numpy(), g[k], rtol=1e-4, atol=5e-5, err_msg=k)      # worst seen 1.9e-5 (resnet101 decoder mean)
+
+
+@pytest.mark.parametrize("tag,encoder,classes", [("r50", "resnet50", 1), ("r34", "resnet34", 2)])
+def test_unetseg_eval_and_train_step_against_reference_vectors(golden, tag, encoder, classes):
+    """G15: UnetSeg (decoders/unet/model.py:109-171, the model train_sup.py:303 trains) assembled from the reference's own
+    ResNet / UnetDecoder / SegmentationHead: masks in eval and train mode, the step's loss (sigmoid + cd_loss,
+    train_sup.py:131-137), every parameter's gradient, running statistics (ONE BatchNorm call per layer and forward)."""
+    from oracle import segcd_ref as G
+    from tests._util import check_grad
+    g = golden("g15_unetseg.npz")
+    seed = int(g[f"{tag}/seed"])
+    x = _t(g[f"{tag}/x"])
+    st = G.synth_state(3, classes, seed, perturb_running=True, encoder=encoder)
+    with torch.no_grad():
+        o = G.unetseg_forward(st, x)
+    np.testing.assert_allclose(o.numpy(), g[f"{tag}/eval"], rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(g[f"{tag}/eval"]).max())))
+    st = G.synth_state(3, classes, seed, encoder=encoder)
+    params = [k for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
+    for k in params:
+        st[k].requires_grad_(True)
+    out = G.unetseg_forward(st, x, training=True)
+    np.testing.assert_allclose(out.detach().numpy(), g[f"{tag}/train"], rtol=1e-3, atol=1e-3)
+    loss = R.cd_loss(torch.sigmoid(out), _t(g[f"{tag}/target"]))
+    assert abs(loss.item() - float(g[f"{tag}/loss"])) < 1e-4
+    loss.backward()
+    worst = (0.0, 1.0)
+    for k in params:
+        if st[k].grad is None or float(np.abs(g[f"{tag}/gs/" + k][1])) < 1e-12:
+            continue
+        r = check_grad(k, st[k].grad, g, rel_max=5e-2, cos_min=0.998, prefix=tag + "/")
+        if r:
+            worst = (max(worst[0], r[0]), min(worst[1], r[1]))
+    print(f"UnetSeg-{encoder} oracle vs reference: worst relative l2 {worst[0]:.2e}, worst cosine {worst[1]:.6f}")
+    for k in [k for k in g if k.startswith(tag + "/rs/")]:
+        name = k[len(tag) + 4:]
+        np.testing.assert_allclose(st[name].detach().numpy(), g[k], rtol=1e-4, atol=5e-5, err_msg=k)
+        if name.endswith("num_batches_tracked"):
+            assert int(g[k]) == 1

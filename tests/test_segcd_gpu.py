@@ -7,7 +7,7 @@ import torch
 
 from oracle import segcd_ref as G
 from stcd_amd.losses import bce_dice_with_logits
-from stcd_amd.segcd import SegCD
+from stcd_amd.segcd import SegCD, UnetSeg
 from tests._util import check_grad, rel_l2_cos, t
 
 pytestmark = pytest.mark.gpu
@@ -378,3 +378,78 @@ def test_segcd_full_size_properties_bf16():
                 assert p.grad.abs().max().item() > 0, name
     rel = ((grads[1] - 2.0 * grads[0]).abs().max() / grads[1].abs().max()).item()
     assert rel < 5e-5, rel
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# UnetSeg: the single-image twin (decoders/unet/model.py:109-171) train_sup.py:303 trains
+@pytest.mark.parametrize("tag,encoder,classes", [("r50", "resnet50", 1), ("r34", "resnet34", 2)])
+def test_unetseg_fp32_matches_reference_vectors(golden, tag, encoder, classes):
+    g = golden("g15_unetseg.npz")
+    seed = int(g[f"{tag}/seed"])
+    x = t(g[f"{tag}/x"]).to(DEV)
+    m = UnetSeg(encoder_name=encoder, classes=classes, dtype="fp32")
+    m.load_state_dict(G.synth_state(3, classes, seed, perturb_running=True, encoder=encoder))
+    m.to(DEV).eval()
+    with torch.no_grad():
+        o = m(x)
+    assert tuple(o.shape) == tuple(g[f"{tag}/eval"].shape)
+    np.testing.assert_allclose(o.cpu().numpy(), g[f"{tag}/eval"], rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(g[f"{tag}/eval"]).max())))
+    m = UnetSeg(encoder_name=encoder, classes=classes, dtype="fp32")
+    m.load_state_dict(G.synth_state(3, classes, seed, encoder=encoder))
+    m.to(DEV).train()
+    out = m(x)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"{tag}/train"], rtol=2e-3, atol=2e-3)
+    loss = bce_dice_with_logits(out, t(g[f"{tag}/target"]).to(DEV))        # train_sup.py:134-135: sigmoid + criterion (= cd_loss)
+    assert abs(loss.item() - float(g[f"{tag}/loss"])) < 2e-4
+    loss.backward()
+    for name, p in m.named_parameters():
+        if float(np.abs(g[f"{tag}/gs/" + name][1])) < 1e-12:
+            continue
+        check_grad(name, p.grad, g, rel_max=SEG_REL, cos_min=SEG_COS, prefix=tag + "/", tag=f"fp32 UnetSeg-{encoder} vs reference G15")
+    sd = m.state_dict()
+    for k in [k for k in g if k.startswith(tag + "/rs/")]:
+        np.testing.assert_allclose(sd[k[len(tag) + 4:]].cpu().numpy(), g[k], rtol=1e-4, atol=5e-5, err_msg=k)      # one BatchNorm call per forward
+
+
+def test_unetseg_bf16_and_checkpoint_exchange_with_segcd(golden):
+    """bf16 UnetSeg against G15 (eval maps, training loss, head / last-decoder gradient directions), a few Adam steps, and the
+    supervised -> change-detection hand-over of the paper's pipeline: UnetSeg's state_dict loads into SegCD unchanged and
+    SegCD's mask_t1 in eval mode IS UnetSeg's output."""
+    from stcd_amd.optim import FlatAdam
+    from tests._util import gf_index
+    g = golden("g15_unetseg.npz")
+    seed = int(g["r50/seed"])
+    x = t(g["r50/x"]).to(DEV)
+    m = UnetSeg(encoder_name="resnet50", dtype="bf16")
+    m.load_state_dict(G.synth_state(3, 1, seed, perturb_running=True))
+    m.to(DEV).eval()
+    with torch.no_grad():
+        o = m(x)
+        r, _ = rel_l2_cos(o.cpu().numpy(), g["r50/eval"])
+        assert r <= 4e-2, r
+        cd = SegCD(encoder_name="resnet50", dtype="bf16")
+        cd.load_state_dict(m.state_dict())
+        cd.to(DEV).eval()
+        m1, m2, ch = cd(x, x.flip(0))
+        assert torch.equal(m1, o) and torch.equal(m2, o.flip(0))
+    m = UnetSeg(encoder_name="resnet50", dtype="bf16")
+    m.load_state_dict(G.synth_state(3, 1, seed))
+    m.to(DEV).train()
+    tgt = t(g["r50/target"]).to(DEV)
+    loss = bce_dice_with_logits(m(x), tgt)
+    assert abs(loss.item() - float(g["r50/loss"])) < 2e-2 * abs(float(g["r50/loss"]))
+    loss.backward()
+    for name, p in m.named_parameters():
+        if name.startswith("segmentation_head") or name.startswith("decoder.blocks.4.conv2"):
+            got = p.grad.detach().cpu().numpy().ravel()[gf_index(name, p.numel())]
+            _, c = rel_l2_cos(got, g["r50/gf/" + name])
+            assert c >= (0.99 if name.startswith("segmentation_head") else 0.9), (name, c)
+    opt = FlatAdam(m, lr=1e-3)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        loss = bce_dice_with_logits(m(x), tgt)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0], losses
