@@ -40,7 +40,7 @@ SEGCD_ENCODERS = {"resnet18": (1, (2, 2, 2, 2)), "resnet34": (1, (3, 4, 6, 3)), 
                   "resnet101": (4, (3, 4, 23, 3)), "resnet152": (4, (3, 8, 36, 3))}       # encoders/resnet.py:126-171
 
 
-def segcd_alg(encoder, classes=1, H=256, W=256, dates=2):
+def segcd_alg(encoder, classes=1, H=256, W=256, dates=2, ffc=False):
     """SURVEY 8d's accounting over SegCD's layer table: per conv call 2 MACs and (input + output + weights) x 2 B, both dates,
     the head on 3 maps, x 3 for fwd + dgrad + wgrad.  resnet50: (127.65e9, 912.2e6) per pair at 256 x 256."""
     X, layers = SEGCD_ENCODERS[encoder]
@@ -57,13 +57,15 @@ def segcd_alg(encoder, classes=1, H=256, W=256, dates=2):
                 convs.append((inpl, pl * X, 1, h, w, s))
             h, w, inpl = h // s, w // s, pl * X
     enc, dec, cin = [512 * X, 256 * X, 128 * X, 64 * X, 64], [256, 128, 64, 32, 16], 512 * X
+    nenc = len(convs)
     for i in range(5):
         h, w = 2 * h, 2 * w
         convs += [(cin + (enc[i + 1] if i < 4 else 0), dec[i], 3, h, w, 1), (dec[i], dec[i], 3, h, w, 1)]
         cin = dec[i]
     heads = 3 if dates == 2 else 1                      # SegCD: head on d1, d2, |d1 - d2|; UnetSeg (dates = 1): on d
-    fl = sum(2 * (hi // s) * (wi // s) * k * k * ci * co for ci, co, k, hi, wi, s in convs) * dates
-    by = sum((hi * wi * ci + (hi // s) * (wi // s) * co + k * k * ci * co) * 2 for ci, co, k, hi, wi, s in convs) * dates
+    passes = [dates] * nenc + [3 if ffc else dates] * (len(convs) - nenc)      # FFCTLCD: the decoder also runs on |f1 - f2|
+    fl = sum(2 * (hi // s) * (wi // s) * k * k * ci * co * n for (ci, co, k, hi, wi, s), n in zip(convs, passes))
+    by = sum((hi * wi * ci + (hi // s) * (wi // s) * co + k * k * ci * co) * 2 * n for (ci, co, k, hi, wi, s), n in zip(convs, passes))
     fl += 2 * H * W * 9 * 16 * classes * heads
     by += (H * W * 16 + H * W * classes + 9 * 16 * classes) * 2 * heads
     return 3.0 * fl, 3.0 * by
@@ -77,8 +79,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub", "snunet", "segcd", "unetseg"],
-                    help="unetseg: the single-image UNet of train_sup.py (one 'pair' = one image)")
+    ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub", "snunet", "segcd", "unetseg", "ffctlcd"],
+                    help="unetseg: the single-image UNet of train_sup.py (one 'pair' = one image); ffctlcd: SegCD's feature-level variant")
     ap.add_argument("--encoder", default="resnet50", choices=sorted(SEGCD_ENCODERS), help="--model segcd: the ResNet encoder")
     ap.add_argument("--batch", type=int, default=16, help="image pairs per GPU per step")
     ap.add_argument("--size", type=int, default=256)
@@ -205,6 +207,12 @@ def main():
         args.label = 1
         model = SegCD(encoder_name=args.encoder, encoder_weights=None, in_channels=3, classes=1, dtype=args.dtype).to(dev).train()
         NAMES["segcd"] = "SegCD-" + args.encoder
+    elif args.model == "ffctlcd":   # the commented alternative of train_pse_cd.py:419: same step as SegCD
+        from stcd_amd.segcd import FFCTLCD
+        args.label = 1
+        model = FFCTLCD(encoder_name=args.encoder, encoder_weights=None, in_channels=3, classes=1, dtype=args.dtype).to(dev).train()
+        NAMES["ffctlcd"] = "FFCTLCD-" + args.encoder
+        args.no_cpu_baseline = True
     elif args.model == "unetseg":   # train_sup.py:303-309: UnetSeg(resnet50), sigmoid + criterion on the mask; a unit is ONE image
         from stcd_amd.segcd import UnetSeg
         args.label = 1
@@ -216,7 +224,7 @@ def main():
         model = cls(3, args.label, dtype=args.dtype).to(dev).train()
     broadcast_parameters(model)
     # torch.optim.AdamW semantics, one launch (weight_decay 0 == the Adam the SegCD script uses)
-    opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0 if args.model in ("segcd", "unetseg") else 0.01)
+    opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0 if args.model in ("segcd", "unetseg", "ffctlcd") else 0.01)
     reducer = FlatGradReducer(model)  # noqa: F841  (installs the gradient hook when world > 1)
 
     a, b, lab = synth.make_batch(args.batch, args.size, args.size, seed=1337 + rank)
@@ -285,7 +293,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{NAMES[args.model]}(3,{args.label}) {args.size}x{args.size} full training step "
-                               f"(fwd + {'cross_entropy' if args.label == 2 else 'sigmoid+cd_loss'} + bwd + {'Adam' if args.model in ('segcd', 'unetseg') else 'AdamW'}), "
+                               f"(fwd + {'cross_entropy' if args.label == 2 else 'sigmoid+cd_loss'} + bwd + {'Adam' if args.model in ('segcd', 'unetseg', 'ffctlcd') else 'AdamW'}), "
                                f"{args.batch} pairs/GPU, " + ("pairs built every step by the on-device pseudo-change generator from uint8 tiles resident in HBM"
                                                              if args.pseudo else "synthetic LEVIR-CD-shaped pairs resident in HBM"),
                    "global_batch": world * args.batch, "image": args.size, "parallelism": f"dp{world}",
@@ -295,9 +303,10 @@ def main():
         "pairs_per_sec_per_rank": [round(v, 2) for v in rank_rates],
     }
     # whole-step roofline: SURVEY 8d's algorithmic figures per pair x pairs per step / measured step time (all ranks)
-    fl_pp, by_pp = (segcd_alg(args.encoder, dates=2 if args.model == "segcd" else 1) if args.model in ("segcd", "unetseg")
+    seg_family = args.model in ("segcd", "unetseg", "ffctlcd")
+    fl_pp, by_pp = (segcd_alg(args.encoder, dates=1 if args.model == "unetseg" else 2, ffc=args.model == "ffctlcd") if seg_family
                     else ALG_PER_PAIR_256[args.model])
-    pmc_key = args.model if (args.model not in ("segcd", "unetseg") or args.encoder == "resnet50") else args.model + "_" + args.encoder
+    pmc_key = args.model if (not seg_family or args.encoder == "resnet50") else args.model + "_" + args.encoder
     sc = (args.size / 256.0) ** 2
     step_s = elapsed / args.steps
     peak_tf_ = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF

@@ -50,6 +50,11 @@ extern "C" {
  * decoder / head on ONE image batch (x2 of stcd_forward is ignored; BatchNorm over the whole batch; logits [batch, label_ch,
  * H, W]).  STCD_ARCH_UNETSEG + k, k = 0..4: resnet50, resnet18, resnet34, resnet101, resnet152 (the order of the ids above). */
 #define STCD_ARCH_UNETSEG 16
+/* smp.FFCTLCD (decoders/unet/model.py:335-423; the commented alternative of train_pse_cd.py:419 / train_stcd.py:637): shared
+ * encoder on both dates, the shared decoder + head on |f1 - f2| (feature level), f1 and f2 -- three decoder passes with their
+ * own BatchNorm batch statistics, in that order --, change = min(head(dec(|f1 - f2|)), |mask_t1 - mask_t2|).  Same outputs as
+ * STCD_ARCH_SEGCD ([3*batch, label_ch, H, W] = mask_t1, mask_t2, change).  STCD_ARCH_FFCTLCD + k, k as above. */
+#define STCD_ARCH_FFCTLCD 32
 
 /* arithmetic / storage type of activations. Parameters, gradients, BN statistics, logits: always fp32. */
 #define STCD_DTYPE_F32 0  /* parity mode: fp32 storage, fp32 FMA */

@@ -17,7 +17,8 @@ Restated from text (the ``segmentation_models_pytorch`` package cannot be import
   Conv2dReLU                 /root/reference/segmentation_models_pytorch/base/modules.py:10-47 (bias-free conv + BN + ReLU)
   SegmentationHead           /root/reference/segmentation_models_pytorch/base/heads.py:5-11 (3x3 conv with bias)
 PINNED by tests/golden/g10_segcd.npz, g11_segcd_2cls.npz (resnet50), g12_segcd_r18.npz, g13_segcd_r34.npz, g14_segcd_r101.npz
-and g15_unetseg.npz (UnetSeg, model.py:109-171: the single-image twin train_sup.py:303 trains):
+and g15_unetseg.npz (UnetSeg, model.py:109-171: the single-image twin train_sup.py:303 trains), g16_ffctlcd.npz (FFCTLCD,
+model.py:335-423):
 the reference's own ResNet (models/resnet.py), UnetDecoder (decoder.py, loaded as a file) and SegmentationHead assembled
 exactly as SegCD.__init__ / forward state (tests/golden/make_golden.py:_segcd_fixture).
 """
@@ -196,3 +197,14 @@ def unetseg_forward(st, x, training=False):
     """UnetSeg.forward (model.py:165-171): masks = head(decoder(*encoder(x))) -- one image batch, one BatchNorm call per layer."""
     d = decoder(st, encoder(st, x, training), training)
     return F.conv2d(d, st["segmentation_head.0.weight"], st["segmentation_head.0.bias"], padding=1)
+
+
+def ffctlcd_forward(st, A, B, training=False):
+    """FFCTLCD.forward (model.py:407-423): the decoder + head on |f1 - f2| FIRST, then on each date's features (three BatchNorm
+    calls per decoder layer, in that order); change = min(head(dec(|f1 - f2|)), |mask_t1 - mask_t2|)."""
+    f1, f2 = encoder(st, A, training), encoder(st, B, training)
+    head = lambda t: F.conv2d(t, st["segmentation_head.0.weight"], st["segmentation_head.0.bias"], padding=1)
+    diffea = head(decoder(st, [torch.abs(a - b) for a, b in zip(f1, f2)], training))
+    m1 = head(decoder(st, f1, training))
+    m2 = head(decoder(st, f2, training))
+    return m1, m2, torch.min(diffea, torch.abs(m1 - m2))

@@ -5,11 +5,11 @@ host-side mirror of the reference's Python interface for the path (model classes
 ``CDTrainer``).  Importing the package does not touch the GPU or load the library; the first model
 construction does, and raises if the library has not been built.
 """
-__all__ = ["SiamUnet_diff", "SiamUnet_conc", "SiamUnet_sub", "SNUNet_ECAM", "SegCD", "UnetSeg"]
+__all__ = ["SiamUnet_diff", "SiamUnet_conc", "SiamUnet_sub", "SNUNet_ECAM", "SegCD", "UnetSeg", "FFCTLCD"]
 
 
 def __getattr__(name):
-    if name in ("SegCD", "UnetSeg"):
+    if name in ("SegCD", "UnetSeg", "FFCTLCD"):
         from . import segcd
         return getattr(segcd, name)
     if name in __all__:

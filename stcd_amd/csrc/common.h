@@ -280,7 +280,8 @@ void launch_bn_eval_prepare(int C, int groups, const float* gamma, const float* 
 // the channel slice of every consumer's concat buffer) and extra sources of a gradient (the consumers' concat-gradient
 // slices are summed by the producer's BatchNorm-backward reduction instead of by scatter-add kernels).
 // Element (g, image-in-group n, pixel, c) of view k lives at p + (both ? g*goff : 0) + (n*HW + pixel)*ld + c; a view with
-// gmask == 2 exists for group 1 only (a tensor of the date-1 images alone), gmask == 3 for both groups.
+// gmask == 2 exists for group 1 only (a tensor of the date-1 images alone), gmask == 3 for both groups (7: three groups);
+// a view of several groups strides by goff per group, a single-group view points at its group's data.
 constexpr int MAX_VIEWS = 6;
 struct SliceViews {
     int n = 0;
@@ -300,6 +301,7 @@ struct BnActArgs {
     float* running_mean = nullptr; float* running_var = nullptr;
     float momentum = 0.1f, eps = 1e-5f;
     SliceViews extra;                       // extra destinations of A
+    int g_first = 0;                        // group whose statistics update the running ones first (then cyclic)
 };
 void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s);
 // skip layers (groups == 2, ReLU, no residual): also writes the bi-temporal fusion F = |a1-a2| (fmode 0) / a2-a1 (1)

@@ -138,8 +138,11 @@ struct GLayer {
     bool grad_base = true;                // dA already holds a contribution when the backward of this layer starts
     ConvOp fwd, dgr[4]; int ndgr = 0; WgradOp wg[8]; int nwg = 0;
     int64_t stat = -1, coef = -1, facc = -1, bacc = -1;
+    int g_first = 0;                      // BatchNorm group the reference normalises first (running-statistic update order)
 };
-enum GStepKind { GS_LAYER = 0, GS_MAXPOOL = 1, GS_UPSAMPLE = 2 };
+enum GStepKind { GS_LAYER = 0, GS_MAXPOOL = 1, GS_UPSAMPLE = 2, GS_ABSDIFF = 3 };
+// GS_ABSDIFF (FFCTLCD): images [2B, 3B) of `src` (C channels of a [3B, h, w, ld] tensor) = |date 0 - date 1|; backward: the
+// gradient of that third group (dsrc) becomes a [2B, h, w, C] contribution buffer (ddst) the producer of the two dates gathers
 struct GStep { int kind = GS_LAYER; int layer = -1; TRef src, dst, dsrc, ddst; int N = 0, h = 0, w = 0, C = 0; };
 
 // ---- SNUNet-ECAM plan (SNUNet.py:63-152)
@@ -188,6 +191,7 @@ struct stcd_engine_impl {
     std::vector<std::array<int, 4>> g_blocks;                // per residual block: (L1, L2, L3, Ld or -1) bottleneck; (L1, -1, L2, Ld or -1) basic
     int seg_x = 4, seg_layers[4] = {3, 4, 6, 3};             // block expansion (4: Bottleneck, 1: BasicBlock) and blocks per stage
     int seg_dates = 2;                                       // 2: SegCD (both dates batched, per-date BatchNorm groups); 1: UnetSeg
+    bool seg_ffc = false;                                    // FFCTLCD: the decoder also runs on |f1 - f2| (a third group)
     TRef g_pool_idc;                                         // identity-branch contribution of layer1.0 to d(max-pool output)
     std::vector<std::array<int, 2>> g_dec;                   // (conv1, conv2) per decoder block
     TRef gP0, gdP0, gX3, gdX3, gFuseTmp;
@@ -1761,16 +1765,17 @@ static int backward_snunet(stcd_engine& e, const float* grad_logits, const float
 // buffer and the producer's BatchNorm-backward reduction gathers them (SliceViews).
 static const int RS_PLANES[4] = {64, 128, 256, 512};
 static bool is_unetseg(int arch) { return arch >= STCD_ARCH_UNETSEG && arch <= STCD_ARCH_UNETSEG + 4; }
-static bool is_segcd(int arch) { return (arch >= STCD_ARCH_SEGCD && arch <= STCD_ARCH_SEGCD_R152) || is_unetseg(arch); }
+static bool is_ffctlcd(int arch) { return arch >= STCD_ARCH_FFCTLCD && arch <= STCD_ARCH_FFCTLCD + 4; }
+static bool is_segcd(int arch) { return (arch >= STCD_ARCH_SEGCD && arch <= STCD_ARCH_SEGCD_R152) || is_unetseg(arch) || is_ffctlcd(arch); }
 
 static const int SEG_DEC[5] = {256, 128, 64, 32, 16};
 
 static int add_glayer(stcd_engine& e, const std::string& conv_name, const std::string& bn_name, int kind, int cin, int cout, bool relu,
-                      bool need_dgrad) {
+                      bool need_dgrad, int bn_calls = 0) {
     GLayer L;
     L.name = conv_name; L.kind = kind; L.relu = relu; L.has_dIn = need_dgrad;
     L.conv = add_conv(e, conv_name, kind, cin, cout, need_dgrad, false);
-    L.bn = add_bn(e, bn_name, cout, e.seg_dates);
+    L.bn = add_bn(e, bn_name, cout, bn_calls ? bn_calls : e.seg_dates);
     e.g_layers.push_back(L);
     return (int)e.g_layers.size() - 1;
 }
@@ -1781,7 +1786,9 @@ static void segcd_encoder_cfg(stcd_engine& e) {
     const int* l = L34;
     e.seg_x = 4;
     e.seg_dates = is_unetseg(e.arch) ? 1 : 2;
-    switch (is_unetseg(e.arch) ? e.arch - STCD_ARCH_UNETSEG + STCD_ARCH_SEGCD : e.arch) {       // same encoder order in both id ranges
+    e.seg_ffc = is_ffctlcd(e.arch);
+    switch (is_unetseg(e.arch) ? e.arch - STCD_ARCH_UNETSEG + STCD_ARCH_SEGCD
+            : is_ffctlcd(e.arch) ? e.arch - STCD_ARCH_FFCTLCD + STCD_ARCH_SEGCD : e.arch) {      // same encoder order in every id range
         case STCD_ARCH_SEGCD_R18: e.seg_x = 1; l = L18; break;
         case STCD_ARCH_SEGCD_R34: e.seg_x = 1; l = L34; break;
         case STCD_ARCH_SEGCD_R101: l = L101; break;
@@ -1823,8 +1830,9 @@ static void build_segcd_tables(stcd_engine& e) {
         const int cskip = i < 4 ? ENC_OUT[i + 1] : 0, cout = SEG_DEC[i];
         const std::string pre = "decoder.blocks." + std::to_string(i);
         std::array<int, 2> d;
-        d[0] = add_glayer(e, pre + ".conv1.0", pre + ".conv1.1", K_CONV3, cin + cskip, cout, true, true);
-        d[1] = add_glayer(e, pre + ".conv2.0", pre + ".conv2.1", K_CONV3, cout, cout, true, true);
+        // FFCTLCD (model.py:407-423) runs the decoder three times per forward: |f1 - f2| first, then date 1, then date 2
+        d[0] = add_glayer(e, pre + ".conv1.0", pre + ".conv1.1", K_CONV3, cin + cskip, cout, true, true, e.seg_ffc ? 3 : 0);
+        d[1] = add_glayer(e, pre + ".conv2.0", pre + ".conv2.1", K_CONV3, cout, cout, true, true, e.seg_ffc ? 3 : 0);
         e.g_dec.push_back(d);
         cin = cout;
     }
@@ -1846,11 +1854,14 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
     for (auto& L : e.g_layers) { L.extra_dst.clear(); L.grad_src.clear(); L.grad_base = true; L.res = TRef(); L.dRes = TRef(); L.ndgr = 0; }
     e.X0 = plain(N, H, W, 8);
     // ---- shapes + activation buffers, forward order
-    auto shape = [&](GLayer& L, const TRef& in, int K, int hi, int wi, int stride) {
+    auto shape = [&](GLayer& L, const TRef& in, int K, int hi, int wi, int stride, int ng = 0) {
         const ConvW& cv = e.convs[L.conv];
-        L.N = N; L.groups = D; L.npg = B; L.in = in; L.K = K; L.Hi = hi; L.Wi = wi; L.Ho = hi / stride; L.Wo = wi / stride; L.C = cv.cout;
-        L.Y = plain(N, L.Ho, L.Wo, L.C); L.A = plain(N, L.Ho, L.Wo, L.C); L.dA = plain(N, L.Ho, L.Wo, L.C);
-        L.stat = ws.take((int64_t)2 * 4 * L.C * 4); L.coef = ws.take((int64_t)2 * 5 * L.C * 4);
+        if (ng == 0) ng = D;
+        const int n = ng * B;
+        L.N = n; L.groups = ng; L.npg = B; L.in = in; L.K = K; L.Hi = hi; L.Wi = wi; L.Ho = hi / stride; L.Wo = wi / stride; L.C = cv.cout;
+        L.Y = plain(n, L.Ho, L.Wo, L.C); L.A = plain(n, L.Ho, L.Wo, L.C); L.dA = plain(n, L.Ho, L.Wo, L.C);
+        L.stat = ws.take((int64_t)std::max(2, ng) * 4 * L.C * 4); L.coef = ws.take((int64_t)std::max(2, ng) * 5 * L.C * 4);
+        L.g_first = 0;
     };
     GLayer& S = e.g_layers[e.g_stem];
     shape(S, e.X0, 8, H, W, 2);
@@ -1905,23 +1916,44 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
     const int skip_layer[4] = {stage_out[2], stage_out[1], stage_out[0], e.g_stem};          // f4, f3, f2, f1
     int xl = stage_out[3];                                                                  // layer producing x
     e.g_layers[xl].grad_base = true;                                                        // f5: the up-sampling gradient alone
+    const bool ffc = e.seg_ffc;
+    const int DG = ffc ? 3 : D, ND = DG * B;                                                // decoder groups / images
+    auto absdiff = [&](const TRef& val, const TRef& grad, int coff, int C, int h_, int w_, GLayer& producer) {
+        // third group of `val` (channels [coff, coff + C)) = |date 0 - date 1|; its gradient returns to `producer` as a contribution
+        TRef tmp = plain(N, h_, w_, C);
+        GStep st; st.kind = GS_ABSDIFF; st.N = B; st.h = h_; st.w = w_; st.C = C;
+        st.src = val; st.src.off += (int64_t)coff * T; st.dsrc = grad; st.dsrc.off += (int64_t)coff * T; st.ddst = tmp;
+        e.g_fwd.push_back(st);
+        producer.grad_src.push_back(view(tmp, 0, C, h_, w_));
+    };
+    if (ffc) {      // x = [f5(date 0); f5(date 1); |f5 - f5|]: the last encoder layer writes the two dates into a 3B-image tensor
+        GLayer& X = e.g_layers[xl];
+        X.A = plain(ND, X.Ho, X.Wo, X.C); X.dA = plain(ND, X.Ho, X.Wo, X.C);
+        absdiff(X.A, X.dA, 0, X.C, X.Ho, X.Wo, X);
+    }
     for (int i = 0; i < 5; ++i) {
         GLayer& X = e.g_layers[xl];
         const int Cx = X.C, hh = 2 * X.Ho, ww = 2 * X.Wo;
         const int Cs = i < 4 ? e.g_layers[skip_layer[i]].C : 0;
-        TRef cat = plain(N, hh, ww, Cx + Cs), dcat = plain(N, hh, ww, Cx + Cs);
-        { GStep st; st.kind = GS_UPSAMPLE; st.src = X.A; st.dst = cat; st.dsrc = X.dA; st.ddst = dcat; st.N = N; st.h = X.Ho; st.w = X.Wo; st.C = Cx; e.g_fwd.push_back(st); }
+        TRef cat = plain(ND, hh, ww, Cx + Cs), dcat = plain(ND, hh, ww, Cx + Cs);
+        { GStep st; st.kind = GS_UPSAMPLE; st.src = X.A; st.dst = cat; st.dsrc = X.dA; st.ddst = dcat; st.N = ND; st.h = X.Ho; st.w = X.Wo; st.C = Cx; e.g_fwd.push_back(st); }
         if (i < 4) {
             GLayer& Sk = e.g_layers[skip_layer[i]];
             Sk.extra_dst.push_back(view(cat, Cx, Cx + Cs, hh, ww));
             Sk.grad_src.push_back(view(dcat, Cx, Cx + Cs, hh, ww));
+            if (ffc) absdiff(cat, dcat, Cx, Cs, hh, ww, Sk);
         }
         GLayer& D1 = e.g_layers[e.g_dec[i][0]]; GLayer& D2 = e.g_layers[e.g_dec[i][1]];
-        shape(D1, cat, Cx + Cs, hh, ww, 1);
-        shape(D2, D1.A, D1.C, hh, ww, 1);
+        shape(D1, cat, Cx + Cs, hh, ww, 1, DG);
+        shape(D2, D1.A, D1.C, hh, ww, 1, DG);
+        if (ffc) D1.g_first = D2.g_first = 2;          // model.py:413-419: decoder(|f1 - f2|) runs before decoder(f1), decoder(f2)
         D1.dIn = dcat;
-        if (e.debug_flags & 1) { D2.dIn = plain(N, hh, ww, D1.C); D1.grad_base = false; D1.grad_src.push_back(view(D2.dIn, 0, D1.C, hh, ww)); }
-        else D2.dIn = D1.dA;
+        if (e.debug_flags & 1) {
+            D2.dIn = plain(ND, hh, ww, D1.C); D1.grad_base = false;
+            ViewRef v = view(D2.dIn, 0, D1.C, hh, ww);
+            if (ffc) v.gmask = 7;
+            D1.grad_src.push_back(v);
+        } else D2.dIn = D1.dA;
         for (int k : {e.g_dec[i][0], e.g_dec[i][1]}) { GStep st; st.layer = k; e.g_fwd.push_back(st); }
         xl = e.g_dec[i][1];
     }
@@ -1933,8 +1965,10 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
     DL.A = e.gX3; DL.dA = e.gdX3;
     DL.grad_base = true;
     if (D == 2) {
-        e.gFuseTmp = plain(N, H, W, 16);
-        DL.grad_src.push_back(view(e.gFuseTmp, 0, 16, H, W));
+        if (!ffc) {      // FFCTLCD's last decoder layer already holds [d(f1); d(f2); d(|f1 - f2|)]: the head reads it as it is
+            e.gFuseTmp = plain(N, H, W, 16);
+            DL.grad_src.push_back(view(e.gFuseTmp, 0, 16, H, W));
+        }
         e.g_raw3 = ws.take((int64_t)3 * B * e.label * H * W * 4); e.g_draw3 = ws.take((int64_t)3 * B * e.label * H * W * 4);
     }
     e.G = plain(nhead, H, W, 8);
@@ -1942,7 +1976,7 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
         if ((int)L.extra_dst.size() > MAX_VIEWS || (int)L.grad_src.size() > MAX_VIEWS) { set_error("internal: too many views"); return 1; }
     // ---- zero arena: accumulators, tickets-free (consumer-side tables), bias accumulator of the head
     e.zero_begin = ws.cur;
-    for (auto& L : e.g_layers) { L.facc = ws.take(bn_acc_bytes(2, L.C)); L.bacc = ws.take(bn_acc_bytes(2, L.C)); }
+    for (auto& L : e.g_layers) { L.facc = ws.take(bn_acc_bytes(std::max(2, L.groups), L.C)); L.bacc = ws.take(bn_acc_bytes(std::max(2, L.groups), L.C)); }
     e.final_bias_acc = ws.take(bn_acc_bytes(1, 8));
     e.zero_end = ws.cur;
     e.scratch8 = ws.take(256);
@@ -2183,6 +2217,7 @@ static void glayer_forward(const Ctx& c, GLayer& L, float* bn_running, bool trai
     a.C = L.C; a.groups = L.groups; a.npg = L.npg; a.H = L.Ho; a.W = L.Wo; a.relu = L.relu ? 1 : 0;
     if (L.res.off >= 0) { a.res = c.at(L.res.off); a.ldres = L.res.ld; }
     a.extra = to_views(c, L.extra_dst);
+    a.g_first = L.g_first;
     ProfScope ps(c, PC_BN_ACT, 0.0, 2.0 * L.N * L.Ho * L.Wo * L.C * (double)dsize(e.dt));
     launch_bn_act(e.dt, a, c.s);
 }
@@ -2240,7 +2275,11 @@ static int forward_segcd(stcd_engine& e, const float* x1, const float* x2, const
         if (st.kind == GS_LAYER) glayer_forward(c, e.g_layers[st.layer], bn_running, training != 0);
         else if (st.kind == GS_MAXPOOL) launch_maxpool3(dt, c.at(st.src.off), st.src.ld, c.at(st.dst.off), st.dst.ld, st.N, st.h, st.w, st.C, s,
                                                         training ? c.at<unsigned char>(e.g_pool_idx) : nullptr);
-        else launch_upsample2(dt, c.at(st.src.off), st.src.ld, c.at(st.dst.off), st.dst.ld, st.N, st.h, st.w, st.C, s);
+        else if (st.kind == GS_ABSDIFF) {
+            const int64_t hw = (int64_t)st.h * st.w;
+            launch_fuse(dt, 0, c.at(st.src.off), st.src.ld, (int64_t)st.N * hw * st.src.ld,
+                        c.at<char>(st.src.off) + (int64_t)2 * st.N * hw * st.src.ld * T, st.src.ld, st.N, hw, st.C, s);
+        } else launch_upsample2(dt, c.at(st.src.off), st.src.ld, c.at(st.dst.off), st.dst.ld, st.N, st.h, st.w, st.C, s);
     }
     if (e.seg_dates == 1) {      // UnetSeg: masks = head(decoder output)
         exec_conv(c, e.g_head_fwd, c.at(e.gX3.off), params + e.convs[e.g_head_conv].b_off, logits, true);
@@ -2248,7 +2287,8 @@ static int forward_segcd(stcd_engine& e, const float* x1, const float* x2, const
         return 0;
     }
     // head: X3[2B:3B] = |d1 - d2| ; raw = conv(X3) = [m1; m2; diffea] ; logits = [m1; m2; min(diffea, |m1 - m2|)]
-    launch_fuse(dt, 0, c.at(e.gX3.off), 16, (int64_t)B * HW * 16, c.at<char>(e.gX3.off) + (int64_t)2 * B * HW * 16 * T, 16, B, HW, 16, s);
+    // (FFCTLCD: X3[2B:3B] is the decoder's output on |f1 - f2|, already in place)
+    if (!e.seg_ffc) launch_fuse(dt, 0, c.at(e.gX3.off), 16, (int64_t)B * HW * 16, c.at<char>(e.gX3.off) + (int64_t)2 * B * HW * 16 * T, 16, B, HW, 16, s);
     exec_conv(c, e.g_head_fwd, c.at(e.gX3.off), params + e.convs[e.g_head_conv].b_off, c.at(e.g_raw3), true);
     launch_segcd_combine(c.at<float>(e.g_raw3), logits, (int64_t)B * e.label * HW, s);
     STCD_HIP(hipGetLastError());
@@ -2273,7 +2313,7 @@ static int backward_segcd(stcd_engine& e, const float* grad_logits, const float*
         exec_wgrad(c, e.g_head_wg, c.at(e.gX3.off), c.at(e.G.off));
         exec_conv(c, e.g_head_dgr, c.at(e.G.off), nullptr, c.at(e.gdX3.off), false);
         // d(d1), d(d2) += -/+ sign(d1 - d2) * d|d1 - d2| : written to a contribution buffer the last decoder layer gathers
-        launch_fuse_bwd(dt, 0, c.at(e.gX3.off), 16, (int64_t)B * HW * 16, c.at<char>(e.gdX3.off) + (int64_t)2 * B * HW * 16 * T, 16,
+        if (!e.seg_ffc) launch_fuse_bwd(dt, 0, c.at(e.gX3.off), 16, (int64_t)B * HW * 16, c.at<char>(e.gdX3.off) + (int64_t)2 * B * HW * 16 * T, 16,
                         c.at(e.gFuseTmp.off), 16, (int64_t)B * HW * 16, B, HW, 16, s);
     }
     for (int k = (int)e.g_fwd.size() - 1; k >= 0; --k) {
@@ -2281,6 +2321,12 @@ static int backward_segcd(stcd_engine& e, const float* grad_logits, const float*
         if (st.kind == GS_LAYER) glayer_backward(c, e.g_layers[st.layer]);
         else if (st.kind == GS_UPSAMPLE)
             launch_upsample2_bwd(dt, c.at(st.ddst.off), st.ddst.ld, c.at(st.dsrc.off), st.dsrc.ld, st.N, st.h, st.w, st.C, s);
+        else if (st.kind == GS_ABSDIFF) {
+            const int64_t hw = (int64_t)st.h * st.w;
+            launch_fuse_bwd(dt, 0, c.at(st.src.off), st.src.ld, (int64_t)st.N * hw * st.src.ld,
+                            c.at<char>(st.dsrc.off) + (int64_t)2 * st.N * hw * st.dsrc.ld * T, st.dsrc.ld,
+                            c.at(st.ddst.off), st.ddst.ld, (int64_t)st.N * hw * st.ddst.ld, st.N, hw, st.C, s);
+        }
         else {      // max-pool: d(P0) = conv1 contribution (written in place) + identity-branch contribution of layer1.0 (its
                     // down-sample's data gradient for Bottleneck encoders, the gated residual gradient itself for BasicBlock ones)
             launch_slice(dt, c.at(st.ddst.off), st.ddst.ld, c.at(e.g_pool_idc.off), e.g_pool_idc.ld, (int64_t)st.N * (st.h / 2) * (st.w / 2), st.C, 1, s);
@@ -2303,7 +2349,7 @@ int stcd_abi_version(void) { return STCD_ABI_VERSION; }
 
 int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out) {
     STCD_CHECK(out != nullptr, "out is null");
-    STCD_CHECK((arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD_R152) || is_unetseg(arch), "unknown arch");
+    STCD_CHECK((arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD_R152) || is_unetseg(arch) || is_ffctlcd(arch), "unknown arch");
     STCD_CHECK(in_ch >= 1 && in_ch <= 8, "in_ch must be in [1,8]");
     STCD_CHECK(label_ch >= 1 && label_ch <= 8, "label_ch must be in [1,8]");
     STCD_CHECK(dtype == STCD_DTYPE_F32 || dtype == STCD_DTYPE_BF16, "unknown dtype");

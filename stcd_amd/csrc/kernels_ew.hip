@@ -223,7 +223,7 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
                     for (int k = 0; k < NS; ++k) {
                         const bool on = k < xs.n && ((xs.gmask[k] >> g) & 1);
                         const int kk = on ? k : 0;                       // an inactive slot re-reads view 0 (valid address), x 0
-                        load8<T>(reinterpret_cast<const T*>(xs.p[kk]) + (xs.gmask[kk] == 3 ? g * xs.goff[kk] : 0) + pc * xs.ld[kk] + cofs, ex[u][k]);
+                        load8<T>(reinterpret_cast<const T*>(xs.p[kk]) + ((xs.gmask[kk] & (xs.gmask[kk] - 1)) ? g * xs.goff[kk] : 0) + pc * xs.ld[kk] + cofs, ex[u][k]);
                     }
                 }
                 if (res) load8<T>(res + ((int64_t)g * ppg + pc) * ldres + cofs, rs[u]);
@@ -304,7 +304,7 @@ void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t p
 __device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __restrict__ facc, const float* __restrict__ gamma,
                                              const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                              float* __restrict__ stat, int C, int groups, int64_t ppg, float momentum, float eps,
-                                             bool publish, int cbase = 0, int CS = 0) {
+                                             bool publish, int cbase = 0, int CS = 0, int g_first = 0) {
     // channels [cbase, cbase + CS) only (CS == 0: all): wide layers give every block one 64-channel slab, so its prologue reads
     // 64 channels' accumulators instead of up to 2048
     if (CS == 0) CS = C;
@@ -313,7 +313,9 @@ __device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __rest
         if (facc) {
             const float gam = gamma[c], bet = beta[c];
             float rm = (publish && rmean) ? rmean[c] : 0.f, rv = (publish && rvar) ? rvar[c] : 0.f;
-            for (int g = 0; g < groups; ++g) {
+            for (int gi = 0; gi < groups; ++gi) {      // the running statistics see the groups in the order the reference calls the
+                int g = gi + g_first;                   // BatchNorm on them: g_first, g_first + 1, ... (cyclic)
+                if (g >= groups) g -= groups;
                 const double s1 = bn_acc_get(facc, groups, C, g, 0, c, BN_FS1), s2 = bn_acc_get(facc, groups, C, g, 1, c, BN_FS2);
                 const double mean = s1 / (double)ppg;
                 double var = s2 / (double)ppg - mean * mean;
@@ -400,11 +402,11 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
          float* __restrict__ stat, const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg,
          int H, int W, int relu, int64_t total, const long long* __restrict__ facc, const float* __restrict__ gamma,
          const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, int groups, float momentum, float eps,
-         const SliceViews xd, int nslab) {
+         const SliceViews xd, int nslab, int g_first) {
     extern __shared__ float bn_tab[];           // [groups][2][CS]
     // block -> (channel slab, block inside the slab): the slab's blocks walk its (quad, 8-channel chunk) items grid-stride
     const int CS = C / nslab, slab = blockIdx.x % nslab, bi = blockIdx.x / nslab, bps = gridDim.x / nslab, cbase = slab * CS;
-    bn_fwd_table(bn_tab, facc, gamma, beta, rmean, rvar, stat, C, groups, (int64_t)npg * H * W, momentum, eps, bi == 0, cbase, CS);
+    bn_fwd_table(bn_tab, facc, gamma, beta, rmean, rvar, stat, C, groups, (int64_t)npg * H * W, momentum, eps, bi == 0, cbase, CS, g_first);
     __syncthreads();
     const int64_t total_s = total / nslab;
     for (int64_t i64 = (int64_t)bi * blockDim.x + threadIdx.x; i64 < total_s; i64 += (int64_t)bps * blockDim.x) {
@@ -458,7 +460,7 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
             store8<T>(A + g * av.goff + pg * av.ld + c0, v[k]);
             for (int e = 0; e < xd.n; ++e)      // dense concatenation: the consumers' input slices, written here (no copy kernels)
                 if ((xd.gmask[e] >> g) & 1)
-                    store8<T>(reinterpret_cast<T*>(xd.p[e]) + (xd.gmask[e] == 3 ? g * xd.goff[e] : 0) + pg * xd.ld[e] + c0, v[k]);
+                    store8<T>(reinterpret_cast<T*>(xd.p[e]) + ((xd.gmask[e] & (xd.gmask[e] - 1)) ? g * xd.goff[e] : 0) + pg * xd.ld[e] + c0, v[k]);
         }
     }
     if (P && yc < Hp && xc < Wp) store8<T>(P + (((int64_t)n * Hp + yc) * Wp + xc) * ldp + c0, best);
@@ -570,12 +572,12 @@ void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s) {
     if (dt == BF16)
         k_bn_act<bf16><<<grid, 256, lds, s>>>((const bf16*)a.Y, a.ldy, (bf16*)a.A, av, (bf16*)a.P, a.ldp, a.stat,
                                                           a.mask, (const bf16*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total, a.facc,
-                                                          a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps, a.extra, nslab);
+                                                          a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps, a.extra, nslab, a.g_first);
     else
         k_bn_act<float><<<grid, 256, lds, s>>>((const float*)a.Y, a.ldy, (float*)a.A, av, (float*)a.P, a.ldp,
                                                            a.stat, a.mask, (const float*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total,
                                                            a.facc, a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps,
-                                                           a.extra, nslab);
+                                                           a.extra, nslab, a.g_first);
 }
 
 template <typename T>

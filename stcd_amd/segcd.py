@@ -225,3 +225,22 @@ class UnetSeg(SegCD):
 
     def _wrap_output(self, out, B):
         return out
+
+
+class FFCTLCD(SegCD):
+    """``FFCTLCD(encoder_name=...).forward(A, B)`` -> ``(mask_t1, mask_t2, change)``: the feature-level variant kept as a commented
+    alternative in the scripts (``smp.FFCTLCD(encoder_name="resnet50", ...)``, train_pse_cd.py:419, train_stcd.py:637;
+    /root/reference/segmentation_models_pytorch/decoders/unet/model.py:335-423).  The shared decoder + head also run on the
+    encoder features' ``|f1 - f2|`` -- three decoder passes per forward (difference, date 1, date 2: each with its own BatchNorm
+    batch statistics, running statistics updated in that order) -- and ``change = min(head(dec(|f1 - f2|)), |mask_t1 - mask_t2|)``.
+    Same ``state_dict`` as SegCD / UnetSeg."""
+
+    FAMILY = "ffctlcd"
+    OUT_MAPS = 3
+
+    def __init__(self, encoder_name: str = "resnet34", encoder_depth: int = 5, encoder_weights: Optional[str] = None,
+                 decoder_use_batchnorm: bool = True, decoder_channels: List[int] = (256, 128, 64, 32, 16),
+                 decoder_attention_type: Optional[str] = None, in_channels: int = 3, classes: int = 1, activation=None,
+                 aux_params: Optional[dict] = None, dtype: Optional[str] = None):
+        super().__init__(encoder_name, encoder_depth, encoder_weights, decoder_use_batchnorm, decoder_channels, decoder_attention_type,
+                         in_channels, classes, activation, aux_params, dtype)

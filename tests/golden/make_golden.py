@@ -566,6 +566,50 @@ def g15_unetseg():
     save("g15_unetseg.npz", **d)
 
 
+def g16_ffctlcd():
+    """FFCTLCD (decoders/unet/model.py:335-423): the reference's ResNet / UnetDecoder / SegmentationHead wired as its forward
+    states -- decoder(|f1 - f2|), decoder(f1), decoder(f2), in that order; the step of the semi-supervised stage like G10."""
+    from oracle import segcd_ref
+    print("G16 FFCTLCD")
+    d = {}
+
+    def ffc(m, A, B):                                                    # FFCTLCD.forward (model.py:407-423)
+        f1, f2 = m.features(A), m.features(B)
+        diffea = m.segmentation_head(m.decoder(*[torch.abs(a - b) for a, b in zip(f1, f2)]))
+        m1 = m.segmentation_head(m.decoder(*f1))
+        m2 = m.segmentation_head(m.decoder(*f2))
+        return m1, m2, torch.min(diffea, torch.abs(m1 - m2))
+
+    for tag, encoder, seed, classes, B, H, W in (("r34", "resnet34", 1600, 1, 3, 96, 96), ("r50", "resnet50", 1610, 2, 4, 96, 64)):
+        x1, x2 = rand_pair(seed + 1, B, H, W)
+        d[f"{tag}/x1"], d[f"{tag}/x2"], d[f"{tag}/seed"] = t2n(x1), t2n(x2), seed
+        ref = _reference_segcd(classes, encoder)
+        ref.load_state_dict(segcd_ref.synth_state(3, classes, seed, perturb_running=True, encoder=encoder))
+        ref.eval()
+        with torch.no_grad():
+            o = ffc(ref, x1, x2)
+        d[f"{tag}/eval/m1"], d[f"{tag}/eval/m2"], d[f"{tag}/eval/change"] = (t2n(t_) for t_ in o)
+        ref = _reference_segcd(classes, encoder)
+        ref.load_state_dict(segcd_ref.synth_state(3, classes, seed, encoder=encoder))
+        ref.train()
+        m1, m2, ch = ffc(ref, x1, x2)
+        rng = np.random.default_rng(seed + 4)
+        tgt = torch.from_numpy((rng.random((B, classes, H, W)) < 0.2).astype(np.float32))
+        seg = torch.from_numpy((rng.random((B, classes, H, W)) < 0.3).astype(np.float32))
+        loss = ref_losses.cd_loss(torch.sigmoid(m1), seg) + ref_losses.cd_loss(torch.sigmoid(ch), tgt) + 0.5 * m2.mean()
+        loss.backward()
+        d[f"{tag}/target"], d[f"{tag}/seg_target"] = t2n(tgt), t2n(seg)
+        d[f"{tag}/train/m1"], d[f"{tag}/train/m2"], d[f"{tag}/train/change"], d[f"{tag}/loss"] = t2n(m1), t2n(m2), t2n(ch), loss.item()
+        for k, v in grad_summary(ref).items():
+            if tag == "r34" or k.startswith("gs/"):          # the second case keeps the per-tensor summaries only (fixture size)
+                d[f"{tag}/{k}"] = v
+        sd = ref.state_dict()
+        for k in ("encoder.bn1", "encoder.layer2.0.downsample.1", "decoder.blocks.0.conv1.1", "decoder.blocks.2.conv2.1", "decoder.blocks.4.conv2.1"):
+            d[f"{tag}/rs/{k}.running_mean"], d[f"{tag}/rs/{k}.running_var"] = t2n(sd[f"{k}.running_mean"]), t2n(sd[f"{k}.running_var"])
+            d[f"{tag}/rs/{k}.num_batches_tracked"] = t2n(sd[f"{k}.num_batches_tracked"])
+    save("g16_ffctlcd.npz", **d)
+
+
 def g12_segcd_r18():
     """SegCD over the BasicBlock encoders of the registry (encoders/resnet.py:126-144): resnet18 ..."""
     _segcd_fixture("g12_segcd_r18.npz", "G12 SegCD resnet18", 1200, 1, 2, 64, 64, encoder="resnet18")
@@ -582,9 +626,9 @@ def g14_segcd_r101():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd,
           "g7": g7_train128, "g8": g8_contrastive, "g10": g10_segcd, "g11": g11_segcd, "g12": g12_segcd_r18, "g13": g13_segcd_r34,
-          "g14": g14_segcd_r101, "g15": g15_unetseg}
+          "g14": g14_segcd_r101, "g15": g15_unetseg, "g16": g16_ffctlcd}
     for w in which:
         fn[w]()

@@ -272,3 +272,56 @@ def test_unetseg_eval_and_train_step_against_reference_vectors(golden, tag, enco
         np.testing.assert_allclose(st[name].detach().numpy(), g[k], rtol=1e-4, atol=5e-5, err_msg=k)
         if name.endswith("num_batches_tracked"):
             assert int(g[k]) == 1
+
+
+def _gs_check(name, grad, summ, rel_max):
+    """Against the per-tensor summary alone ([sum, l2, first 8, 24 strided samples], make_golden.grad_summary)."""
+    gflat = grad.detach().double().flatten()
+    n = gflat.numel()
+    idx = (np.arange(24) * max(n // 24, 1)) % n
+    got = np.concatenate([gflat[:8].numpy() if n >= 8 else np.pad(gflat.numpy(), (0, 8 - n)), gflat[idx].numpy()])
+    want = np.asarray(summ[2:], dtype=np.float64)
+    l2 = float(summ[1])
+    assert abs(float(gflat.norm()) - l2) <= 2 * rel_max * l2 + 1e-12, (name, float(gflat.norm()), l2)
+    # 32 samples of a tensor with rms l2/sqrt(n): bound their error against that scale
+    assert np.abs(got - want).max() <= 6 * rel_max * max(l2 / np.sqrt(n), np.abs(want).max()), (name, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("tag,encoder,classes", [("r34", "resnet34", 1), ("r50", "resnet50", 2)])
+def test_ffctlcd_eval_and_train_step_against_reference_vectors(golden, tag, encoder, classes):
+    """G16: FFCTLCD (decoders/unet/model.py:335-423) wired from the reference's own ResNet / UnetDecoder / SegmentationHead:
+    three outputs in eval and train mode, the loss, gradients, and running statistics -- the decoder's BatchNorms are called
+    three times per forward (|f1 - f2| first), the encoder's twice."""
+    from oracle import segcd_ref as G
+    from tests._util import check_grad
+    g = golden("g16_ffctlcd.npz")
+    seed = int(g[f"{tag}/seed"])
+    x1, x2 = _t(g[f"{tag}/x1"]), _t(g[f"{tag}/x2"])
+    st = G.synth_state(3, classes, seed, perturb_running=True, encoder=encoder)
+    with torch.no_grad():
+        o = G.ffctlcd_forward(st, x1, x2)
+    for k, v in zip(("m1", "m2", "change"), o):
+        ref = g[f"{tag}/eval/{k}"]
+        np.testing.assert_allclose(v.numpy(), ref, rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(ref).max())))
+    st = G.synth_state(3, classes, seed, encoder=encoder)
+    params = [k for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
+    for k in params:
+        st[k].requires_grad_(True)
+    m1, m2, ch = G.ffctlcd_forward(st, x1, x2, training=True)
+    for k, v in zip(("m1", "m2", "change"), (m1, m2, ch)):
+        np.testing.assert_allclose(v.detach().numpy(), g[f"{tag}/train/{k}"], rtol=1e-3, atol=1e-3)
+    loss = R.cd_loss(torch.sigmoid(m1), _t(g[f"{tag}/seg_target"])) + R.cd_loss(torch.sigmoid(ch), _t(g[f"{tag}/target"])) + 0.5 * m2.mean()
+    assert abs(loss.item() - float(g[f"{tag}/loss"])) < 1e-4
+    loss.backward()
+    for k in params:
+        if st[k].grad is None or float(np.abs(g[f"{tag}/gs/" + k][1])) < 1e-12:
+            continue
+        if f"{tag}/gf/{k}" in g:
+            check_grad(k, st[k].grad, g, rel_max=5e-2, cos_min=0.998, prefix=tag + "/")
+        else:
+            _gs_check(k, st[k].grad, g[f"{tag}/gs/" + k], 5e-2)
+    for k in [k for k in g if k.startswith(tag + "/rs/")]:
+        name = k[len(tag) + 4:]
+        np.testing.assert_allclose(st[name].detach().numpy(), g[k], rtol=1e-4, atol=5e-5, err_msg=k)
+        if name.endswith("num_batches_tracked"):
+            assert int(g[k]) == (3 if name.startswith("decoder") else 2)

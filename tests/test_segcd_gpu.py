@@ -7,7 +7,7 @@ import torch
 
 from oracle import segcd_ref as G
 from stcd_amd.losses import bce_dice_with_logits
-from stcd_amd.segcd import SegCD, UnetSeg
+from stcd_amd.segcd import FFCTLCD, SegCD, UnetSeg
 from tests._util import check_grad, rel_l2_cos, t
 
 pytestmark = pytest.mark.gpu
@@ -453,3 +453,104 @@ def test_unetseg_bf16_and_checkpoint_exchange_with_segcd(golden):
         opt.step()
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0], losses
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FFCTLCD (decoders/unet/model.py:335-423): the decoder also runs on |f1 - f2| -- a third BatchNorm group on the engine
+@pytest.mark.parametrize("tag,encoder,classes", [("r34", "resnet34", 1), ("r50", "resnet50", 2)])
+def test_ffctlcd_fp32_matches_reference_vectors(golden, tag, encoder, classes):
+    from tests.test_oracle_golden import _gs_check
+    g = golden("g16_ffctlcd.npz")
+    seed = int(g[f"{tag}/seed"])
+    x1, x2 = t(g[f"{tag}/x1"]).to(DEV), t(g[f"{tag}/x2"]).to(DEV)
+    m = FFCTLCD(encoder_name=encoder, classes=classes, dtype="fp32")
+    m.load_state_dict(G.synth_state(3, classes, seed, perturb_running=True, encoder=encoder))
+    m.to(DEV).eval()
+    with torch.no_grad():
+        o = m(x1, x2)
+    for k, v in zip(("m1", "m2", "change"), o):
+        ref = g[f"{tag}/eval/{k}"]
+        np.testing.assert_allclose(v.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    m = FFCTLCD(encoder_name=encoder, classes=classes, dtype="fp32")
+    m.load_state_dict(G.synth_state(3, classes, seed, encoder=encoder))
+    m.to(DEV).train()
+    m1, m2, ch = m(x1, x2)
+    for k, v in zip(("m1", "m2", "change"), (m1, m2, ch)):
+        np.testing.assert_allclose(v.detach().cpu().numpy(), g[f"{tag}/train/{k}"], rtol=2e-3, atol=2e-3, err_msg=k)
+    loss = _loss(m1, m2, ch, t(g[f"{tag}/seg_target"]).to(DEV), t(g[f"{tag}/target"]).to(DEV))
+    assert abs(loss.item() - float(g[f"{tag}/loss"])) < 2e-4
+    loss.backward()
+    for name, p in m.named_parameters():
+        if float(np.abs(g[f"{tag}/gs/" + name][1])) < 1e-12:
+            continue
+        if f"{tag}/gf/{name}" in g:
+            check_grad(name, p.grad, g, rel_max=SEG_REL, cos_min=SEG_COS, prefix=tag + "/", tag=f"fp32 FFCTLCD-{encoder} vs reference G16")
+        else:
+            _gs_check(name, p.grad.cpu(), g[f"{tag}/gs/" + name], SEG_REL)
+    sd = m.state_dict()
+    for k in [k for k in g if k.startswith(tag + "/rs/")]:      # decoder BatchNorms: |f1 - f2| first, then date 1, date 2; 3 calls
+        np.testing.assert_allclose(sd[k[len(tag) + 4:]].cpu().numpy(), g[k], rtol=1e-4, atol=5e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("dtype,encoder,B,H,W", [("fp32", "resnet18", 2, 64, 64), ("bf16", "resnet34", 2, 64, 96), ("bf16", "resnet50", 3, 96, 64)])
+def test_ffctlcd_layer_local_in_place(dtype, encoder, B, H, W):
+    """The three-group decoder checked in place (stcd_ws_tensor_*): every decoder layer's conv output / weight gradient /
+    per-group BatchNorm + ReLU from its own stored tensors, the |f1 - f2| group of every decoder input, the skip / up-sampling
+    plumbing with three groups, and the head."""
+    rng = np.random.default_rng(51)
+    x1 = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32)).to(DEV)
+    x2 = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32)).to(DEV)
+    tgt = torch.from_numpy((rng.random((B, 1, H, W)) < 0.2).astype(np.float32)).to(DEV)
+    m = FFCTLCD(encoder_name=encoder, dtype=dtype)
+    m.load_state_dict(G.synth_state(3, 1, 13, encoder=encoder))
+    m._engine.set_debug(1)
+    m.to(DEV).train()
+    o = m(x1, x2)
+    loss = bce_dice_with_logits(o[2], tgt) + bce_dice_with_logits(o[0], tgt) + 0.5 * o[1].mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    ws = m._engine.ws_tensors()
+    tol = 2e-4 if dtype == "fp32" else 6e-3
+    wq = (lambda w: w.detach().to(torch.bfloat16).float()) if dtype == "bf16" else (lambda w: w.detach())
+    worst = {}
+
+    def chk(kind, name, got, want, t_=tol):
+        r = float((got.float() - want).norm() / want.norm().clamp_min(1e-30))
+        if r >= worst.get(kind, (0.0, ""))[0]:
+            worst[kind] = (r, name)
+        assert r <= t_, (kind, name, r)
+
+    basic = G.ENCODERS[encoder][0] == 1
+    last = {li: f"encoder.layer{li}.{G.ENCODERS[encoder][1][li - 1] - 1}.conv{2 if basic else 3}" for li in (1, 2, 3, 4)}
+    skips = [last[3], last[2], last[1], "encoder.conv1"]
+    rq = (lambda v: v.to(torch.bfloat16).float()) if dtype == "bf16" else (lambda v: v)      # the difference is stored in the activation type
+    x = _nchw(ws[last[4] + ".A"])                                    # [2B]: the two dates
+    x = torch.cat([x, rq((x[:B] - x[B:]).abs())])                    # + |f5 - f5|
+    for i, blk in enumerate(m.decoder.blocks):
+        cat = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
+        if i < 4:
+            sk = _nchw(ws[skips[i] + ".A"])
+            cat = torch.cat([cat, torch.cat([sk, rq((sk[:B] - sk[B:]).abs())])], dim=1)
+        stored = _nchw(ws[f"decoder.blocks.{i}.conv1.0.in"])
+        assert stored.shape[0] == 3 * B
+        assert torch.equal(stored, cat), i                         # three groups: date 1, date 2, |difference|
+        for cname, (conv, bn) in ((f"decoder.blocks.{i}.conv1.0", (blk.conv1[0], blk.conv1[1])), (f"decoder.blocks.{i}.conv2.0", (blk.conv2[0], blk.conv2[1]))):
+            X, Y, A, dY = _nchw(ws[cname + ".in"]), _nchw(ws[cname + ".Y"]), _nchw(ws[cname + ".A"]), _nchw(ws[cname + ".dY"])
+            Wt = wq(conv.weight)
+            chk("conv output", cname, Y, torch.nn.functional.conv2d(X, Wt, None, 1, 1))
+            chk("weight gradient", cname, conv.weight.grad, torch.nn.grad.conv2d_weight(X, conv.weight.shape, dY, 1, 1), 2e-4 if dtype == "fp32" else 2e-3)
+            chk("input gradient", cname, _nchw(ws[cname + ".dIn"]), torch.nn.grad.conv2d_input(X.shape, Wt, dY, 1, 1))
+            outs = []
+            for d in range(3):
+                y = Y[d * B:(d + 1) * B]
+                mu, var = y.mean(dim=(0, 2, 3), keepdim=True), y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+                outs.append(torch.relu((y - mu) * torch.rsqrt(var + 1e-5) * bn.weight.detach().view(1, -1, 1, 1) + bn.bias.detach().view(1, -1, 1, 1)))
+            chk("bn+relu", cname, A, torch.cat(outs), 1e-4 if dtype == "fp32" else 1.2e-2)
+        x = _nchw(ws[f"decoder.blocks.{i}.conv2.0.A"])
+    hw, hb = wq(m.segmentation_head[0].weight), m.segmentation_head[0].bias.detach()
+    head = lambda t_: torch.nn.functional.conv2d(t_, hw, hb, padding=1)
+    m1, m2, dif = head(x[:B]), head(x[B:2 * B]), head(x[2 * B:])
+    want = (m1, m2, torch.min(dif, (m1 - m2).abs()))
+    for k in range(3):
+        chk("head", f"output {k}", o[k].detach(), want[k], 1e-4 if dtype == "fp32" else 2e-2)
+    print(f"FFCTLCD-{encoder} {dtype} B={B} {H}x{W} layer-local worst relative l2: " + ", ".join(f"{k} {v[0]:.1e} ({v[1]})" for k, v in worst.items()))
