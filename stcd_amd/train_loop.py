@@ -114,3 +114,53 @@ def train_cd_epoch(model, trainloader, valloader, optimizer, args, device="cuda:
         if on_epoch_end is not None:
             on_epoch_end(rec)
     return best_model, history
+
+
+def train_seg_epoch(model, trainloader, valloader, optimizer, args, device="cuda:0", writer=None, on_epoch_end=None):
+    """The supervised segmentation loop of /root/reference/train_sup.py:112-185 (``pred = model(image)``; sigmoid + criterion;
+    Poly LR; validation F1 / IoU of class 1; best-by-IoU checkpoint) with the per-step host syncs removed: the loss is
+    accumulated on the device and the metric is the device-side confusion matrix.  Returns (best_model, history)."""
+    previous_best, best_model, history = 0.0, None, []
+    lr_scheduler = Poly(optimizer=optimizer, num_epochs=args.n_epochs, iters_per_epoch=len(trainloader))
+    for epoch in range(1, args.n_epochs + 1):
+        model.train()
+        total, n_it = torch.zeros((), device=device), 0
+        for image, label in trainloader:
+            image, label = image.to(device, non_blocking=True), label.to(device, non_blocking=True).unsqueeze(1)
+            optimizer.zero_grad()
+            seg_loss = bce_dice_with_logits(_unwrap(model(image)), label.float())      # train_sup.py:133-135
+            seg_loss.backward()
+            optimizer.step()
+            total += seg_loss.detach()
+            n_it += 1
+            lr_scheduler.step(epoch=epoch - 1)
+        rec = {"epoch": epoch, "seg_loss": (total / max(n_it, 1)).item()}
+        model.eval()
+        with torch.no_grad(), frozen_weights(model):
+            acc = SegmentationMetric(numClass=2, device=device)
+            vtot, vn = torch.zeros((), device=device), 0
+            for image, label in valloader:
+                image, label = image.to(device), label.to(device).unsqueeze(1)
+                pred = _unwrap(model(image))
+                vtot += bce_dice_with_logits(pred, label.float())
+                vn += 1
+                acc.add_logits(pred, label)                                            # pred > 0.5 after the sigmoid (train_sup.py:162)
+            rec.update(val_loss=(vtot / max(vn, 1)).item(), val_f1=float(acc.F1score()[1]), val_iou=float(acc.IntersectionOverUnion()[1]))
+        if writer is not None:
+            for k, v in rec.items():
+                if k != "epoch":
+                    writer.add_scalar(k, v, epoch)
+        history.append(rec)
+        save_name = getattr(args, "save_name", None)
+        iou = rec["val_iou"]
+        if iou > previous_best:                                                        # train_sup.py:174-181
+            if save_name:
+                if previous_best != 0 and os.path.exists(os.path.join(save_name, "%.2f_best_model.pth" % previous_best)):
+                    os.remove(os.path.join(save_name, "%.2f_best_model.pth" % previous_best))
+                os.makedirs(save_name, exist_ok=True)
+                torch.save((model.module if hasattr(model, "module") else model).state_dict(), os.path.join(save_name, "%.2f_best_model.pth" % iou))
+            previous_best = iou
+            best_model = deepcopy(model)
+        if on_epoch_end is not None:
+            on_epoch_end(rec)
+    return best_model, history

@@ -243,3 +243,21 @@ def test_semi_supervised_example_runs_and_learns(monkeypatch):
     hist = mod.main()
     assert len(hist) == 3 and all(np.isfinite([h["seg_loss"], h["cd_loss"], h["ct_loss"]]).all() for h in hist)
     assert hist[-1]["cd_loss"] < hist[0]["cd_loss"]
+
+
+def test_supervised_example_runs_learns_and_hands_over(monkeypatch, capsys):
+    """examples/train_sup_synth.py: the loop of train_sup.py (UnetSeg, sigmoid + BCE/Dice, Adam + Poly, best-by-IoU) on synthetic
+    tiles for four short epochs -- finite, the loss falls -- and the hand-over of the best weights to SegCD: identical dates give a
+    zero change map (|mask_t1 - mask_t2| = 0 bounds it from above)."""
+    import importlib.util
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_sup_synth", os.path.join(repo, "examples", "train_sup_synth.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = mod.main(["--n_epochs", "4", "--batch_size", "4", "--img_height", "64", "--img_width", "64", "--train_tiles", "16", "--val_tiles", "8",
+                     "--encoder", "resnet18"])
+    assert len(hist) == 4 and all(np.isfinite([h["seg_loss"], h["val_loss"]]).all() for h in hist)
+    assert hist[-1]["seg_loss"] < hist[0]["seg_loss"]
+    out = capsys.readouterr().out
+    assert "identical dates = 0" in out, out[-300:]
