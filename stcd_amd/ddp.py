@@ -57,14 +57,16 @@ class FlatGradReducer:
     (stream-side wait, the host never blocks).  gloo path (CPU tests, or GPU tensors in a CPU-transport test):
     staged through host memory, synchronous."""
 
-    def __init__(self, model, group=None, overlap: bool = True):
+    def __init__(self, model, group=None, overlap: bool = True, force: bool = False):
+        """force: install the hook even in a one-rank group (the collectives then average over one rank: an identity that still
+        runs the whole RCCL path -- side stream, async all_reduce, final wait -- on a single GPU)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
         self.overlap = overlap
         self._comm = None
         self._works = []
-        if self.world > 1:
+        if self.world > 1 or (force and dist.is_initialized()):
             model.grad_stage_hook = self._hook
 
     def _hook(self, stage: int, g: torch.Tensor):

@@ -144,3 +144,68 @@ def test_two_ranks_over_rccl(overlap):
         np.testing.assert_allclose(got[r][0], want.numpy(), rtol=1e-4, atol=1e-6 * float(want.abs().max()) + 1e-9)
         np.testing.assert_allclose(got[r][1], want_params, rtol=1e-5, atol=2e-6)
     np.testing.assert_array_equal(got[0][1], got[1][1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same RCCL branch on ONE GPU: a one-rank "nccl" group.  ReduceOp.AVG over one rank is the identity, so gradients and the
+# optimizer step must equal the plain single-process ones bit for bit -- while the side-stream wait, record_stream, the two
+# asynchronous RCCL all_reduce calls per backward and the stage-1 wait all really execute (several steps, both families'
+# stage layouts: FC-Siam has two gradient stages, SegCD one).
+def _nccl_one_rank_worker(port, q, state, overlap, family):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    from stcd_amd.ddp import FlatGradReducer, broadcast_parameters
+    from stcd_amd.optim import FlatAdamW
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    out = {}
+    for reduced in (False, True):
+        m = _family_model(family, state).to(dev).train()
+        if reduced:
+            broadcast_parameters(m)
+            red = FlatGradReducer(m, overlap=overlap, force=True)
+            assert m.grad_stage_hook is not None and red.backend == "nccl"
+        opt = FlatAdamW(m, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+        for step in range(3):
+            x1, x2, y = _data(step)
+            opt.zero_grad(set_to_none=True)
+            o = m(x1.to(dev), x2.to(dev))
+            o = o[-1] if isinstance(o, (list, tuple)) else o
+            loss = torch.nn.functional.cross_entropy(o, y.to(dev)) if family == "diff" else o.square().mean()
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        out[reduced] = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu().numpy()
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def _family_model(family, state):
+    if family == "diff":
+        from stcd_amd.modules import SiamUnet_diff
+        m = SiamUnet_diff(3, 2, dtype="fp32")
+        m.load_state_dict(state)
+        m.set_dropout_p(0.0)
+        return m
+    from stcd_amd.segcd import SegCD
+    m = SegCD(encoder_name="resnet18", dtype="fp32")
+    m.load_state_dict(state)
+    return m
+
+
+@pytest.mark.parametrize("family,overlap", [("diff", True), ("diff", False), ("segcd", True)])
+def test_one_rank_rccl_group_runs_the_collective_path(family, overlap):
+    from oracle import fcsiam_ref as R
+    from oracle import segcd_ref as G
+    state = R.synth_state("diff", 3, 2, seed=9) if family == "diff" else G.synth_state(3, 1, 9, encoder="resnet18")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    p = ctx.Process(target=_nccl_one_rank_worker, args=(port, q, state, overlap, family))
+    p.start()
+    out = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    np.testing.assert_array_equal(out[True], out[False])
