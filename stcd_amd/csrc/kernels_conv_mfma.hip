@@ -1259,7 +1259,10 @@ constexpr int RES_HW = 18;     // halo edge of the 16 x 16 output tile
 
 // CW = channels per pipeline step (32: 64-B pixel rows; 64: full 128-B lines and half as many steps -- used whenever
 // Ci % 64 == 0, where the wider co slice it leaves room for also halves the re-reads of X through L2).
-template <int NT, int CW, bool SH = false>
+// PIPE: the (32-channel chunk, column shift) stages of a step are software-pipelined -- the LDS reads of stage s + 1 (6 halo
+// fragments + 3 x NT filter fragments) are issued before the MFMAs of stage s, into a second register set; without it the
+// compiler issues every stage's reads right in front of their first use and the wave waits out the LDS latency 3-6 times per step.
+template <int NT, int CW, bool SH = false, bool PIPE = false>
 __global__ void __launch_bounds__(256, (CW == 64 && NT == 4) ? 1 : 2)
 k_conv_res(const ConvResArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1402,6 +1405,41 @@ k_conv_res(const ConvResArgs a) {
         const bool have_next = nxt.tile < tile_end;
         if (have_next) RES_FETCH(nxt);
         const char* hb = halo0 + (SH ? 0 : buf) * HALO_BYTES;
+        if constexpr (PIPE) {
+            constexpr int NSTG = KSC * 3;
+            bf16x8 ab[2][6], wb[2][3][NT];
+            const char* const fb0 = filt + (int64_t)(cur.c * KSC) * (ntaps * NT * 1024) + lane * 16;
+#define RES_LOAD_STAGE(S_, B_)                                                                                        \
+            do {                                                                                                      \
+                constexpr int ks_ = (S_) / 3, dx_ = (S_) % 3;                                                         \
+                _Pragma("unroll") for (int hr = 0; hr < 6; ++hr)                                                      \
+                    ab[B_][hr] = *reinterpret_cast<const bf16x8*>(hb + aoff[ks_][dx_] + hr * (RES_HW * CW * 2));      \
+                _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                                      \
+                    _Pragma("unroll") for (int t2 = 0; t2 < NT; ++t2)                                                 \
+                        wb[B_][dy][t2] = *reinterpret_cast<const bf16x8*>(fb0 + ks_ * (ntaps * NT * 1024) + a.tix[dy][dx_] * (NT * 1024) + t2 * 1024); \
+            } while (0)
+#define RES_MMA_STAGE(B_)                                                                                             \
+            do {                                                                                                      \
+                _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                                      \
+                    _Pragma("unroll") for (int t2 = 0; t2 < NT; ++t2)                                                 \
+                        _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                 \
+                            acc[m][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[B_][dy][t2], ab[B_][m + dy], acc[m][t2], 0, 0, 0); \
+            } while (0)
+            RES_LOAD_STAGE(0, 0);
+            if constexpr (NSTG > 1) { RES_LOAD_STAGE(1, 1); __builtin_amdgcn_sched_barrier(0); }
+            RES_MMA_STAGE(0);
+            if constexpr (NSTG > 2) { RES_LOAD_STAGE(2, 0); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (NSTG > 1) RES_MMA_STAGE(1);
+            if constexpr (NSTG > 3) { RES_LOAD_STAGE(3, 1); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (NSTG > 2) RES_MMA_STAGE(0);
+            if constexpr (NSTG > 4) { RES_LOAD_STAGE(4, 0); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (NSTG > 3) RES_MMA_STAGE(1);
+            if constexpr (NSTG > 5) { RES_LOAD_STAGE(5, 1); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (NSTG > 4) RES_MMA_STAGE(0);
+            if constexpr (NSTG > 5) RES_MMA_STAGE(1);
+#undef RES_LOAD_STAGE
+#undef RES_MMA_STAGE
+        } else
 #pragma unroll
         for (int ks = 0; ks < KSC; ++ks) {
             const char* fb = filt + (int64_t)(cur.c * KSC + ks) * (ntaps * NT * 1024) + lane * 16;
@@ -1594,6 +1632,20 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
         }                                                                                                         \
         k_conv_res<N_, W_><<<(unsigned)rp.blocks, 256, (size_t)rp.lds_bytes, s>>>(a);                             \
     } while (0)
+#define LAUNCH_RES_PIPE(N_, W_)                                                                                   \
+    do {                                                                                                          \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute((const void*)k_conv_res<N_, W_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        k_conv_res<N_, W_, false, true><<<(unsigned)rp.blocks, 256, (size_t)rp.lds_bytes, s>>>(a);               \
+    } while (0)
+    // measured (SNUNet / SegCD, 16 x 256^2): <1, 64> 0.67 -> 0.58 ms per step (-13 %); the CW = 32 variants do not move (their
+    // layers sit on the HBM roofline: 134 MB in + 134 MB out per 32 -> 32 full-resolution layer in 66 us), <2, 64> has no registers
+    // left for the second fragment set.  Default: <1, 64> only; STCD_CONV_RES_PIPE=1 pipelines every variant that fits, 0 none.
+    static const int pipe_env = [] { const char* e = getenv("STCD_CONV_RES_PIPE"); return e ? atoi(e) : -1; }();
+    const int pipe = pipe_env >= 0 ? pipe_env : (rp.CW == 64 && rp.NT == 1);
 #define LAUNCH_RES_SH(N_)                                                                                         \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
@@ -1607,18 +1659,19 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
         if (rp.NT == 2) LAUNCH_RES_SH(2); else LAUNCH_RES_SH(4);
     } else if (rp.CW == 64) {
         switch (rp.NT) {
-            case 1: LAUNCH_RES(1, 64); break;
-            case 2: LAUNCH_RES(2, 64); break;
+            case 1: if (pipe) LAUNCH_RES_PIPE(1, 64); else LAUNCH_RES(1, 64); break;
+            case 2: if (pipe) LAUNCH_RES_PIPE(2, 64); else LAUNCH_RES(2, 64); break;
             default: LAUNCH_RES(4, 64); break;
         }
     } else {
         switch (rp.NT) {
-            case 1: LAUNCH_RES(1, 32); break;
-            case 2: LAUNCH_RES(2, 32); break;
-            default: LAUNCH_RES(4, 32); break;
+            case 1: if (pipe) LAUNCH_RES_PIPE(1, 32); else LAUNCH_RES(1, 32); break;
+            case 2: if (pipe) LAUNCH_RES_PIPE(2, 32); else LAUNCH_RES(2, 32); break;
+            default: LAUNCH_RES(4, 32); break;       // NT = 4 has no registers for a second fragment set (it spills)
         }
     }
 #undef LAUNCH_RES
+#undef LAUNCH_RES_PIPE
 #undef LAUNCH_RES_SH
     return 0;
 }
