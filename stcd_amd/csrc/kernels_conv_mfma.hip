@@ -1703,6 +1703,9 @@ struct ConvGemmArgs {
     int Mg;                        // positions per group
     int tiles_m, tiles_m8, tiles_n;
     unsigned in_bytes;
+    int tap[9];                    // (dy << 16) | (dx & 0xffff) per tap, as 32-bit words: a uniform index into them is a SCALAR
+                                   // load (the int8 arrays of g compile to global_load_sbyte, whose vmcnt(0) wait also waits for
+                                   // every fetch still in flight -- that had serialised the two register sets)
 };
 
 template <int W>
@@ -1772,7 +1775,8 @@ k_conv_gemm(const ConvGemmArgs a) {
     do {                                                                                                               \
         const int ss_ = __builtin_amdgcn_readfirstlane(S_);                     /* scalar step index */                \
         const int cc_ = ss_ / ntaps, tt_ = ss_ - cc_ * ntaps;                                                          \
-        const int tdy_ = a.g.dy[tt_], tdx_ = a.g.dx[tt_];                                                              \
+        const int tw_ = a.tap[tt_];                                                                                    \
+        const int tdy_ = tw_ >> 16, tdx_ = (int)(short)(tw_ & 0xffff);                                                 \
         const int toff_ = (tdy_ * a.g.wi + tdx_) * a.g.ldi * 2;                                                        \
         _Pragma("unroll") for (int p = 0; p < XP; ++p) {                                                               \
             const bool ok_ = (unsigned)((xyx[p] >> 16) + tdy_) < (unsigned)a.g.hi && (unsigned)((int)(short)(xyx[p] & 0xffff) + tdx_ + chx) < (unsigned)a.g.wi; \
@@ -1824,13 +1828,18 @@ k_conv_gemm(const ConvGemmArgs a) {
     GM_FETCH(min(1, nc - 1), pxb, pwb);
     GM_STASH(0, pxa, pwa);
     __syncthreads();
+    // sched_barrier: without it the compiler sinks the fetch below the MFMAs (right in front of the stash of the OTHER set),
+    // which (a) gives the loads half an iteration instead of one and a half to land and (b) lets it reuse the fetch registers
+    // for the LDS fragment reads of the same half -- every ds_read then waits for the outstanding global loads (vmcnt) first
     for (int c = 0; c < nc; c += 2) {
         GM_FETCH(min(c + 2, nc - 1), pxa, pwa);
+        __builtin_amdgcn_sched_barrier(0);
         GM_COMPUTE(0);
         GM_STASH(1, pxb, pwb);
         barrier_lds();
         if (c + 1 >= nc) break;
         GM_FETCH(min(c + 3, nc - 1), pxb, pwb);
+        __builtin_amdgcn_sched_barrier(0);
         GM_COMPUTE(1);
         GM_STASH(0, pxa, pwa);
         barrier_lds();
@@ -1945,6 +1954,7 @@ int launch_conv_gemm(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvG
     a.Mg = (g.n / groups) * g.hm * g.wm;
     a.tiles_m = gp.tiles_m; a.tiles_m8 = (gp.tiles_m + 7) / 8; a.tiles_n = gp.tiles_n;
     a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
+    for (int t = 0; t < 9; ++t) a.tap[t] = t < g.ntaps ? (int)(((unsigned)(int)g.dy[t] << 16) | ((unsigned)(int)g.dx[t] & 0xffffu)) : 0;
     if (gp.W == 4) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_conv_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }

@@ -6,6 +6,7 @@ Differences, all on the host side: the loss is the fused HIP kernel (sigmoid ins
 device (no ``.cpu()`` per step, train_pse_cd.py:231), TensorBoard is optional (absent in this image)."""
 from __future__ import annotations
 
+import contextlib
 import os
 from copy import deepcopy
 
@@ -14,6 +15,25 @@ import torch
 from .losses import bce_dice_with_logits
 from .modules import frozen_weights
 from .metrics import SegmentationMetric
+
+
+@contextlib.contextmanager
+def quiet_gc():
+    """Keep Python's cyclic garbage collector off the step loop's back.
+
+    A full collection walks every container object of the process; with a module tree of several hundred parameter tensors,
+    BatchNorm buffers, gradient views and holder modules that is milliseconds of host time, and it lands in the middle of a
+    step's launch sequence: the GPU drains its queue and idles.  Measured on SegCD-resnet50 (16 pairs, 256^2): 10.35 -> 9.47 ms per
+    step; at 8 pairs 8.10 -> 6.42 ms (`bench.py`, STCD_BENCH_GC=default reproduces the slow case).  ``gc.freeze()`` moves
+    everything alive at loop entry into the permanent generation, so the collector only ever looks at the few objects a step
+    creates; collection itself stays enabled, and the objects are handed back on exit."""
+    import gc
+    gc.collect()
+    gc.freeze()
+    try:
+        yield
+    finally:
+        gc.unfreeze()
 
 
 class Poly:
@@ -53,6 +73,11 @@ def _unwrap(out):
 
 def train_cd_epoch(model, trainloader, valloader, optimizer, args, device="cuda:0", writer=None, on_epoch_end=None):
     """Returns (best_model, history) where history is a list of per-epoch dicts (loss, train/val F1 and IoU)."""
+    with quiet_gc():
+        return _train_cd_epoch(model, trainloader, valloader, optimizer, args, device, writer, on_epoch_end)
+
+
+def _train_cd_epoch(model, trainloader, valloader, optimizer, args, device, writer, on_epoch_end):
     previous_best = 0.0
     best_model = None
     history = []
@@ -120,6 +145,11 @@ def train_seg_epoch(model, trainloader, valloader, optimizer, args, device="cuda
     """The supervised segmentation loop of /root/reference/train_sup.py:112-185 (``pred = model(image)``; sigmoid + criterion;
     Poly LR; validation F1 / IoU of class 1; best-by-IoU checkpoint) with the per-step host syncs removed: the loss is
     accumulated on the device and the metric is the device-side confusion matrix.  Returns (best_model, history)."""
+    with quiet_gc():
+        return _train_seg_epoch(model, trainloader, valloader, optimizer, args, device, writer, on_epoch_end)
+
+
+def _train_seg_epoch(model, trainloader, valloader, optimizer, args, device, writer, on_epoch_end):
     previous_best, best_model, history = 0.0, None, []
     lr_scheduler = Poly(optimizer=optimizer, num_epochs=args.n_epochs, iters_per_epoch=len(trainloader))
     for epoch in range(1, args.n_epochs + 1):

@@ -311,7 +311,12 @@ class CDTrainer:
         self.G_loss.backward()
 
     def train_models(self):
+        from .train_loop import quiet_gc
         self._load_checkpoint()
+        with quiet_gc():        # keep full cyclic collections over the module tree out of the step loop (train_loop.quiet_gc)
+            self._train_epochs()
+
+    def _train_epochs(self):
         for self.epoch_id in range(self.epoch_to_start, self.max_num_epochs):
             self._clear_cache()
             self.is_training = True
