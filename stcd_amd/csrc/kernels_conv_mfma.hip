@@ -38,7 +38,15 @@ struct ConvMfmaArgs {
     int dymin, dxmin, HH, HWp, swmask;
     int tiles_x, tiles_y;
     int halo_bytes, wbuf_bytes;
+    int tap[9];            // (dy << 16) | (dx & 0xffff): 32-bit words, so a uniform tap index is a SCALAR load (see ConvGemmArgs)
 };
+
+// host: the packed tap table of a geometry
+static inline void fill_taps(const stcd_conv_geom& g, int* tap) {
+    for (int t = 0; t < 9; ++t) tap[t] = t < g.ntaps ? (int)(((unsigned)(int)g.dy[t] << 16) | ((unsigned)(int)g.dx[t] & 0xffffu)) : 0;
+}
+#define TAP_DY(w_) ((w_) >> 16)
+#define TAP_DX(w_) ((int)(short)((w_) & 0xffff))
 
 template <int NT>
 __device__ __forceinline__ void conv_mfma_body(const ConvMfmaArgs& a, const int bx, const int cob) {
@@ -56,8 +64,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvMfmaArgs& a, const int 
     bf16* wl = reinterpret_cast<bf16*>(smem + a.halo_bytes);
     int* tapoff = reinterpret_cast<int*>(smem + a.halo_bytes + 2 * a.wbuf_bytes);   // [9] pixel offset, [9] dx (mode B)
     if (tid < a.g.ntaps) {
-        tapoff[tid] = (a.g.dy[tid] - a.dymin) * HWp + (a.g.dx[tid] - a.dxmin);
-        tapoff[9 + tid] = a.g.dx[tid] - a.dxmin;
+        int tw = 0;
+#pragma unroll
+        for (int tt = 0; tt < 9; ++tt) tw = tid == tt ? a.tap[tt] : tw;      // scalar loads + selects (no per-lane byte loads)
+        tapoff[tid] = (TAP_DY(tw) - a.dymin) * HWp + (TAP_DX(tw) - a.dxmin);
+        tapoff[9 + tid] = TAP_DX(tw) - a.dxmin;
     }
 
     f32x4 acc[2][NT];
@@ -147,7 +158,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvMfmaArgs& a, const int 
                     const bf16* wsrc = a.wf + ((int64_t)(cc * ntaps + t + 1) * a.KS) * a.NTtot * 512;
                     W_LOAD(wsrc);
                 }
-                const int tdy = a.g.dy[t] - a.dymin, tdx = a.g.dx[t] - a.dxmin;
+                const int tw = a.tap[t];
+                const int tdy = TAP_DY(tw) - a.dymin, tdx = TAP_DX(tw) - a.dxmin;
                 for (int ks = 0; ks < a.KS; ++ks) {
                     bf16x8 af[2];
 #pragma unroll
@@ -381,6 +393,7 @@ static size_t conv_mfma_args(const stcd_conv_geom& g, const ConvMfmaPlan& p, con
     a.tiles_y = (g.hm + 7) / 8;
     a.halo_bytes = (a.HH * a.HWp * p.CiB * 2 + 255) & ~255;
     a.wbuf_bytes = p.modeB ? ((p.KS * p.NT * 1024 + 1) / 2 + 255) & ~255 : (p.KS * p.NT * 1024 + 255) & ~255;
+    fill_taps(g, a.tap);
     return (size_t)a.halo_bytes + 2 * (size_t)a.wbuf_bytes + 128;
 }
 
@@ -973,6 +986,7 @@ struct ConvSmallArgs {
     int halo_bytes;
     long long* stat_acc;   // nullable: BatchNorm forward accumulators int64 [BN_REP][groups][2][cpad] (common.h)
     int cpad;
+    int tap[9];            // packed taps (fill_taps)
 };
 
 template <int NT, int KSMAX>
@@ -998,7 +1012,10 @@ k_conv_small(const ConvSmallArgs a) {
             const int kl = ks * 32 + 8 * q;
             int t = kl / Ci, c = kl - t * Ci;
             if (t >= a.g.ntaps) { t = 0; c = 0; }
-            aoff[ks] = ((a.g.dy[t] - a.dymin) * HWp + (a.g.dx[t] - a.dxmin)) * Ci + c;
+            int tw = 0;
+#pragma unroll
+            for (int tt = 0; tt < 9; ++tt) tw = t == tt ? a.tap[tt] : tw;    // per-lane tap: scalar loads + selects
+            aoff[ks] = ((TAP_DY(tw) - a.dymin) * HWp + (TAP_DX(tw) - a.dxmin)) * Ci + c;
         } else {
 #pragma unroll
             for (int t2 = 0; t2 < NT; ++t2) wreg[ks][t2] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -1216,6 +1233,7 @@ int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_mo
     a.halo_bytes = (a.HH * a.HWp * g.ci * 2 + 255) & ~255;
     a.stat_acc = stat_acc;
     a.cpad = cpad;
+    fill_taps(g, a.tap);
     if (g.n % groups != 0) return 1;
     const int blocks = conv_small_blocks(g, groups);
     size_t lds = std::max<size_t>(2 * (size_t)a.halo_bytes, 4 * 2 * 16 * 2 * 4 * 2);
@@ -1954,7 +1972,7 @@ int launch_conv_gemm(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvG
     a.Mg = (g.n / groups) * g.hm * g.wm;
     a.tiles_m = gp.tiles_m; a.tiles_m8 = (gp.tiles_m + 7) / 8; a.tiles_n = gp.tiles_n;
     a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
-    for (int t = 0; t < 9; ++t) a.tap[t] = t < g.ntaps ? (int)(((unsigned)(int)g.dy[t] << 16) | ((unsigned)(int)g.dx[t] & 0xffffu)) : 0;
+    fill_taps(g, a.tap);
     if (gp.W == 4) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_conv_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
