@@ -1305,9 +1305,15 @@ k_conv_res(const ConvResArgs a) {
         const int ntl = f % NT, ft = f / NT, t = ft % ntaps, c32 = ft / ntaps;
         return ((int64_t)((c32 / a.KSp) * ntaps + t) * a.KSp + (c32 % a.KSp)) * a.NTtot + slice * NT + ntl;
     };
+    // Branch-free on purpose: a fragment index past the slice is clamped to the last fragment for the load AND for the store
+    // (the same bytes written twice), and the wave index is made scalar.  With `if (f < nfrag) store` the compiler had sunk
+    // every load into its store's block: nine (and, for deep slices, eighteen) fully serialised load -> wait -> store round
+    // trips in the prologue of every block.
+    const int swid = __builtin_amdgcn_readfirstlane(wid);
     uint4 fv[FB];
 #pragma unroll
-    for (int k = 0; k < FB; ++k) fv[k] = *reinterpret_cast<const uint4*>(a.wf + (filt_src(min(wid + 4 * k, nfrag - 1)) * 64 + lane) * 8);
+    for (int k = 0; k < FB; ++k) fv[k] = *reinterpret_cast<const uint4*>(a.wf + (filt_src(min(swid + 4 * k, nfrag - 1)) * 64 + lane) * 8);
+    // (no sched_barrier here: with one, the compiler keeps fv[] in scratch memory)
 
     // ---- halo staging plan: piece i = tid + p*256 = pixel (i >> LG8), 16-B chunk ch = tid & SW (the same for every p);
     //      only the halo coordinates are kept per piece, offsets are rebuilt from them (2 FMAs) at use.
@@ -1407,14 +1413,14 @@ k_conv_res(const ConvResArgs a) {
     {
 #pragma unroll
         for (int k = 0; k < FB; ++k)
-            if (wid + 4 * k < nfrag) *reinterpret_cast<uint4*>(filt + ((int64_t)(wid + 4 * k) * 64 + lane) * 16) = fv[k];
-        for (int f0 = wid + 4 * FB; f0 < nfrag; f0 += 4 * FB) {
+            *reinterpret_cast<uint4*>(filt + ((int64_t)min(swid + 4 * k, nfrag - 1) * 64 + lane) * 16) = fv[k];
+        for (int f0 = swid + 4 * FB; f0 < nfrag; f0 += 4 * FB) {
             uint4 v[FB];
 #pragma unroll
             for (int k = 0; k < FB; ++k) v[k] = *reinterpret_cast<const uint4*>(a.wf + (filt_src(min(f0 + 4 * k, nfrag - 1)) * 64 + lane) * 8);
 #pragma unroll
             for (int k = 0; k < FB; ++k)
-                if (f0 + 4 * k < nfrag) *reinterpret_cast<uint4*>(filt + ((int64_t)(f0 + 4 * k) * 64 + lane) * 16) = v[k];
+                *reinterpret_cast<uint4*>(filt + ((int64_t)min(f0 + 4 * k, nfrag - 1) * 64 + lane) * 16) = v[k];
         }
     }
     if (cur.tile < tile_end) RES_STASH(0);
