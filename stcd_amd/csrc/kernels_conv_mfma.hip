@@ -1003,24 +1003,22 @@ k_conv_small(const ConvSmallArgs a) {
     // ---- filter fragments -> registers; per-lane LDS offset of each k-step's 8-channel piece
     bf16x8 wreg[KSMAX][NT];
     int aoff[KSMAX];
+    // branch-free: every k-step slot loads (the index clamped to the last real step), so the KSMAX x NT loads leave as one
+    // batch; with `if (ks < KS) load` each one sat in its own block behind an s_waitcnt vmcnt(0).  Unused slots are never
+    // multiplied (the MFMA section tests ks < KS), their registers just hold a copy of the last step.
 #pragma unroll
     for (int ks = 0; ks < KSMAX; ++ks) {
-        if (ks < KS) {
+        const int kk = min(ks, KS - 1);
 #pragma unroll
-            for (int t2 = 0; t2 < NT; ++t2)
-                wreg[ks][t2] = *reinterpret_cast<const bf16x8*>(a.wf + ((int64_t)(ks * a.NTtot + t2) * 64 + lane) * 8);
-            const int kl = ks * 32 + 8 * q;
-            int t = kl / Ci, c = kl - t * Ci;
-            if (t >= a.g.ntaps) { t = 0; c = 0; }
-            int tw = 0;
+        for (int t2 = 0; t2 < NT; ++t2)
+            wreg[ks][t2] = *reinterpret_cast<const bf16x8*>(a.wf + ((int64_t)(kk * a.NTtot + t2) * 64 + lane) * 8);
+        const int kl = kk * 32 + 8 * q;
+        int t = kl / Ci, c = kl - t * Ci;
+        if (t >= a.g.ntaps) { t = 0; c = 0; }
+        int tw = 0;
 #pragma unroll
-            for (int tt = 0; tt < 9; ++tt) tw = t == tt ? a.tap[tt] : tw;    // per-lane tap: scalar loads + selects
-            aoff[ks] = ((TAP_DY(tw) - a.dymin) * HWp + (TAP_DX(tw) - a.dxmin)) * Ci + c;
-        } else {
-#pragma unroll
-            for (int t2 = 0; t2 < NT; ++t2) wreg[ks][t2] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            aoff[ks] = 0;
-        }
+        for (int tt = 0; tt < 9; ++tt) tw = t == tt ? a.tap[tt] : tw;    // per-lane tap: scalar loads + selects
+        aoff[ks] = ((TAP_DY(tw) - a.dymin) * HWp + (TAP_DX(tw) - a.dxmin)) * Ci + c;
     }
 
     const int bpg = gridDim.x / a.groups, grp = blockIdx.x / bpg, bl = blockIdx.x - grp * bpg;

@@ -167,7 +167,7 @@ int bn_stats_chunks(int64_t ppg, int C) {
 
 // NS > 0: the gradient is first GATHERED from up to NS extra views (dense-concat consumers, see SliceViews): all loads of a
 // trip are issued before any arithmetic (predicated, branch-free), two pixels per trip to bound the registers.
-template <typename T, int MODE, int NS = 0>
+template <typename T, int MODE, int NS = 0, bool RES = false>
 __global__ void __launch_bounds__(256)
 k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, const float* __restrict__ stat,
             const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg, int64_t HW, int relu,
@@ -226,7 +226,7 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
                         load8<T>(reinterpret_cast<const T*>(xs.p[kk]) + ((xs.gmask[kk] & (xs.gmask[kk] - 1)) ? g * xs.goff[kk] : 0) + pc * xs.ld[kk] + cofs, ex[u][k]);
                     }
                 }
-                if (res) load8<T>(res + ((int64_t)g * ppg + pc) * ldres + cofs, rs[u]);
+                if constexpr (RES) load8<T>(res + ((int64_t)g * ppg + pc) * ldres + cofs, rs[u]);
                 if (mask) {
                     const int nig = (int)((uint32_t)pc / (uint32_t)HW);
                     const float4* mp = reinterpret_cast<const float4*>(mask + ((int64_t)(g * npg + nig)) * C + cofs);
@@ -263,7 +263,7 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float z = y[u][j] * scale[j] + shift[j];
-                    if (res) z += rs[u][j];
+                    if constexpr (RES) z += rs[u][j];
                     float dz = d[u][j] * (mask ? mk[u][j] : 1.f);
                     if (relu && !(z > 0.f)) dz = 0.f;
                     s1[j] += dz;
@@ -396,7 +396,10 @@ void launch_bn_eval_prepare(int C, int groups, const float* gamma, const float* 
 // ------------------------------------------------------------------ BN-apply + ReLU + Dropout2d (+ 2x2 max-pool)
 // thread -> (2x2 cell, channel block).  One pass: reads the raw conv output once, writes the activation once
 // and, when a pool follows, the pooled map too (saves re-reading the full-resolution tensor).
-template <typename T>
+// RES (and OPT / RES of the two backward kernels): whether the optional residual / extra tensor exists is a TEMPLATE parameter --
+// as a run-time `if (res) load` every such load sat in its own block behind an s_waitcnt vmcnt(0), so the 4 pixels of a thread
+// were fetched one round trip after the other instead of as one batch.
+template <typename T, bool RES>
 __global__ void __launch_bounds__(256)
 k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restrict__ P, int ldp,
          float* __restrict__ stat, const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg,
@@ -441,7 +444,7 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
         ok[k] = y < H && x < W;
         pix[k] = ((int64_t)n * H + (ok[k] ? y : 2 * yc)) * W + (ok[k] ? x : 2 * xc);
         load8<T>(Y + pix[k] * ldy + c0, v[k]);
-        if (res) load8<T>(res + pix[k] * ldres + c0, rs[k]);
+        if constexpr (RES) load8<T>(res + pix[k] * ldres + c0, rs[k]);
     }
     float best[8];
 #pragma unroll
@@ -449,7 +452,7 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float z = v[k][j] * sc[j] + sh[j];
-            if (res) z += rs[k][j];              // residual add before the ReLU (SNUNet conv_block_nested, SNUNet.py:25)
+            if constexpr (RES) z += rs[k][j];    // residual add before the ReLU (SNUNet conv_block_nested, SNUNet.py:25)
             if (relu) z = fmaxf(z, 0.f);
             v[k][j] = round_as<T>(z * mk[j]);
             best[j] = k == 0 ? v[k][j] : fmaxf(best[j], v[k][j]);   // pooled cells are complete quads: every k is inside
@@ -569,15 +572,10 @@ void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s) {
     const int nslab = bn_slabs(a.C);
     const size_t lds = (size_t)a.groups * 2 * (a.C / nslab) * 4;
     const int grid = std::max(1, ew_grid(total) / nslab) * nslab;
-    if (dt == BF16)
-        k_bn_act<bf16><<<grid, 256, lds, s>>>((const bf16*)a.Y, a.ldy, (bf16*)a.A, av, (bf16*)a.P, a.ldp, a.stat,
-                                                          a.mask, (const bf16*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total, a.facc,
-                                                          a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps, a.extra, nslab, a.g_first);
-    else
-        k_bn_act<float><<<grid, 256, lds, s>>>((const float*)a.Y, a.ldy, (float*)a.A, av, (float*)a.P, a.ldp,
-                                                           a.stat, a.mask, (const float*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total,
-                                                           a.facc, a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps,
-                                                           a.extra, nslab, a.g_first);
+#define BN_ACT(T_, R_) k_bn_act<T_, R_><<<grid, 256, lds, s>>>((const T_*)a.Y, a.ldy, (T_*)a.A, av, (T_*)a.P, a.ldp, a.stat, a.mask, (const T_*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total, a.facc, a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps, a.extra, nslab, a.g_first)
+    if (dt == BF16) { if (a.res) BN_ACT(bf16, true); else BN_ACT(bf16, false); }
+    else { if (a.res) BN_ACT(float, true); else BN_ACT(float, false); }
+#undef BN_ACT
 }
 
 template <typename T>
@@ -833,7 +831,7 @@ __global__ void k_rep_pad_bwd(T* __restrict__ dD, int ld, int H, int W, int h0, 
 // k_bn_bwd_finalize: bw[g][0..4][C] = (scale, shift, b = -scale*k2*invstd, mean, c = -scale*k1).
 // (y - mean) is formed explicitly: folding mean into c cancels catastrophically in fp32.
 // thread -> (4 consecutive pixels, 8 channels): the 4x8 constants are loaded once as float4s.
-template <typename T, int PX>
+template <typename T, int PX, int OPT>       // OPT: 0 plain, 1 a residual (res), 2 an extra gradient term (extra)
 __global__ void __launch_bounds__(256)
 k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, const T* __restrict__ Y, int ldy,
                const float* __restrict__ stat, const long long* __restrict__ bacc, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -864,8 +862,8 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
     for (int k = 0; k < PX; ++k) {
         load8<T>(Y + (p0 + k) * ldy + c0, y[k]);
         load8<T>(dA + g * dav.goff + (pig0 + k) * dav.ld + c0, d[k]);
-        if (res) load8<T>(res + (p0 + k) * ldres + c0, rs[k]);
-        if (extra) load8<T>(extra + (p0 + k) * ldex + c0, ex[k]);
+        if constexpr (OPT == 1) load8<T>(res + (p0 + k) * ldres + c0, rs[k]);
+        if constexpr (OPT == 2) load8<T>(extra + (p0 + k) * ldex + c0, ex[k]);
     }
 #pragma unroll
     for (int k = 0; k < PX; ++k) {
@@ -874,11 +872,11 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
         for (int j = 0; j < 8; ++j) {
             float dz = mask ? d[k][j] * mk[j] : d[k][j];
             float z = y[k][j] * sc[j] + sh[j];
-            if (res) z += rs[k][j];
+            if constexpr (OPT == 1) z += rs[k][j];
             if (relu && !(z > 0.f)) dz = 0.f;
             dzv[j] = dz;
             o[j] = sc[j] * dz + kb[j] * (y[k][j] - mu[j]) + kc[j];
-            if (extra) o[j] += ex[k][j];
+            if constexpr (OPT == 2) o[j] += ex[k][j];
         }
         if (dZout) store8<T>(dZout + (p0 + k) * lddz + c0, dzv);
         store8<T>(dY + (p0 + k) * lddy + c0, o);
@@ -1314,20 +1312,24 @@ void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, con
     const int nslab = bn_slabs(C);
     if (xs.n > 0) {
         const int ns = xs.n <= 2 ? 2 : xs.n <= 4 ? 4 : MAX_VIEWS;
-#define RED_NS(T_, N_) k_bn_reduce<T_, 1, N_><<<dim3(bn_stats_chunks((int64_t)npg * HW, C / nslab) * nslab, groups), 256, 0, s>>>((const T_*)Y, ldy, (const T_*)dA, GV{ldda, da_goff}, stat, mask, (const T_*)res, ldres, C, npg, HW, relu, (int64_t)npg * HW, bn_stats_chunks((int64_t)npg * HW, C / nslab), bacc, xs, base_valid, (T_*)dA_sum, nslab)
+#define RED_NS(T_, N_) RED_NS_R(T_, N_, res != nullptr)
+#define RED_NS_R(T_, N_, HASRES_) if (HASRES_) RED_NS_K(T_, N_, true); else RED_NS_K(T_, N_, false)
+#define RED_NS_K(T_, N_, R_) k_bn_reduce<T_, 1, N_, R_><<<dim3(bn_stats_chunks((int64_t)npg * HW, C / nslab) * nslab, groups), 256, 0, s>>>((const T_*)Y, ldy, (const T_*)dA, GV{ldda, da_goff}, stat, mask, (const T_*)res, ldres, C, npg, HW, relu, (int64_t)npg * HW, bn_stats_chunks((int64_t)npg * HW, C / nslab), bacc, xs, base_valid, (T_*)dA_sum, nslab)
         if (dt == BF16) { if (ns == 2) RED_NS(bf16, 2); else if (ns == 4) RED_NS(bf16, 4); else RED_NS(bf16, MAX_VIEWS); }
         else { if (ns == 2) RED_NS(float, 2); else if (ns == 4) RED_NS(float, 4); else RED_NS(float, MAX_VIEWS); }
 #undef RED_NS
+#undef RED_NS_R
+#undef RED_NS_K
         return;
     }
     int64_t ppg = (int64_t)npg * HW;
     int nchunk = bn_stats_chunks(ppg, C / nslab);
     dim3 grid(nchunk * nslab, groups);
     GV dav{ldda, da_goff};
-    if (dt == BF16)
-        k_bn_reduce<bf16, 1><<<grid, 256, 0, s>>>((const bf16*)Y, ldy, (const bf16*)dA, dav, stat, mask, (const bf16*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc, xs, base_valid, (bf16*)dA_sum, nslab);
-    else
-        k_bn_reduce<float, 1><<<grid, 256, 0, s>>>((const float*)Y, ldy, (const float*)dA, dav, stat, mask, (const float*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc, xs, base_valid, (float*)dA_sum, nslab);
+#define RED0(T_, R_) k_bn_reduce<T_, 1, 0, R_><<<grid, 256, 0, s>>>((const T_*)Y, ldy, (const T_*)dA, dav, stat, mask, (const T_*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc, xs, base_valid, (T_*)dA_sum, nslab)
+    if (dt == BF16) { if (res) RED0(bf16, true); else RED0(bf16, false); }
+    else { if (res) RED0(float, true); else RED0(float, false); }
+#undef RED0
 }
 
 void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
@@ -1340,7 +1342,8 @@ void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void
     const int px = (HW % 4 == 0) ? 4 : 1;        // odd-sized maps (ReplicationPad2d branch): one pixel per thread
     int64_t total = (int64_t)groups * npg * HW / px * (C / 8);
     const int grid = std::max(1, ew_grid(total) / nslab) * nslab;
-#define BWD_APPLY(T_, PX_) k_bn_bwd_apply<T_, PX_><<<grid, 256, lds, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, stat, bacc, dgamma, dbeta, groups, mask, (const T_*)res, ldres, (T_*)dZout, lddz, (const T_*)extra, ldex, C, npg, HW, relu, total, nslab, dbeta_copy)
+#define BWD_APPLY(T_, PX_) do { if (res) BWD_APPLY_O(T_, PX_, 1); else if (extra) BWD_APPLY_O(T_, PX_, 2); else BWD_APPLY_O(T_, PX_, 0); } while (0)
+#define BWD_APPLY_O(T_, PX_, O_) k_bn_bwd_apply<T_, PX_, O_><<<grid, 256, lds, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, stat, bacc, dgamma, dbeta, groups, mask, (const T_*)res, ldres, (T_*)dZout, lddz, (const T_*)extra, ldex, C, npg, HW, relu, total, nslab, dbeta_copy)
     if (dt == BF16) { if (px == 4) BWD_APPLY(bf16, 4); else BWD_APPLY(bf16, 1); }
     else { if (px == 4) BWD_APPLY(float, 4); else BWD_APPLY(float, 1); }
 #undef BWD_APPLY
