@@ -167,7 +167,7 @@ int bn_stats_chunks(int64_t ppg, int C) {
 
 // NS > 0: the gradient is first GATHERED from up to NS extra views (dense-concat consumers, see SliceViews): all loads of a
 // trip are issued before any arithmetic (predicated, branch-free), two pixels per trip to bound the registers.
-template <typename T, int MODE, int NS = 0, bool RES = false>
+template <typename T, int MODE, int NS = 0, bool RES = false, bool MASK = false>
 __global__ void __launch_bounds__(256)
 k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, const float* __restrict__ stat,
             const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg, int64_t HW, int relu,
@@ -227,7 +227,7 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
                     }
                 }
                 if constexpr (RES) load8<T>(res + ((int64_t)g * ppg + pc) * ldres + cofs, rs[u]);
-                if (mask) {
+                if constexpr (MASK) {
                     const int nig = (int)((uint32_t)pc / (uint32_t)HW);
                     const float4* mp = reinterpret_cast<const float4*>(mask + ((int64_t)(g * npg + nig)) * C + cofs);
                     const float4 m0 = mp[0], m1 = mp[1];
@@ -264,7 +264,7 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
                 for (int j = 0; j < 8; ++j) {
                     float z = y[u][j] * scale[j] + shift[j];
                     if constexpr (RES) z += rs[u][j];
-                    float dz = d[u][j] * (mask ? mk[u][j] : 1.f);
+                    float dz = d[u][j] * (MASK ? mk[u][j] : 1.f);
                     if (relu && !(z > 0.f)) dz = 0.f;
                     s1[j] += dz;
                     s2[j] += dz * (y[u][j] - mean[j]) * invstd[j];
@@ -399,7 +399,7 @@ void launch_bn_eval_prepare(int C, int groups, const float* gamma, const float* 
 // RES (and OPT / RES of the two backward kernels): whether the optional residual / extra tensor exists is a TEMPLATE parameter --
 // as a run-time `if (res) load` every such load sat in its own block behind an s_waitcnt vmcnt(0), so the 4 pixels of a thread
 // were fetched one round trip after the other instead of as one batch.
-template <typename T, bool RES>
+template <typename T, bool RES, bool MASK>
 __global__ void __launch_bounds__(256)
 k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restrict__ P, int ldp,
          float* __restrict__ stat, const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg,
@@ -425,7 +425,7 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
     {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { sc[j] = bn_tab[(g * 2 + 0) * CS + c0l + j]; sh[j] = bn_tab[(g * 2 + 1) * CS + c0l + j]; }
-        if (mask) {
+        if constexpr (MASK) {
             const float4* mp = reinterpret_cast<const float4*>(mask + (int64_t)n * C + c0);
             const float4 m0 = mp[0], m1 = mp[1];
             mk[0] = m0.x; mk[1] = m0.y; mk[2] = m0.z; mk[3] = m0.w; mk[4] = m1.x; mk[5] = m1.y; mk[6] = m1.z; mk[7] = m1.w;
@@ -473,7 +473,7 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
 // Skip layers (last conv of an encoder level): both dates of a pair in one thread, so the bi-temporal skip fusion
 // F = |a1 - a2| (mode 0) or a2 - a1 (mode 1) is written in the same pass -- the separate fusion kernel would re-read
 // both activations.  Same arithmetic as k_bn_act per date (affine, ReLU, Dropout2d mask, rounding, 2x2 max-pool).
-template <typename T>
+template <typename T, bool MASK>
 __global__ void __launch_bounds__(256)
 k_bn_act_pair(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restrict__ P, int ldp, T* __restrict__ F, int ldf,
               int fmode, float* __restrict__ stat, const float* __restrict__ mask, int C, int npg, int H, int W, int64_t total,
@@ -528,14 +528,14 @@ k_bn_act_pair(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __r
             float sc[8], sh[8], mk[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { sc[j] = bn_tab[(g * 2 + 0) * C + c0 + j]; sh[j] = bn_tab[(g * 2 + 1) * C + c0 + j]; }
-            if (mask) ld8f(mask + ((int64_t)g * npg + nb) * C + c0, mk);
+            if constexpr (MASK) ld8f(mask + ((int64_t)g * npg + nb) * C + c0, mk);
             float best[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float z = fmaxf(vv[g][k][j] * sc[j] + sh[j], 0.f);
-                    vv[g][k][j] = round_as<T>(mask ? z * mk[j] : z);
+                    vv[g][k][j] = round_as<T>(MASK ? z * mk[j] : z);
                     best[j] = k == 0 ? vv[g][k][j] : fmaxf(best[j], vv[g][k][j]);
                 }
                 if (ok[k]) store8<T>(A + g * av.goff + pix[k] * av.ld + c0, vv[g][k]);
@@ -556,14 +556,10 @@ void launch_bn_act_pair(int dt, const BnActArgs& a, void* F, int ldf, int fmode,
     GV av{a.lda, a.a_group_off};
     const size_t lds = (size_t)2 * 2 * a.C * 4;
     const int grid = ew_grid(total);
-    if (dt == BF16)
-        k_bn_act_pair<bf16><<<grid, 256, lds, s>>>((const bf16*)a.Y, a.ldy, (bf16*)a.A, av, (bf16*)a.P, a.ldp, (bf16*)F, ldf, fmode,
-                                                               a.stat, a.mask, a.C, a.npg, a.H, a.W, total, a.facc, a.gamma, a.beta,
-                                                               a.running_mean, a.running_var, a.momentum, a.eps);
-    else
-        k_bn_act_pair<float><<<grid, 256, lds, s>>>((const float*)a.Y, a.ldy, (float*)a.A, av, (float*)a.P, a.ldp, (float*)F, ldf,
-                                                                fmode, a.stat, a.mask, a.C, a.npg, a.H, a.W, total, a.facc, a.gamma, a.beta,
-                                                                a.running_mean, a.running_var, a.momentum, a.eps);
+#define ACT_PAIR(T_, M_) k_bn_act_pair<T_, M_><<<grid, 256, lds, s>>>((const T_*)a.Y, a.ldy, (T_*)a.A, av, (T_*)a.P, a.ldp, (T_*)F, ldf, fmode, a.stat, a.mask, a.C, a.npg, a.H, a.W, total, a.facc, a.gamma, a.beta, a.running_mean, a.running_var, a.momentum, a.eps)
+    if (dt == BF16) { if (a.mask) ACT_PAIR(bf16, true); else ACT_PAIR(bf16, false); }
+    else { if (a.mask) ACT_PAIR(float, true); else ACT_PAIR(float, false); }
+#undef ACT_PAIR
 }
 
 void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s) {
@@ -572,10 +568,12 @@ void launch_bn_act(int dt, const BnActArgs& a, hipStream_t s) {
     const int nslab = bn_slabs(a.C);
     const size_t lds = (size_t)a.groups * 2 * (a.C / nslab) * 4;
     const int grid = std::max(1, ew_grid(total) / nslab) * nslab;
-#define BN_ACT(T_, R_) k_bn_act<T_, R_><<<grid, 256, lds, s>>>((const T_*)a.Y, a.ldy, (T_*)a.A, av, (T_*)a.P, a.ldp, a.stat, a.mask, (const T_*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total, a.facc, a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps, a.extra, nslab, a.g_first)
+#define BN_ACT(T_, R_) do { if (a.mask) BN_ACT_M(T_, R_, true); else BN_ACT_M(T_, R_, false); } while (0)
+#define BN_ACT_M(T_, R_, M_) k_bn_act<T_, R_, M_><<<grid, 256, lds, s>>>((const T_*)a.Y, a.ldy, (T_*)a.A, av, (T_*)a.P, a.ldp, a.stat, a.mask, (const T_*)a.res, a.ldres, a.C, a.npg, a.H, a.W, a.relu, total, a.facc, a.gamma, a.beta, a.running_mean, a.running_var, a.groups, a.momentum, a.eps, a.extra, nslab, a.g_first)
     if (dt == BF16) { if (a.res) BN_ACT(bf16, true); else BN_ACT(bf16, false); }
     else { if (a.res) BN_ACT(float, true); else BN_ACT(float, false); }
 #undef BN_ACT
+#undef BN_ACT_M
 }
 
 template <typename T>
@@ -702,7 +700,7 @@ __global__ void k_fuse_bwd(int mode, const T* __restrict__ A, GV av, const T* __
 // |a1-a2|, -/+g for a2-a1, as k_fuse_bwd); the BatchNorm backward then needs sum(dz) and sum(dz*xhat) of it.  Doing the
 // three in one pass saves three tensor round trips per level.  grid = (chunks, 2 dates); thread = one 2x2 quad x 8
 // channels of one image; partial rows as k_bn_reduce<T,1> writes them (chunks = gridDim.x rows per date).
-template <typename T>
+template <typename T, bool MASK>
 __global__ void __launch_bounds__(256)
 k_skip_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int ldd,
            const T* __restrict__ dP, int ldp, T* __restrict__ dA, GV dav, const float* __restrict__ stat,
@@ -725,7 +723,7 @@ k_skip_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ Y, in
         float mean[8], invstd[8], scale[8], shift[8], mk[8];
         const float* st = stat + (int64_t)g * 4 * C + c0;
         ld8f(st, mean); ld8f(st + C, invstd); ld8f(st + 2 * C, scale); ld8f(st + 3 * C, shift);
-        if (mask) ld8f(mask + ((int64_t)g * B + nb) * C + c0, mk);
+        if constexpr (MASK) ld8f(mask + ((int64_t)g * B + nb) * C + c0, mk);
         // this date's and the other date's activations of the quad (clamped inside the map), pooled gradient
         float as[4][8], ao[4][8], gp[8];
         bool ok[4];
@@ -766,7 +764,7 @@ k_skip_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ Y, in
                 da = round_as<T>(da);
                 v[j] = da;
                 const float z = y[j] * scale[j] + shift[j];
-                float dz = mask ? da * mk[j] : da;
+                float dz = MASK ? da * mk[j] : da;
                 if (!(z > 0.f)) dz = 0.f;
                 if (ok[k]) { s1[j] += dz; s2[j] += dz * (y[j] - mean[j]) * invstd[j]; }
             }
@@ -831,7 +829,7 @@ __global__ void k_rep_pad_bwd(T* __restrict__ dD, int ld, int H, int W, int h0, 
 // k_bn_bwd_finalize: bw[g][0..4][C] = (scale, shift, b = -scale*k2*invstd, mean, c = -scale*k1).
 // (y - mean) is formed explicitly: folding mean into c cancels catastrophically in fp32.
 // thread -> (4 consecutive pixels, 8 channels): the 4x8 constants are loaded once as float4s.
-template <typename T, int PX, int OPT>       // OPT: 0 plain, 1 a residual (res), 2 an extra gradient term (extra)
+template <typename T, int PX, int OPT, bool MASK>       // OPT: 0 plain, 1 a residual (res), 2 an extra gradient term (extra); MASK: Dropout2d mask
 __global__ void __launch_bounds__(256)
 k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, const T* __restrict__ Y, int ldy,
                const float* __restrict__ stat, const long long* __restrict__ bacc, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -855,7 +853,7 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
     const float* w = bw_tab + (int64_t)g * 5 * CS + c0l;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = w[j]; sh[j] = w[CS + j]; kb[j] = w[2 * CS + j]; mu[j] = w[3 * CS + j]; kc[j] = w[4 * CS + j]; }
-    if (mask) ld8f(mask + (int64_t)n * C + c0, mk);
+    if constexpr (MASK) ld8f(mask + (int64_t)n * C + c0, mk);
     // all loads of the PX pixels first (dY may alias dA: every thread reads its own elements before it writes them)
     float y[PX][8], d[PX][8], rs[PX][8], ex[PX][8];
 #pragma unroll
@@ -870,7 +868,7 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
         float o[8], dzv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float dz = mask ? d[k][j] * mk[j] : d[k][j];
+            float dz = MASK ? d[k][j] * mk[j] : d[k][j];
             float z = y[k][j] * sc[j] + sh[j];
             if constexpr (OPT == 1) z += rs[k][j];
             if (relu && !(z > 0.f)) dz = 0.f;
@@ -1313,12 +1311,14 @@ void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, con
     if (xs.n > 0) {
         const int ns = xs.n <= 2 ? 2 : xs.n <= 4 ? 4 : MAX_VIEWS;
 #define RED_NS(T_, N_) RED_NS_R(T_, N_, res != nullptr)
-#define RED_NS_R(T_, N_, HASRES_) if (HASRES_) RED_NS_K(T_, N_, true); else RED_NS_K(T_, N_, false)
-#define RED_NS_K(T_, N_, R_) k_bn_reduce<T_, 1, N_, R_><<<dim3(bn_stats_chunks((int64_t)npg * HW, C / nslab) * nslab, groups), 256, 0, s>>>((const T_*)Y, ldy, (const T_*)dA, GV{ldda, da_goff}, stat, mask, (const T_*)res, ldres, C, npg, HW, relu, (int64_t)npg * HW, bn_stats_chunks((int64_t)npg * HW, C / nslab), bacc, xs, base_valid, (T_*)dA_sum, nslab)
+#define RED_NS_R(T_, N_, HASRES_) if (HASRES_) RED_NS_M(T_, N_, true); else RED_NS_M(T_, N_, false)
+#define RED_NS_M(T_, N_, R_) do { if (mask) RED_NS_K(T_, N_, R_, true); else RED_NS_K(T_, N_, R_, false); } while (0)
+#define RED_NS_K(T_, N_, R_, M_) k_bn_reduce<T_, 1, N_, R_, M_><<<dim3(bn_stats_chunks((int64_t)npg * HW, C / nslab) * nslab, groups), 256, 0, s>>>((const T_*)Y, ldy, (const T_*)dA, GV{ldda, da_goff}, stat, mask, (const T_*)res, ldres, C, npg, HW, relu, (int64_t)npg * HW, bn_stats_chunks((int64_t)npg * HW, C / nslab), bacc, xs, base_valid, (T_*)dA_sum, nslab)
         if (dt == BF16) { if (ns == 2) RED_NS(bf16, 2); else if (ns == 4) RED_NS(bf16, 4); else RED_NS(bf16, MAX_VIEWS); }
         else { if (ns == 2) RED_NS(float, 2); else if (ns == 4) RED_NS(float, 4); else RED_NS(float, MAX_VIEWS); }
 #undef RED_NS
 #undef RED_NS_R
+#undef RED_NS_M
 #undef RED_NS_K
         return;
     }
@@ -1326,10 +1326,12 @@ void launch_bn_bwd_reduce(int dt, const void* dA, int ldda, int64_t da_goff, con
     int nchunk = bn_stats_chunks(ppg, C / nslab);
     dim3 grid(nchunk * nslab, groups);
     GV dav{ldda, da_goff};
-#define RED0(T_, R_) k_bn_reduce<T_, 1, 0, R_><<<grid, 256, 0, s>>>((const T_*)Y, ldy, (const T_*)dA, dav, stat, mask, (const T_*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc, xs, base_valid, (T_*)dA_sum, nslab)
+#define RED0(T_, R_) do { if (mask) RED0_M(T_, R_, true); else RED0_M(T_, R_, false); } while (0)
+#define RED0_M(T_, R_, M_) k_bn_reduce<T_, 1, 0, R_, M_><<<grid, 256, 0, s>>>((const T_*)Y, ldy, (const T_*)dA, dav, stat, mask, (const T_*)res, ldres, C, npg, HW, relu, ppg, nchunk, bacc, xs, base_valid, (T_*)dA_sum, nslab)
     if (dt == BF16) { if (res) RED0(bf16, true); else RED0(bf16, false); }
     else { if (res) RED0(float, true); else RED0(float, false); }
 #undef RED0
+#undef RED0_M
 }
 
 void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void* dY, int lddy, const void* Y, int ldy,
@@ -1342,8 +1344,9 @@ void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void
     const int px = (HW % 4 == 0) ? 4 : 1;        // odd-sized maps (ReplicationPad2d branch): one pixel per thread
     int64_t total = (int64_t)groups * npg * HW / px * (C / 8);
     const int grid = std::max(1, ew_grid(total) / nslab) * nslab;
-#define BWD_APPLY(T_, PX_) do { if (res) BWD_APPLY_O(T_, PX_, 1); else if (extra) BWD_APPLY_O(T_, PX_, 2); else BWD_APPLY_O(T_, PX_, 0); } while (0)
-#define BWD_APPLY_O(T_, PX_, O_) k_bn_bwd_apply<T_, PX_, O_><<<grid, 256, lds, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, stat, bacc, dgamma, dbeta, groups, mask, (const T_*)res, ldres, (T_*)dZout, lddz, (const T_*)extra, ldex, C, npg, HW, relu, total, nslab, dbeta_copy)
+#define BWD_APPLY(T_, PX_) do { if (res) BWD_APPLY_M(T_, PX_, 1); else if (extra) BWD_APPLY_M(T_, PX_, 2); else BWD_APPLY_M(T_, PX_, 0); } while (0)
+#define BWD_APPLY_M(T_, PX_, O_) do { if (mask) BWD_APPLY_O(T_, PX_, O_, true); else BWD_APPLY_O(T_, PX_, O_, false); } while (0)
+#define BWD_APPLY_O(T_, PX_, O_, M_) k_bn_bwd_apply<T_, PX_, O_, M_><<<grid, 256, lds, s>>>((const T_*)dA, dav, (T_*)dY, lddy, (const T_*)Y, ldy, stat, bacc, dgamma, dbeta, groups, mask, (const T_*)res, ldres, (T_*)dZout, lddz, (const T_*)extra, ldex, C, npg, HW, relu, total, nslab, dbeta_copy)
     if (dt == BF16) { if (px == 4) BWD_APPLY(bf16, 4); else BWD_APPLY(bf16, 1); }
     else { if (px == 4) BWD_APPLY(float, 4); else BWD_APPLY(float, 1); }
 #undef BWD_APPLY
@@ -1365,12 +1368,10 @@ void launch_skip_bwd(int dt, int mode, const void* A, int lda, int64_t a_goff, c
     const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
     GV av{lda, a_goff}, dav{ldda, da_goff};
     dim3 grid((unsigned)cdiv(total, 256), 2);
-    if (dt == BF16)
-        k_skip_bwd<bf16><<<grid, 256, 0, s>>>(mode, (const bf16*)A, av, (const bf16*)Y, ldy, (const bf16*)dD, ldd, (const bf16*)dP, ldp,
-                                              (bf16*)dA, dav, stat, mask, B, H, W, C, total, partial);
-    else
-        k_skip_bwd<float><<<grid, 256, 0, s>>>(mode, (const float*)A, av, (const float*)Y, ldy, (const float*)dD, ldd, (const float*)dP,
-                                               ldp, (float*)dA, dav, stat, mask, B, H, W, C, total, partial);
+#define SKIP_BWD(T_, M_) k_skip_bwd<T_, M_><<<grid, 256, 0, s>>>(mode, (const T_*)A, av, (const T_*)Y, ldy, (const T_*)dD, ldd, (const T_*)dP, ldp, (T_*)dA, dav, stat, mask, B, H, W, C, total, partial)
+    if (dt == BF16) { if (mask) SKIP_BWD(bf16, true); else SKIP_BWD(bf16, false); }
+    else { if (mask) SKIP_BWD(float, true); else SKIP_BWD(float, false); }
+#undef SKIP_BWD
 }
 
 void launch_fuse(int dt, int mode, const void* A, int lda, int64_t a_goff, void* D, int ldd, int B, int64_t HW, int C,
