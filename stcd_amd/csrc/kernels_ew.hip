@@ -700,7 +700,7 @@ __global__ void k_fuse_bwd(int mode, const T* __restrict__ A, GV av, const T* __
 // |a1-a2|, -/+g for a2-a1, as k_fuse_bwd); the BatchNorm backward then needs sum(dz) and sum(dz*xhat) of it.  Doing the
 // three in one pass saves three tensor round trips per level.  grid = (chunks, 2 dates); thread = one 2x2 quad x 8
 // channels of one image; partial rows as k_bn_reduce<T,1> writes them (chunks = gridDim.x rows per date).
-template <typename T, bool MASK>
+template <typename T, bool MASK, int MODE>
 __global__ void __launch_bounds__(256)
 k_skip_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int ldd,
            const T* __restrict__ dP, int ldp, T* __restrict__ dA, GV dav, const float* __restrict__ stat,
@@ -734,9 +734,17 @@ k_skip_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ Y, in
             ok[k] = y < H && x < W;
             pix[k] = ((int64_t)nb * H + (ok[k] ? y : 2 * yc)) * W + (ok[k] ? x : 2 * xc);
             load8<T>(A + g * av.goff + pix[k] * av.ld + c0, as[k]);
-            if (mode == 0) load8<T>(A + (1 - g) * av.goff + pix[k] * av.ld + c0, ao[k]);
+            if constexpr (MODE == 0) load8<T>(A + (1 - g) * av.goff + pix[k] * av.ld + c0, ao[k]);
         }
-        if (pooled) load8<T>(dP + ((((int64_t)g * B + nb) * Hp + yc) * Wp + xc) * ldp + c0, gp);
+        // branch-free: an un-pooled border cell re-reads cell (0, 0) of its image and ignores it (arg = -1 below)
+        load8<T>(dP + ((((int64_t)g * B + nb) * Hp + (pooled ? yc : 0)) * Wp + (pooled ? xc : 0)) * ldp + c0, gp);
+        // the second phase's inputs are requested here as well, before the arg-max arithmetic waits for the first phase
+        float gk4[4][8], y4[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            load8<T>(dD + pix[k] * ldd + c0, gk4[k]);
+            load8<T>(Y + ((int64_t)g * B * H * W + pix[k]) * ldy + c0, y4[k]);
+        }
         int arg[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -749,14 +757,14 @@ k_skip_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ Y, in
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float gk[8], y[8], v[8];
-            load8<T>(dD + pix[k] * ldd + c0, gk);
-            load8<T>(Y + ((int64_t)g * B * H * W + pix[k]) * ldy + c0, y);
+            float v[8];
+            const float (&gk)[8] = gk4[k];
+            const float (&y)[8] = y4[k];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 // date 0 receives +sign(a0-a1)*g, date 1 the negative; "sub" (f2 - f1): date 0 gets -g, date 1 +g
                 float sgn;
-                if (mode == 0) { const float d = g == 0 ? as[k][j] - ao[k][j] : ao[k][j] - as[k][j]; sgn = (float)((d > 0.f) - (d < 0.f)); }
+                if constexpr (MODE == 0) { const float d = g == 0 ? as[k][j] - ao[k][j] : ao[k][j] - as[k][j]; sgn = (float)((d > 0.f) - (d < 0.f)); }
                 else sgn = -1.f;
                 if (g == 1) sgn = -sgn;
                 float da = sgn * gk[j];
@@ -1368,10 +1376,12 @@ void launch_skip_bwd(int dt, int mode, const void* A, int lda, int64_t a_goff, c
     const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
     GV av{lda, a_goff}, dav{ldda, da_goff};
     dim3 grid((unsigned)cdiv(total, 256), 2);
-#define SKIP_BWD(T_, M_) k_skip_bwd<T_, M_><<<grid, 256, 0, s>>>(mode, (const T_*)A, av, (const T_*)Y, ldy, (const T_*)dD, ldd, (const T_*)dP, ldp, (T_*)dA, dav, stat, mask, B, H, W, C, total, partial)
+#define SKIP_BWD(T_, M_) do { if (mode == 0) SKIP_BWD_K(T_, M_, 0); else SKIP_BWD_K(T_, M_, 1); } while (0)
+#define SKIP_BWD_K(T_, M_, MODE_) k_skip_bwd<T_, M_, MODE_><<<grid, 256, 0, s>>>(mode, (const T_*)A, av, (const T_*)Y, ldy, (const T_*)dD, ldd, (const T_*)dP, ldp, (T_*)dA, dav, stat, mask, B, H, W, C, total, partial)
     if (dt == BF16) { if (mask) SKIP_BWD(bf16, true); else SKIP_BWD(bf16, false); }
     else { if (mask) SKIP_BWD(float, true); else SKIP_BWD(float, false); }
 #undef SKIP_BWD
+#undef SKIP_BWD_K
 }
 
 void launch_fuse(int dt, int mode, const void* A, int lda, int64_t a_goff, void* D, int ldd, int B, int64_t HW, int C,
