@@ -187,6 +187,22 @@ def pmc_traffic(kernel, model):
                     return int(float(line.split()[-1])), os.path.relpath(path, REPO)
                 except ValueError:
                     pass
+    # the engine's timers name a kernel CLASS ("k_bn_reduce<T, 1>"); rocprofv3 lists every template instantiation of it under
+    # its own (differently spelled) name: launch-weighted mean over the rows of the same base name
+    base = kernel.split("<")[0]
+    for path in _pmc_files(model):
+        tot = launches = 0
+        for line in open(path):
+            if line.startswith(base + "<") or line.startswith(base + " "):
+                f = line.split()
+                try:
+                    n, b = int(f[-4]), float(f[-1])
+                except (ValueError, IndexError):
+                    continue
+                tot += n * b
+                launches += n
+        if launches:
+            return int(tot / launches), os.path.relpath(path, REPO)
     return None, None
 
 

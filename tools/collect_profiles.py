@@ -63,6 +63,12 @@ for tot, k, n, fb, wb in rows:
     if dom and (k == dom or (len(dom) > 48 and k[:48] == dom[:48]) or k.startswith(dom.split("<")[0] + "<") and k.replace(" ", "") == dom.replace(" ", "")):
         r["traffic"] = int(tot); r["traffic_source"] = f"profiles/{tag}_pmc_traffic.txt"
         break
+if dom and r.get("traffic") is None:      # a kernel CLASS of the engine's timers: launch-weighted mean over its instantiations
+    base = dom.split("<")[0]
+    fam = [(tot, n) for tot, k, n, fb, wb in rows if k.startswith(base + "<") or k == base]
+    if fam:
+        r["traffic"] = int(sum(t * n for t, n in fam) / sum(n for _, n in fam))
+        r["traffic_source"] = f"profiles/{tag}_pmc_traffic.txt (launch-weighted mean over {len(fam)} instantiations)"
 r["traffic_step"] = int(step_total); r["traffic_step_source"] = f"profiles/{tag}_pmc_traffic.txt"
 if "step" in r and r["step"].get("alg_bytes"):
     r["traffic_step_over_algorithmic"] = round(step_total / r["step"]["alg_bytes"], 3)
