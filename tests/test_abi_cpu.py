@@ -111,3 +111,27 @@ def test_header_is_plain_c_and_usable_without_python(tmp_path):
     assert "workspace" in out and "rejected bad shape" in out
     out = subprocess.check_output([exe, "3", "1", "32"], text=True)
     assert "params 146 tensors / 12034980 floats" in out and "conv0_0.conv1.weight" in out
+
+
+@pytest.mark.parametrize("cls_name,encoder,classes", [("SegCD", "resnet50", 1), ("SegCD", "resnet18", 2), ("SegCD", "resnet34", 1), ("SegCD", "resnet101", 1),
+                                                      ("SegCD", "resnet152", 1), ("UnetSeg", "resnet50", 1), ("UnetSeg", "resnet34", 2),
+                                                      ("FFCTLCD", "resnet34", 1), ("FFCTLCD", "resnet50", 2)])
+def test_segcd_family_state_dict_layout_is_the_reference_layout(cls_name, encoder, classes):
+    """SegCD / UnetSeg / FFCTLCD over every supported encoder: the module's state_dict keys, order and shapes are the reference's
+    (oracle.segcd_ref.param_specs, pinned against the reference's own classes by the G10-G16 fixtures), the engine enumerates the
+    same parameters (HipChangeDetector._check_layout ran in the constructor), and a reference-shaped state dict loads strictly."""
+    from oracle import segcd_ref as G
+    from stcd_amd import segcd
+    m = getattr(segcd, cls_name)(encoder_name=encoder, classes=classes)
+    specs = G.param_specs(3, classes, encoder)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [n for n, _, _ in specs]
+    for (n, shape, _), v in zip(specs, sd.values()):
+        assert tuple(v.shape) == tuple(shape), n
+    st = G.synth_state(3, classes, 5, perturb_running=True, encoder=encoder)
+    m.load_state_dict(st, strict=True)
+    for k in ("encoder.conv1.weight", "decoder.blocks.4.conv2.1.running_var", "segmentation_head.0.bias"):
+        assert torch.equal(m.state_dict()[k], st[k]), k
+    calls = {b.name: b.calls_per_forward for b in m._engine.bns}
+    enc_calls, dec_calls = {"SegCD": (2, 2), "UnetSeg": (1, 1), "FFCTLCD": (2, 3)}[cls_name]
+    assert calls["encoder.bn1"] == enc_calls and calls["decoder.blocks.0.conv1.1"] == dec_calls      # num_batches_tracked increments
