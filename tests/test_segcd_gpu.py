@@ -554,3 +554,42 @@ def test_ffctlcd_layer_local_in_place(dtype, encoder, B, H, W):
     for k in range(3):
         chk("head", f"output {k}", o[k].detach(), want[k], 1e-4 if dtype == "fp32" else 2e-2)
     print(f"FFCTLCD-{encoder} {dtype} B={B} {H}x{W} layer-local worst relative l2: " + ", ".join(f"{k} {v[0]:.1e} ({v[1]})" for k, v in worst.items()))
+
+
+def test_ffctlcd_bf16_tracks_reference_vectors_and_trains(golden):
+    """bf16 FFCTLCD against G16 (eval maps at 4e-2 relative l2, training loss at 2e-2, the head's gradient direction), then 12 Adam
+    steps on the fixture's batch: finite, and the loss falls."""
+    from stcd_amd.optim import FlatAdam
+    from tests._util import gf_index
+    g = golden("g16_ffctlcd.npz")
+    seed = int(g["r34/seed"])
+    x1, x2 = t(g["r34/x1"]).to(DEV), t(g["r34/x2"]).to(DEV)
+    m = FFCTLCD(encoder_name="resnet34", dtype="bf16")
+    m.load_state_dict(G.synth_state(3, 1, seed, perturb_running=True, encoder="resnet34"))
+    m.to(DEV).eval()
+    with torch.no_grad():
+        o = m(x1, x2)
+    for k, v in zip(("m1", "m2"), o):
+        r, _ = rel_l2_cos(v.cpu().numpy(), g[f"r34/eval/{k}"])
+        assert r <= 4e-2, (k, r)
+    m = FFCTLCD(encoder_name="resnet34", dtype="bf16")
+    m.load_state_dict(G.synth_state(3, 1, seed, encoder="resnet34"))
+    m.to(DEV).train()
+    seg, tgt = t(g["r34/seg_target"]).to(DEV), t(g["r34/target"]).to(DEV)
+    loss = _loss(*m(x1, x2), seg, tgt)
+    assert abs(loss.item() - float(g["r34/loss"])) < 2e-2 * abs(float(g["r34/loss"]))
+    loss.backward()
+    for name, p in m.named_parameters():
+        if name.startswith("segmentation_head"):
+            got = p.grad.detach().cpu().numpy().ravel()[gf_index(name, p.numel())]
+            _, c = rel_l2_cos(got, g["r34/gf/" + name])
+            assert c >= 0.99, (name, c)
+    opt = FlatAdam(m, lr=1e-3)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        loss = _loss(*m(x1, x2), seg, tgt)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
