@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STCD_ABI_VERSION 1
+#define STCD_ABI_VERSION 2
 
 /* network family: replaces the class chosen by define_G (networks.py:145-169) */
 #define STCD_ARCH_DIFF 0   /* "SiamUnet_abs"  -> SiamUnet_diff  */
@@ -55,6 +55,15 @@ extern "C" {
  * own BatchNorm batch statistics, in that order --, change = min(head(dec(|f1 - f2|)), |mask_t1 - mask_t2|).  Same outputs as
  * STCD_ARCH_SEGCD ([3*batch, label_ch, H, W] = mask_t1, mask_t2, change).  STCD_ARCH_FFCTLCD + k, k as above. */
 #define STCD_ARCH_FFCTLCD 32
+
+/* ChangeFormerV6 (/root/reference/models/ChangeFormer.py:1669-1701; define_G name "ChangeFormerV6", models/networks.py:195-196;
+ * BASELINE.json configs[4]): hierarchical transformer encoder shared by both dates + MLP / conv-difference decoder.  Its forward
+ * returns FIVE maps [p_c4, p_c3, p_c2, p_c1, cp] (ChangeFormer.py:1578-1622): `logits` of stcd_forward holds them back to back
+ * (stcd_cf_output_info gives offset / size of each; stcd_output_floats the total), `grad_logits` of stcd_backward has the same
+ * layout and only the gradient of the LAST map (cp) is propagated (the reference's loss uses G_pred[-1], models/trainer.py:311).
+ * H and W must be divisible by 32.  stcd_create(STCD_ARCH_CHANGEFORMER, ...) builds the V6 configuration with embed_dim 256;
+ * stcd_create_changeformer takes any configuration of the same class family. */
+#define STCD_ARCH_CHANGEFORMER 64
 
 /* arithmetic / storage type of activations. Parameters, gradients, BN statistics, logits: always fp32. */
 #define STCD_DTYPE_F32 0  /* parity mode: fp32 storage, fp32 FMA */
@@ -84,12 +93,48 @@ typedef struct stcd_dropout_info {
     int64_t offset;  /* element offset into the flat fp32 mask buffer; mask[row*channels + c] in {0, 1/(1-p)} */
 } stcd_dropout_info;
 
+/* ChangeFormerV6.__init__ / EncoderTransformer_v3.__init__ arguments (ChangeFormer.py:1671-1691, 1344-1348) */
+typedef struct stcd_cf_config {
+    int32_t in_ch, out_ch;          /* input_nc, output_nc */
+    int32_t embed_dims[4];          /* [64, 128, 320, 512] */
+    int32_t depths[4];              /* [3, 3, 4, 3] */
+    int32_t num_heads[4];           /* [1, 2, 4, 8] */
+    int32_t sr_ratios[4];           /* [8, 4, 2, 1] */
+    int32_t mlp_ratio;              /* 4 */
+    int32_t embedding_dim;          /* embed_dim = 256: decoder width */
+    int32_t patch1, patch;          /* patch_embed1: k7 s4; patch_embed2..4: k = patch_size = 7, s2 */
+    float drop_rate, attn_drop, drop_path_rate;   /* 0.1, 0.1, 0.1 */
+    float diff_drop;                /* conv_diff's nn.Dropout(p=0.6), ChangeFormer.py:1143 */
+} stcd_cf_config;
+
+/* one Dropout / DropPath site of the configured ChangeFormer engine: masks are never stored -- element i of the site (linear index
+ * over dims, the engine's NHWC / [image, head, query, key] order; encoder sites hold both dates: 2*batch images, date 1 first)
+ * is kept iff (fmix32(i * 0x9E3779B1 + stcd_cf_site_seed(seed, site)) >> 8) >= floor(p * 2^24), and scaled by 1 / (1 - p). */
+typedef struct stcd_cf_site {
+    char name[96];                  /* e.g. "Tenc_x2.block1.0.attn.attn_drop", "TDec_x2.diff_c4.3" */
+    int32_t ndim;
+    int32_t dims[4];
+    float p;
+} stcd_cf_site;
+
 const char* stcd_last_error(void);
 int stcd_abi_version(void);
 
 /* ---- engine lifecycle: replaces Module.__init__ (SiamUnet_diff.py:13-92, SNUNet.py:65-113) ---- */
 int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out);
+int stcd_cf_default_config(stcd_cf_config* cfg);                     /* the ChangeFormerV6 values above */
+int stcd_create_changeformer(const stcd_cf_config* cfg, int dtype, stcd_engine** out);
 void stcd_destroy(stcd_engine* e);
+/* floats of the `logits` / `grad_logits` buffers for the current configuration (every family) */
+int64_t stcd_output_floats(const stcd_engine* e);
+/* ChangeFormer: output map i (0..4 = p_c4, p_c3, p_c2, p_c1, cp), each [batch, out_ch, height, width] fp32 NCHW at `offset` floats */
+int stcd_cf_output_info(const stcd_engine* e, int i, int64_t* offset, int* height, int* width);
+int stcd_cf_num_sites(const stcd_engine* e);
+int stcd_cf_site_get(const stcd_engine* e, int i, stcd_cf_site* out);
+uint32_t stcd_cf_site_seed(uint64_t seed, int site);
+/* change the element-wise dropout rates of a ChangeFormer engine (re-run stcd_configure afterwards); DropPath rates are fixed at
+ * creation (they are a per-block schedule) */
+int stcd_cf_set_drop_rates(stcd_engine* e, float drop_rate, float attn_drop, float diff_drop);
 
 /* ---- parameter / buffer enumeration in the reference's registration order (state_dict compatibility,
  *      /root/reference/models/trainer.py:138,183; basic_model.py:35) ---- */
@@ -292,6 +337,49 @@ int stcd_op_rep_pad_bwd(int dtype, const stcd_map_geom* g, void* dd, int ld, int
 int stcd_op_skip_bwd(int dtype, int mode, const stcd_map_geom* g, const void* a, int lda, const void* y, int ldy, const void* dd,
                      int ldd, const void* dpool, int ldp, const float* stat, const float* mask, void* da, int ldda, void* dy,
                      int lddy, float* dgamma, float* dbeta, void* scratch, int64_t scratch_bytes, void* hip_stream);
+
+/* ---- per-op entry points of the ChangeFormer kernels (contiguous tensors: tokens [rows, c] / maps [n, h, w, c] NHWC, activation dtype
+ *      per `dtype`); each runs the launch sequence the engine runs for that step.  Dropout inside an op: site 0 of `seed`
+ *      (stcd_cf_site above; DropPath of stcd_op_cf_resid_drop: site 1), p == 0 disables it. ---- */
+int64_t stcd_op_cf_scratch_bytes(int64_t rows, int channels, int n, int q_tokens, int kv_tokens);
+/* OverlapPatchEmbed.proj / Attention.sr as GEMMs (ChangeFormer.py:207-208, 315): col [n*ho*wo, ldc], column ci*k*k + ky*k + kx */
+int stcd_op_cf_im2col(int dtype, const void* x, void* col, int ldc, int n, int h, int w, int c, int k, int stride, int pad, void* hip_stream);
+int stcd_op_cf_col2im(int dtype, const void* dcol, int ldc, void* dx, int n, int h, int w, int c, int k, int stride, int pad, int accumulate,
+                      void* hip_stream);
+/* nn.LayerNorm(c, eps) per row (ChangeFormer.py:209,317,478,486); stats fp32 [rows][2] = mean, 1/sqrt(var + eps) */
+int stcd_op_cf_layernorm(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats, int64_t rows, int c, float eps,
+                         void* hip_stream);
+/* dx = [add] + LayerNorm-backward(dy [+ dy2]); dgamma, dbeta fp32 [c] overwritten */
+int stcd_op_cf_layernorm_bwd(int dtype, const void* dy, const void* dy2, const void* x, const float* stats, const float* gamma, const void* add,
+                             void* dx, float* dgamma, float* dbeta, void* scratch, int64_t rows, int c, void* hip_stream);
+int stcd_op_cf_colsum(int dtype, const void* x, int64_t rows, int c, float* out, void* scratch, void* hip_stream);
+/* Attention.forward between the q / kv projections and proj (ChangeFormer.py:347-354): q [n, q_tokens, heads*d], kv [n, kv_tokens, 2*heads*d]
+ * (k then v, head-major channels), out [n, q_tokens, heads*d], lse fp32 [n, heads, q_tokens]; scale = d^-0.5; attn_drop probability p */
+int stcd_op_cf_attention(int dtype, const void* q, const void* kv, void* out, float* lse, int n, int q_tokens, int kv_tokens, int heads, int d,
+                         float p, uint64_t seed, void* hip_stream);
+int64_t stcd_op_cf_attention_scratch_bytes(int n, int q_tokens, int kv_tokens, int heads, int d);
+int stcd_op_cf_attention_bwd(int dtype, const void* q, const void* kv, const void* out, const void* dout, const float* lse, void* dq, void* dkv,
+                             void* scratch, int n, int q_tokens, int kv_tokens, int heads, int d, float p, uint64_t seed, void* hip_stream);
+/* Mlp between fc1 and fc2 (ChangeFormer.py:289-292, 517-523): u = depthwise3x3(h) + b, a = dropout(GELU(u)); w = [ch][1][3][3] */
+int stcd_op_cf_dwgelu(int dtype, const void* h, void* u, void* a, const float* w, const float* b, int n, int height, int width, int ch, float p,
+                      uint64_t seed, void* hip_stream);
+int64_t stcd_op_cf_dwgelu_scratch_bytes(int n, int height, int width, int ch);
+/* da is overwritten with the gated gradient; dh = d(h); dw [ch][9], db [ch] overwritten */
+int stcd_op_cf_dwgelu_bwd(int dtype, const void* h, const void* u, void* da, void* dh, const float* w, float* dw, float* db, void* scratch, int n,
+                          int height, int width, int ch, float p, uint64_t seed, void* hip_stream);
+/* Block.forward's x + drop_path(dropout(y)) (ChangeFormer.py:505-509) over [n, rows_per_img, c]; backward != 0: out = d(y) from y = d(out) */
+int stcd_op_cf_resid_drop(int dtype, const void* x, const void* y, void* out, int n, int64_t rows_per_img, int c, float p, float path_p,
+                          uint64_t seed, int backward, void* hip_stream);
+/* F.interpolate(mode="bilinear", align_corners=False) (ChangeFormer.py:1585,1591) [n,h,w,c] -> [n,out_h,out_w,c]; backward != 0: src is the
+ * gradient of the large map, dst receives the gradient of the small one; accumulate != 0: dst += */
+int stcd_op_cf_bilinear(int dtype, const void* src, void* dst, int n, int h, int w, int out_h, int out_w, int c, int accumulate, int backward,
+                        void* hip_stream);
+/* op: 0 PReLU(x; alpha[0]) | 1 x * dropout(p) | 2 relu(x) | 3 x * [y > 0] | 4 alpha_f * x + beta_f * y (y nullable) */
+int stcd_op_cf_elementwise(int dtype, int op, const void* x, const void* y, void* out, int64_t rows, int c, const float* alpha, float alpha_f,
+                           float beta_f, float p, uint64_t seed, void* hip_stream);
+/* dy = dz * (y > 0 ? 1 : alpha[0]); dalpha[0] = sum dz * y * [y <= 0] */
+int stcd_op_cf_prelu_bwd(int dtype, const void* dz, const void* y, void* dy, const float* alpha, float* dalpha, void* scratch, int64_t rows, int c,
+                         void* hip_stream);
 
 #ifdef __cplusplus
 }

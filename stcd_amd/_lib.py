@@ -19,6 +19,7 @@ ARCH_DIFF, ARCH_CONC, ARCH_SUB, ARCH_SNUNET, ARCH_SEGCD = 0, 1, 2, 3, 4
 ARCH_SEGCD_R18, ARCH_SEGCD_R34, ARCH_SEGCD_R101, ARCH_SEGCD_R152 = 5, 6, 7, 8
 ARCH_UNETSEG = 16          # + 0..4: resnet50, resnet18, resnet34, resnet101, resnet152
 ARCH_FFCTLCD = 32          # + 0..4, same order
+ARCH_CHANGEFORMER = 64     # ChangeFormerV6
 DTYPE_F32, DTYPE_BF16 = 0, 1
 ARCH_IDS = {"diff": ARCH_DIFF, "conc": ARCH_CONC, "sub": ARCH_SUB, "snunet": ARCH_SNUNET, "segcd": ARCH_SEGCD,
             "segcd_resnet50": ARCH_SEGCD, "segcd_resnet18": ARCH_SEGCD_R18, "segcd_resnet34": ARCH_SEGCD_R34,
@@ -26,7 +27,8 @@ ARCH_IDS = {"diff": ARCH_DIFF, "conc": ARCH_CONC, "sub": ARCH_SUB, "snunet": ARC
             "unetseg_resnet50": ARCH_UNETSEG, "unetseg_resnet18": ARCH_UNETSEG + 1, "unetseg_resnet34": ARCH_UNETSEG + 2,
             "unetseg_resnet101": ARCH_UNETSEG + 3, "unetseg_resnet152": ARCH_UNETSEG + 4,
             "ffctlcd_resnet50": ARCH_FFCTLCD, "ffctlcd_resnet18": ARCH_FFCTLCD + 1, "ffctlcd_resnet34": ARCH_FFCTLCD + 2,
-            "ffctlcd_resnet101": ARCH_FFCTLCD + 3, "ffctlcd_resnet152": ARCH_FFCTLCD + 4}
+            "ffctlcd_resnet101": ARCH_FFCTLCD + 3, "ffctlcd_resnet152": ARCH_FFCTLCD + 4,
+            "changeformer": ARCH_CHANGEFORMER}
 DTYPE_IDS = {"fp32": DTYPE_F32, "f32": DTYPE_F32, "bf16": DTYPE_BF16}
 
 
@@ -57,6 +59,17 @@ class WsTensor(C.Structure):
                 ("ld", C.c_int), ("dtype", C.c_int)]
 
 
+class CfConfig(C.Structure):
+    _fields_ = [("in_ch", C.c_int32), ("out_ch", C.c_int32), ("embed_dims", C.c_int32 * 4), ("depths", C.c_int32 * 4),
+                ("num_heads", C.c_int32 * 4), ("sr_ratios", C.c_int32 * 4), ("mlp_ratio", C.c_int32), ("embedding_dim", C.c_int32),
+                ("patch1", C.c_int32), ("patch", C.c_int32), ("drop_rate", C.c_float), ("attn_drop", C.c_float),
+                ("drop_path_rate", C.c_float), ("diff_drop", C.c_float)]
+
+
+class CfSite(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("ndim", C.c_int32), ("dims", C.c_int32 * 4), ("p", C.c_float)]
+
+
 class MapGeom(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("groups", C.c_int32)]
 
@@ -67,6 +80,14 @@ _PROTOS = {
     "stcd_abi_version": (_i, []),
     "stcd_create": (_i, [_i, _i, _i, _i, C.POINTER(_vp)]),
     "stcd_destroy": (None, [_vp]),
+    "stcd_cf_default_config": (_i, [C.POINTER(CfConfig)]),
+    "stcd_create_changeformer": (_i, [C.POINTER(CfConfig), _i, C.POINTER(_vp)]),
+    "stcd_output_floats": (_i64, [_vp]),
+    "stcd_cf_output_info": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),
+    "stcd_cf_num_sites": (_i, [_vp]),
+    "stcd_cf_site_get": (_i, [_vp, _i, C.POINTER(CfSite)]),
+    "stcd_cf_site_seed": (C.c_uint32, [C.c_uint64, _i]),
+    "stcd_cf_set_drop_rates": (_i, [_vp, _f, _f, _f]),
     "stcd_num_params": (_i, [_vp]),
     "stcd_param_info": (_i, [_vp, _i, C.POINTER(TensorInfo)]),
     "stcd_param_floats": (_i64, [_vp]),
@@ -115,6 +136,22 @@ _PROTOS = {
     "stcd_op_rep_pad": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _i, _i, _vp]),
     "stcd_op_rep_pad_bwd": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _i, _i, _vp]),
     "stcd_op_skip_bwd": (_i, [_i, _i, C.POINTER(MapGeom), _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp]),
+    "stcd_op_cf_scratch_bytes": (_i64, [_i64, _i, _i, _i, _i]),
+    "stcd_op_cf_im2col": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "stcd_op_cf_col2im": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "stcd_op_cf_layernorm": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
+    "stcd_op_cf_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "stcd_op_cf_colsum": (_i, [_i, _vp, _i64, _i, _vp, _vp, _vp]),
+    "stcd_op_cf_attention": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, C.c_uint64, _vp]),
+    "stcd_op_cf_attention_scratch_bytes": (_i64, [_i, _i, _i, _i, _i]),
+    "stcd_op_cf_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, C.c_uint64, _vp]),
+    "stcd_op_cf_dwgelu": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, C.c_uint64, _vp]),
+    "stcd_op_cf_dwgelu_scratch_bytes": (_i64, [_i, _i, _i, _i]),
+    "stcd_op_cf_dwgelu_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, C.c_uint64, _vp]),
+    "stcd_op_cf_resid_drop": (_i, [_i, _vp, _vp, _vp, _i, _i64, _i, _f, _f, C.c_uint64, _i, _vp]),
+    "stcd_op_cf_bilinear": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "stcd_op_cf_elementwise": (_i, [_i, _i, _vp, _vp, _vp, _i64, _i, _vp, _f, _f, _f, C.c_uint64, _vp]),
+    "stcd_op_cf_prelu_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
 }
 EXPORTS = tuple(_PROTOS)
 
@@ -137,7 +174,7 @@ def lib():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.stcd_abi_version() != 1:
+        if l.stcd_abi_version() != 2:
             raise StcdError("libstcd_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -392,4 +392,92 @@ int64_t augment_scratch_bytes(int N, int H, int W);
 void launch_confusion(const float* logits, const int64_t* target, int B, int Cn, int64_t HW, int64_t* cm,
                       hipStream_t s);
 
+// ---- ChangeFormer (transformer) kernels, kernels_tf.hip.  Tokens are NHWC pixels: a [n, N = h*w, C] sequence IS the
+//      [n, h, w, C] map.  Every Dropout / DropPath site draws its mask from a counter hash of (site seed, element index in the
+//      layout named at the launcher), so no mask is ever stored: the backward recomputes it.
+struct DropSite {
+    uint32_t seed = 0;     // stcd_cf_site_seed(step seed, site index)
+    uint32_t thr = 0;      // floor(p * 2^24); 0: identity (evaluation mode or p == 0)
+    float scale = 1.f;     // 1 / (1 - p)
+};
+__host__ __device__ inline uint32_t cf_hash(uint32_t idx, uint32_t seed) {
+    uint32_t h = idx * 0x9E3779B1u + seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ inline float cf_keep(uint32_t idx, const DropSite& d) { return (cf_hash(idx, d.seed) >> 8) >= d.thr ? d.scale : 0.f; }
+uint32_t cf_site_seed(uint64_t seed, int site);
+DropSite cf_make_site(uint64_t seed, int site, float p, bool training);
+
+// im2col with the reference's K order (ci, ky, kx): col[(n, oy, ox)][ci*k*k + ky*k + kx] = X[n, oy*stride - pad + ky, ox*stride - pad + kx, ci]
+// (zero outside the image; columns [C*k*k, ldc) are zero-filled).  Patch embeddings (k7 s4 p3, k7 s2 p3) and the spatial-reduction
+// convs (k = stride = sr, pad 0: a pure permutation) become plain GEMMs over it.
+void launch_im2col(int dt, const void* X, int ldx, void* col, int ldc, int n, int H, int W, int C, int k, int stride, int pad, int Ho,
+                   int Wo, hipStream_t s);
+// dX[n, y, x, ci] (=, or += when accumulate) sum over the patches that contain the pixel of dcol
+void launch_col2im(int dt, const void* dcol, int ldc, void* dX, int lddx, int n, int H, int W, int C, int k, int stride, int pad, int Ho,
+                   int Wo, int accumulate, hipStream_t s);
+// LayerNorm over the C channels of each of M rows; stats fp32 [M][2] = mean, rstd (kept for the backward)
+void launch_layernorm(int dt, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, float* stats, int64_t M,
+                      int C, float eps, hipStream_t s);
+int64_t layernorm_bwd_scratch_floats(int64_t M, int C);
+// dx = [add] + LayerNorm-backward(dy [+ dy2]); dgamma / dbeta (fp32 [C]) overwritten (two-phase, fixed order: reproducible)
+void launch_layernorm_bwd(int dt, const void* dy, int lddy, const void* dy2, int lddy2, const void* x, int ldx, const float* stats,
+                          const float* gamma, const void* add, int ldadd, void* dx, int lddx, float* dgamma, float* dbeta,
+                          float* scratch, int64_t M, int C, hipStream_t s);
+// out[c] = sum over M rows of X[.., c] (fp32, two-phase fixed order); scratch >= colsum_scratch_floats(M, C)
+int64_t colsum_scratch_floats(int64_t M, int C);
+void launch_colsum(int dt, const void* X, int ld, int64_t M, int C, float* out, float* scratch, hipStream_t s);
+// BatchNorm batch statistics in double precision (few values per channel: see kernels_tf.hip): fills stat [4][C] = mean, invstd,
+// scale, shift (what launch_bn_act reads with facc == gamma == nullptr, and the BN-backward kernels) and updates the running statistics
+int64_t bn_precise_scratch_floats(int64_t M, int C);
+void launch_bn_stats_precise(int dt, const void* Z, int ld, int64_t M, int C, const float* gamma, const float* beta, float* rmean,
+                             float* rvar, float* stat, float* scratch, float momentum, float eps, hipStream_t s);
+// softmax attention with spatial-reduction keys (ChangeFormer.py:334-358): q [n, N, heads*d] (channel = head*d + j), kv [n, Nkv, 2*heads*d]
+// (k at channel head*d + j, v at heads*d + head*d + j), out [n, N, heads*d]; lse fp32 [n, heads, N] = log-sum-exp of the scaled scores;
+// attention dropout on the probabilities, element index ((img*heads + head)*N + i)*Nkv + j.  impl 0: plain-FMA kernels (fp32 math,
+// any dtype), 1: MFMA (bf16, d in {64, 80}... see kernels_attn.hip)
+void launch_attn_fwd(int dt, const void* q, int ldq, const void* kv, int ldkv, void* out, int ldo, float* lse, int n, int N, int Nkv,
+                     int heads, int d, float scale, DropSite drop, hipStream_t s);
+int64_t attn_bwd_scratch_floats(int n, int N, int Nkv, int heads, int d);
+// dq [n, N, heads*d], dkv [n, Nkv, 2*heads*d]; scratch: fp32 (row terms D + the dK/dV partial slabs)
+void launch_attn_bwd(int dt, const void* q, int ldq, const void* kv, int ldkv, const void* out, int ldo, const void* dout, int lddo,
+                     const float* lse, void* dq, int lddq, void* dkv, int lddkv, float* scratch, int n, int N, int Nkv, int heads, int d,
+                     float scale, DropSite drop, hipStream_t s);
+// Mix-FFN middle (ChangeFormer.py:287-295, 517-523): u = depthwise3x3(h) + b ; a = dropout(GELU(u)).  w: reference layout [Ch][1][3][3]
+void launch_dwgelu_fwd(int dt, const void* h, void* u, void* a, const float* w, const float* b, int n, int H, int W, int Ch,
+                       DropSite drop, hipStream_t s);
+int64_t dwgelu_bwd_scratch_floats(int n, int H, int W, int Ch);
+// g = da * mask * GELU'(u) (written over da), dh = depthwise3x3^T(g), dw [Ch][9], db [Ch] overwritten
+void launch_dwgelu_bwd(int dt, const void* h, const void* u, void* da, void* dh, const float* w, float* dw, float* db, float* scratch,
+                       int n, int H, int W, int Ch, DropSite drop, hipStream_t s);
+// out = x + droppath(img) * dropout(idx) * y over [n, rows_per_img, C] (element index = linear NHWC index); out may alias x
+void launch_resid_drop(int dt, const void* x, const void* y, void* out, int n, int64_t rows_per_img, int C, DropSite drop, DropSite path,
+                       hipStream_t s);
+// dy = droppath(img) * dropout(idx) * dout
+void launch_resid_drop_bwd(int dt, const void* dout, void* dy, int n, int64_t rows_per_img, int C, DropSite drop, DropSite path,
+                           hipStream_t s);
+// bilinear resize, align_corners = False (F.interpolate, ChangeFormer.py:1585,1591): src [n,h,w,C] -> dst [n,H,W,C] (= or +=)
+void launch_bilinear(int dt, const void* src, int lds, void* dst, int ldd, int n, int h, int w, int H, int W, int C, int accumulate,
+                     hipStream_t s);
+void launch_bilinear_bwd(int dt, const void* ddst, int ldd, void* dsrc, int lds, int n, int h, int w, int H, int W, int C, int accumulate,
+                         hipStream_t s);
+// elementwise family over [rows, C] tensors with pixel strides
+// z = PReLU(y; alpha[0])
+void launch_prelu(int dt, const void* y, int ldy, void* z, int ldz, const float* alpha, int64_t rows, int C, hipStream_t s);
+// dy = dz * (y > 0 ? 1 : alpha) ; dalpha[0] = sum dz * y * [y <= 0] (overwritten; scratch >= 2048 doubles)
+void launch_prelu_bwd(int dt, const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, const float* alpha, float* dalpha,
+                      float* scratch, int64_t rows, int C, hipStream_t s);
+// out = x * dropout(linear index over [rows, C]) ; out may alias x (forward and backward are the same map)
+void launch_dropout_ew(int dt, const void* x, int ldx, void* out, int ldo, int64_t rows, int C, DropSite drop, hipStream_t s);
+// out = relu(x) ; dx = dy * [a > 0] (a = the ReLU's OUTPUT)
+void launch_relu(int dt, const void* x, int ldx, void* out, int ldo, int64_t rows, int C, hipStream_t s);
+void launch_relu_bwd(int dt, const void* dy, int lddy, const void* a, int lda, void* dx, int lddx, int64_t rows, int C, hipStream_t s);
+// out = alpha * x + beta * y (y nullable; out may alias x or y)
+void launch_axpby(int dt, float alpha, const void* x, int ldx, float beta, const void* y, int ldy, void* out, int ldo, int64_t rows, int C,
+                  hipStream_t s);
+// fp32 NCHW [n, C, H, W] maps of the auxiliary prediction heads (ChangeFormer.py:1151-1157: ReLU - BatchNorm2d(C) - Conv3x3(C -> C), C <= 8)
+void launch_aux_head(const float* y, float* out, const float* bn_w, const float* bn_b, float* running_mean, float* running_var,
+                     const float* w, const float* b, float* stat, int n, int C, int H, int W, int training, hipStream_t s);
+
 }  // namespace stcd

@@ -171,8 +171,10 @@ struct SnUp {                                                // up: ConvTranspos
     int64_t bias_acc = -1; bool bias_fused = false; int coff = 0;
 };
 
+struct CfPlan;                                                  // ChangeFormer plan (engine_cf.inl)
 struct stcd_engine_impl {
     Prof prof;
+    std::shared_ptr<CfPlan> cf;
     std::vector<NBlock> sn_blocks;
     std::vector<SnUp> sn_ups;
     std::vector<int> sn_order;                               // forward order of blocks (index into sn_blocks)
@@ -2339,6 +2341,8 @@ static int backward_segcd(stcd_engine& e, const float* grad_logits, const float*
     return 0;
 }
 
+#include "engine_cf.inl"
+
 }  // namespace stcd
 
 // ================================================================================================ C ABI
@@ -2347,14 +2351,7 @@ extern "C" {
 const char* stcd_last_error(void) { return stcd::g_err.c_str(); }
 int stcd_abi_version(void) { return STCD_ABI_VERSION; }
 
-int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out) {
-    STCD_CHECK(out != nullptr, "out is null");
-    STCD_CHECK((arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD_R152) || is_unetseg(arch) || is_ffctlcd(arch), "unknown arch");
-    STCD_CHECK(in_ch >= 1 && in_ch <= 8, "in_ch must be in [1,8]");
-    STCD_CHECK(label_ch >= 1 && label_ch <= 8, "label_ch must be in [1,8]");
-    STCD_CHECK(dtype == STCD_DTYPE_F32 || dtype == STCD_DTYPE_BF16, "unknown dtype");
-    std::unique_ptr<stcd_engine> e(new stcd_engine());
-    e->arch = arch; e->in_ch = in_ch; e->label = label_ch; e->dt = dtype;
+static void engine_env_switches(stcd_engine* e) {
     const char* env = getenv("STCD_FORCE_REF_KERNELS");
     e->use_mfma = !(env && env[0] == '1');
     env = getenv("STCD_NO_SMALL_KERNEL");
@@ -2373,6 +2370,93 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
     if (env && atoi(env) > 0) e->wgroup_rounds = atoi(env);
     env = getenv("STCD_WGRAD_MIN_TILES");
     if (env && atoi(env) > 0) e->wgroup_min_tiles = atoi(env);
+}
+
+int stcd_cf_default_config(stcd_cf_config* cfg) {
+    STCD_CHECK(cfg != nullptr, "cfg is null");
+    static const int E[4] = {64, 128, 320, 512}, DP[4] = {3, 3, 4, 3}, HD[4] = {1, 2, 4, 8}, SR[4] = {8, 4, 2, 1};
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->in_ch = 3; cfg->out_ch = 2;
+    for (int i = 0; i < 4; ++i) { cfg->embed_dims[i] = E[i]; cfg->depths[i] = DP[i]; cfg->num_heads[i] = HD[i]; cfg->sr_ratios[i] = SR[i]; }
+    cfg->mlp_ratio = 4; cfg->embedding_dim = 256; cfg->patch1 = 7; cfg->patch = 7;
+    cfg->drop_rate = 0.1f; cfg->attn_drop = 0.1f; cfg->drop_path_rate = 0.1f; cfg->diff_drop = 0.6f;
+    return 0;
+}
+
+int stcd_create_changeformer(const stcd_cf_config* cfg, int dtype, stcd_engine** out) {
+    STCD_CHECK(out != nullptr && cfg != nullptr, "null argument");
+    STCD_CHECK(cfg->in_ch >= 1 && cfg->in_ch <= 8, "in_ch must be in [1,8]");
+    STCD_CHECK(cfg->out_ch >= 1 && cfg->out_ch <= 8, "out_ch must be in [1,8]");
+    STCD_CHECK(dtype == STCD_DTYPE_F32 || dtype == STCD_DTYPE_BF16, "unknown dtype");
+    STCD_CHECK(cfg->mlp_ratio >= 1 && cfg->embedding_dim >= 8 && cfg->embedding_dim % 8 == 0, "embedding_dim must be a positive multiple of 8");
+    STCD_CHECK((cfg->embedding_dim & (cfg->embedding_dim - 1)) == 0, "embedding_dim must be a power of two (BatchNorm kernels)");
+    STCD_CHECK((cfg->patch1 & 1) && (cfg->patch & 1) && cfg->patch1 >= 3 && cfg->patch >= 3, "patch sizes must be odd and >= 3");
+    for (int i = 0; i < 4; ++i) {
+        STCD_CHECK(cfg->embed_dims[i] >= 8 && cfg->embed_dims[i] % 8 == 0 && cfg->embed_dims[i] <= 1024, "embed_dims must be multiples of 8, <= 1024");
+        STCD_CHECK(cfg->depths[i] >= 1 && cfg->num_heads[i] >= 1 && cfg->sr_ratios[i] >= 1, "depths, num_heads and sr_ratios must be >= 1");
+        STCD_CHECK(cfg->embed_dims[i] % cfg->num_heads[i] == 0, "embed_dims must be divisible by num_heads");
+    }
+    for (float p : {cfg->drop_rate, cfg->attn_drop, cfg->drop_path_rate, cfg->diff_drop}) STCD_CHECK(p >= 0.f && p < 1.f, "drop rates must be in [0,1)");
+    std::unique_ptr<stcd_engine> e(new stcd_engine());
+    e->arch = STCD_ARCH_CHANGEFORMER; e->in_ch = cfg->in_ch; e->label = cfg->out_ch; e->dt = dtype;
+    engine_env_switches(e.get());
+    e->cf = std::make_shared<CfPlan>();
+    CfPlan& P = *e->cf;
+    for (int i = 0; i < 4; ++i) { P.E[i] = cfg->embed_dims[i]; P.depths[i] = cfg->depths[i]; P.heads[i] = cfg->num_heads[i]; P.srs[i] = cfg->sr_ratios[i]; }
+    P.mlp_ratio = cfg->mlp_ratio; P.D = cfg->embedding_dim; P.patch1 = cfg->patch1; P.patch = cfg->patch;
+    P.drop = cfg->drop_rate; P.attn_drop = cfg->attn_drop; P.drop_path = cfg->drop_path_rate; P.diff_drop = cfg->diff_drop;
+    build_cf_tables(*e);
+    *out = e.release();
+    return 0;
+}
+
+int stcd_cf_num_sites(const stcd_engine* e) { return e && e->cf && e->configured ? (int)e->cf->sites.size() : 0; }
+int stcd_cf_site_get(const stcd_engine* e, int i, stcd_cf_site* out) {
+    STCD_CHECK(e && e->cf && e->configured && out && i >= 0 && i < (int)e->cf->sites.size(), "bad argument");
+    memset(out, 0, sizeof(*out));
+    const CfPlan::Site& s = e->cf->sites[i];
+    snprintf(out->name, sizeof(out->name), "%s", s.name.c_str());
+    out->ndim = s.nd;
+    for (int k = 0; k < s.nd; ++k) out->dims[k] = s.dims[k];
+    out->p = s.p;
+    return 0;
+}
+uint32_t stcd_cf_site_seed(uint64_t seed, int site) { return cf_site_seed(seed, site); }
+int stcd_cf_set_drop_rates(stcd_engine* e, float drop_rate, float attn_drop, float diff_drop) {
+    STCD_CHECK(e && e->cf, "not a ChangeFormer engine");
+    for (float p : {drop_rate, attn_drop, diff_drop}) STCD_CHECK(p >= 0.f && p < 1.f, "drop rates must be in [0,1)");
+    e->cf->drop = drop_rate; e->cf->attn_drop = attn_drop; e->cf->diff_drop = diff_drop;
+    e->configured = false;      // the site table is rebuilt by the next stcd_configure
+    return 0;
+}
+int64_t stcd_output_floats(const stcd_engine* e) {
+    if (!e || !e->configured) return 0;
+    if (e->cf) return e->cf->out_floats;
+    const int maps = (is_segcd(e->arch) && !is_unetseg(e->arch)) ? 3 : 1;
+    return (int64_t)maps * e->B * e->label * e->H * e->W;
+}
+int stcd_cf_output_info(const stcd_engine* e, int i, int64_t* offset, int* height, int* width) {
+    STCD_CHECK(e && e->cf && e->configured && offset && height && width && i >= 0 && i < 5, "bad argument");
+    if (i < 4) { *offset = e->cf->df[i].out_off; *height = e->cf->df[i].h; *width = e->cf->df[i].w; }
+    else { *offset = e->cf->cp_off; *height = e->H; *width = e->W; }
+    return 0;
+}
+
+int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out) {
+    STCD_CHECK(out != nullptr, "out is null");
+    if (is_cf(arch)) {
+        stcd_cf_config cfg;
+        stcd_cf_default_config(&cfg);
+        cfg.in_ch = in_ch; cfg.out_ch = label_ch;
+        return stcd_create_changeformer(&cfg, dtype, out);
+    }
+    STCD_CHECK((arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD_R152) || is_unetseg(arch) || is_ffctlcd(arch), "unknown arch");
+    STCD_CHECK(in_ch >= 1 && in_ch <= 8, "in_ch must be in [1,8]");
+    STCD_CHECK(label_ch >= 1 && label_ch <= 8, "label_ch must be in [1,8]");
+    STCD_CHECK(dtype == STCD_DTYPE_F32 || dtype == STCD_DTYPE_BF16, "unknown dtype");
+    std::unique_ptr<stcd_engine> e(new stcd_engine());
+    e->arch = arch; e->in_ch = in_ch; e->label = label_ch; e->dt = dtype;
+    engine_env_switches(e.get());
     if (arch == STCD_ARCH_SNUNET) build_snunet_tables(*e);
     else if (is_segcd(arch)) build_segcd_tables(*e);
     else build_fcsiam_tables(*e);
@@ -2408,7 +2492,10 @@ int stcd_configure(stcd_engine* e, int batch, int height, int width) {
     e->configured = false;
     e->packed_tag = 0; e->packed_ws = nullptr; e->packed_level = -1;
     e->B = batch; e->H = height; e->W = width;
-    if (e->arch == STCD_ARCH_SNUNET) {
+    if (is_cf(e->arch)) {
+        STCD_CHECK(height % 32 == 0 && width % 32 == 0, "ChangeFormer needs height and width divisible by 32 (stride-4 patch embedding, sr_ratio 8)");
+        if (configure_cf(*e, batch, height, width)) return 1;
+    } else if (e->arch == STCD_ARCH_SNUNET) {
         STCD_CHECK(height % 16 == 0 && width % 16 == 0, "SNUNet needs height and width divisible by 16 (the reference's cat of up-sampled maps fails otherwise)");
         if (configure_snunet(*e, batch, height, width)) return 1;
     } else if (is_segcd(e->arch)) {
@@ -2445,7 +2532,9 @@ int stcd_forward(stcd_engine* e, const float* x1, const float* x2, const float* 
     STCD_CHECK(e && e->configured, "engine not configured");
     STCD_CHECK(x1 && x2 && params && bn_running && logits && workspace, "null pointer argument");
     e->fwd_training = false;
-    int rc = e->arch == STCD_ARCH_SNUNET
+    int rc = is_cf(e->arch)
+                 ? forward_cf(*e, x1, x2, params, bn_running, dropout_masks, dropout_seed, training, logits, workspace, (hipStream_t)hip_stream)
+             : e->arch == STCD_ARCH_SNUNET
                  ? forward_snunet(*e, x1, x2, params, bn_running, training, logits, workspace, (hipStream_t)hip_stream)
                  : is_segcd(e->arch)
                        ? forward_segcd(*e, x1, x2, params, bn_running, training, logits, workspace, (hipStream_t)hip_stream)
@@ -2461,6 +2550,7 @@ int stcd_backward(stcd_engine* e, const float* grad_logits, const float* params,
     STCD_CHECK(e->fwd_training, "backward requires a preceding training-mode forward on this engine");
     STCD_CHECK(grad_logits && params && grads && workspace, "null pointer argument");
     STCD_CHECK(stage >= -1 && stage <= 1, "stage must be -1, 0 or 1");
+    if (is_cf(e->arch)) return backward_cf(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
     if (e->arch == STCD_ARCH_SNUNET) return backward_snunet(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
     if (is_segcd(e->arch)) return backward_segcd(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);
     return backward_fcsiam(*e, grad_logits, params, grads, workspace, stage, (hipStream_t)hip_stream);

@@ -47,11 +47,30 @@ def _stream():
 
 
 class Engine:
-    def __init__(self, arch: str, in_ch: int, label_ch: int, dtype: str = "bf16"):
+    def __init__(self, arch: str, in_ch: int, label_ch: int, dtype: str = "bf16", cf_config: Optional[dict] = None):
         self._l = _lib.lib()
         self.arch, self.in_ch, self.label_ch, self.dtype = arch, in_ch, label_ch, dtype
+        self.cf_config = dict(cf_config) if cf_config else None
         h = C.c_void_p()
-        _lib.check(self._l.stcd_create(_lib.ARCH_IDS[arch], in_ch, label_ch, _lib.DTYPE_IDS[dtype], C.byref(h)))
+        if arch == "changeformer":
+            # ChangeFormerV6.__init__ values (/root/reference/models/ChangeFormer.py:1671-1691) unless overridden
+            cfg = _lib.CfConfig()
+            _lib.check(self._l.stcd_cf_default_config(C.byref(cfg)))
+            cfg.in_ch, cfg.out_ch = in_ch, label_ch
+            for k, v in (self.cf_config or {}).items():
+                if k in ("embed_dims", "depths", "num_heads", "sr_ratios"):
+                    arr = getattr(cfg, k)
+                    for i in range(4):
+                        arr[i] = int(v[i])
+                elif k in ("drop_rate", "attn_drop", "drop_path_rate", "diff_drop"):
+                    setattr(cfg, k, float(v))
+                elif k in ("mlp_ratio", "embedding_dim", "patch1", "patch"):
+                    setattr(cfg, k, int(v))
+                else:
+                    raise _lib.StcdError(f"unknown ChangeFormer option {k!r}")
+            _lib.check(self._l.stcd_create_changeformer(C.byref(cfg), _lib.DTYPE_IDS[dtype], C.byref(h)))
+        else:
+            _lib.check(self._l.stcd_create(_lib.ARCH_IDS[arch], in_ch, label_ch, _lib.DTYPE_IDS[dtype], C.byref(h)))
         self._h = h
         self.params: List[ParamInfo] = []
         ti = _lib.TensorInfo()
@@ -83,13 +102,13 @@ class Engine:
 
     # pickling / deepcopy re-create the native handle (it is process-local)
     def __getstate__(self):
-        return {"arch": self.arch, "in_ch": self.in_ch, "label_ch": self.label_ch, "dtype": self.dtype}
+        return {"arch": self.arch, "in_ch": self.in_ch, "label_ch": self.label_ch, "dtype": self.dtype, "cf_config": self.cf_config}
 
     def __setstate__(self, st):
-        self.__init__(st["arch"], st["in_ch"], st["label_ch"], st["dtype"])
+        self.__init__(st["arch"], st["in_ch"], st["label_ch"], st["dtype"], st.get("cf_config"))
 
     def __deepcopy__(self, memo):
-        return Engine(self.arch, self.in_ch, self.label_ch, self.dtype)
+        return Engine(self.arch, self.in_ch, self.label_ch, self.dtype, self.cf_config)
 
     def set_dropout_p(self, p: float):
         _lib.check(self._l.stcd_set_dropout_p(self._h, C.c_float(p)))
@@ -107,6 +126,32 @@ class Engine:
         self.dropout_floats = self._l.stcd_dropout_floats(self._h)
         self.workspace = None   # release before re-allocating
         self.workspace = torch.empty(self._l.stcd_workspace_bytes(self._h), dtype=torch.uint8, device=device)
+
+    # ------------------------------------------------------------------ ChangeFormer: output layout, dropout sites
+    def output_floats(self) -> int:
+        return int(self._l.stcd_output_floats(self._h))
+
+    def cf_outputs(self):
+        """-> [(offset, height, width)] of the five maps [p_c4, p_c3, p_c2, p_c1, cp] inside the flat output buffer."""
+        out = []
+        for i in range(5):
+            off, hh, ww = C.c_int64(), C.c_int(), C.c_int()
+            _lib.check(self._l.stcd_cf_output_info(self._h, i, C.byref(off), C.byref(hh), C.byref(ww)))
+            out.append((off.value, hh.value, ww.value))
+        return out
+
+    def cf_sites(self):
+        """-> [(name, dims, p)] of every Dropout / DropPath site in the engine's order (see stcd_cf_site in the header)."""
+        st = _lib.CfSite()
+        out = []
+        for i in range(self._l.stcd_cf_num_sites(self._h)):
+            _lib.check(self._l.stcd_cf_site_get(self._h, i, C.byref(st)))
+            out.append((st.name.decode(), tuple(st.dims[k] for k in range(st.ndim)), float(st.p)))
+        return out
+
+    def cf_set_drop_rates(self, drop_rate: float, attn_drop: float, diff_drop: float):
+        _lib.check(self._l.stcd_cf_set_drop_rates(self._h, C.c_float(drop_rate), C.c_float(attn_drop), C.c_float(diff_drop)))
+        self.shape = None
 
     def pack_masks(self, masks: dict, device) -> torch.Tensor:
         """name -> [rows, C] tensors (oracle convention) into the engine's flat mask buffer."""

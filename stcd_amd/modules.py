@@ -46,6 +46,10 @@ class _EngineFn(torch.autograd.Function):
         ctx.model = model
         ctx.ticket = model._engine.ticket
         n = model.OUT_MAPS
+        if n == 0:      # maps of different sizes in one flat buffer (ChangeFormer): the model splits / merges them
+            ctx.set_materialize_grads(False)
+            ctx.flat = logits
+            return tuple(model._split_outputs(logits))
         if n == 1:
             return logits
         # several maps per pair (SegCD): one autograd output each, so an unused map costs nothing in the backward (slicing ONE
@@ -61,7 +65,9 @@ class _EngineFn(torch.autograd.Function):
         if ctx.ticket != model._engine.ticket:
             raise StcdError("backward() for a forward pass whose saved activations were overwritten by a later "
                             "forward of the same module (the engine keeps one step of activations)")
-        if len(grads) == 1:
+        if model.OUT_MAPS == 0:
+            g = model._merge_grads(ctx.flat, grads)
+        elif len(grads) == 1:
             g = grads[0].contiguous()
         else:
             live = [gk for gk in grads if gk is not None]
@@ -104,9 +110,9 @@ class HipChangeDetector(nn.Module):
     RETURNS_LIST = False
     OUT_MAPS = 1          # maps per pair in the engine's output buffer ([OUT_MAPS*B, label, H, W])
 
-    def __init__(self, in_ch: int, label_ch: int, dtype: Optional[str] = None):
+    def __init__(self, in_ch: int, label_ch: int, dtype: Optional[str] = None, cf_config: Optional[dict] = None):
         super().__init__()
-        self._engine = Engine(self.ARCH, in_ch, label_ch, dtype or default_dtype())
+        self._engine = Engine(self.ARCH, in_ch, label_ch, dtype or default_dtype(), cf_config)
         self._flat_params: Optional[torch.Tensor] = None
         self._flat_grads: Optional[torch.Tensor] = None
         self._flat_bn: Optional[torch.Tensor] = None
@@ -228,7 +234,10 @@ class HipChangeDetector(nn.Module):
     def _run_forward(self, x1, x2, training: bool):
         eng = self._engine
         B, _, H, W = x1.shape
-        logits = torch.empty((self.OUT_MAPS * B, eng.label_ch, H, W), dtype=torch.float32, device=x1.device)
+        if self.OUT_MAPS == 0:
+            logits = torch.empty(eng.output_floats(), dtype=torch.float32, device=x1.device)
+        else:
+            logits = torch.empty((self.OUT_MAPS * B, eng.label_ch, H, W), dtype=torch.float32, device=x1.device)
         masks = None
         pend = getattr(self, "_pending_masks", None)
         if training and pend is not None:
@@ -281,7 +290,9 @@ class HipChangeDetector(nn.Module):
                 out = _EngineFn.apply(self, self._anchor, x1, x2)
             else:
                 out = self._run_forward(x1, x2, self.training)
-                if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                if self.OUT_MAPS == 0:
+                    out = tuple(self._split_outputs(out))
+                elif torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                     out = _NoEvalGradFn.apply(out, self._anchor)
         return self._wrap_output(out, B)
 

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(raw, name), f"{name} declared in stcd_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.lib().stcd_abi_version() == 1
+    assert _lib.lib().stcd_abi_version() == 2
 
 
 @pytest.mark.parametrize("cls,arch", [(SiamUnet_diff, "diff"), (SiamUnet_conc, "conc"), (SiamUnet_sub, "sub")])

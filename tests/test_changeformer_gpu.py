@@ -1,0 +1,228 @@
+"""ChangeFormerV6 through the HIP engine against the CPU oracle (oracle/changeformer_ref.py; the encoder / decoder classes are
+restated from /root/reference/models/ChangeFormer.py:195-358,472-523,1342-1701 -- parity unpinned, see the oracle's header --, the
+decoder-head blocks are pinned by tests/golden/g17_cf_base.npz).  fp32 engine: the five outputs and the loss at 1e-3, every
+parameter's gradient per tensor (relative l2 / cosine, tests/_util.py), BatchNorm running statistics; identical dropout masks on
+both sides (the engine's counter hash, reproduced by oracle.changeformer_ref.engine_masks from the engine's own site table)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import changeformer_ref as R
+from stcd_amd._lib import StcdError
+from stcd_amd.changeformer import ChangeFormerV6
+from tests import _util
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TINY = dict(embed_dims=(64, 64, 128, 128), depths=(2, 1, 1, 2), num_heads=(1, 2, 2, 4))
+
+
+def build(cfg_name, dtype, out_ch=2, seed=3, drop=None):
+    if cfg_name == "tiny":
+        ocfg = R.CFConfig.tiny(out_ch)
+        kw = dict(embed_dim=64, config=dict(TINY))
+    else:
+        ocfg = R.CFConfig(out_ch=out_ch)
+        kw = dict(embed_dim=256, config={})
+    if drop is not None:
+        ocfg.drop_rate, ocfg.attn_drop, ocfg.drop_path_rate, ocfg.diff_drop = drop
+        kw["config"].update(drop_rate=drop[0], attn_drop=drop[1], drop_path_rate=drop[2], diff_drop=drop[3])
+    st = R.synth_state(ocfg, seed, perturb_running=True)
+    m = ChangeFormerV6(3, out_ch, False, dtype=dtype, **kw)
+    m.load_state_dict(st)
+    return ocfg, st, m.to(DEV)
+
+
+def data(B, H, W, out_ch, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    x1, x2 = torch.randn(B, 3, H, W, generator=g), torch.randn(B, 3, H, W, generator=g)
+    if out_ch == 1:
+        tgt = (torch.rand(B, 1, H, W, generator=g) < 0.3).float()
+    else:
+        tgt = (torch.rand(B, H, W, generator=g) < 0.3).long()
+    return x1, x2, tgt
+
+
+def loss_fn(cp, tgt):
+    return F.cross_entropy(cp, tgt) if cp.shape[1] > 1 else F.binary_cross_entropy_with_logits(cp, tgt)
+
+
+def oracle_step(ocfg, st, x1, x2, tgt, masks, dt=torch.float32):
+    """one training step of the oracle; dt = float64: reference gradients free of the CPU path's own fp32 summation noise"""
+    ref = {k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in st.items()}
+    x1, x2 = x1.to(dt), x2.to(dt)
+    if tgt.dtype.is_floating_point:
+        tgt = tgt.to(dt)
+    masks = None if masks is None else {k: v.to(dt) for k, v in masks.items()}
+    for k, v in ref.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    outs = R.forward(ocfg, ref, x1, x2, True, masks)
+    loss = loss_fn(outs[-1], tgt)
+    loss.backward()
+    return ref, outs, loss
+
+
+@pytest.mark.parametrize("cfg_name,B,H,W,out_ch,drop", [
+    ("tiny", 2, 64, 64, 2, None),                        # every dropout family on (0.1 / 0.1 / 0.1 / 0.6)
+    ("tiny", 1, 64, 96, 1, (0.0, 0.0, 0.0, 0.0)),        # no randomness at all; one class; non-square
+    ("tiny", 3, 32, 32, 2, (0.2, 0.0, 0.3, 0.0)),        # stage-4 token map 1x1
+    ("v6", 1, 64, 64, 2, None),                          # the reference's V6 widths: head dim 80 in stage 3, 41 M parameters
+])
+def test_fp32_training_step_matches_the_oracle(cfg_name, B, H, W, out_ch, drop):
+    ocfg, st, m = build(cfg_name, "fp32", out_ch, drop=drop)
+    x1, x2, tgt = data(B, H, W, out_ch)
+    m.train()
+    m.set_seed(424242)
+    outs = m(x1.to(DEV), x2.to(DEV))
+    assert isinstance(outs, list) and len(outs) == 5
+    loss = loss_fn(outs[-1], tgt.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    sites = m._engine.cf_sites()
+    assert [(n, tuple(d)) for n, d, _ in sites] == [(n, tuple(d)) for n, d, _ in R.site_list(ocfg, B, H, W)]
+    for (_, _, pe), (_, _, po) in zip(sites, R.site_list(ocfg, B, H, W)):
+        assert abs(pe - po) < 1e-6
+    masks = R.engine_masks(ocfg, B, H, W, 424242, sites=sites)
+    ref, routs, rloss = oracle_step(ocfg, st, x1, x2, tgt, masks, torch.float64)
+    for k, (o, r) in enumerate(zip(outs, routs)):
+        assert tuple(o.shape) == tuple(r.shape)
+        err = float((o.detach().cpu().double() - r.detach()).abs().max())
+        assert err <= 1e-4 * max(1.0, float(r.detach().abs().max())), f"output {k}: max abs error {err:.3e}"     # north_star: 1e-3
+    assert abs(loss.item() - rloss.item()) <= 1e-5 * max(1.0, abs(rloss.item()))
+    worst, bad = (0.0, 1.0), []
+    named = dict(m.named_parameters())
+    for name, p in named.items():
+        rg = ref[name].grad
+        if rg is None:                                   # auxiliary heads: not on the loss's path in the reference either
+            assert "make_pred" in name
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        got = p.grad.detach().cpu()
+        scale = float(rg.abs().max())
+        if scale < 1e-7:                                 # a bias in front of a train-mode BatchNorm: zero by construction
+            assert float(got.abs().max()) < 1e-5, name
+            continue
+        rel, cos = _util.rel_l2_cos(got.numpy(), rg.numpy())
+        # 1e-3 per tensor.  Two tensor classes sit directly behind a gate (ResidualBlock's ReLU, conv_diff's PReLU slope -- a scalar
+        # sum of signed terms): a pre-activation within fp32 rounding of zero flips its gate, and the CPU oracle moves these same
+        # tensors by up to 3e-3 between its own fp32 and fp64 runs on these fixtures (measured) -- they get 5e-3.
+        gated = (".conv1.conv2d." in name and "dense_" in name) or (name.startswith("TDec_x2.diff_c") and name.endswith((".1.weight", ".5.weight")))
+        if not (rel <= (5e-3 if gated else 1e-3) and cos >= (0.99998 if gated else 0.999999)):
+            bad.append(f"{name}: relative l2 error {rel:.3e}, cosine {cos:.7f}")
+        worst = (max(worst[0], rel), min(worst[1], cos))
+    assert not bad, f"{len(bad)} tensors off: " + "; ".join(bad[:12])
+    _util.ACHIEVED[f"changeformer-{cfg_name}-fp32 {B}x{H}x{W} out{out_ch}"] = worst
+    # BatchNorm running statistics and counters after the step
+    sd = m.state_dict()
+    for k, v in ref.items():
+        if "running" in k:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), v.float().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+        elif k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v), k
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny", "v6"])
+def test_fp32_eval_forward_matches_the_oracle(cfg_name):
+    ocfg, st, m = build(cfg_name, "fp32")
+    x1, x2, _ = data(2, 64, 64, 2, seed=5)
+    m.eval()
+    with torch.no_grad():
+        outs = m(x1.to(DEV), x2.to(DEV))
+        routs = R.forward(ocfg, st, x1, x2, False)
+    for k, (o, r) in enumerate(zip(outs, routs)):
+        err = float((o.cpu() - r).abs().max())
+        assert err <= 1e-4 * max(1.0, float(r.abs().max())), f"eval output {k}: {err:.3e}"
+    # the change mask (argmax of cp) is the same map
+    assert float((outs[-1].argmax(1).cpu() != routs[-1].argmax(1)).float().mean()) < 1e-3
+
+
+def test_same_seed_same_step_and_new_seed_new_masks():
+    _, _, m = build("tiny", "fp32")
+    x1, x2, tgt = data(2, 64, 64, 2)
+    m.train()
+    res = []
+    for seed in (7, 7, 8):
+        m.set_seed(seed)
+        m.zero_grad(set_to_none=True)
+        o = m(x1.to(DEV), x2.to(DEV))[-1]
+        loss_fn(o, tgt.to(DEV)).backward()
+        res.append((o.detach().clone(), m.Tenc_x2.block1[0].attn.q.weight.grad.detach().clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "a step is a pure function of its seed"
+    assert not torch.equal(res[0][0], res[2][0])
+
+
+def test_auxiliary_gradients_are_refused_loudly():
+    _, _, m = build("tiny", "fp32")
+    x1, x2, tgt = data(1, 64, 64, 2)
+    m.train()
+    outs = m(x1.to(DEV), x2.to(DEV))
+    with pytest.raises(StcdError):
+        (outs[0].sum() + outs[-1].sum()).backward()
+
+
+@pytest.mark.parametrize("cfg_name,dtype,bound", [("tiny", "fp32", 2e-5), ("v6", "fp32", 5e-5), ("tiny", "bf16", 3e-2), ("v6", "bf16", 4e-2)])
+def test_every_stored_tensor_in_place(cfg_name, dtype, bound):
+    """The engine's stored activations (stcd_ws_tensor_* introspection) against the oracle's intermediates of the same training
+    forward, tensor by tensor: token maps of every block, stage outputs, every decoder map.  Relative l2 per tensor: fp32 at
+    rounding level; bf16 bounded at every depth (the error of ~100 bf16-stored layers does not build up beyond a few per cent)."""
+    ocfg, st, m = build(cfg_name, dtype)
+    B, H, W = 2, 64, 64
+    x1, x2, _ = data(B, H, W, 2, seed=21)
+    m.train()
+    m.set_seed(5)
+    with torch.no_grad():
+        m(x1.to(DEV), x2.to(DEV))
+    torch.cuda.synchronize()
+    masks = R.engine_masks(ocfg, B, H, W, 5, sites=m._engine.cf_sites())
+    R.TAPS = {}
+    try:
+        R.forward(ocfg, {k: v.clone() for k, v in st.items()}, x1, x2, True, masks)
+        taps = R.TAPS
+    finally:
+        R.TAPS = None
+    ws = m._engine.ws_tensors()
+    checked, worst = 0, (0.0, "")
+    for name, t in taps.items():
+        if name not in ws or name.endswith((".pr", ".f2")):       # (pr / f2: the engine stores the branch BEFORE its dropout)
+            continue
+        got = ws[name].float().cpu()
+        assert tuple(got.shape) == tuple(t.shape), name
+        rel = float((got - t).norm() / t.norm())
+        worst = max(worst, (rel, name))
+        checked += 1
+    assert checked >= 40, checked
+    print(f"{cfg_name} {dtype}: {checked} stored tensors, worst relative l2 error {worst[0]:.3e} ({worst[1]})")
+    assert worst[0] <= bound, worst
+
+
+@pytest.mark.parametrize("cfg_name,B,H,W", [("tiny", 2, 64, 64), ("v6", 2, 64, 64)])
+def test_bf16_step_tracks_the_fp32_oracle(cfg_name, B, H, W):
+    """bf16 storage through ~100 layers: statistical bounds on the outputs, the loss and per-tensor gradient cosines against
+    the fp32 oracle on identical masks (the tight bf16 bounds are per op: tests/test_cf_ops_gpu.py)."""
+    ocfg, st, m = build(cfg_name, "bf16")
+    x1, x2, tgt = data(B, H, W, 2)
+    m.train()
+    m.set_seed(99)
+    outs = m(x1.to(DEV), x2.to(DEV))
+    loss = loss_fn(outs[-1], tgt.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    masks = R.engine_masks(ocfg, B, H, W, 99, sites=m._engine.cf_sites())
+    ref, routs, rloss = oracle_step(ocfg, st, x1, x2, tgt, masks)
+    rel_out = float((outs[-1].detach().cpu() - routs[-1].detach()).norm() / routs[-1].detach().norm())
+    assert rel_out < 5e-2, f"cp relative l2 error {rel_out:.3e}"
+    assert abs(loss.item() - rloss.item()) < 3e-2
+    coss = []
+    for name, p in m.named_parameters():
+        rg = ref[name].grad
+        if rg is None or float(rg.abs().max()) < 1e-7:
+            continue
+        _, cos = _util.rel_l2_cos(p.grad.detach().cpu().numpy(), rg.numpy())
+        coss.append((cos, name))
+    coss.sort()
+    print("bf16 gradient cosines: worst", coss[:5], "median", coss[len(coss) // 2][0])
+    print("relative l2 error of cp:", rel_out, "loss", loss.item(), rloss.item())
+    assert coss[len(coss) // 2][0] > 0.98, coss[len(coss) // 2]
+    assert coss[0][0] > 0.85, coss[0]
