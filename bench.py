@@ -72,7 +72,67 @@ def segcd_alg(encoder, classes=1, H=256, W=256, dates=2, ffc=False):
     return 3.0 * fl, 3.0 * by
 
 
-NAMES = {"diff": "SiamUnet_diff", "conc": "SiamUnet_conc", "sub": "SiamUnet_sub", "snunet": "SNUNet_ECAM", "segcd": "SegCD-resnet50"}
+def changeformer_alg(H=512, W=512, out_ch=2, E=(64, 128, 320, 512), depths=(3, 3, 4, 3), srs=(8, 4, 2, 1), D=256, mlp=4, k1=7, k=7):
+    """SURVEY 8d's accounting over ChangeFormerV6's layer table (/root/reference/models/ChangeFormer.py:1342-1631): per matrix
+    product / convolution call 2 MACs and (input + output + weights) x 2 B, attention 4 N Nkv C flops and (q + k + v + out) x 2 B,
+    both dates through the encoder, x 3 for fwd + dgrad + wgrad.  Per image PAIR."""
+    fl = by = 0.0
+
+    def op(m, kk, n):                      # [m, kk] x [kk, n]
+        nonlocal fl, by
+        fl += 2.0 * m * kk * n
+        by += (m * kk + m * n + kk * n) * 2.0
+
+    h, w, cin = H, W, 3
+    hs = []
+    for s in range(4):
+        kk, st = (k1, 4) if s == 0 else (k, 2)
+        hi, wi = h, w
+        h, w = (h + 2 * (kk // 2) - kk) // st + 1, (w + 2 * (kk // 2) - kk) // st + 1
+        C, N = E[s], h * w
+        Nk = (h // srs[s]) * (w // srs[s]) if srs[s] > 1 else N
+        for _date in range(2):
+            fl += 2.0 * N * kk * kk * cin * C
+            by += (hi * wi * cin + N * C + kk * kk * cin * C) * 2.0
+            for _ in range(depths[s]):
+                op(N, C, C)                                     # q
+                if srs[s] > 1:
+                    op(Nk, C * srs[s] ** 2, C)                  # sr
+                op(Nk, C, 2 * C)                                # kv
+                fl += 4.0 * N * Nk * C
+                by += (2 * N * C + 2 * Nk * C) * 2.0            # attention
+                op(N, C, C)                                     # proj
+                op(N, C, mlp * C)                               # fc1
+                fl += 2.0 * 9 * N * mlp * C
+                by += (2 * N * mlp * C) * 2.0                   # depthwise 3x3
+                op(N, mlp * C, C)                               # fc2
+        hs.append((h, w))
+        cin = C
+    def conv3(px, ci, co):                 # 3x3 stride-1 convolution over px pixels: every tensor counted once
+        nonlocal fl, by
+        fl += 2.0 * px * 9 * ci * co
+        by += (px * ci + px * co + 9 * ci * co) * 2.0
+
+    for s in range(4):
+        hh, ww = hs[s]
+        op(2 * hh * ww, E[s], D)                                # linear_c on both dates
+        conv3(hh * ww, 2 * D, D)                                # conv_diff
+        conv3(hh * ww, D, D)
+        conv3(hh * ww, D, out_ch)                               # make_prediction
+        conv3(hh * ww, out_ch, out_ch)
+    h1, w1 = hs[0]
+    op(h1 * w1, 4 * D, D)                                       # linear_fuse
+    for sc in (1, 2):                                           # convd2x + dense_2x at 2 h1, convd1x + dense_1x at 4 h1
+        hi, wi = h1 * sc, w1 * sc
+        fl += 2.0 * hi * wi * 16 * D * D
+        by += (hi * wi * D + 4 * hi * wi * D + 16 * D * D) * 2.0
+        conv3(4 * hi * wi, D, D)
+        conv3(4 * hi * wi, D, D)
+    conv3(H * W, D, out_ch)                                     # change_probability
+    return 3.0 * fl, 3.0 * by
+
+
+NAMES = {"changeformer": "ChangeFormerV6", "diff": "SiamUnet_diff", "conc": "SiamUnet_conc", "sub": "SiamUnet_sub", "snunet": "SNUNet_ECAM", "segcd": "SegCD-resnet50"}
 
 
 def parse():
@@ -80,7 +140,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub", "snunet", "segcd", "unetseg", "ffctlcd"],
+    ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub", "snunet", "segcd", "unetseg", "ffctlcd", "changeformer"],
                     help="unetseg: the single-image UNet of train_sup.py (one 'pair' = one image); ffctlcd: SegCD's feature-level variant")
     ap.add_argument("--encoder", default="resnet50", choices=sorted(SEGCD_ENCODERS), help="--model segcd: the ResNet encoder")
     ap.add_argument("--batch", type=int, default=16, help="image pairs per GPU per step")
@@ -92,7 +152,7 @@ def parse():
                          "(stcd_pseudo_pair: blend + normalise + labels), then trains on them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=8)      # bounded CPU sample: ~10-20 s of host work in total
+    ap.add_argument("--cpu-pairs", type=int, default=16)     # bounded CPU sample: ~10-30 s of host work in total (16 = the GPU's batch)
     ap.add_argument("--cpu-steps", type=int, default=20)
     return ap.parse_args()
 
@@ -120,8 +180,44 @@ def cpu_baseline_segcd(size, pairs, steps, encoder="resnet50"):
         if i > 0:
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return {"value": round(pairs / med, 3), "unit": "image-pairs/sec", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(pairs / med, 3), "unit": "image-pairs/sec", "cores": torch.get_num_threads(), "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": f"oracle/segcd_ref.py SegCD({encoder}) fp32, {pairs} pairs {size}x{size}, median of {steps} full steps after 1 warm-up "
+                      f"({med * 1e3:.0f} ms/step)"}
+
+
+def _host_cores():
+    """all host cores the process may use, the box's own core count stated beside it."""
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    env = os.environ.get("STCD_CPU_THREADS")
+    torch.set_num_threads(max(1, min(ncpu, int(env))) if env else max(1, ncpu))
+    return {"cores": torch.get_num_threads(), "host_cpu_count": os.cpu_count(), "usable_cpus": ncpu}
+
+
+def cpu_baseline_changeformer(size, pairs, steps):
+    """oracle/changeformer_ref.py timed on the host: ChangeFormerV6 fwd + cross-entropy on cp + bwd + AdamW, fp32, all host threads,
+    dropout masks drawn once (one 512 x 512 pair is ~2.5 TFLOP of CPU work per step: a one-pair, one-step sample)."""
+    from oracle import changeformer_ref as CF
+    from stcd_amd import synth
+    cores = _host_cores()
+    a, b, lab = synth.make_batch(pairs, size, size, seed=1337)
+    A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab)
+    cfg = CF.CFConfig()
+    st = CF.synth_state(cfg, seed=1)
+    params = [v.requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
+    opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01)
+    masks = CF.random_masks(cfg, pairs, size, size, seed=2)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(CF.forward(cfg, st, A, B, True, masks)[-1], L)
+        loss.backward()
+        opt.step()
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(pairs / med, 4), "unit": "image-pairs/sec", **cores, "kind": "port",
+            "sample": f"oracle/changeformer_ref.py ChangeFormerV6(3,2) fp32, {pairs} pair(s) {size}x{size}, median of {steps} full step(s) after 1 warm-up "
                       f"({med * 1e3:.0f} ms/step)"}
 
 
@@ -131,8 +227,9 @@ def cpu_baseline(arch, label, size, pairs, steps, encoder="resnet50"):
     from oracle import snunet_ref as SN
     from stcd_amd import synth
 
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(max(1, min(ncpu, int(os.environ.get("STCD_CPU_THREADS", "16")))))
+    if arch == "changeformer":
+        return cpu_baseline_changeformer(size, min(pairs, 1), min(steps, 1))
+    cores = _host_cores()
     a, b, lab = synth.make_batch(pairs, size, size, seed=1337)
     A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab)
     if arch == "segcd":
@@ -152,7 +249,7 @@ def cpu_baseline(arch, label, size, pairs, steps, encoder="resnet50"):
         if i > 0:
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return {"value": round(pairs / med, 3), "unit": "image-pairs/sec", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(pairs / med, 3), "unit": "image-pairs/sec", **cores, "kind": "port",
             "sample": f"oracle/{'snunet_ref.py SNUNet_ECAM' if arch == 'snunet' else 'fcsiam_ref.py SiamUnet_' + arch}(3,{label}) fp32, {pairs} pairs {size}x{size}, "
                       f"median of {steps} full steps after 1 warm-up ({med * 1e3:.0f} ms/step)"}
 
@@ -219,7 +316,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU fallback"
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(1337)
-    if args.model == "segcd":       # train_pse_cd.py:426-431: SegCD(resnet50), 1 class, Adam(lr 1e-3), BCE+Dice on sigmoid(change)
+    if args.model == "changeformer":   # BASELINE.json configs[4]: ChangeFormerV6, 512 x 512, batch 32 over 8 GPUs = 4 pairs per GPU
+        from stcd_amd.changeformer import ChangeFormerV6
+        args.label = 2
+        if args.size == 256 and "--size" not in sys.argv:
+            args.size = 512
+        if args.batch == 16 and "--batch" not in sys.argv:
+            args.batch = 4
+        model = ChangeFormerV6(3, 2, dtype=args.dtype).to(dev).train()
+    elif args.model == "segcd":       # train_pse_cd.py:426-431: SegCD(resnet50), 1 class, Adam(lr 1e-3), BCE+Dice on sigmoid(change)
         from stcd_amd.segcd import SegCD
         args.label = 1
         model = SegCD(encoder_name=args.encoder, encoder_weights=None, in_channels=3, classes=1, dtype=args.dtype).to(dev).train()
@@ -319,7 +424,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{NAMES[args.model]}(3,{args.label}) {args.size}x{args.size} full training step "
-                               f"(fwd + {'cross_entropy' if args.label == 2 else 'sigmoid+cd_loss'} + bwd + {'Adam' if args.model in ('segcd', 'unetseg', 'ffctlcd') else 'AdamW'}), "
+                               f"(fwd + {'cross_entropy' if args.label == 2 else 'sigmoid+cd_loss'}{' on cp' if args.model == 'changeformer' else ''} + bwd + {'Adam' if args.model in ('segcd', 'unetseg', 'ffctlcd') else 'AdamW'}), "
                                f"{args.batch} pairs/GPU, " + ("pairs built every step by the on-device pseudo-change generator from uint8 tiles resident in HBM"
                                                              if args.pseudo else "synthetic LEVIR-CD-shaped pairs resident in HBM"),
                    "global_batch": world * args.batch, "image": args.size, "parallelism": f"dp{world}",
@@ -331,9 +436,9 @@ def main():
     # whole-step roofline: SURVEY 8d's algorithmic figures per pair x pairs per step / measured step time (all ranks)
     seg_family = args.model in ("segcd", "unetseg", "ffctlcd")
     fl_pp, by_pp = (segcd_alg(args.encoder, dates=1 if args.model == "unetseg" else 2, ffc=args.model == "ffctlcd") if seg_family
-                    else ALG_PER_PAIR_256[args.model])
+                    else changeformer_alg(args.size, args.size) if args.model == "changeformer" else ALG_PER_PAIR_256[args.model])
     pmc_key = args.model if (not seg_family or args.encoder == "resnet50") else args.model + "_" + args.encoder
-    sc = (args.size / 256.0) ** 2
+    sc = 1.0 if args.model == "changeformer" else (args.size / 256.0) ** 2
     step_s = elapsed / args.steps
     peak_tf_ = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
     by_scale = 1.0 if args.dtype == "bf16" else 2.0
@@ -352,8 +457,17 @@ def main():
         prof = eng.profile_read()
         kern = eng.profile_kernels()
         eng.profile_enable(False)
-        dom = max(kern, key=lambda k: kern[k]["ms"])       # the dominant KERNEL (one name in the rocprofv3 summary)
-        p = kern[dom]
+        # the dominant KERNEL: template instantiations of one kernel (k_conv_res<2, 32, false>, <1, 64, false> ...) are ONE kernel
+        # for this purpose -- merged by base name, so a kernel split over many instantiations cannot hide behind a smaller one
+        merged = {}
+        for k_, v_ in kern.items():
+            mname = k_.split("<")[0]
+            mm = merged.setdefault(mname, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "parts": []})
+            for f_ in ("ms", "launches", "flops", "bytes"):
+                mm[f_] += v_[f_]
+            mm["parts"].append(k_)
+        dom = max(merged, key=lambda k: merged[k]["ms"])
+        p = merged[dom]
         # a HIP-event pair around nothing still reads ~4-5 us (two marker packets); around a kernel one marker's cost
         # overlaps the dispatch, so HALF the empty-pair reading is taken off every launch -- checked against the
         # rocprofv3 --kernel-trace average of the same kernel (profiles/): raw events sit ~12 % above it, this within 2 %
@@ -377,14 +491,14 @@ def main():
         result["roofline"] = {
             "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "stcd::" + dom, "avg_launch_us": round(secs * 1e6 / max(p["launches"], 1), 3),
+            "kernel": "stcd::" + dom, "instantiations": sorted(p["parts"]), "avg_launch_us": round(secs * 1e6 / max(p["launches"], 1), 3),
             "avg_launch_us_raw": round(raw_us, 3), "event_pair_overhead_us": round(ev_us, 3),
             "launches_per_step": p["launches"] // nprof,
             "alg_bytes_per_launch": round(p["bytes"] / max(p["launches"], 1)),
             "alg_flops_per_launch": round(p["flops"] / max(p["launches"], 1)),
             "other_bound_frac": round(min(hbm_frac, mfma_frac), 4),
             "class_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in prof.items()},
-            "kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+            "kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("STCD_BENCH_TOP_KERNELS", "8"))]},
             "instrumented_ms_per_step": round(tot_ms / nprof, 4),
             "launches_per_step_all_kernels": sum(v["launches"] for v in kern.values()) // nprof,
             "step": step_roof,

@@ -440,6 +440,14 @@ void launch_bn_stats_precise(int dt, const void* Z, int ld, int64_t M, int C, co
 void launch_attn_fwd(int dt, const void* q, int ldq, const void* kv, int ldkv, void* out, int ldo, float* lse, int n, int N, int Nkv,
                      int heads, int d, float scale, DropSite drop, hipStream_t s);
 int64_t attn_bwd_scratch_floats(int n, int N, int Nkv, int heads, int d);
+// matrix-core path (kernels_attn.hip): bf16, head dimension a multiple of 16 (<= 128), Nkv <= 256; STCD_NO_MFMA_ATTENTION=1 disables it
+bool attn_mfma_ok(int dt, int Nkv, int d);
+int64_t attn_mfma_bwd_scratch_floats(int n, int N, int Nkv, int heads, int d);
+int launch_attn_fwd_mfma(const void* q, int ldq, const void* kv, int ldkv, void* out, int ldo, float* lse, int n, int N, int Nkv, int heads,
+                         int d, float scale, DropSite drop, hipStream_t s);
+int launch_attn_bwd_mfma(const void* q, int ldq, const void* kv, int ldkv, const void* out, int ldo, const void* dout, int lddo,
+                         const float* lse, void* dq, int lddq, void* dkv, int lddkv, float* scratch, int n, int N, int Nkv, int heads, int d,
+                         float scale, DropSite drop, hipStream_t s);
 // dq [n, N, heads*d], dkv [n, Nkv, 2*heads*d]; scratch: fp32 (row terms D + the dK/dV partial slabs)
 void launch_attn_bwd(int dt, const void* q, int ldq, const void* kv, int ldkv, const void* out, int ldo, const void* dout, int lddo,
                      const float* lse, void* dq, int lddq, void* dkv, int lddkv, float* scratch, int n, int N, int Nkv, int heads, int d,

@@ -31,14 +31,21 @@ template <typename T>
 __device__ __forceinline__ T from_float(float v) { return (T)v; }
 
 // ------------------------------------------------------------------------------------------------ partial-sum finish
-// out[j] = sum_b partial[b * stride + j], j < n0 -> out0[j], else out1[j - n0]; fixed order: reproducible
-__global__ void k_partial_finish(const float* __restrict__ partial, int nblk, int64_t stride, int n0, int n, float* __restrict__ out0,
-                                 float* __restrict__ out1) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+// out[j] = sum_b partial[b * stride + j], j < n0 -> out0[j], else out1[j - n0]; fixed summation tree: reproducible.
+// 32 lanes share one output (strided partial sums, then a butterfly), 8 outputs per block.
+__global__ void __launch_bounds__(256)
+k_partial_finish(const float* __restrict__ partial, int nblk, int64_t stride, int n0, int n, float* __restrict__ out0,
+                 float* __restrict__ out1) {
+    const int j = blockIdx.x * 8 + (threadIdx.x >> 5), bl = threadIdx.x & 31;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * stride + j];
-    if (j < n0) out0[j] = s; else out1[j - n0] = s;
+    if (j < n)
+        for (int b = bl; b < nblk; b += 32) s += partial[(int64_t)b * stride + j];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (j < n && bl == 0) { if (j < n0) out0[j] = s; else out1[j - n0] = s; }
+}
+static inline void launch_partial_finish(const float* partial, int nblk, int64_t stride, int n0, int n, float* out0, float* out1, hipStream_t s) {
+    k_partial_finish<<<cdiv(n, 8), 256, 0, s>>>(partial, nblk, stride, n0, n, out0, out1);
 }
 
 // ------------------------------------------------------------------------------------------------ im2col / col2im
@@ -114,20 +121,31 @@ void launch_col2im(int dt, const void* dcol, int ldc, void* dX, int lddx, int n,
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // nn.LayerNorm(C, eps) over the channels of every token (ChangeFormer.py:209,317,478,486,1363: eps 1e-5 for the patch-embedding /
-// spatial-reduction norms, 1e-6 for the block / stage norms).  One wave per row, the row in registers (two-pass variance).
-template <typename T, int NP>
+// spatial-reduction norms, 1e-6 for the block / stage norms).  LPR lanes share one row (8 for C = 64 ... 64 for C >= 320), so a wave
+// holds 64 / LPR rows at once (a 64-channel token is 128 bytes: one row per wave left 56 lanes idle and the kernel latency-bound);
+// the row lives in registers, two-pass variance.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename T, int LPR, int NP>
 __global__ void __launch_bounds__(256)
 k_ln_fwd(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, const float* __restrict__ gamma, const float* __restrict__ beta,
          float* __restrict__ stats, int64_t M, int C, float eps) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, np = C >> 3;
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, np = C >> 3, rl = lane / LPR, pl = lane % LPR;
     const float invC = 1.f / (float)C;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < M; row += (int64_t)gridDim.x * 4) {
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * RPW; row0 < M; row0 += (int64_t)gridDim.x * 4 * RPW) {
+        const int64_t row = row0 + rl;
+        const bool rok = row < M;
         float v[NP][8];
         float s = 0.f;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int piece = lane + 64 * p;
-            if (piece < np) {
+            const int piece = pl + LPR * p;
+            if (rok && piece < np) {
                 load8(x + row * ldx + piece * 8, v[p]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += v[p][j];
@@ -136,19 +154,19 @@ k_ln_fwd(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, const flo
                 for (int j = 0; j < 8; ++j) v[p][j] = 0.f;
             }
         }
-        const float mean = wave_sum(s) * invC;
+        const float mean = group_sum<LPR>(s) * invC;
         float q = 0.f;
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-            if (lane + 64 * p < np) {
+            if (pl + LPR * p < np) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float d = v[p][j] - mean; q += d * d; }
             }
-        const float rstd = 1.f / sqrtf(wave_sum(q) * invC + eps);
+        const float rstd = 1.f / sqrtf(group_sum<LPR>(q) * invC + eps);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int piece = lane + 64 * p;
-            if (piece < np) {
+            const int piece = pl + LPR * p;
+            if (rok && piece < np) {
                 float g[8], b[8], o[8];
                 load8(gamma + piece * 8, g);
                 load8(beta + piece * 8, b);
@@ -157,46 +175,58 @@ k_ln_fwd(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, const flo
                 store8(y + row * ldy + piece * 8, o);
             }
         }
-        if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+        if (rok && pl == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
     }
 }
+static inline int ln_lpr(int C) { const int np = C / 8; return np <= 8 ? 8 : np <= 16 ? 16 : np <= 32 ? 32 : 64; }
 void launch_layernorm(int dt, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, float* stats, int64_t M,
                       int C, float eps, hipStream_t s) {
-    const unsigned grid = (unsigned)std::min<int64_t>((M + 3) / 4, 8192);
+    const int lpr = ln_lpr(C), rpb = 4 * (64 / lpr);
+    const unsigned grid = (unsigned)std::min<int64_t>((M + rpb - 1) / rpb, 4096);
     if (grid == 0) return;
-#define LN_F(T_, NP_) k_ln_fwd<T_, NP_><<<grid, 256, 0, s>>>((const T_*)x, ldx, (T_*)y, ldy, gamma, beta, stats, M, C, eps)
-    if (C <= 512) { if (dt == BF16) LN_F(bf16, 1); else LN_F(float, 1); }
-    else { if (dt == BF16) LN_F(bf16, 4); else LN_F(float, 4); }
+#define LN_F(T_, L_, NP_) k_ln_fwd<T_, L_, NP_><<<grid, 256, 0, s>>>((const T_*)x, ldx, (T_*)y, ldy, gamma, beta, stats, M, C, eps)
+#define LN_FT(L_, NP_) do { if (dt == BF16) LN_F(bf16, L_, NP_); else LN_F(float, L_, NP_); } while (0)
+    if (lpr == 8) LN_FT(8, 1);
+    else if (lpr == 16) LN_FT(16, 1);
+    else if (lpr == 32) LN_FT(32, 1);
+    else if (C <= 512) LN_FT(64, 1);
+    else LN_FT(64, 4);
+#undef LN_FT
 #undef LN_F
 }
 
-static inline int ln_bwd_blocks(int64_t M) { return (int)std::min<int64_t>((M + 3) / 4, 512); }
-int64_t layernorm_bwd_scratch_floats(int64_t M, int C) { return (int64_t)ln_bwd_blocks(M) * 2 * C + 16; }
+static inline int ln_bwd_blocks(int64_t M, int C) { const int rpb = 4 * (64 / ln_lpr(C)); return (int)std::max<int64_t>(1, std::min<int64_t>((M + rpb - 1) / rpb, 1024)); }
+int64_t layernorm_bwd_scratch_floats(int64_t M, int C) { return (int64_t)ln_bwd_blocks(M, C) * 2 * C + 16; }
 
-template <typename T, int NP>
+template <typename T, int LPR, int NP>
 __global__ void __launch_bounds__(256)
 k_ln_bwd(const T* __restrict__ dy, int lddy, const T* __restrict__ dy2, int lddy2, const T* __restrict__ x, int ldx,
          const float* __restrict__ stats, const float* __restrict__ gamma, const T* __restrict__ add, int ldadd, T* __restrict__ dx, int lddx,
          float* __restrict__ partial, int64_t M, int C) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* red = reinterpret_cast<float*>(smem_raw);          // [4 waves][2][C]
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, np = C >> 3;
+    constexpr int RPW = 64 / LPR;
+    float* red = reinterpret_cast<float*>(smem_raw);          // [4 waves * RPW row groups][2][C]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, np = C >> 3, rl = lane / LPR, pl = lane % LPR;
     const float invC = 1.f / (float)C;
     float dg[NP][8], db[NP][8], gm[NP][8];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dg[p][j] = 0.f; db[p][j] = 0.f; gm[p][j] = 0.f; }
-        if (lane + 64 * p < np) load8(gamma + (lane + 64 * p) * 8, gm[p]);
+        if (pl + LPR * p < np) load8(gamma + (pl + LPR * p) * 8, gm[p]);
     }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < M; row += (int64_t)gridDim.x * 4) {
-        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * RPW; row0 < M; row0 += (int64_t)gridDim.x * 4 * RPW) {
+        const int64_t row = row0 + rl;
+        const bool rok = row < M;
+        const float mean = rok ? stats[row * 2] : 0.f, rstd = rok ? stats[row * 2 + 1] : 0.f;
         float g[NP][8], xh[NP][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int piece = lane + 64 * p;
-            if (piece < np) {
+            const int piece = pl + LPR * p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { g[p][j] = 0.f; xh[p][j] = 0.f; }
+            if (rok && piece < np) {
                 float d[8], xv[8];
                 load8(dy + row * lddy + piece * 8, d);
                 if (dy2) {
@@ -217,12 +247,12 @@ k_ln_bwd(const T* __restrict__ dy, int lddy, const T* __restrict__ dy2, int lddy
                 }
             }
         }
-        s1 = wave_sum(s1) * invC;
-        s2 = wave_sum(s2) * invC;
+        s1 = group_sum<LPR>(s1) * invC;
+        s2 = group_sum<LPR>(s2) * invC;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int piece = lane + 64 * p;
-            if (piece < np) {
+            const int piece = pl + LPR * p;
+            if (rok && piece < np) {
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = rstd * (g[p][j] - s1 - xh[p][j] * s2);
@@ -236,37 +266,45 @@ k_ln_bwd(const T* __restrict__ dy, int lddy, const T* __restrict__ dy2, int lddy
             }
         }
     }
+    const int slot = wid * RPW + rl;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int piece = lane + 64 * p;
+        const int piece = pl + LPR * p;
         if (piece < np) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                red[(wid * 2 + 0) * C + piece * 8 + j] = dg[p][j];
-                red[(wid * 2 + 1) * C + piece * 8 + j] = db[p][j];
+                red[(slot * 2 + 0) * C + piece * 8 + j] = dg[p][j];
+                red[(slot * 2 + 1) * C + piece * 8 + j] = db[p][j];
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256)
-        partial[(int64_t)blockIdx.x * 2 * C + i] = red[i] + red[2 * C + i] + red[4 * C + i] + red[6 * C + i];
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float sm = 0.f;
+        for (int k = 0; k < 4 * RPW; ++k) sm += red[k * 2 * C + i];
+        partial[(int64_t)blockIdx.x * 2 * C + i] = sm;
+    }
 }
 void launch_layernorm_bwd(int dt, const void* dy, int lddy, const void* dy2, int lddy2, const void* x, int ldx, const float* stats,
                           const float* gamma, const void* add, int ldadd, void* dx, int lddx, float* dgamma, float* dbeta,
                           float* scratch, int64_t M, int C, hipStream_t s) {
-    const int grid = ln_bwd_blocks(M);
-    if (grid == 0) return;
-    const size_t lds = (size_t)8 * C * 4;
-#define LN_B(T_, NP_) k_ln_bwd<T_, NP_><<<grid, 256, lds, s>>>((const T_*)dy, lddy, (const T_*)dy2, lddy2, (const T_*)x, ldx, stats, gamma, \
-                                                               (const T_*)add, ldadd, (T_*)dx, lddx, scratch, M, C)
-    if (C <= 512) { if (dt == BF16) LN_B(bf16, 1); else LN_B(float, 1); }
-    else { if (dt == BF16) LN_B(bf16, 4); else LN_B(float, 4); }
+    const int grid = ln_bwd_blocks(M, C), lpr = ln_lpr(C);
+    const size_t lds = (size_t)4 * (64 / lpr) * 2 * C * 4;
+#define LN_B(T_, L_, NP_) k_ln_bwd<T_, L_, NP_><<<grid, 256, lds, s>>>((const T_*)dy, lddy, (const T_*)dy2, lddy2, (const T_*)x, ldx, stats, gamma, \
+                                                                   (const T_*)add, ldadd, (T_*)dx, lddx, scratch, M, C)
+#define LN_BT(L_, NP_) do { if (dt == BF16) LN_B(bf16, L_, NP_); else LN_B(float, L_, NP_); } while (0)
+    if (lpr == 8) LN_BT(8, 1);
+    else if (lpr == 16) LN_BT(16, 1);
+    else if (lpr == 32) LN_BT(32, 1);
+    else if (C <= 512) LN_BT(64, 1);
+    else LN_BT(64, 4);
+#undef LN_BT
 #undef LN_B
-    k_partial_finish<<<cdiv(2 * C, 256), 256, 0, s>>>(scratch, grid, (int64_t)2 * C, C, 2 * C, dgamma, dbeta);
+    launch_partial_finish(scratch, grid, (int64_t)2 * C, C, 2 * C, dgamma, dbeta, s);
 }
 
 // ------------------------------------------------------------------------------------------------ column sums (bias gradients)
-static inline int colsum_blocks(int64_t M) { return (int)std::max<int64_t>(1, std::min<int64_t>((M + 255) / 256, 256)); }
+static inline int colsum_blocks(int64_t M) { return (int)std::max<int64_t>(1, std::min<int64_t>((M + 127) / 128, 2048)); }
 int64_t colsum_scratch_floats(int64_t M, int C) { return (int64_t)colsum_blocks(M) * C + 16; }
 
 template <typename T>
@@ -303,7 +341,7 @@ void launch_colsum(int dt, const void* X, int ld, int64_t M, int C, float* out, 
     const int grid = colsum_blocks(M);
     if (dt == BF16) k_colsum<bf16><<<grid, 256, 0, s>>>((const bf16*)X, ld, M, C, scratch);
     else k_colsum<float><<<grid, 256, 0, s>>>((const float*)X, ld, M, C, scratch);
-    k_partial_finish<<<cdiv(C, 256), 256, 0, s>>>(scratch, grid, (int64_t)C, C, C, out, out);
+    launch_partial_finish(scratch, grid, (int64_t)C, C, C, out, out, s);
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm statistics, double precision
@@ -437,6 +475,7 @@ k_attn_fwd_ref(const T* __restrict__ q, int ldq, const T* __restrict__ kv, int l
 }
 void launch_attn_fwd(int dt, const void* q, int ldq, const void* kv, int ldkv, void* out, int ldo, float* lse, int n, int N, int Nkv,
                      int heads, int d, float scale, DropSite drop, hipStream_t s) {
+    if (attn_mfma_ok(dt, Nkv, d) && launch_attn_fwd_mfma(q, ldq, kv, ldkv, out, ldo, lse, n, N, Nkv, heads, d, scale, drop, s) == 0) return;
     dim3 grid(cdiv(N, 64), heads, n);
 #define AT_F(T_, D_) k_attn_fwd_ref<T_, D_><<<grid, 64, 0, s>>>((const T_*)q, ldq, (const T_*)kv, ldkv, (T_*)out, ldo, lse, N, Nkv, heads, d, scale, drop)
     if (d <= 64) { if (dt == BF16) AT_F(bf16, 64); else AT_F(float, 64); }
@@ -569,11 +608,15 @@ __global__ void k_sum_slabs(const float* __restrict__ partial, int nslab, int64_
 }
 static inline int attn_qsplit(int N) { return std::max(1, std::min(32, (N + 255) / 256)); }
 int64_t attn_bwd_scratch_floats(int n, int N, int Nkv, int heads, int d) {
-    return (int64_t)n * heads * N + (int64_t)attn_qsplit(N) * n * Nkv * 2 * heads * d + 64;
+    const int64_t ref = (int64_t)n * heads * N + (int64_t)attn_qsplit(N) * n * Nkv * 2 * heads * d + 64;
+    return std::max(ref, attn_mfma_bwd_scratch_floats(n, N, Nkv, heads, d));
 }
 void launch_attn_bwd(int dt, const void* q, int ldq, const void* kv, int ldkv, const void* out, int ldo, const void* dout, int lddo,
                      const float* lse, void* dq, int lddq, void* dkv, int lddkv, float* scratch, int n, int N, int Nkv, int heads, int d,
                      float scale, DropSite drop, hipStream_t s) {
+    if (attn_mfma_ok(dt, Nkv, d) &&
+        launch_attn_bwd_mfma(q, ldq, kv, ldkv, out, ldo, dout, lddo, lse, dq, lddq, dkv, lddkv, scratch, n, N, Nkv, heads, d, scale, drop, s) == 0)
+        return;
     float* Drow = scratch;
     float* partial = scratch + (((int64_t)n * heads * N + 15) & ~(int64_t)15);
     const int QS = attn_qsplit(N), qper = ((N + QS - 1) / QS + 15) & ~15;
@@ -677,7 +720,7 @@ k_dw_bwd_data(const T* __restrict__ g, T* __restrict__ dh, const float* __restri
     store8(dh + pix * Ch + c0, acc);
 }
 // filter / bias gradients: block = 8 pieces (64 channels: one 128-B line per pixel in bf16) x 32 pixel lanes over a pixel slice
-constexpr int DW_PPB = 2048;
+constexpr int DW_PPB = 512;
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_dw_bwd_filter(const T* __restrict__ g, const T* __restrict__ h, float* __restrict__ partial, int H, int W, int Ch, int64_t npix) {

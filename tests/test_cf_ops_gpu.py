@@ -168,7 +168,8 @@ def _attn_ref(q, kv, heads, mask):
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("n,N,Nkv,heads,d,p", [(2, 256, 4, 1, 64, 0.1), (2, 64, 4, 2, 64, 0.0), (1, 100, 37, 4, 80, 0.1), (2, 70, 70, 8, 64, 0.1),
-                                                (1, 300, 64, 2, 32, 0.25), (1, 130, 33, 1, 128, 0.1)])
+                                                (1, 300, 64, 2, 32, 0.25), (1, 130, 33, 1, 128, 0.1), (2, 1000, 256, 2, 64, 0.1),
+                                                (1, 700, 200, 4, 80, 0.1), (1, 64, 300, 1, 64, 0.1)])
 def test_attention_forward_backward(dtype, n, N, Nkv, heads, d, p):
     g = torch.Generator().manual_seed(N * 7 + Nkv)
     C_ = heads * d
