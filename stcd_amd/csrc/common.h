@@ -428,6 +428,19 @@ void launch_layernorm_bwd(int dt, const void* dy, int lddy, const void* dy2, int
 // out[c] = sum over M rows of X[.., c] (fp32, two-phase fixed order); scratch >= colsum_scratch_floats(M, C)
 int64_t colsum_scratch_floats(int64_t M, int C);
 void launch_colsum(int dt, const void* X, int ld, int64_t M, int C, float* out, float* scratch, hipStream_t s);
+// all column sums (bias gradients) of a backward stage as ONE grouped launch + one finish launch over a device job table
+struct ColsumJob {
+    int64_t x_off;            // byte offset of the [M, C] tensor (pixel stride ld) in the workspace
+    int64_t M;
+    int64_t out_off;          // float offset of the C outputs in the flat gradient buffer
+    int64_t part_off;         // float offset of this job's partial sums [nblocks][C] in the partial buffer
+    int ld, C;
+    int start_block, nblocks; // blocks of the reduction launch
+    int fin_start, pad_;      // first block of the finish launch (ceil(C / 8) blocks per job)
+};
+int colsum_job_blocks(int64_t M);
+void launch_colsum_group(int dt, const ColsumJob* jobs_dev, int njobs, int total_blocks, int fin_blocks, const char* ws, float* partial,
+                         float* grads, hipStream_t s);
 // BatchNorm batch statistics in double precision (few values per channel: see kernels_tf.hip): fills stat [4][C] = mean, invstd,
 // scale, shift (what launch_bn_act reads with facc == gamma == nullptr, and the BN-backward kernels) and updates the running statistics
 int64_t bn_precise_scratch_floats(int64_t M, int C);

@@ -75,6 +75,9 @@ struct CfPlan {
     CfUp up2, up1; CfRes res2, res1;
     int head_conv = -1; ConvOp head_fwd, head_dgr; WgradOp head_wg;
     int64_t scratch = -1, scratch_floats = 0;
+    std::vector<ColsumJob> cjobs[2];          // bias gradients per backward stage (grouped launch at the end of the stage)
+    int64_t cjobs_off[2] = {-1, -1}, cpart_off = -1;
+    int cj_blocks[2] = {0, 0}, cj_fin[2] = {0, 0};
     int nsites = 0;
     uint64_t seed = 0;
     int64_t out_floats = 0, cp_off = 0;
@@ -245,6 +248,16 @@ static int configure_cf(stcd_engine& e, int B, int H, int W) {
     auto recT = [&](const std::string& name, const CfT& t) { rec(name, t.v, t.n, t.h, t.w, t.c); rec(name + ".grad", t.g, t.n, t.h, t.w, t.c); };
     int64_t scratch_floats = 4096;
     auto need = [&](int64_t f) { scratch_floats = std::max(scratch_floats, f); };
+    int64_t cpart_floats[2] = {0, 0};
+    P.cjobs[0].clear(); P.cjobs[1].clear(); P.cj_blocks[0] = P.cj_blocks[1] = 0; P.cj_fin[0] = P.cj_fin[1] = 0;
+    auto add_colsum = [&](int stage, const TRef& dy, int64_t M, int C, int64_t out_off) {
+        ColsumJob j{};
+        j.x_off = dy.off; j.M = M; j.out_off = out_off; j.ld = dy.ld; j.C = C;
+        j.nblocks = colsum_job_blocks(M); j.start_block = P.cj_blocks[stage]; j.fin_start = P.cj_fin[stage];
+        j.part_off = cpart_floats[stage];
+        P.cj_blocks[stage] += j.nblocks; P.cj_fin[stage] += (C + 7) / 8; cpart_floats[stage] += (int64_t)j.nblocks * C;
+        P.cjobs[stage].push_back(j);
+    };
     auto bind_conv = [&](ConvOp& op, const stcd_conv_geom& g, int conv, bool dgrad, int tap0, int kreal, int nreal, int groups = 1) {
         op.g = g; op.conv = conv; op.dgrad = dgrad; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
         op.plan = ConvMfmaPlan(); op.wf = -1; op.small = false; op.res = ConvResPlan(); op.res_groups = groups; op.gemm = ConvGemmPlan();
@@ -266,9 +279,10 @@ static int configure_cf(stcd_engine& e, int B, int H, int W) {
         e.wgrad_ops.push_back(&op);
     };
     // a 1x1-geometry GEMM over an [n, h, w, K] map (x.ld may exceed K: a slice)
-    auto bind_linear = [&](CfGemm& G, const TRef& x, const TRef& dx, int n, int h, int w, const TRef& y, const TRef& dy, int stage) {
+    auto bind_linear = [&](CfGemm& G, const TRef& x, const TRef& dx, int n, int h, int w, const TRef& y, const TRef& dy, int stage, bool bias_grad = true) {
         const ConvW& cv = e.convs[G.conv];
         G.x = x; G.y = y; G.dy = dy; G.dx = dx; G.has_dgr = dx.off >= 0 && cv.dgrad.ntaps > 0;
+        if (bias_grad && cv.b_off >= 0) add_colsum(stage, dy, (int64_t)n * h * w, cv.cout, cv.b_off);
         bind_conv(G.fwd, geom1(n, h, w, cv.kin_p, x.ld, cv.cout, y.ld), G.conv, false, 0, cv.cin, cv.cout);
         bind_wgrad(G.wg, geom1(n, h, w, cv.kin_p, x.ld, cv.cout, dy.ld), G.conv, x.off, dy.off, stage);
         if (G.has_dgr) bind_conv(G.dgr, geom1(n, h, w, cv.dgrad.kpad, dy.ld, cv.cin, dx.ld), G.conv, true, 0, cv.cout, cv.cin);
@@ -276,6 +290,7 @@ static int configure_cf(stcd_engine& e, int B, int H, int W) {
     auto bind_conv3 = [&](CfGemm& G, const TRef& x, const TRef& dx, int K, int n, int h, int w, const TRef& y, const TRef& dy, int stage) {
         const ConvW& cv = e.convs[G.conv];
         G.x = x; G.y = y; G.dy = dy; G.dx = dx; G.has_dgr = dx.off >= 0;
+        if (cv.b_off >= 0) add_colsum(stage, dy, (int64_t)n * h * w, cv.cout, cv.b_off);
         bind_conv(G.fwd, geom3(n, h, w, K, x.ld, cv.cout, y.ld), G.conv, false, 0, cv.cin, cv.cout);
         bind_wgrad(G.wg, geom3(n, h, w, K, x.ld, cv.cout, dy.ld), G.conv, x.off, dy.off, stage);
         if (G.has_dgr) bind_conv(G.dgr, geom3(n, h, w, cv.dgrad.kpad, dy.ld, cv.cin, dx.ld), G.conv, true, 0, cv.cout, cv.cin);
@@ -401,13 +416,14 @@ static int configure_cf(stcd_engine& e, int B, int H, int W) {
     }
     P.cp_off = out_off; P.out_floats = out_off + (int64_t)B * e.label * H * W;
     P.fy = mk(B, h1, w1, D); P.fa = mk(B, h1, w1, D);
-    bind_linear(P.fuse, P.fcat.v, P.fcat.g, B, h1, w1, P.fy.v, P.fy.g, 0);
+    bind_linear(P.fuse, P.fcat.v, P.fcat.g, B, h1, w1, P.fy.v, P.fy.g, 0, false);      // bias in front of a train-mode BatchNorm: zero gradient
     P.fuse_bn.C = D; P.fuse_bn.n = B; P.fuse_bn.h = h1; P.fuse_bn.w = w1; P.fuse_bn.stat = ws.take((int64_t)2 * 4 * D * 4);
     recT("dec.fcat", P.fcat); recT("dec.fy", P.fy); recT("dec.fa", P.fa);
     auto bind_up = [&](CfUp& U, const CfT& in, int h, int w) {
         U.in = in;
         U.out = mk(B, 2 * h, 2 * w, D);
         U.dtmp = TRef(); U.dtmp.off = ws.take((int64_t)B * h * w * D * T); U.dtmp.ld = D;
+        add_colsum(0, U.out.g, (int64_t)B * 4 * h * w, D, U.b_off);
         for (int ph = 0; ph < 4; ++ph) {
             const int py = ph >> 1, px = ph & 1;
             const ConvW& cv = e.convs[U.conv[ph]];
@@ -460,6 +476,8 @@ static int configure_cf(stcd_engine& e, int B, int H, int W) {
     e.scratch8 = ws.take(256);
     e.masks = ws.take(256);
     P.scratch_floats = scratch_floats; P.scratch = ws.take(scratch_floats * 4);
+    P.cpart_off = ws.take(std::max(cpart_floats[0], cpart_floats[1]) * 4 + 16);
+    for (int st = 0; st < 2; ++st) P.cjobs_off[st] = ws.take((int64_t)P.cjobs[st].size() * sizeof(ColsumJob) + 16);
     for (auto& c : e.convs) {
         c.wpk_fwd = ws.take((int64_t)c.fwd.ntaps * c.fwd.kpad * c.fwd.wld * 4);
         if (c.dgrad.ntaps) c.wpk_dgrad = ws.take((int64_t)c.dgrad.ntaps * c.dgrad.kpad * c.dgrad.wld * 4);
@@ -489,16 +507,16 @@ static void cf_gemm_fwd(const Ctx& c, const CfGemm& G, const StatReq* sr = nullp
     exec_conv(c, G.fwd, c.at(G.x.off), cv.b_off >= 0 ? c.params + cv.b_off : nullptr, c.at(G.y.off), false, sr, fused);
 }
 // weight gradient (grouped launch at the end of the stage), bias gradient, data gradient
-static void cf_gemm_bwd(const Ctx& c, const CfGemm& G, bool bias = true) {
-    stcd_engine& e = c.e;
-    const ConvW& cv = e.convs[G.conv];
+// (the bias gradient -- the column sums of dy -- runs in the stage's grouped launch: cf_colsum_stage)
+static void cf_gemm_bwd(const Ctx& c, const CfGemm& G) {
     exec_wgrad(c, G.wg, c.at(G.x.off), c.at(G.dy.off));
-    if (bias && cv.b_off >= 0) {
-        ProfScope ps(c, PC_POOL_FUSE, 0.0, 0.0, "k_colsum");
-        launch_colsum(e.dt, c.at(G.dy.off), G.dy.ld, (int64_t)G.wg.g.n * G.wg.g.hm * G.wg.g.wm, cv.cout, c.grads + cv.b_off,
-                      c.at<float>(e.cf->scratch), c.s);
-    }
     if (G.has_dgr) exec_conv(c, G.dgr, c.at(G.dy.off), nullptr, c.at(G.dx.off), false);
+}
+static void cf_colsum_stage(const Ctx& c, int stage) {
+    const CfPlan& P = *c.e.cf;
+    ProfScope ps(c, PC_POOL_FUSE, 0.0, 0.0, "k_colsum_group");
+    launch_colsum_group(c.e.dt, c.at<ColsumJob>(P.cjobs_off[stage]), (int)P.cjobs[stage].size(), P.cj_blocks[stage], P.cj_fin[stage], c.ws,
+                        c.at<float>(P.cpart_off), c.grads, c.s);
 }
 static void cf_ln_fwd(const Ctx& c, const CfLN& L, const TRef& x, const TRef& y) {
     ProfScope ps(c, PC_BN_ACT, 0.0, 2.0 * L.M * L.C * (double)dsize(c.e.dt), "k_ln_fwd");
@@ -630,7 +648,6 @@ static void cf_up_backward(const Ctx& c, const CfUp& U) {
     const int D = U.out.c;
     const int64_t rows_in = (int64_t)U.in.n * U.in.h * U.in.w;
     for (int ph = 0; ph < 4; ++ph) exec_wgrad(c, U.wg[ph], c.at(U.in.v.off), c.at(U.out.g.off));
-    launch_colsum(e.dt, c.at(U.out.g.off), U.out.g.ld, 4 * rows_in, D, c.grads + U.b_off, c.at<float>(e.cf->scratch), c.s);
     exec_conv(c, U.dgr[0], c.at(U.out.g.off), nullptr, c.at(U.in.g.off), false);
     exec_conv(c, U.dgr[1], c.at(U.out.g.off), nullptr, c.at(U.dtmp.off), false);
     launch_axpby(e.dt, 1.f, c.at(U.in.g.off), U.in.g.ld, 1.f, c.at(U.dtmp.off), U.dtmp.ld, c.at(U.in.g.off), U.in.g.ld, rows_in, D, c.s);
@@ -665,6 +682,10 @@ static int forward_cf(stcd_engine& e, const float* x1, const float* x2, const fl
     const int B = e.B, N2 = 2 * B, dt = e.dt, D = P.D;
     const int64_t T = (int64_t)dsize(dt);
     P.seed = seed;
+    if (e.jobs_uploaded_ws != (const void*)c.ws)
+        for (int st = 0; st < 2; ++st)
+            if (!P.cjobs[st].empty())
+                STCD_HIP(hipMemcpyAsync(c.at(P.cjobs_off[st]), P.cjobs[st].data(), P.cjobs[st].size() * sizeof(ColsumJob), hipMemcpyHostToDevice, s));
     if (pack_all_weights(c, tr)) return 1;
     if (tr) STCD_HIP(hipMemsetAsync(c.at(e.zero_begin), 0, e.zero_end - e.zero_begin, s));
     launch_in_pack(dt, x1, x2, c.at(e.X0.off), B, e.in_ch, e.H, e.W, s);
@@ -743,7 +764,7 @@ static int backward_cf(stcd_engine& e, const float* grad_logits, const float* pa
         cf_res_backward(c, P.res2);
         cf_up_backward(c, P.up2);
         cf_bn_backward(c, P.fuse_bn, P.fa.g, P.fy.v, P.fy.g);
-        cf_gemm_bwd(c, P.fuse, false);             // bias in front of a train-mode BatchNorm: zero gradient
+        cf_gemm_bwd(c, P.fuse);
         for (int k = 3; k >= 0; --k) {
             const CfDiff& F = P.df[k];
             const int64_t rows = (int64_t)B * F.h * F.w;
@@ -756,7 +777,7 @@ static int backward_cf(stcd_engine& e, const float* grad_logits, const float* pa
             launch_dropout_ew(dt, c.at(F.c.g.off), F.c.g.ld, c.at(F.bb.g.off), D, rows, D, cf_site(e, F.site0 + 1, P.diff_drop, true), s);
             cf_bn_backward(c, F.bnb, F.bb.g, F.zb.v, F.zb.g);
             launch_prelu_bwd(dt, c.at(F.zb.g.off), D, c.at(F.yb.v.off), D, c.at(F.yb.g.off), D, params + F.alpha_b, grads + F.alpha_b, c.at<float>(P.scratch), rows, D, s);
-            cf_gemm_bwd(c, F.cb);                  // (PReLU sits between the conv and the BatchNorm: the bias has a gradient)
+            cf_gemm_bwd(c, F.cb);                  // (PReLU sits between the conv and the BatchNorm: the biases have gradients)
             launch_dropout_ew(dt, c.at(F.aa.g.off), D, c.at(F.ba.g.off), D, rows, D, cf_site(e, F.site0, P.diff_drop, true), s);
             cf_bn_backward(c, F.bna, F.ba.g, F.za.v, F.za.g);
             launch_prelu_bwd(dt, c.at(F.za.g.off), D, c.at(F.ya.v.off), D, c.at(F.ya.g.off), D, params + F.alpha_a, grads + F.alpha_a, c.at<float>(P.scratch), rows, D, s);
@@ -766,6 +787,7 @@ static int backward_cf(stcd_engine& e, const float* grad_logits, const float* pa
             cf_gemm_bwd(c, F.lin);                 // -> d(stage output) (written; the next stage's patch embedding accumulates)
         }
         reduce_stage(c, 0);
+        cf_colsum_stage(c, 0);
         launch_bias_finish(c.at<BiasJob>(e.bias_jobs_off), (int)e.bias_jobs.size(), c.ws, c.grads, s);
     }
     if (stage < 0 || stage == 1) {
@@ -782,6 +804,7 @@ static int backward_cf(stcd_engine& e, const float* grad_logits, const float* pa
             }
         }
         reduce_stage(c, 1);
+        cf_colsum_stage(c, 1);
     }
     STCD_HIP(hipGetLastError());
     return 0;

@@ -111,8 +111,99 @@ __global__ void k_col2im(const T* __restrict__ dcol, int ldc, T* __restrict__ dX
         *d = from_float<T>(acc);
     }
 }
+// Overlapping patches (stride < k: the patch embeddings).  The gather above reads one 2-byte element per lane and patch; here a block
+// owns an 8 x 8 input tile x 64 channels, walks the output positions whose patches touch the tile, stages each position's
+// (contiguous) 64-channel slice of the dcol row in LDS and adds its taps into an fp32 tile accumulator in LDS -- every global
+// access is a full line.  Two taps of one position never hit the same pixel, so the adds of one position need no atomics.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_col2im_tile(const T* __restrict__ dcol, int ldc, T* __restrict__ dX, int lddx, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo,
+              int tiles_x, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int TS = 8, CB = 64;
+    float* acc = reinterpret_cast<float*>(smem_raw);                 // [64 pixels][64 channels]
+    T* rowb = reinterpret_cast<T*>(acc + TS * TS * CB);              // [64 channels][k * k]
+    const int kk = k * k, tid = threadIdx.x, cl = tid & 63, qd = tid >> 6;
+    const int ty0 = (blockIdx.x / tiles_x) * TS, tx0 = (blockIdx.x % tiles_x) * TS, n = blockIdx.y, c0 = blockIdx.z * CB;
+    const int cw = C - c0 < CB ? C - c0 : CB;                        // channels of this chunk
+    for (int i = tid; i < TS * TS * CB; i += 256) acc[i] = 0.f;
+    // output positions whose patch [o * stride - pad, o * stride - pad + k) meets the tile rows / columns
+    int oy_lo = (ty0 + pad - k + 1 + stride - 1) / stride, oy_hi = (ty0 + TS - 1 + pad) / stride;
+    int ox_lo = (tx0 + pad - k + 1 + stride - 1) / stride, ox_hi = (tx0 + TS - 1 + pad) / stride;
+    if (ty0 + pad - k + 1 < 0) oy_lo = 0;
+    if (tx0 + pad - k + 1 < 0) ox_lo = 0;
+    oy_hi = oy_hi < Ho - 1 ? oy_hi : Ho - 1;
+    ox_hi = ox_hi < Wo - 1 ? ox_hi : Wo - 1;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            __syncthreads();
+            const T* src = dcol + ((int64_t)(n * Ho + oy) * Wo + ox) * ldc + (int64_t)c0 * kk;
+            for (int i = tid; i < cw * kk; i += 256) rowb[i] = src[i];
+            __syncthreads();
+            if (cl < cw) {
+                const int by = oy * stride - pad - ty0, bx = ox * stride - pad - tx0;
+                for (int t = qd; t < kk; t += 4) {
+                    const int ky = t / k, kx = t - ky * k, py = by + ky, px = bx + kx;
+                    if ((unsigned)py < (unsigned)TS && (unsigned)px < (unsigned)TS) acc[(py * TS + px) * CB + cl] += (float)rowb[cl * kk + t];
+                }
+            }
+        }
+    __syncthreads();
+    for (int i = tid; i < TS * TS * CB; i += 256) {
+        const int pix = i >> 6, c = i & 63, y = ty0 + (pix >> 3), x = tx0 + (pix & 7);
+        if (c < cw && y < H && x < W) {
+            T* d = dX + ((int64_t)(n * H + y) * W + x) * lddx + c0 + c;
+            float v = acc[i];
+            if (accumulate) v += (float)*d;
+            *d = from_float<T>(v);
+        }
+    }
+}
+// Non-overlapping patches (k == stride, no padding: the spatial-reduction convs): a pure permutation, the mirror image of k_im2col --
+// the dcol row is read as it lies, transposed through the same LDS tile and leaves pixel by pixel with contiguous channels.
+template <typename T>
+__global__ void k_col2im_patch(const T* __restrict__ dcol, int ldc, T* __restrict__ dX, int lddx, int H, int W, int C, int k, int Ho, int Wo,
+                               int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* tile = reinterpret_cast<T*>(smem_raw);
+    const int pix = blockIdx.x;
+    const int ox = pix % Wo, t_ = pix / Wo, oy = t_ % Ho, n = t_ / Ho;
+    const int kk = k * k, P = C + 2;
+    const T* src = dcol + (int64_t)pix * ldc;
+    for (int e = threadIdx.x; e < kk * C; e += blockDim.x) {
+        const int c = e / kk, t = e - c * kk;
+        tile[t * P + c] = src[e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kk * C; e += blockDim.x) {
+        const int t = e / C, c = e - t * C, ky = t / k, kx = t - ky * k;
+        const int iy = oy * k + ky, ix = ox * k + kx;
+        if (iy < H && ix < W) {
+            T* d = dX + ((int64_t)(n * H + iy) * W + ix) * lddx + c;
+            float v = (float)tile[t * P + c];
+            if (accumulate) v += (float)*d;
+            *d = from_float<T>(v);
+        }
+    }
+}
 void launch_col2im(int dt, const void* dcol, int ldc, void* dX, int lddx, int n, int H, int W, int C, int k, int stride, int pad, int Ho,
                    int Wo, int accumulate, hipStream_t s) {
+    if (stride == k && pad == 0 && H == Ho * k && W == Wo * k && (size_t)k * k * (C + 2) * dsize(dt) <= 64 * 1024) {
+        const size_t lds = (size_t)k * k * (C + 2) * dsize(dt);
+        const unsigned grid = (unsigned)((int64_t)n * Ho * Wo);
+        if (dt == BF16) k_col2im_patch<bf16><<<grid, 256, lds, s>>>((const bf16*)dcol, ldc, (bf16*)dX, lddx, H, W, C, k, Ho, Wo, accumulate);
+        else k_col2im_patch<float><<<grid, 256, lds, s>>>((const float*)dcol, ldc, (float*)dX, lddx, H, W, C, k, Ho, Wo, accumulate);
+        return;
+    }
+    static const bool no_tile = [] { const char* e = getenv("STCD_NO_COL2IM_TILE"); return e && e[0] == '1'; }();
+    if (stride < k && !no_tile) {
+        const int tx = (W + 7) / 8, ty = (H + 7) / 8;
+        const size_t lds = (size_t)64 * 64 * 4 + (size_t)64 * k * k * dsize(dt);
+        dim3 grid(tx * ty, n, (C + 63) / 64);
+        if (dt == BF16) k_col2im_tile<bf16><<<grid, 256, lds, s>>>((const bf16*)dcol, ldc, (bf16*)dX, lddx, H, W, C, k, stride, pad, Ho, Wo, tx, accumulate);
+        else k_col2im_tile<float><<<grid, 256, lds, s>>>((const float*)dcol, ldc, (float*)dX, lddx, H, W, C, k, stride, pad, Ho, Wo, tx, accumulate);
+        return;
+    }
     const int threads = std::min(256, ((C + 63) / 64) * 64);
     const unsigned grid = (unsigned)((int64_t)n * H * W);
     if (dt == BF16) k_col2im<bf16><<<grid, threads, 0, s>>>((const bf16*)dcol, ldc, (bf16*)dX, lddx, H, W, C, k, stride, pad, Ho, Wo, accumulate);
@@ -344,6 +435,73 @@ void launch_colsum(int dt, const void* X, int ld, int64_t M, int C, float* out, 
     launch_partial_finish(scratch, grid, (int64_t)C, C, C, out, out, s);
 }
 
+// grouped form: ALL bias gradients of a backward stage in two launches (a ChangeFormer step has ~100 of them, most of a few
+// microseconds: launch-bound one by one).  Block -> job by binary search over the jobs' first blocks (uniform: scalar loads).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_colsum_group(const ColsumJob* __restrict__ jobs, int njobs, const char* __restrict__ ws, float* __restrict__ partial) {
+    __shared__ float red[256 * 8];
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].start_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ColsumJob& jb = jobs[lo];
+    const int bidx = blockIdx.x - jb.start_block, C = jb.C, ld = jb.ld;
+    const int64_t M = jb.M;
+    const T* X = reinterpret_cast<const T*>(ws + jb.x_off);
+    float* part = partial + jb.part_off;
+    const int np = C >> 3;
+    const int PW = np < 256 ? np : 256, RL = 256 / PW;
+    const int pl = threadIdx.x % PW, rl = threadIdx.x / PW;
+    const int64_t rows_per = (M + jb.nblocks - 1) / jb.nblocks, r0 = (int64_t)bidx * rows_per, r1 = r0 + rows_per < M ? r0 + rows_per : M;
+    for (int pc = 0; pc < np; pc += PW) {
+        const int piece = pc + pl;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (rl < RL && piece < np)
+            for (int64_t r = r0 + rl; r < r1; r += RL) {
+                float v[8];
+                load8(X + r * ld + piece * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[j];
+        __syncthreads();
+        for (int i = threadIdx.x; i < PW * 8; i += 256) {
+            const int p2 = i >> 3, j = i & 7;
+            float sm = 0.f;
+            for (int r = 0; r < RL; ++r) sm += red[(r * PW + p2) * 8 + j];
+            if (pc + p2 < np) part[(int64_t)bidx * C + (pc + p2) * 8 + j] = sm;
+        }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256)
+k_colsum_group_finish(const ColsumJob* __restrict__ jobs, int njobs, const float* __restrict__ partial, float* __restrict__ grads) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].fin_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ColsumJob& jb = jobs[lo];
+    const int j = ((int)blockIdx.x - jb.fin_start) * 8 + (threadIdx.x >> 5), bl = threadIdx.x & 31;
+    float sm = 0.f;
+    if (j < jb.C)
+        for (int b = bl; b < jb.nblocks; b += 32) sm += partial[jb.part_off + (int64_t)b * jb.C + j];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+    if (j < jb.C && bl == 0) grads[jb.out_off + j] = sm;
+}
+int colsum_job_blocks(int64_t M) { return colsum_blocks(M); }
+void launch_colsum_group(int dt, const ColsumJob* jobs_dev, int njobs, int total_blocks, int fin_blocks, const char* ws, float* partial,
+                         float* grads, hipStream_t s) {
+    if (njobs <= 0) return;
+    if (dt == BF16) k_colsum_group<bf16><<<total_blocks, 256, 0, s>>>(jobs_dev, njobs, ws, partial);
+    else k_colsum_group<float><<<total_blocks, 256, 0, s>>>(jobs_dev, njobs, ws, partial);
+    k_colsum_group_finish<<<fin_blocks, 256, 0, s>>>(jobs_dev, njobs, partial, grads);
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm statistics, double precision
 // The decoder's BatchNorm layers see FEW values per channel on small inputs (B x 1 x 1 at the deepest scale of a 32x32 tile): the
 // fixed-point accumulators of the convolutional families (common.h: sum x^2 at 2^-18) resolve such a variance to a few per cent
@@ -385,10 +543,13 @@ k_chan_moments(const T* __restrict__ X, int ld, int64_t M, int C, double* __rest
 __global__ void k_bn_finish(const double* __restrict__ partial, int nblk, int64_t M, int C, const float* __restrict__ gamma,
                             const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ stat,
                             float momentum, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), bl = threadIdx.x & 31;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) { s1 += partial[((int64_t)b * 2) * C + c]; s2 += partial[((int64_t)b * 2 + 1) * C + c]; }
+    if (c < C)
+        for (int b = bl; b < nblk; b += 32) { s1 += partial[((int64_t)b * 2) * C + c]; s2 += partial[((int64_t)b * 2 + 1) * C + c]; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (c >= C || bl != 0) return;
     const double mean = s1 / (double)M;
     double var = s2 / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -406,7 +567,7 @@ void launch_bn_stats_precise(int dt, const void* Z, int ld, int64_t M, int C, co
     double* partial = reinterpret_cast<double*>(scratch);
     if (dt == BF16) k_chan_moments<bf16><<<grid, 256, 0, s>>>((const bf16*)Z, ld, M, C, partial);
     else k_chan_moments<float><<<grid, 256, 0, s>>>((const float*)Z, ld, M, C, partial);
-    k_bn_finish<<<cdiv(C, 256), 256, 0, s>>>(partial, grid, M, C, gamma, beta, rmean, rvar, stat, momentum, eps);
+    k_bn_finish<<<cdiv(C, 8), 256, 0, s>>>(partial, grid, M, C, gamma, beta, rmean, rvar, stat, momentum, eps);
 }
 
 // ------------------------------------------------------------------------------------------------ attention, plain-FMA kernels
@@ -1007,10 +1168,12 @@ k_prelu_dalpha(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int 
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
-__global__ void k_sum_doubles(const double* __restrict__ partial, int n, float* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_sum_doubles(const double* __restrict__ partial, int n, float* __restrict__ out) {
     double s = 0.0;
-    for (int b = 0; b < n; ++b) s += partial[b];
-    out[0] = (float)s;
+    for (int b = threadIdx.x; b < n; b += 64) s += partial[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) out[0] = (float)s;
 }
 void launch_prelu_bwd(int dt, const void* dz, int lddz, const void* y, int ldy, void* dy, int lddy, const float* alpha, float* dalpha,
                       float* scratch, int64_t rows, int C, hipStream_t s) {
@@ -1019,7 +1182,7 @@ void launch_prelu_bwd(int dt, const void* dz, int lddz, const void* y, int ldy, 
     double* part = reinterpret_cast<double*>(scratch);
     if (dt == BF16) k_prelu_dalpha<bf16><<<grid, 256, 0, s>>>((const bf16*)dz, lddz, (const bf16*)y, ldy, C, tot, part);
     else k_prelu_dalpha<float><<<grid, 256, 0, s>>>((const float*)dz, lddz, (const float*)y, ldy, C, tot, part);
-    k_sum_doubles<<<1, 1, 0, s>>>(part, grid, dalpha);
+    k_sum_doubles<<<1, 64, 0, s>>>(part, grid, dalpha);
     EW_LAUNCH(5, dz, lddz, y, ldy, dy, lddy, 0.f, 0.f, alpha, DropSite());      // after the reduction: dy may alias dz
 }
 #undef EW_LAUNCH
