@@ -17,7 +17,7 @@ _ON_PATH = {
 }
 _OFF_PATH = ("Unet", "SiamUnet_cross_conc", "DTCDSCN", "IFNet", "base_resnet18", "base_transformer_pos_s4",
              "base_transformer_pos_s4_dd8", "base_transformer_pos_s4_dd8_dedim8", "ChangeFormerV1", "ChangeFormerV2",
-             "ChangeFormerV3", "ChangeFormerV4", "ChangeFormerV5", "ChangeFormerV6", "ChangeGNNV1", "ChangeGNNV2",
+             "ChangeFormerV3", "ChangeFormerV4", "ChangeFormerV5", "ChangeGNNV1", "ChangeGNNV2",
              "ChangeGNNV2_sub", "ChangeGNNV2_abs", "ChangeGNNV2_conc", "GNN")
 
 
@@ -87,7 +87,10 @@ def init_net(net, init_type="normal", init_gain=0.02, gpu_ids=[]):
 
 def define_G(args, init_type="normal", init_gain=0.02, gpu_ids=[]):
     name = args.net_G
-    if name in _ON_PATH:
+    if name == "ChangeFormerV6":                           # networks.py:195-196: ChangeFormerV6(embed_dim=args.embed_dim), two classes
+        from .changeformer import ChangeFormerV6
+        net = ChangeFormerV6(embed_dim=getattr(args, "embed_dim", 256))
+    elif name in _ON_PATH:
         net = _ON_PATH[name](args.n_class)
     elif name in _OFF_PATH:
         raise NotImplementedError("Generator model name [%s] is outside the accelerated hot path of this build" % name)

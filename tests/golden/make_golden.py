@@ -625,10 +625,31 @@ def g14_segcd_r101():
     _segcd_fixture("g14_segcd_r101.npz", "G14 SegCD resnet101, 2 x 128 x 128", 1400, 1, 2, 128, 128, encoder="resnet101")
 
 
+def g17_cf_base():
+    """The three classes of /root/reference/models/ChangeFormerBaseNetworks.py that ChangeFormerV6's decoder head is built from
+    (ConvLayer :85-96, UpsampleConvLayer :99-106, ResidualBlock :109-120) -- the part of ChangeFormer that imports here (the model
+    file itself needs timm): inputs, parameters, outputs, and every gradient for a fixed upstream gradient."""
+    from models.ChangeFormerBaseNetworks import ConvLayer, ResidualBlock, UpsampleConvLayer
+    torch.manual_seed(1700)
+    d = {}
+    cases = {"res": (ResidualBlock(16), (2, 16, 12, 10)),
+             "up": (UpsampleConvLayer(16, 24, kernel_size=4, stride=2), (2, 16, 6, 5)),
+             "conv": (ConvLayer(16, 2, kernel_size=3, stride=1, padding=1), (3, 16, 9, 7))}
+    for tag, (mod, shape) in cases.items():
+        x = torch.randn(*shape, requires_grad=True)
+        y = mod(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        d[f"{tag}/x"], d[f"{tag}/y"], d[f"{tag}/gy"], d[f"{tag}/gx"] = t2n(x), t2n(y), t2n(gy), t2n(x.grad)
+        for k, v in mod.named_parameters():
+            d[f"{tag}/p/{k}"], d[f"{tag}/g/{k}"] = t2n(v), t2n(v.grad)
+    save("g17_cf_base.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd,
           "g7": g7_train128, "g8": g8_contrastive, "g10": g10_segcd, "g11": g11_segcd, "g12": g12_segcd_r18, "g13": g13_segcd_r34,
-          "g14": g14_segcd_r101, "g15": g15_unetseg, "g16": g16_ffctlcd}
+          "g14": g14_segcd_r101, "g15": g15_unetseg, "g16": g16_ffctlcd, "g17": g17_cf_base}
     for w in which:
         fn[w]()
