@@ -180,17 +180,36 @@ def cpu_baseline_segcd(size, pairs, steps, encoder="resnet50"):
         if i > 0:
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return {"value": round(pairs / med, 3), "unit": "image-pairs/sec", "cores": torch.get_num_threads(), "host_cpu_count": os.cpu_count(), "kind": "port",
+    return {"value": round(pairs / med, 3), "unit": "image-pairs/sec", **_host_cores(), "kind": "port",
             "sample": f"oracle/segcd_ref.py SegCD({encoder}) fp32, {pairs} pairs {size}x{size}, median of {steps} full steps after 1 warm-up "
                       f"({med * 1e3:.0f} ms/step)"}
 
 
+def _cgroup_cpus():
+    """CPU quota of this container (cgroup v2 cpu.max, v1 cfs quota), None when unlimited: a GPU box hands each job a SHARE of the
+    host's cores -- running one thread per host core against a 16-core quota is a slowdown, not a baseline."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(float(q) / float(per) + 0.999))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, (q + per - 1) // per)
+    except (OSError, ValueError):
+        return None
+
+
 def _host_cores():
-    """all host cores the process may use, the box's own core count stated beside it."""
+    """all host cores the process may use (affinity mask and cgroup quota), the box's own core count stated
+    beside it.  STCD_CPU_THREADS overrides."""
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = _cgroup_cpus()
+    usable = min(ncpu, quota) if quota else ncpu
     env = os.environ.get("STCD_CPU_THREADS")
-    torch.set_num_threads(max(1, min(ncpu, int(env))) if env else max(1, ncpu))
-    return {"cores": torch.get_num_threads(), "host_cpu_count": os.cpu_count(), "usable_cpus": ncpu}
+    torch.set_num_threads(max(1, int(env)) if env else max(1, usable))
+    return {"cores": torch.get_num_threads(), "host_cpu_count": os.cpu_count(), "affinity_cpus": ncpu, "cgroup_cpus": quota}
 
 
 def cpu_baseline_changeformer(size, pairs, steps):
@@ -199,15 +218,15 @@ def cpu_baseline_changeformer(size, pairs, steps):
     from oracle import changeformer_ref as CF
     from stcd_amd import synth
     cores = _host_cores()
-    a, b, lab = synth.make_batch(pairs, size, size, seed=1337)
-    A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab)
     cfg = CF.CFConfig()
     st = CF.synth_state(cfg, seed=1)
     params = [v.requires_grad_(True) for k, v in st.items() if v.dtype.is_floating_point and "running" not in k]
     opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01)
-    masks = CF.random_masks(cfg, pairs, size, size, seed=2)
     times = []
-    for i in range(steps + 1):
+    for i, sz in enumerate([128] + [size] * steps):          # one small warm-up step (thread pools, allocator), then the timed ones
+        a, b, lab = synth.make_batch(pairs, sz, sz, seed=1337)
+        A, B, L = torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab)
+        masks = CF.random_masks(cfg, pairs, sz, sz, seed=2)
         t0 = time.perf_counter()
         opt.zero_grad()
         loss = torch.nn.functional.cross_entropy(CF.forward(cfg, st, A, B, True, masks)[-1], L)
@@ -217,8 +236,8 @@ def cpu_baseline_changeformer(size, pairs, steps):
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     return {"value": round(pairs / med, 4), "unit": "image-pairs/sec", **cores, "kind": "port",
-            "sample": f"oracle/changeformer_ref.py ChangeFormerV6(3,2) fp32, {pairs} pair(s) {size}x{size}, median of {steps} full step(s) after 1 warm-up "
-                      f"({med * 1e3:.0f} ms/step)"}
+            "sample": f"oracle/changeformer_ref.py ChangeFormerV6(3,2) fp32, {pairs} pair(s) {size}x{size}, {steps} full step(s) after one 128x128 "
+                      f"warm-up step ({med * 1e3:.0f} ms/step)"}
 
 
 def cpu_baseline(arch, label, size, pairs, steps, encoder="resnet50"):
