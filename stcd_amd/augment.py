@@ -40,6 +40,39 @@ def draw_params(pairs: int, seed: int, jitter_p: float = 0.5, gray_p: float = 0.
     return p
 
 
+_SCRATCH = {}      # (device, bytes) -> scratch tensor: one allocation per shape, not per call
+_PINNED = {}       # N -> pinned host staging buffer for the parameter upload
+
+
+def _scratch_for(device, nbytes):
+    key = (str(device), int(nbytes))
+    t = _SCRATCH.get(key)
+    if t is None:
+        t = _SCRATCH[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return t
+
+
+def _upload_params(params, n, device):
+    """[N,8] fp32 on the device; host arrays go through a pinned staging buffer with a non-blocking copy (a pageable
+    torch.as_tensor(...).to(device) synchronises the host with the stream every step)."""
+    if torch.is_tensor(params):
+        return params.to(device=device, dtype=torch.float32).contiguous()
+    a = np.ascontiguousarray(np.asarray(params, np.float32))
+    if a.shape != (n, 8):
+        raise StcdError(f"params must be [N,8], got {a.shape}")
+    pin = _PINNED.get(n)
+    if pin is None:
+        pin = _PINNED[n] = torch.empty((n, 8), dtype=torch.float32).pin_memory()
+    ev = _PINNED.get(("ev", n))
+    if ev is not None:
+        ev.synchronize()                    # the previous upload from this staging buffer has left the host
+    pin.copy_(torch.from_numpy(a))
+    dev = pin.to(device, non_blocking=True)
+    ev = _PINNED[("ev", n)] = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    return dev
+
+
 def augment(x: torch.Tensor, params, mean: Sequence[float] = MEAN, std: Sequence[float] = STD, out: Optional[torch.Tensor] = None):
     """x: normalised fp32 [N,3,H,W] on the GPU; params: [N,8] (numpy or tensor).  Returns the augmented, normalised batch."""
     if not x.is_cuda:
@@ -48,13 +81,17 @@ def augment(x: torch.Tensor, params, mean: Sequence[float] = MEAN, std: Sequence
         raise StcdError(f"expected fp32 [N,3,H,W], got {tuple(x.shape)} {x.dtype}")
     x = x.contiguous()
     N, _, H, W = x.shape
-    prm = torch.as_tensor(np.asarray(params, np.float32) if not torch.is_tensor(params) else params, dtype=torch.float32).to(x.device).contiguous()
+    prm = _upload_params(params, N, x.device)
     if tuple(prm.shape) != (N, 8):
         raise StcdError(f"params must be [N,8], got {tuple(prm.shape)}")
-    out = torch.empty_like(x) if out is None else out
+    if out is None:
+        out = torch.empty_like(x)
+    elif (not out.is_cuda or out.device != x.device or out.dtype != torch.float32 or tuple(out.shape) != tuple(x.shape)
+          or not out.is_contiguous() or out.data_ptr() == x.data_ptr()):
+        raise StcdError(f"out must be a contiguous fp32 {tuple(x.shape)} tensor on {x.device}, distinct from x")
     l = _lib.lib()
     nb = l.stcd_augment_scratch_bytes(N, H, W)
-    scratch = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    scratch = _scratch_for(x.device, nb)
     m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
     with torch.cuda.device(x.device):
         _lib.check(l.stcd_augment(C.c_void_p(x.data_ptr()), C.c_void_p(prm.data_ptr()), N, H, W, m3, s3, C.c_void_p(out.data_ptr()),

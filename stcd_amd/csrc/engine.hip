@@ -11,6 +11,8 @@
 // Layer tables restate /root/reference/models/SiamUnet_diff.py:13-92 (+ SiamUnet_conc.py:54-87); the forward
 // order follows SiamUnet_diff.py:94-181.
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <array>
 #include <cstring>
 #include <memory>
@@ -201,6 +203,7 @@ struct stcd_engine_impl {
     int64_t g_raw3 = -1, g_draw3 = -1;
     ConvOp g_head_fwd, g_head_dgr; WgradOp g_head_wg;
     int arch = 0, in_ch = 3, label = 2, dt = F32;
+    int64_t min_bn_count = 0;                                // fewest values per channel any BatchNorm layer of the current plan sees
     float drop_p = 0.2f;
     std::vector<stcd_tensor_info> params;
     int64_t param_floats = 0, enc_param_end = 0;
@@ -465,7 +468,10 @@ static void conv_work(const stcd_engine& e, const stcd_conv_geom& g, int kreal, 
 static void pick_gemm_or_res(const stcd_engine& e, ConvOp& op, const stcd_conv_geom& g, int groups) {
     op.gemm = ConvGemmPlan();
     if (!e.use_gemm || op.small) return;
-    static const int mode = [] { const char* v = getenv("STCD_GEMM_OVER_RES"); return v ? atoi(v) : 0; }();
+    static const int env_mode = [] { const char* v = getenv("STCD_GEMM_OVER_RES"); return v ? atoi(v) : -1; }();
+    // (ChangeFormer's 256-channel decoder convolutions get 16-channel output slices from the resident-filter kernel, i.e. X is
+    //  re-read 16 times through L2: the GEMM kernel's 128 x 128 tile measured 8.3 vs 9.5 ms per step there; a tie elsewhere)
+    const int mode = env_mode >= 0 ? env_mode : (e.cf ? 1 : 0);
     if (op.res.ok && !(mode == 2 || (mode == 1 && op.res.NT == 1))) return;
     op.gemm = conv_gemm_plan(g, op.plan, groups);
     if (op.gemm.ok) op.res = ConvResPlan();
@@ -2503,6 +2509,14 @@ int stcd_configure(stcd_engine* e, int batch, int height, int width) {
         STCD_CHECK((int64_t)3 * batch * height * width * 16 < ((int64_t)1 << 31), "tensor too large for 32-bit pixel indexing");
         if (configure_segcd(*e, batch, height, width)) return 1;
     } else if (configure_fcsiam(*e, batch, height, width)) return 1;
+    // torch's BatchNorm2d refuses a training forward with one value per channel ("Expected more than 1 value per channel when
+    // training"): remember the smallest per-channel sample count of the plan, stcd_forward checks it
+    e->min_bn_count = INT64_MAX;
+    for (const auto& L : e->enc) e->min_bn_count = std::min<int64_t>(e->min_bn_count, (int64_t)L.npg * L.H * L.W);
+    for (const auto& L : e->dec) e->min_bn_count = std::min<int64_t>(e->min_bn_count, (int64_t)L.npg * L.H * L.W);
+    for (const auto& b : e->sn_blocks) e->min_bn_count = std::min<int64_t>(e->min_bn_count, (int64_t)b.npg * b.H * b.W);
+    for (const auto& L : e->g_layers) e->min_bn_count = std::min<int64_t>(e->min_bn_count, (int64_t)L.npg * L.Ho * L.Wo);
+    if (e->cf) e->min_bn_count = std::min<int64_t>(e->min_bn_count, (int64_t)batch * (height / 32) * (width / 32));
     e->configured = true;
     e->fwd_training = false;
     return 0;
@@ -2531,6 +2545,8 @@ int stcd_forward(stcd_engine* e, const float* x1, const float* x2, const float* 
                  void* hip_stream) {
     STCD_CHECK(e && e->configured, "engine not configured");
     STCD_CHECK(x1 && x2 && params && bn_running && logits && workspace, "null pointer argument");
+    STCD_CHECK(!(training && e->min_bn_count <= 1), "Expected more than 1 value per channel when training: a BatchNorm layer of this network sees "
+               "one value per channel at this batch / image size (torch.nn.BatchNorm2d raises the same)");
     e->fwd_training = false;
     int rc = is_cf(e->arch)
                  ? forward_cf(*e, x1, x2, params, bn_running, dropout_masks, dropout_seed, training, logits, workspace, (hipStream_t)hip_stream)

@@ -1659,14 +1659,17 @@ __global__ void k_segcd_combine(const float* __restrict__ raw, float* __restrict
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float m1 = raw[i], m2 = raw[n + i], df = raw[2 * n + i];
-    out[i] = m1; out[n + i] = m2; out[2 * n + i] = fminf(df, fabsf(m1 - m2));
+    const float ds = fabsf(m1 - m2);
+    // torch.min propagates NaN (fminf would return the other operand and hide a diverged branch)
+    out[i] = m1; out[n + i] = m2; out[2 * n + i] = (df != df || ds != ds) ? df + ds : fminf(df, ds);
 }
 __global__ void k_segcd_combine_bwd(const float* __restrict__ raw, const float* __restrict__ g, float* __restrict__ draw, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float m1 = raw[i], m2 = raw[n + i], df = raw[2 * n + i], gc = g[2 * n + i];
     const float d = m1 - m2, ds = fabsf(d);
-    const float wf = df < ds ? 1.f : (df == ds ? 0.5f : 0.f);
+    // a NaN in either branch poisons both gradients, as torch.min's backward does through the NaN it forwarded
+    const float wf = (df != df || ds != ds) ? df + ds : (df < ds ? 1.f : (df == ds ? 0.5f : 0.f));
     const float gs = gc * (1.f - wf) * (float)((d > 0.f) - (d < 0.f));
     draw[i] = g[i] + gs; draw[n + i] = g[n + i] - gs; draw[2 * n + i] = gc * wf;
 }

@@ -57,9 +57,16 @@ class FlatGradReducer:
     (stream-side wait, the host never blocks).  gloo path (CPU tests, or GPU tensors in a CPU-transport test):
     staged through host memory, synchronous."""
 
-    def __init__(self, model, group=None, overlap: bool = True, force: bool = False):
+    def __init__(self, model, group=None, overlap: bool = True, force: bool = False, bucket_dtype: str = "fp32"):
         """force: install the hook even in a one-rank group (the collectives then average over one rank: an identity that still
-        runs the whole RCCL path -- side stream, async all_reduce, final wait -- on a single GPU)."""
+        runs the whole RCCL path -- side stream, async all_reduce, final wait -- on a single GPU).
+        bucket_dtype "bf16" (SNUNet's 48 MB of gradients): the buckets travel as bf16 with fp32 ACCUMULATION -- a direct
+        reduce-scatter (all_to_all of bf16 shards: every rank sends shard j straight to rank j over its own xGMI link), an fp32 mean of
+        the received shards, and an all_gather of the bf16 result: half the bytes of the fp32 all-reduce, one rounding of the inputs and
+        one of the mean, no bf16 running sums."""
+        if bucket_dtype not in ("fp32", "bf16"):
+            raise ValueError("bucket_dtype must be 'fp32' or 'bf16'")
+        self.bucket_dtype = bucket_dtype
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
@@ -69,7 +76,39 @@ class FlatGradReducer:
         if self.world > 1 or (force and dist.is_initialized()):
             model.grad_stage_hook = self._hook
 
+    def _reduce_bf16(self, g: torch.Tensor):
+        """g <- bf16(mean over ranks, in fp32, of bf16(g_rank)): direct reduce-scatter + all-gather over bf16 payloads."""
+        w, n = self.world, g.numel()
+        per = (n + w - 1) // w
+        send = torch.zeros(per * w, dtype=torch.bfloat16, device=g.device)
+        send[:n].copy_(g)
+        if g.is_cuda and self.backend == "nccl":
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=self.group)               # shard j of every rank -> rank j
+            shard = (recv.view(w, per).float().sum(0) / w).to(torch.bfloat16)
+            out = torch.empty_like(send)
+            dist.all_gather_into_tensor(out, shard, group=self.group)
+        else:      # gloo (CPU-transport tests): no all_to_all there -- gather the bf16 buckets, same arithmetic per shard
+            h = send.cpu() if send.is_cuda else send
+            parts = [torch.empty_like(h) for _ in range(w)]
+            dist.all_gather(parts, h, group=self.group)
+            out = (torch.stack([p.float() for p in parts]).sum(0) / w).to(torch.bfloat16)
+        g.copy_(out[:n].to(device=g.device, dtype=g.dtype))
+
     def _hook(self, stage: int, g: torch.Tensor):
+        if g.numel() > 0 and self.bucket_dtype == "bf16":
+            if g.is_cuda and self.backend == "nccl" and self.overlap:
+                if self._comm is None:
+                    self._comm = torch.cuda.Stream(device=g.device)
+                self._comm.wait_stream(torch.cuda.current_stream(g.device))
+                g.record_stream(self._comm)
+                with torch.cuda.stream(self._comm):
+                    self._reduce_bf16(g)
+                if stage == 1:
+                    torch.cuda.current_stream(g.device).wait_stream(self._comm)
+            else:
+                self._reduce_bf16(g)
+            return
         if g.numel() > 0:
             if g.is_cuda and self.backend == "nccl":
                 if self.overlap:

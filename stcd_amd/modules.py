@@ -182,6 +182,18 @@ class HipChangeDetector(nn.Module):
         self._flat_params = None   # .to()/.cuda()/.float() re-created the tensors: re-flatten lazily
         return out
 
+    def _weights_changed(self):
+        """Inside frozen_weights(): the parameters were rewritten after all (load_state_dict, an optimizer step): take a new tag so
+        the next forward repacks instead of computing with stale filter images."""
+        if getattr(self, "_freeze_depth", 0) > 0:
+            self._freeze_count = getattr(self, "_freeze_count", 0) + 1
+            self._engine.set_weights_tag(self._freeze_count)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._weights_changed()
+        return out
+
     def __deepcopy__(self, memo):
         new = type(self)(self._engine.in_ch, self._engine.label_ch, self._engine.dtype)
         new.load_state_dict({k: v.detach().clone() for k, v in self.state_dict().items()})
@@ -206,12 +218,19 @@ class HipChangeDetector(nn.Module):
 
         @contextlib.contextmanager
         def _ctx():
-            self._freeze_count = getattr(self, "_freeze_count", 0) + 1
-            self._engine.set_weights_tag(self._freeze_count)
+            # re-entrant: nested contexts (a user loop already inside frozen_weights() calling CDTrainer's validation, which wraps
+            # itself again) share the outermost tag; the vouch ends when the OUTERMOST context exits
+            depth = getattr(self, "_freeze_depth", 0)
+            if depth == 0:
+                self._freeze_count = getattr(self, "_freeze_count", 0) + 1
+                self._engine.set_weights_tag(self._freeze_count)
+            self._freeze_depth = depth + 1
             try:
                 yield self
             finally:
-                self._engine.set_weights_tag(0)
+                self._freeze_depth -= 1
+                if self._freeze_depth == 0:
+                    self._engine.set_weights_tag(0)
         return _ctx()
 
     # ------------------------------------------------------------------ knobs

@@ -76,6 +76,8 @@ class _FlatAdamBase(torch.optim.Optimizer):
         fg = self._gather_grads()
         fp = m._flat_params
         self._step += 1
+        if hasattr(m, "_weights_changed"):
+            m._weights_changed()            # a step inside model.frozen_weights(): the vouch is void, the next forward repacks
         with torch.cuda.device(fp.device):
             _lib.check(_lib.lib().stcd_adam_step(
                 C.c_void_p(fp.data_ptr()), C.c_void_p(fg.data_ptr()), C.c_void_p(self._exp_avg.data_ptr()),

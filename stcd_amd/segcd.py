@@ -127,7 +127,7 @@ class _UnetDecoder(nn.Module):
 
 
 class SegCD(HipChangeDetector):
-    """``SegCD(encoder_name="resnet50", encoder_weights=..., in_channels=3, classes=1).forward(A, B)`` ->
+    """``SegCD(encoder_name="resnet34", encoder_weights=..., in_channels=3, classes=1).forward(A, B)`` ->
     ``(mask_t1, mask_t2, change)`` with ``change = min(head(|d1 - d2|), |mask_t1 - mask_t2|)`` (model.py:316-332).
 
     Supported configurations: the one the scripts use (resnet50) and the other plain ResNet encoders of the registry
@@ -140,10 +140,14 @@ class SegCD(HipChangeDetector):
     FAMILY = "segcd"
     OUT_MAPS = 3
 
-    def __init__(self, encoder_name: str = "resnet50", encoder_depth: int = 5, encoder_weights: Optional[str] = None,
+    def __init__(self, encoder_name: str = "resnet34", encoder_depth: int = 5, encoder_weights: Optional[str] = None,
                  decoder_use_batchnorm: bool = True, decoder_channels: List[int] = (256, 128, 64, 32, 16),
                  decoder_attention_type: Optional[str] = None, in_channels: int = 3, classes: int = 1, activation=None,
                  aux_params: Optional[dict] = None, dtype: Optional[str] = None):
+        # Defaults: encoder_name "resnet34" as the reference's SegCD (decoders/unet/model.py:270-272) and the two sibling classes, so a
+        # bare or positional call ported from the reference builds the same network (the scripts pass "resnet50" explicitly,
+        # train_pse_cd.py:426).  encoder_weights defaults to None, NOT the reference's "imagenet": a deliberate deviation -- there is
+        # no network here to fetch the checkpoint from; pass "imagenet" (hub cache) or a path to load it.
         if (encoder_name not in _ENCODERS or encoder_depth != 5 or decoder_use_batchnorm is not True or tuple(decoder_channels) != (256, 128, 64, 32, 16)
                 or decoder_attention_type is not None or activation is not None or aux_params is not None):
             raise NotImplementedError("SegCD on the HIP engine: resnet18 / 34 / 50 / 101 / 152 encoder, depth 5, BatchNorm decoder "

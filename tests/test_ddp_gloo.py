@@ -69,13 +69,45 @@ def test_two_rank_gradient_average_gloo():
     assert res == {0: True, 1: True}
 
 
+def _worker_bf16(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from stcd_amd.ddp import FlatGradReducer, init_distributed
+
+    init_distributed(backend="gloo")
+    m = StandInModel(n0=1001, n1=333)                 # bucket sizes that do not divide by the world size
+    FlatGradReducer(m, bucket_dtype="bf16")
+    gen = torch.Generator().manual_seed(5)
+    base = torch.randn(m.w.numel(), generator=gen)    # the same on both ranks; rank r contributes base * (r + 1) + r * 1e-3
+    g = base * (rank + 1) + rank * 1e-3
+    for stage, (b, e) in ((0, m.stage0_range), (1, m.stage1_range)):
+        m.grad_stage_hook(stage, g[b:e])
+    per_rank = [(base * (r + 1) + r * 1e-3).to(torch.bfloat16).float() for r in range(world)]
+    want = (sum(per_rank) / world).to(torch.bfloat16).float()          # one rounding of the inputs, fp32 mean, one rounding of the mean
+    q.put((rank, bool(torch.equal(g, want))))
+    dist.destroy_process_group()
+
+
+def test_two_rank_bf16_buckets_accumulate_in_fp32():
+    """bucket_dtype="bf16": the result is bf16(mean_fp32(bf16(g_rank))) on every rank, bit for bit (SURVEY 8e option)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # The REAL stage ranges of every engine family (stcd_grad_stage_range through the C ABI: no GPU needed for queries) drive
 # the reducer: the two slices must be disjoint, cover the flat gradient buffer, stage 0 must hold exactly the decoder's
 # tensors (final first, so its collective overlaps the encoder's backward), and a 2-rank run over those slices must
 # deliver the mean everywhere -- also with a trainer-shaped epoch metric all-reduce.
 ARCHES = [("diff", 0), ("conc", 1), ("sub", 2), ("snunet", 3), ("segcd", 4), ("segcd_resnet18", 5), ("segcd_resnet101", 7),
-          ("unetseg_resnet34", 18), ("ffctlcd_resnet50", 32)]
+          ("unetseg_resnet34", 18), ("ffctlcd_resnet50", 32), ("changeformer", 64)]
 SINGLE_STAGE = ("snunet", "segcd", "unetseg", "ffctlcd")
 
 
@@ -97,7 +129,7 @@ def test_stage_ranges_partition_the_gradient_buffer(arch, _id):
         in1 = s1[0] <= off and off + numel <= s1[1]
         assert in0 != in1, name
         if not arch.startswith(SINGLE_STAGE):
-            dec = name.split(".")[0].endswith("d") or name.startswith("upconv")
+            dec = name.startswith("TDec_x2.") if arch == "changeformer" else (name.split(".")[0].endswith("d") or name.startswith("upconv"))
             assert in0 == dec, f"{name}: stage 0 must finalise exactly the decoder's gradients"
     if arch.startswith(SINGLE_STAGE):
         assert s1[1] - s1[0] == 0                                         # single-stage plan: everything final after stage 0

@@ -20,7 +20,8 @@ def test_define_G_registry_and_errors():
     with pytest.raises(NotImplementedError, match="not recognized"):
         define_G(NS(net_G="nope", n_class=2))
     with pytest.raises(NotImplementedError, match="outside"):
-        define_G(NS(net_G="ChangeFormerV6", n_class=2))
+        define_G(NS(net_G="ChangeFormerV5", n_class=2))
+    assert type(define_G(NS(net_G="ChangeFormerV6", n_class=2, embed_dim=64))).__name__ == "ChangeFormerV6"
 
 
 def test_init_weights_normal_statistics():

@@ -70,7 +70,7 @@ def test_segcd_fp32_matches_oracle_on_other_shapes(B, H, W, cin):
     x2 = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32))
     w1, w2, w3 = (torch.from_numpy(rng.standard_normal((B, 2, H, W)).astype(np.float32)) for _ in range(3))
     st = G.synth_state(cin, 2, seed)
-    m = SegCD(in_channels=cin, classes=2, dtype="fp32")
+    m = SegCD(encoder_name="resnet50", in_channels=cin, classes=2, dtype="fp32")
     m.load_state_dict(st)
     m.to(DEV).train()
     o = m(x1.to(DEV), x2.to(DEV))
@@ -109,7 +109,7 @@ def test_segcd_rejects_unsupported_configs_and_sizes():
         SegCD(encoder_name="resnext50_32x4d")
     with pytest.raises(NotImplementedError):
         SegCD(encoder_name="resnet34", decoder_attention_type="scse")
-    m = SegCD(dtype="fp32").to(DEV)
+    m = SegCD(encoder_name="resnet50", dtype="fp32").to(DEV)
     with pytest.raises(Exception, match="divisible by 32"):
         m(torch.zeros(1, 3, 48, 48, device=DEV), torch.zeros(1, 3, 48, 48, device=DEV))
 
@@ -282,7 +282,7 @@ def test_segcd_bf16_training_tracks_fp32():
     curves = {}
     for dt in ("fp32", "bf16"):
         torch.manual_seed(5)
-        m = SegCD(dtype=dt).to(DEV).train()
+        m = SegCD(encoder_name="resnet50", dtype=dt).to(DEV).train()
         opt = FlatAdamW(m, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0)
         losses = []
         for _ in range(30):
@@ -313,7 +313,7 @@ def test_semi_supervised_step_of_train_stcd_vs_oracle():
     lab = lambda p: torch.from_numpy((rng.random((B, 1, H, W)) < p).astype(np.float32))
     s_label_A, cd_label, CL = lab(0.3), lab(0.2), lab(0.25)
     st = G.synth_state(3, 1, 17)
-    m = SegCD(dtype="fp32")
+    m = SegCD(encoder_name="resnet50", dtype="fp32")
     m.load_state_dict(st)
     m.to(DEV).train()
     dA, dB, dl = torch.cat((image_A, CA)).to(DEV), torch.cat((image_B, CB)).to(DEV), torch.cat((cd_label, CL)).to(DEV)
@@ -355,7 +355,7 @@ def test_segcd_full_size_properties_bf16():
     a, b, _ = synth.make_batch(16, 256, 256, seed=79)
     A, Bt = t(a).to(DEV), t(b).to(DEV)
     torch.manual_seed(8)
-    m = SegCD(dtype="bf16").to(DEV)
+    m = SegCD(encoder_name="resnet50", dtype="bf16").to(DEV)
     m.eval()
     with torch.no_grad():
         full = [o.clone() for o in m(A, Bt)]

@@ -20,7 +20,7 @@ def run(dt, out):
     for k in st:
         if k.endswith("bn3.weight"):
             st[k] = st[k] * rg
-    m = SegCD(dtype=dt)
+    m = SegCD(encoder_name="resnet50", dtype=dt)
     m.load_state_dict(st)
     m.to(dev).eval()
     with torch.no_grad():
