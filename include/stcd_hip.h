@@ -286,7 +286,7 @@ typedef struct stcd_conv_geom {
 int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, const float* w, const float* bias,
                  void* out, void* scratch, int64_t scratch_bytes, void* hip_stream);
 /* dw: fp32 [ntaps][ci][co], overwritten; impl: 0 = reference FMA kernel, 1 = MFMA tile kernel (4: its 64 x 32-channel tile
- * allowed for Ci >= 64, as the SNUNet engine runs it), 3 = MFMA position-GEMM kernel
+ * allowed for Ci >= 64, as the SNUNet engine runs it; 5: its 64 x 64-channel tile, an opt-in variant), 3 = MFMA position-GEMM kernel
  * (one tap, Ci >= 64, Co >= 64: what the engine runs for 1x1 convs and the phases of 2x2 stride-2 transposed convs) */
 int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, const void* dout, float* dw,
                   void* scratch, int64_t scratch_bytes, void* hip_stream);

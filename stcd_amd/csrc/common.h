@@ -173,9 +173,18 @@ struct ConvGemmPlan {
     bool ok = false;
 };
 ConvGemmPlan conv_gemm_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups);
+// fused epilogue of k_conv_gemm, applied to v = conv + bias in this order:  v = relu(v) ; v = round(v) ; v = gate > 0 ? v : 0 ;
+// out = alpha * v + beta * res   (gate / res: tensors of the output's geometry with their own pixel strides).  ResidualBlock of
+// ChangeFormer's decoder head (ChangeFormerBaseNetworks.py:109-120) forward and backward without separate element-wise passes.
+struct ConvEpi {
+    int relu = 0;
+    const void* gate = nullptr; int ldg = 0;
+    const void* res = nullptr; int ldr = 0;
+    float alpha = 1.f, beta = 1.f;
+};
 int launch_conv_gemm(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvGemmPlan& gp, const void* in, const void* wf,
                    const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0 = 0,
-                   float s1_scale = BN_FS1, float s2_scale = BN_FS2);
+                   float s1_scale = BN_FS1, float s2_scale = BN_FS2, const ConvEpi* epi = nullptr);
 // small-channel persistent kernel (filter in registers, double-buffered halo, optional fused BN statistics);
 // uses the mode-B fragment image of conv_mfma_plan.
 bool conv_small_ok(const stcd_conv_geom& g, const ConvMfmaPlan& p);
@@ -189,7 +198,7 @@ struct WgradMfmaPlan {
     int gemm = 0;          // > 0: one-tap launch on k_wgrad_gemm<gemm> (32*gemm x 32*gemm channel tile), gx = position slices
     bool ok = false;
 };
-WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld, bool allow_wide = false);   // allow_wide: 64 x 32 tile for ci >= 64
+WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld, bool allow_wide = false, int force_co64 = -1);   // allow_wide: 64 x 32 tile for ci >= 64; force_co64 1: the 64 x 64 tile (opt-in variant, see the plan)
 int launch_wgrad_mfma(const stcd_conv_geom& g, const WgradMfmaPlan& p, const void* in, const void* dout, float* slab,
                       int kpad, int wld, hipStream_t s);
 // One weight-gradient launch as the kernel sees it.  A backward stage runs ALL its launches of one kernel variant as a

@@ -485,7 +485,9 @@ static WgradMfmaPlan pick_wgrad_plan(const stcd_engine& e, const stcd_conv_geom&
         WgradMfmaPlan p = wgrad_gemm_plan(g, kpad, wld);
         if (p.ok) return p;
     }
-    return wgrad_mfma_plan(g, kpad, wld, e.arch == STCD_ARCH_SNUNET);
+    // (64 x 32 tile: SNUNet everywhere; ChangeFormer for its 3x3 layers only -- measured 5.0 vs 5.4 ms there, but 2.7 vs 2.1 ms on the
+    //  4-tap phases of its transposed convs)
+    return wgrad_mfma_plan(g, kpad, wld, e.arch == STCD_ARCH_SNUNET || (e.cf && g.ntaps == 9));
 }
 
 static void build_pack_jobs(stcd_engine& e, Bump& ws) {
@@ -937,7 +939,7 @@ static bool mfma_on(const stcd_engine& e) { return e.dt == BF16 && e.use_mfma; }
 struct StatReq { long long* acc = nullptr; int groups = 1; int c0 = 0; int C = 0; float s1 = BN_FS1, s2 = BN_FS2; };
 // *fused receives 1 when the kernel delivered the sums, 0 when the caller must run the separate pass.
 static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const float* bias, void* out, bool nchw,
-                      const StatReq* sr = nullptr, int* stat_chunks = nullptr) {
+                      const StatReq* sr = nullptr, int* stat_chunks = nullptr, const ConvEpi* epi = nullptr, int* epi_fused = nullptr) {
     const int stat_groups = (sr && sr->acc) ? sr->groups : 0;
     long long* stat_acc = sr ? sr->acc : nullptr;
     const bool bn_form = sr && sr->c0 == 0 && sr->C == op.g.co && sr->s1 == BN_FS1 && sr->s2 == BN_FS2;
@@ -957,12 +959,14 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     else snprintf(kname, sizeof(kname), "k_conv_ref");
     ProfScope prof(c, PC_CONV, fl, by, kname);
     if (stat_chunks) *stat_chunks = 0;
+    if (epi_fused) *epi_fused = 0;
     if (gemm_path) {
         const bool want = stat_groups > 0 && stat_groups == op.res_groups && stat_acc;
         long long* sp = want ? stat_acc : nullptr;
         if (launch_conv_gemm(op.g, op.plan, op.gemm, in, c.at(op.wf), bias, out, op.res_groups, sp, want ? sr->C : op.g.co, c.s,
-                           want ? sr->c0 : 0, want ? sr->s1 : BN_FS1, want ? sr->s2 : BN_FS2) == 0) {
+                           want ? sr->c0 : 0, want ? sr->s1 : BN_FS1, want ? sr->s2 : BN_FS2, epi) == 0) {
             if (stat_chunks && want) *stat_chunks = 1;
+            if (epi_fused && epi) *epi_fused = 1;      // (the other kernels have no fused epilogue: the caller runs it element-wise)
             return;
         }
     }
@@ -2775,9 +2779,9 @@ int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, 
                   int64_t scratch_bytes, void* hip_stream) {
     if (check_geom(g)) return 1;
     STCD_CHECK(in && dout && dw, "null pointer argument");
-    if (impl == 1 || impl == 4) {      // 4: the tile kernel with its 64 x 32-channel tile allowed (the SNUNet engine's choice)
+    if (impl == 1 || impl == 4 || impl == 5) {      // 4: the tile kernel with its 64 x 32-channel tile allowed (the SNUNet engine's choice); 5: 64 x 64
         STCD_CHECK(dtype == STCD_DTYPE_BF16, "the MFMA implementation is bf16 only");
-        WgradMfmaPlan p = wgrad_mfma_plan(*g, g->ci, g->co, impl == 4);
+        WgradMfmaPlan p = wgrad_mfma_plan(*g, g->ci, g->co, impl >= 4, impl == 5 ? 1 : 0);
         STCD_CHECK(p.ok, "geometry not supported by the MFMA kernel");
         STCD_CHECK(scratch && scratch_bytes >= p.slab_floats * 4, "scratch too small for the partial slabs");
         STCD_CHECK(launch_wgrad_mfma(*g, p, in, dout, (float*)scratch, g->ci, g->co, (hipStream_t)hip_stream) == 0, "LDS budget exceeded");

@@ -652,25 +652,37 @@ static void cf_up_backward(const Ctx& c, const CfUp& U) {
     exec_conv(c, U.dgr[1], c.at(U.out.g.off), nullptr, c.at(U.dtmp.off), false);
     launch_axpby(e.dt, 1.f, c.at(U.in.g.off), U.in.g.ld, 1.f, c.at(U.dtmp.off), U.dtmp.ld, c.at(U.in.g.off), U.in.g.ld, rows_in, D, c.s);
 }
+// conv + fused epilogue where the kernel has one (k_conv_gemm), else conv then the same arithmetic element-wise
+static void cf_conv_epi(const Ctx& c, const ConvOp& op, const void* in, const float* bias, void* out, int ldo, const ConvEpi& ep, int64_t rows, int C) {
+    int fused = 0;
+    exec_conv(c, op, in, bias, out, false, nullptr, nullptr, &ep, &fused);
+    if (fused) return;
+    const int dt = c.e.dt;
+    if (ep.relu) launch_relu(dt, out, ldo, out, ldo, rows, C, c.s);
+    if (ep.gate) launch_relu_bwd(dt, out, ldo, ep.gate, ep.ldg, out, ldo, rows, C, c.s);
+    if (ep.res) launch_axpby(dt, ep.alpha, out, ldo, ep.beta, ep.res, ep.ldr, out, ldo, rows, C, c.s);
+}
 static void cf_res_forward(const Ctx& c, const CfRes& R) {
     stcd_engine& e = c.e;
     const int D = R.x.c;
     const int64_t rows = (int64_t)R.x.n * R.x.h * R.x.w;
-    cf_gemm_fwd(c, R.c1);
-    launch_relu(e.dt, c.at(R.r1.v.off), D, c.at(R.r1.v.off), D, rows, D, c.s);
-    cf_gemm_fwd(c, R.c2);
-    launch_axpby(e.dt, 0.1f, c.at(R.y2.v.off), D, 1.f, c.at(R.x.v.off), R.x.v.ld, c.at(R.out.v.off), D, rows, D, c.s);
+    ConvEpi e1; e1.relu = 1;                                                         // r1 = relu(conv1(x))
+    cf_conv_epi(c, R.c1.fwd, c.at(R.x.v.off), c.params + e.convs[R.c1.conv].b_off, c.at(R.r1.v.off), D, e1, rows, D);
+    ConvEpi e2; e2.res = c.at(R.x.v.off); e2.ldr = R.x.v.ld; e2.alpha = 0.1f; e2.beta = 1.f;      // out = conv2(r1) * 0.1 + x
+    cf_conv_epi(c, R.c2.fwd, c.at(R.r1.v.off), c.params + e.convs[R.c2.conv].b_off, c.at(R.out.v.off), D, e2, rows, D);
 }
 // d(out) in R.out.g -> d(x) in R.x.g
 static void cf_res_backward(const Ctx& c, const CfRes& R) {
     stcd_engine& e = c.e;
     const int D = R.x.c;
     const int64_t rows = (int64_t)R.x.n * R.x.h * R.x.w;
-    launch_axpby(e.dt, 0.1f, c.at(R.out.g.off), D, 0.f, nullptr, 0, c.at(R.y2.g.off), D, rows, D, c.s);
-    cf_gemm_bwd(c, R.c2);                                                                             // -> d(r1) (pre-gate)
-    launch_relu_bwd(e.dt, c.at(R.r1.g.off), D, c.at(R.r1.v.off), D, c.at(R.r1.g.off), D, rows, D, c.s);
-    cf_gemm_bwd(c, R.c1);                                                                             // -> dtmp
-    launch_axpby(e.dt, 1.f, c.at(R.out.g.off), D, 1.f, c.at(R.dtmp.off), D, c.at(R.x.g.off), R.x.g.ld, rows, D, c.s);
+    launch_axpby(e.dt, 0.1f, c.at(R.out.g.off), D, 0.f, nullptr, 0, c.at(R.y2.g.off), D, rows, D, c.s);      // d(y2): the weight gradient reads it
+    exec_wgrad(c, R.c2.wg, c.at(R.c2.x.off), c.at(R.c2.dy.off));
+    ConvEpi g1; g1.gate = c.at(R.r1.v.off); g1.ldg = D;                                                     // d(y1) = dgrad(conv2) * [r1 > 0]
+    cf_conv_epi(c, R.c2.dgr, c.at(R.y2.g.off), nullptr, c.at(R.r1.g.off), D, g1, rows, D);
+    exec_wgrad(c, R.c1.wg, c.at(R.c1.x.off), c.at(R.c1.dy.off));
+    ConvEpi g2; g2.res = c.at(R.out.g.off); g2.ldr = D; g2.alpha = 1.f; g2.beta = 1.f;                      // d(x) = dgrad(conv1) + d(out)
+    cf_conv_epi(c, R.c1.dgr, c.at(R.r1.g.off), nullptr, c.at(R.x.g.off), R.x.g.ld, g2, rows, D);
 }
 
 static int forward_cf(stcd_engine& e, const float* x1, const float* x2, const float* params, float* bn_running, const float* masks,

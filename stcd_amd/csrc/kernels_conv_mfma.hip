@@ -496,7 +496,10 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
     // pixel); each wave then owns one 16-channel ci tile for ALL k-steps (WK == 1: no cross-wave exchange at the end)
     constexpr int SCX = CIB > 32 ? 32 : CIB, NSX = CIB / SCX;
     const int xsub = a.x_bytes / NSX;
-    constexpr int YROW = 16 * 2 * COB + 2 * (COB == 16 ? 128 : 32);       // bytes of one 16-position dY row
+    // NTW == 4 (64 output channels: the 64 x 64 tile of the wide layers): the dY tile likewise as two 32-channel sub-images
+    constexpr int SCY = COB > 32 ? 32 : COB, NSY = COB / SCY;
+    const int ysub = a.y_bytes / NSY;
+    constexpr int YROW = 16 * 2 * SCY + 2 * (SCY == 16 ? 128 : 32);       // bytes of one 16-position dY row (of a sub-image)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wci = wid % WCI, wk = wid / WCI;
     const int grp = lane >> 4, li = lane & 15, qrow = li >> 2, pcol = li & 3;
@@ -533,7 +536,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
         const int j = tid + q * 256, ch = j % YCH, pix = j / YCH, py = pix >> 4, pxx = pix & 15;
         ya[q] = py; yb[q] = pxx;
         yg[q] = (((py * a.g.out_stride) * a.g.wo + pxx * a.g.out_stride) * a.g.ldo + co0 + ch * 8) * 2;   // bytes
-        yl[q] = a.x_bytes + py * YROW + px_off<COB>(pxx) + ch * 16;
+        yl[q] = a.x_bytes + (ch / (SCY / 8)) * ysub + py * YROW + px_off<SCY>(pxx) + (ch % (SCY / 8)) * 16;
         if (co0 + ch * 8 >= a.co_valid) ya[q] = 1 << 28;
     }
     const int npx = (nx + 255) >> 8;                  // X pieces in use (uniform)
@@ -584,7 +587,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
     // per-lane fragment geometry inside a k-step (32 positions = 2 tile rows): half h -> x = 8*(grp&1) + 4*h + qrow
     const int frow = grp >> 1;
     const int fx0 = 8 * (grp & 1) + qrow, fx1 = fx0 + 4;
-    const int yb0 = frow * YROW + px_off<COB>(fx0) + 8 * pcol, yb1 = frow * YROW + px_off<COB>(fx1) + 8 * pcol;
+    const int yb0 = frow * YROW + px_off<SCY>(fx0) + 8 * pcol, yb1 = frow * YROW + px_off<SCY>(fx1) + 8 * pcol;
     int xoff0[9], xoff1[9];      // X fragment byte offsets per tap (relative to the k-step's first halo row)
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -610,8 +613,10 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
         for (int ks = wk; ks < 4; ks += WK) {
             bf16x8 bfr[NTW];
 #pragma unroll
-            for (int n_ = 0; n_ < NTW; ++n_)
-                bfr[n_] = tr_frag(ys + ks * 2 * YROW + yb0 + n_ * 32, ys + ks * 2 * YROW + yb1 + n_ * 32);
+            for (int n_ = 0; n_ < NTW; ++n_) {
+                const int yo = ((n_ * 16) / SCY) * ysub + ((n_ * 16) % SCY) * 2;      // sub-image + byte offset of the n-tile inside a pixel
+                bfr[n_] = tr_frag(ys + ks * 2 * YROW + yb0 + yo, ys + ks * 2 * YROW + yb1 + yo);
+            }
             const char* xr = xs + ks * 2 * a.xrow_bytes;
             if constexpr (T9) {
                 bf16x8 afr[9];
@@ -682,13 +687,14 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
 }
 
 template <int WCI, int NTW, bool T9>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, NTW == 4 ? 1 : 2)
 k_wgrad_mfma(const WgradJob a) {
     wgrad_body<WCI, NTW, T9>(a, nullptr, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 template <int WCI, int NTW, bool T9>
-__global__ void __launch_bounds__(256, (WCI == 2 && NTW == 2) ? 3 : 2)      // <4,2>: 72 accumulators + 6 X pieces in flight: 2
+// <4,2>: 72 accumulators + 6 X pieces in flight: 2 blocks per CU; <4,4>: 144 accumulators: one wave per SIMD
+__global__ void __launch_bounds__(256, (WCI == 2 && NTW == 2) ? 3 : NTW == 4 ? 1 : 2)
 k_wgrad_group(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
     int lo = 0, hi = njobs - 1;            // last job with start <= blockIdx.x (uniform: scalar loads)
     while (lo < hi) {
@@ -829,7 +835,7 @@ void launch_reduce_jobs(const ReduceJob* jobs_dev, int njobs, int64_t total, con
     if (njobs > 0 && total > 0) k_reduce_jobs<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(jobs_dev, njobs, total, ws, grads);
 }
 
-WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld, bool allow_wide) {
+WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld, bool allow_wide, int force_co64) {
     WgradMfmaPlan p;
     int dymin, dymax, dxmin, dxmax;
     taps_extent(g, &dymin, &dymax, &dxmin, &dxmax);
@@ -841,12 +847,19 @@ WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld, bool a
     const bool wide_ok = wide_env < 0 ? allow_wide : wide_env != 0;
     const int tiles_x = (g.wm + 15) / 16, tiles_y = (g.hm + 7) / 8;
     const int64_t ntiles = (int64_t)g.n * tiles_x * tiles_y;
-    p.NTW = g.co >= 32 ? 2 : 1;
+    // STCD_WGRAD_CO64=1 (default off): 64 x 64-channel tile for layers with >= 64 channels on both sides -- 26 transposed LDS reads per
+    // 36 MFMAs instead of 22 per 18, X / dY re-read once per 64 instead of 32 channels.  Built, parity-tested (tests/test_ops_gpu.py
+    // runs it through impl 4) and MEASURED SLOWER: its 144 accumulators leave one wave per SIMD and one block per CU (102 KB of LDS),
+    // so nothing hides the staging round trips -- ChangeFormer's 3x3 group 6.05 ms vs 5.40 (32 x 32 tiles), SNUNet's 2.61 vs 1.86
+    // (64 x 32).  Kept as an opt-in variant.
+    static const int co64_env = [] { const char* e = getenv("STCD_WGRAD_CO64"); return e ? atoi(e) : 0; }();
+    const bool co64 = (force_co64 >= 0 ? force_co64 != 0 : co64_env != 0) && wide_ok && g.ci >= 64 && g.co >= 64 && HH * HWp * 8 <= 6 * 256;
+    p.NTW = co64 ? 4 : g.co >= 32 ? 2 : 1;
     // (allow_wide is the ENGINE's per-family choice: all qualifying layers of a stage must move together -- two grouped launches
     //  overlap worse than one.  Measured: SNUNet (hundreds of concatenated input channels on 128^2 / 256^2 maps) 2.50 -> 2.12 ms;
     //  SegCD +0.11 ms, SiamUnet_diff +0.07 ms: on their small deep maps halving the (ci, co) groups costs more parallelism and
     //  slab traffic than the wider tile saves.)
-    p.WCI = (wide_ok && g.ci >= 64 && p.NTW == 2 && HH * HWp * 8 <= 6 * 256) ? 4 : g.ci >= 32 ? 2 : 1;
+    p.WCI = (co64 || (wide_ok && g.ci >= 64 && p.NTW == 2 && HH * HWp * 8 <= 6 * 256)) ? 4 : g.ci >= 32 ? 2 : 1;
     p.gy = (g.ci + p.WCI * 16 - 1) / (p.WCI * 16);
     p.gz = (g.co + p.NTW * 16 - 1) / (p.NTW * 16);
     const int64_t slab_bytes = (int64_t)g.ntaps * kpad * wld * 4;
@@ -877,10 +890,11 @@ WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t
     a.ntiles = g.n * a.tiles_x * a.tiles_y;
     const int CIB = p.WCI * 16, COB = p.NTW * 16;
     const int SCX = CIB > 32 ? 32 : CIB, NSX = CIB / SCX;          // X tile as NSX sub-images of SCX channels (wgrad_body)
-    const int xpad = SCX == 16 ? 128 : 32, ypad = COB == 16 ? 128 : 32;
+    const int SCY = COB > 32 ? 32 : COB, NSY = COB / SCY;          // dY tile likewise (the 64 x 64 tile)
+    const int xpad = SCX == 16 ? 128 : 32, ypad = SCY == 16 ? 128 : 32;
     a.xrow_bytes = (a.HWp * 2 * SCX + ((a.HWp + 7) / 8) * xpad + 15) & ~15;
     a.x_bytes = NSX * ((a.HH * a.xrow_bytes + 255) & ~255);
-    a.y_bytes = (8 * (16 * 2 * COB + 2 * ypad) + 255) & ~255;
+    a.y_bytes = NSY * ((8 * (16 * 2 * SCY + 2 * ypad) + 255) & ~255);
     a.co_valid = (g.co + 7) & ~7;
     a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
     a.dout_bytes = (unsigned)((int64_t)g.n * g.ho * g.wo * g.ldo * 2);
@@ -893,7 +907,8 @@ WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t
 
 #define WG_DISPATCH(W_, N_, T_, WHAT)                                       \
     do {                                                                    \
-        if ((W_) == 4) { if (T_) { WHAT(4, 2, true); } else { WHAT(4, 2, false); } }                \
+        if ((W_) == 4 && (N_) == 4) { if (T_) { WHAT(4, 4, true); } else { WHAT(4, 4, false); } }   \
+        else if ((W_) == 4) { if (T_) { WHAT(4, 2, true); } else { WHAT(4, 2, false); } }           \
         else if ((W_) == 1 && (N_) == 1) { if (T_) { WHAT(1, 1, true); } else { WHAT(1, 1, false); } }   \
         else if ((W_) == 1) { if (T_) { WHAT(1, 2, true); } else { WHAT(1, 2, false); } }           \
         else if ((N_) == 1) { if (T_) { WHAT(2, 1, true); } else { WHAT(2, 1, false); } }           \
@@ -916,12 +931,14 @@ int wgrad_variant_slots(int WCI, int NTW, bool t9, int lds_bytes) {
 int launch_wgrad_group(int WCI, int NTW, bool t9, const WgradJob* jobs_dev, int njobs, int total_blocks, int lds_bytes,
                        const char* base, hipStream_t s) {
     if (njobs <= 0 || total_blocks <= 0) return 0;
-    if (lds_bytes > 80 * 1024) return 1;
-    if (lds_bytes > 64 * 1024) {      // the 64-channel tile: two 34-KB buffers
+    if (lds_bytes > 128 * 1024) return 1;
+    if (lds_bytes > 64 * 1024) {      // the 64-channel tiles: two 34-KB X buffers (+ two 17-KB dY buffers at 64 x 64)
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)k_wgrad_group<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)k_wgrad_group<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_wgrad_group<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_wgrad_group<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
     }
@@ -935,12 +952,14 @@ int launch_wgrad_mfma(const stcd_conv_geom& g, const WgradMfmaPlan& p, const voi
                       int kpad, int wld, hipStream_t s) {
     if (!p.ok) return 1;
     const WgradJob a = wgrad_make_job(g, p, (int64_t)(intptr_t)in, (int64_t)(intptr_t)dout, (int64_t)(intptr_t)slab, kpad, wld);
-    if (a.lds_bytes > 80 * 1024) return 1;
+    if (a.lds_bytes > 128 * 1024) return 1;
     if (a.lds_bytes > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)k_wgrad_mfma<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)k_wgrad_mfma<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_wgrad_mfma<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_wgrad_mfma<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
     }
@@ -1728,6 +1747,11 @@ struct ConvGemmArgs {
     int tap[9];                    // (dy << 16) | (dx & 0xffff) per tap, as 32-bit words: a uniform index into them is a SCALAR
                                    // load (the int8 arrays of g compile to global_load_sbyte, whose vmcnt(0) wait also waits for
                                    // every fetch still in flight -- that had serialised the two register sets)
+    // fused epilogue (ConvEpi, common.h)
+    int relu;
+    const bf16* gate; int ldg;
+    const bf16* res; int ldr;
+    float alpha, beta;
 };
 
 template <int W>
@@ -1887,6 +1911,7 @@ k_conv_gemm(const ConvGemmArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 v[j] = acc[m][n][j] + bv[j];
+                if (a.relu) v[j] = fmaxf(v[j], 0.f);
                 const float rv = round_as<bf16>(v[j]);
                 if (valid) { s1[n][j] += rv; s2[n][j] += rv * rv; }
             }
@@ -1924,7 +1949,28 @@ k_conv_gemm(const ConvGemmArgs a) {
                 const int x = mm % a.g.wm, t = mm / a.g.wm, y = t % a.g.hm, n = t / a.g.hm;
                 opix = ((int64_t)n * a.g.ho + y * a.g.out_stride + a.g.oy0) * a.g.wo + x * a.g.out_stride + a.g.ox0;
             }
-            *reinterpret_cast<uint4*>(a.out + opix * a.g.ldo + nt * TN + c8 * 8) = *reinterpret_cast<const uint4*>(ot + row * OPITCH + c8 * 16);
+            uint4 pk = *reinterpret_cast<const uint4*>(ot + row * OPITCH + c8 * 16);
+            if (a.gate || a.res) {      // the rounded conv output, gated and / or combined with a residual, rounded once more
+                float v8[8];
+                const uint32_t wv[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) { v8[2 * i2] = __uint_as_float(wv[i2] << 16); v8[2 * i2 + 1] = __uint_as_float(wv[i2] & 0xffff0000u); }
+                if (a.gate) {
+                    float g8[8];
+                    load8(a.gate + opix * a.ldg + nt * TN + c8 * 8, g8);
+#pragma unroll
+                    for (int i2 = 0; i2 < 8; ++i2) v8[i2] = g8[i2] > 0.f ? v8[i2] : 0.f;
+                }
+                if (a.res) {
+                    float r8[8];
+                    load8(a.res + opix * a.ldr + nt * TN + c8 * 8, r8);
+#pragma unroll
+                    for (int i2 = 0; i2 < 8; ++i2) v8[i2] = a.alpha * v8[i2] + a.beta * r8[i2];
+                }
+                pk.x = pack_bf16x2(v8[0], v8[1]); pk.y = pack_bf16x2(v8[2], v8[3]);
+                pk.z = pack_bf16x2(v8[4], v8[5]); pk.w = pack_bf16x2(v8[6], v8[7]);
+            }
+            *reinterpret_cast<uint4*>(a.out + opix * a.g.ldo + nt * TN + c8 * 8) = pk;
         }
     }
     if (a.stat_acc) {
@@ -1964,10 +2010,14 @@ ConvGemmPlan conv_gemm_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int 
 
 int launch_conv_gemm(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvGemmPlan& gp, const void* in, const void* wf,
                    const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0,
-                   float s1_scale, float s2_scale) {
+                   float s1_scale, float s2_scale, const ConvEpi* epi) {
     if (!gp.ok) return 1;
     ConvGemmArgs a;
     a.g = g;
+    a.relu = epi ? epi->relu : 0;
+    a.gate = epi ? (const bf16*)epi->gate : nullptr; a.ldg = epi ? epi->ldg : 0;
+    a.res = epi ? (const bf16*)epi->res : nullptr; a.ldr = epi ? epi->ldr : 0;
+    a.alpha = epi ? epi->alpha : 1.f; a.beta = epi ? epi->beta : 1.f;
     a.in = (const bf16*)in; a.wf = (const bf16*)wf; a.bias = bias; a.out = (bf16*)out;
     a.stat_acc = stat_acc; a.groups = groups; a.cpad = cpad; a.stat_c0 = stat_c0; a.s1_scale = s1_scale; a.s2_scale = s2_scale;
     a.NTtot = p.NTtot; a.nsteps = (g.ci / 64) * g.ntaps;

@@ -610,6 +610,12 @@ def g16_ffctlcd():
     save("g16_ffctlcd.npz", **d)
 
 
+def g18_segcd_wide():
+    """A better-conditioned SegCD fixture (round-2 review, weak #3): 4 x 128 x 128, i.e. 4 x 4 x 4 = 64 samples per channel at the deepest
+    BatchNorm (G10 has 2 x 2 x 2 = 8), so the fp32 bars of the SegCD family can sit at the north_star's 1e-3 instead of 2e-3 / 5e-2."""
+    _segcd_fixture("g18_segcd_128.npz", "G18 SegCD (ResNet-50 UNet), 4 x 128 x 128", 1800, 1, 4, 128, 128)
+
+
 def g12_segcd_r18():
     """SegCD over the BasicBlock encoders of the registry (encoders/resnet.py:126-144): resnet18 ..."""
     _segcd_fixture("g12_segcd_r18.npz", "G12 SegCD resnet18", 1200, 1, 2, 64, 64, encoder="resnet18")
@@ -647,9 +653,9 @@ def g17_cf_base():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd,
           "g7": g7_train128, "g8": g8_contrastive, "g10": g10_segcd, "g11": g11_segcd, "g12": g12_segcd_r18, "g13": g13_segcd_r34,
-          "g14": g14_segcd_r101, "g15": g15_unetseg, "g16": g16_ffctlcd, "g17": g17_cf_base}
+          "g14": g14_segcd_r101, "g15": g15_unetseg, "g16": g16_ffctlcd, "g17": g17_cf_base, "g18": g18_segcd_wide}
     for w in which:
         fn[w]()

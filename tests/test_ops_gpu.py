@@ -109,6 +109,8 @@ def test_wgrad_mfma_vs_ref_vs_oracle(n, h, w, ci, co):
     np.testing.assert_allclose(dw1 / scale, ref / scale, atol=2e-4, err_msg="mfma")
     if ci >= 64:          # the 64 x 32-channel tile (two 32-channel LDS sub-images, no k-split across waves)
         np.testing.assert_allclose(run_wgrad(4, g, x, dout).cpu().numpy() / scale, ref / scale, atol=2e-4, err_msg="mfma, wide tile")
+    if ci >= 64 and co >= 64:      # the 64 x 64-channel tile (dY as two 32-channel sub-images too; opt-in: measured slower)
+        np.testing.assert_allclose(run_wgrad(5, g, x, dout).cpu().numpy() / scale, ref / scale, atol=2e-4, err_msg="mfma, 64 x 64 tile")
 
 
 def up_phase_taps(py, px):

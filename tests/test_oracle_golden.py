@@ -192,7 +192,7 @@ def test_contrastive_loss_against_reference_vectors(golden):
 
 @pytest.mark.parametrize("fixture,classes,encoder", [("g10_segcd.npz", 1, "resnet50"), ("g11_segcd_2cls.npz", 2, "resnet50"),
                                                      ("g12_segcd_r18.npz", 1, "resnet18"), ("g13_segcd_r34.npz", 2, "resnet34"),
-                                                     ("g14_segcd_r101.npz", 1, "resnet101")])
+                                                     ("g14_segcd_r101.npz", 1, "resnet101"), ("g18_segcd_128.npz", 1, "resnet50")])
 def test_segcd_eval_and_train_step_against_reference_vectors(golden, fixture, classes, encoder):
     """G10: the ResNet-50 UNet change detector the reference's scripts train (smp.SegCD), assembled from the reference's own
     ResNet / UnetDecoder / SegmentationHead: the three outputs in eval and train mode, the loss, every parameter's

@@ -59,6 +59,40 @@ def test_segcd_fp32_matches_reference_vectors(golden, fixture, classes, encoder)
         np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), g[k], rtol=1e-4, atol=5e-5, err_msg=k)
 
 
+def test_segcd_fp32_at_the_north_star_bar_on_a_well_conditioned_fixture(golden):
+    """G18 (round-2 review, weak #3): the reference's SegCD(resnet50) at 4 x 128 x 128 -- 64 samples per channel at the deepest
+    BatchNorm instead of G10's 8.  With the fixture's conditioning out of the way the fp32 engine meets the north_star's 1e-3 on
+    every map (train mode included) and per-tensor gradient bars of 3e-2 / 0.9995 (G10: 5e-2 / 0.998)."""
+    g = golden("g18_segcd_128.npz")
+    seed = int(g["seed"])
+    x1, x2 = t(g["x1"]).to(DEV), t(g["x2"]).to(DEV)
+    m = SegCD(encoder_name="resnet50", classes=1, dtype="fp32")
+    m.load_state_dict(G.synth_state(3, 1, seed, perturb_running=True))
+    m.to(DEV).eval()
+    with torch.no_grad():
+        o = m(x1, x2)
+    for k, v in zip(("m1", "m2", "change"), o):
+        np.testing.assert_allclose(v.cpu().numpy(), g[f"eval/{k}"], rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(g[f"eval/{k}"]).max())), err_msg=k)
+    m = SegCD(encoder_name="resnet50", classes=1, dtype="fp32")
+    m.load_state_dict(G.synth_state(3, 1, seed))
+    m.to(DEV).train()
+    m1, m2, ch = m(x1, x2)
+    worst = 0.0
+    for k, v in zip(("m1", "m2", "change"), (m1, m2, ch)):
+        worst = max(worst, float(np.abs(v.detach().cpu().numpy() - g[f"train/{k}"]).max()))
+        np.testing.assert_allclose(v.detach().cpu().numpy(), g[f"train/{k}"], rtol=1e-3, atol=1e-3, err_msg=k)
+    loss = _loss(m1, m2, ch, t(g["seg_target"]).to(DEV), t(g["target"]).to(DEV))
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    for name, p in m.named_parameters():
+        if float(np.abs(g["gs/" + name][1])) < 1e-12:
+            continue
+        # 3e-2 / 0.9995: the pinned CPU oracle itself sits at 2.68e-2 / 0.999642 against this fixture (stem weight: ~110 piecewise-linear
+        # layers between it and the loss; tests/test_oracle_golden.py) -- the engine measured 2.65e-2 / 0.999648, every other tensor < 2e-2
+        check_grad(name, p.grad, g, rel_max=3e-2, tag="fp32 SegCD vs reference G18 (4 x 128 x 128)")
+    print(f"G18: worst train-mode map error {worst:.2e}")
+
+
 @pytest.mark.parametrize("B,H,W,cin", [(1, 128, 160, 3), (3, 96, 64, 3), (3, 96, 96, 5)])
 def test_segcd_fp32_matches_oracle_on_other_shapes(B, H, W, cin):
     """Odd batch, non-square sizes, 2 classes against the CPU oracle run in fp64 (gradients of the whole step).  Sizes keep >= 18
