@@ -150,6 +150,8 @@ def parse():
     ap.add_argument("--pseudo", action="store_true",
                     help="BASELINE.json configs[3]: every step first builds its pairs on the device from resident uint8 tiles "
                          "(stcd_pseudo_pair: blend + normalise + labels), then trains on them")
+    ap.add_argument("--graph", action="store_true", help="replay the step as ONE captured hipGraph (stcd_amd.train_loop.GraphedTrainStep): "
+                                                          "small batches of the SegCD family are host-bound otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16)     # bounded CPU sample: ~10-30 s of host work in total (16 = the GPU's batch)
@@ -397,6 +399,18 @@ def main():
         opt.step()
         return loss
 
+    if args.graph:
+        from stcd_amd.train_loop import GraphedTrainStep
+        assert world == 1 and not args.pseudo, "--graph: single GPU, resident inputs"
+        lossf = (lambda out, y: cross_entropy(out[-1] if isinstance(out, (list, tuple)) else out, y)) if args.label == 2 else \
+                (lambda out, y: bce_dice_with_logits(out[-1] if isinstance(out, (list, tuple)) else out, y))
+        gstep = GraphedTrainStep(model, opt, lossf, (A,) if args.model == "unetseg" else (A, B), L if args.label == 2 else Lf)
+        eager_step = step
+
+        def step():                                       # noqa: F811  (the timed loop calls whatever `step` is)
+            return gstep(*(((A,) if args.model == "unetseg" else (A, B)) + ((L if args.label == 2 else Lf),)))
+        args.no_roofline = True                            # the per-kernel timers bracket launches: not meaningful inside a replay
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -451,6 +465,7 @@ def main():
         "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
         "collective_backend": dist.get_backend() if world > 1 else None,
         "pairs_per_sec_per_rank": [round(v, 2) for v in rank_rates],
+        "graph_replay": bool(args.graph),
     }
     # whole-step roofline: SURVEY 8d's algorithmic figures per pair x pairs per step / measured step time (all ranks)
     seg_family = args.model in ("segcd", "unetseg", "ffctlcd")

@@ -243,6 +243,13 @@ int stcd_confusion_update(const float* logits, const int64_t* target, int batch,
 int stcd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel, int64_t step,
                    double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled, void* hip_stream);
 
+/* The same update for a CAPTURED training step (hipGraph): the step-dependent scalars come from device memory, so one captured launch
+ * serves every replay.  stcd_adam_hyper fills a HOST array of 8 floats for (step, lr, ...) with exactly the scalars stcd_adam_step
+ * forms (the caller keeps it in pinned memory and makes its copy to hyper_dev8 part of the graph); stcd_adam_step_dev reads them. */
+int stcd_adam_hyper(int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay, float* hyper_host8);
+int stcd_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel, const float* hyper_dev8,
+                       int decoupled, void* hip_stream);
+
 /* ---- pseudo-change pair synthesis on the device (replaces the file-based assembly of data/dataset.py:468-482 plus
  *      ToTensor/Normalize :499-500 and the paired cutout :24-57; the reference holds NO generator arithmetic, so the
  *      blend below is this library's own specification -- oracle/pseudo_ref.py restates it, parity is unpinned).

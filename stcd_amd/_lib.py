@@ -117,6 +117,8 @@ _PROTOS = {
     "stcd_loss_contrastive": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "stcd_confusion_update": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp]),
     "stcd_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, _d, _i, _vp]),
+    "stcd_adam_hyper": (_i, [_i64, _d, _d, _d, _d, _d, C.POINTER(_f)]),
+    "stcd_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _i, _vp]),
     "stcd_pseudo_pair": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _vp, _vp, _vp, _vp]),
     "stcd_augment_scratch_bytes": (_i64, [_i, _i, _i]),
     "stcd_augment": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp, _i64, _vp]),

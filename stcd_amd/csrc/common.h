@@ -392,6 +392,7 @@ void launch_loss_contrastive(const float* pred, const int64_t* cd_label, const i
                              float* dpred, void* scratch, hipStream_t s);
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float omb1, float beta2, float omb2, float eps,
                  float wd, int decoupled, float step_size, float inv_bc2_sqrt, hipStream_t s);
+void launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int decoupled, hipStream_t s);
 void launch_pseudo_pair(const uint8_t* A, const uint8_t* donor, const uint8_t* mask, const uint8_t* change, const float* alpha,
                         const int32_t* erase, uint64_t seed, int B, int H, int W, const float* mean, const float* std_,
                         float* x1, float* x2, int64_t* c_label, int64_t* s_label_a, int64_t* s_label_b, hipStream_t s);

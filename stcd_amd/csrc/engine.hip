@@ -2691,6 +2691,22 @@ int stcd_adam_step(float* params, const float* grads, float* exp_avg, float* exp
     return 0;
 }
 
+int stcd_adam_hyper(int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay, float* hyper_host8) {
+    STCD_CHECK(hyper_host8 != nullptr && step >= 1, "bad argument");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hyper_host8[0] = (float)lr; hyper_host8[1] = (float)(1.0 - beta1); hyper_host8[2] = (float)beta2; hyper_host8[3] = (float)(1.0 - beta2);
+    hyper_host8[4] = (float)eps; hyper_host8[5] = (float)weight_decay; hyper_host8[6] = (float)(lr / bc1); hyper_host8[7] = (float)(1.0 / sqrt(bc2));
+    return 0;
+}
+int stcd_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel, const float* hyper_dev8,
+                       int decoupled, void* hip_stream) {
+    STCD_CHECK(params && grads && exp_avg && exp_avg_sq && hyper_dev8, "null pointer argument");
+    STCD_CHECK(numel >= 1, "numel must be >= 1");
+    launch_adam_dev(params, grads, exp_avg, exp_avg_sq, numel, hyper_dev8, decoupled ? 1 : 0, (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
 int stcd_pseudo_pair(const uint8_t* img_a, const uint8_t* donor, const uint8_t* mask, const uint8_t* change, const float* alpha,
                      const int32_t* erase_xywh, uint64_t seed, int batch, int height, int width, const float* mean3,
                      const float* std3, float* x1, float* x2, int64_t* c_label, int64_t* s_label_a, int64_t* s_label_b,

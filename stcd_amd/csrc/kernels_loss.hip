@@ -298,6 +298,33 @@ k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
             if (i0 + j < n) { p[i0 + j] = pv[j]; m[i0 + j] = mv[j]; v[i0 + j] = vv[j]; }
     }
 }
+// the same update with its step-dependent scalars read from DEVICE memory (hyper fp32 [8] = lr, 1 - beta1, beta2, 1 - beta2, eps,
+// weight decay, step size, 1 / sqrt(bias correction 2)): a captured hipGraph of the training step replays with this step's values,
+// which the host writes into a pinned buffer whose copy is part of the graph
+__global__ void __launch_bounds__(256)
+k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+           const float* __restrict__ hyper, int decoupled) {
+    const float lr = hyper[0], omb1 = hyper[1], beta2 = hyper[2], omb2 = hyper[3], eps = hyper[4], wd = hyper[5], step_size = hyper[6],
+                inv_bc2_sqrt = hyper[7];
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = i0 + j;
+        if (i >= n) break;
+        float pv = p[i], gr = g[i], mv = m[i], vv = v[i];
+        if (decoupled) pv *= 1.f - lr * wd;
+        else gr = gr + wd * pv;
+        mv = mv + (gr - mv) * omb1;
+        vv = vv * beta2 + omb2 * gr * gr;
+        const float denom = sqrtf(vv) * inv_bc2_sqrt + eps;
+        pv = pv - step_size * (mv / denom);
+        p[i] = pv; m[i] = mv; v[i] = vv;
+    }
+}
+void launch_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, int decoupled, hipStream_t s) {
+    const int64_t threads = (n + 3) / 4;
+    k_adam_dev<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(p, g, m, v, n, hyper, decoupled);
+}
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float omb1, float beta2, float omb2, float eps,
                  float wd, int decoupled, float step_size, float inv_bc2_sqrt, hipStream_t s) {
     const int64_t threads = (n + 3) / 4;

@@ -86,6 +86,48 @@ class _FlatAdamBase(torch.optim.Optimizer):
                 C.c_void_p(torch.cuda.current_stream(fp.device).cuda_stream)))
         return loss
 
+    # ---- captured steps (stcd_amd.train_loop.GraphedTrainStep): the step-dependent scalars live in DEVICE memory, so ONE captured
+    #      launch serves every replay.  The host writes them into a ring of pinned slots and enqueues the slot's copy in front of the
+    #      replay (stream order); a slot is rewritten only after the copy that read it has completed (event), so the host may run
+    #      several steps ahead of the GPU.
+    _SLOTS = 8
+
+    def prepare_graph_step(self):
+        """Host side of a graphed step (call BEFORE graph.replay()): advance the step count, write this step's scalars into the next
+        pinned slot and enqueue its copy to the device buffer the captured kernel reads."""
+        self._ensure_state()
+        g = self.param_groups[0]
+        dev = self._model._flat_params.device
+        if getattr(self, "_hyper_pin", None) is None:
+            self._hyper_pin = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(self._SLOTS)]
+            self._hyper_ev = [None] * self._SLOTS
+            self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._step += 1
+        k = self._step % self._SLOTS
+        if self._hyper_ev[k] is not None:
+            self._hyper_ev[k].synchronize()
+        arr = (C.c_float * 8)()
+        _lib.check(_lib.lib().stcd_adam_hyper(self._step, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                              float(g["weight_decay"]), arr))
+        self._hyper_pin[k].copy_(torch.tensor(list(arr), dtype=torch.float32))
+        self._hyper_dev.copy_(self._hyper_pin[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._hyper_ev[k] = ev
+
+    @torch.no_grad()
+    def step_graph(self):
+        """Device side (call INSIDE the capture): one launch that reads the step's scalars from device memory."""
+        m = self._model
+        fg, fp = self._gather_grads(), m._flat_params
+        if hasattr(m, "_weights_changed"):
+            m._weights_changed()
+        with torch.cuda.device(fp.device):
+            _lib.check(_lib.lib().stcd_adam_step_dev(
+                C.c_void_p(fp.data_ptr()), C.c_void_p(fg.data_ptr()), C.c_void_p(self._exp_avg.data_ptr()),
+                C.c_void_p(self._exp_avg_sq.data_ptr()), fp.numel(), C.c_void_p(self._hyper_dev.data_ptr()), 1 if self.DECOUPLED else 0,
+                C.c_void_p(torch.cuda.current_stream(fp.device).cuda_stream)))
+
     # ---- checkpoints: torch's per-parameter layout ({'state': {i: {step, exp_avg, exp_avg_sq}}, 'param_groups'})
     def state_dict(self):
         sd = super().state_dict()

@@ -194,3 +194,90 @@ def _train_seg_epoch(model, trainloader, valloader, optimizer, args, device, wri
         if on_epoch_end is not None:
             on_epoch_end(rec)
     return best_model, history
+
+
+class GraphedTrainStep:
+    """One training step -- zero_grad, forward, loss, backward, fused Adam -- captured ONCE as a hipGraph and replayed.
+
+    An engine step is hundreds of kernel launches (SegCD-resnet50: 326) and the host needs ~10 us to enqueue each, i.e. ~3.3 ms per
+    step whatever the batch; a replayed graph costs the host one call (0.36 ms), which frees the CPU for the input pipeline.  (The
+    round-2 review expected it to shorten small-batch steps as well; measured below: it does not.)  What makes the step capturable: forward and backward are sync-free stream work on
+    caller-provided buffers; the only per-step host values are the optimizer's scalars (learning rate, bias corrections), which
+    the captured Adam launch reads from device memory -- the host writes them into a ring of pinned slots and enqueues the copy in
+    front of each replay (``FlatAdam.prepare_graph_step`` / ``step_graph``, ``stcd_adam_step_dev``).  Learning-rate schedulers keep
+    working: they change ``param_groups`` on the host between replays.
+
+    MEASURED (MI355X, SegCD-resnet50, bf16, 256 x 256; gpurun_out/segcd_graph.jsonl): host enqueue time falls from 3.7 / 5.3 / 7.8 ms to
+    0.36 ms per step at 2 / 8 / 16 pairs -- and the step time does not move (4.39 -> 4.51, 6.29 -> 6.40, 9.29 -> 9.37 ms).  The eager
+    step was never waiting for the host (enqueue < step time in every case): what bounds a small-batch step is the GPU-side cost
+    of ~330 dependent dispatches (~13 us each), which a graph replays one by one all the same.  The remedy is fewer launches.
+
+    Limits (raised loudly): families whose dropout seed is a launch argument (FC-Siam, ChangeFormer) would replay ONE mask set --
+    refused unless their dropout is off; fixed input shapes; the optimizer must be ``FlatAdam`` / ``FlatAdamW``.
+
+        step = GraphedTrainStep(model, opt, lambda outs, y: bce_dice_with_logits(outs[-1], y), (A, B), target)
+        for A, B, y in loader: loss = step(A, B, y); sched.step()
+    """
+
+    GRAPH_SAFE = ("segcd", "unetseg", "ffctlcd", "snunet")
+
+    def __init__(self, model, optimizer, loss_fn, example_inputs, example_target, warmup: int = 3):
+        from ._lib import StcdError
+        from .modules import HipChangeDetector
+        from .optim import _FlatAdamBase
+        inner = model.module if hasattr(model, "module") and not isinstance(model, HipChangeDetector) else model
+        if not isinstance(inner, HipChangeDetector) or not isinstance(optimizer, _FlatAdamBase):
+            raise StcdError("GraphedTrainStep drives an engine module with a FlatAdam / FlatAdamW optimizer")
+        arch = inner._engine.arch
+        if not arch.startswith(self.GRAPH_SAFE) and getattr(inner, "_drop_p", 0.2) > 0.0:
+            raise StcdError(f"{arch}: the dropout seed of this family is a launch argument -- a captured step would replay one mask set; "
+                            "set_dropout_p(0) first, or train it eagerly")
+        if inner.grad_stage_hook is not None:
+            raise StcdError("a data-parallel gradient hook is installed: collectives are not captured; use the eager step")
+        self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
+        self._x = [t.detach().clone() for t in example_inputs]
+        self._y = example_target.detach().clone()
+        model.train()
+        inner._ensure_flat(self._x[0].device)
+        optimizer._ensure_state()
+        # the warm-up steps below are real training steps on the example batch: snapshot the training state and put it back, so
+        # constructing the object leaves model and optimizer exactly where they were
+        snap = (inner._flat_params.clone(), inner._flat_bn.clone(), inner._nbt.clone(), optimizer._exp_avg.clone(),
+                optimizer._exp_avg_sq.clone(), optimizer._step, inner._steps)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up on a side stream (first-use uploads, allocator, autograd buffers)
+            for _ in range(max(1, warmup)):
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            inner._flat_params.copy_(snap[0]); inner._flat_bn.copy_(snap[1]); inner._nbt.copy_(snap[2])
+            optimizer._exp_avg.copy_(snap[3]); optimizer._exp_avg_sq.copy_(snap[4])
+        optimizer._step, inner._steps = snap[5], snap[6]
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.prepare_graph_step()                       # allocates the scalar buffers the captured launch points at
+        optimizer._step -= 1                                 # (the first replay prepares its own scalars)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph):
+            optimizer.zero_grad(set_to_none=True)
+            loss = loss_fn(model(*self._x), self._y)
+            loss.backward()
+            optimizer.step_graph()
+            self._loss = loss.detach()
+
+    def _eager_step(self):
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.loss_fn(self.model(*self._x), self._y)
+        loss.backward()
+        self.opt.step()
+        return loss
+
+    def __call__(self, *args):
+        *xs, y = args
+        for dst, src in zip(self._x, xs):
+            dst.copy_(src, non_blocking=True)
+        self._y.copy_(y, non_blocking=True)
+        self.opt.prepare_graph_step()                        # host scalars of THIS step -> device buffer (stream-ordered before the replay)
+        self.graph.replay()
+        return self._loss

@@ -244,6 +244,55 @@ def test_f1_parity_with_statistics_over_reference_seeds(dtype):
         assert eng.std(ddof=1) <= 3.0 * max(ref.std(ddof=1), 0.3)
 
 
+@pytest.mark.parametrize("family", ["segcd", "snunet"])
+def test_graphed_training_step_equals_the_eager_one(family):
+    """stcd_amd.train_loop.GraphedTrainStep: the whole step (zero_grad, forward, BCE+Dice, backward, fused Adam) captured as one
+    hipGraph and replayed -- with a Poly schedule changing the learning rate between replays -- ends bit-identical to the same
+    steps run eagerly (same kernels, same order; the optimizer's scalars travel through the pinned buffer)."""
+    from stcd_amd.losses import bce_dice_with_logits
+    from stcd_amd.optim import FlatAdam
+    from stcd_amd.train_loop import GraphedTrainStep, Poly
+
+    def build():
+        torch.manual_seed(3)
+        if family == "segcd":
+            from stcd_amd.segcd import SegCD
+            m = SegCD(encoder_name="resnet18", classes=1, dtype="bf16")
+        else:
+            from stcd_amd.modules import SNUNet_ECAM
+            m = SNUNet_ECAM(3, 1, dtype="bf16")
+        return m.to(DEV).train()
+
+    a, b, lab = synth.make_batch(12, 64, 64, seed=9)
+    A, B, L = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), torch.from_numpy(lab).float().unsqueeze(1).to(DEV)
+    loss_fn = lambda out, y: bce_dice_with_logits(out[-1] if isinstance(out, (tuple, list)) else out, y)
+    results = []
+    for graphed in (False, True):
+        m = build()
+        opt = FlatAdam(m, lr=1e-3)
+        sched = Poly(opt, 1, 6)
+        step = GraphedTrainStep(m, opt, loss_fn, (A[:2], B[:2]), L[:2]) if graphed else None
+        losses = []
+        for it in range(6):
+            sl = slice(2 * it, 2 * it + 2)
+            if graphed:
+                losses.append(step(A[sl], B[sl], L[sl]).clone())
+            else:
+                opt.zero_grad(set_to_none=True)
+                loss = loss_fn(m(A[sl], B[sl]), L[sl])
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach().clone())
+            sched.step(epoch=0)
+        torch.cuda.synchronize()
+        results.append((torch.stack(losses).cpu(), m._flat_params.detach().cpu().clone(), m._flat_bn.detach().cpu().clone(), opt._step))
+    (l0, p0, b0, s0), (l1, p1, b1, s1) = results
+    assert s0 == s1 == 6
+    assert torch.equal(l0, l1), (l0, l1)
+    assert torch.equal(p0, p1) and torch.equal(b0, b1)
+    assert float(l0[-1]) < float(l0[0])
+
+
 def test_semi_supervised_example_runs_and_learns(monkeypatch):
     """examples/train_stcd_synth.py: the loop of train_stcd.py (SegCD, seg + cd + contrastive losses, device-side pair synthesis and
     augmentation) for three short epochs: finite, and the change loss falls."""
