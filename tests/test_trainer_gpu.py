@@ -158,6 +158,9 @@ def test_example_script_runs_and_learns(monkeypatch, net):
     assert hist[-1]["cd_loss"] < hist[0]["cd_loss"]
 
 
+_F1_DATA = {}
+
+
 def _f1_run(g, dtype):
     """One training run of the engine on a reference fixture's protocol (same initial weights, batch order, Dropout2d masks):
     -> (losses per step, validation F1 per epoch in points)."""
@@ -168,10 +171,12 @@ def _f1_run(g, dtype):
     from stcd_amd.train_loop import Poly
 
     n_tr, n_va, size, bs, epochs, seed = (int(g[k]) for k in ("n_train", "n_val", "size", "batch", "epochs", "seed"))
-    a, b, lab = synth.make_batch(n_tr, size, size, seed=int(g["data_seed_train"]))
-    va, vb, vlab = synth.make_batch(n_va, size, size, seed=int(g["data_seed_val"]))
-    A, B, L = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), torch.from_numpy(lab).to(DEV)
-    VA, VB, VL = torch.from_numpy(va).to(DEV), torch.from_numpy(vb).to(DEV), torch.from_numpy(vlab).to(DEV)
+    key = (n_tr, n_va, size, int(g["data_seed_train"]), int(g["data_seed_val"]))
+    if key not in _F1_DATA:          # every seed trains on the same synthetic slice: build it (seconds of host work) once
+        a, b, lab = synth.make_batch(n_tr, size, size, seed=int(g["data_seed_train"]))
+        va, vb, vlab = synth.make_batch(n_va, size, size, seed=int(g["data_seed_val"]))
+        _F1_DATA[key] = tuple(torch.from_numpy(t_).to(DEV) for t_ in (a, b, lab, va, vb, vlab))
+    A, B, L, VA, VB, VL = _F1_DATA[key]
     m = SiamUnet_diff(3, 1, dtype=dtype)
     m.load_state_dict(R.synth_state("diff", 3, 1, seed))
     m.to(DEV)
@@ -218,6 +223,8 @@ def test_f1_parity_with_statistics_over_reference_seeds(dtype):
     from tests._util import ACHIEVED
     fixtures = _f1_fixtures()
     assert len(fixtures) >= 1
+    if dtype == "fp32":
+        fixtures = fixtures[:3]      # the parity-mode engine on three of the seeds; bf16 (the path the bench times) on all of them
     eng, ref = [], []
     for g in fixtures:
         epochs, ipe = int(g["epochs"]), int(g["n_train"]) // int(g["batch"])
