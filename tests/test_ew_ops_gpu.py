@@ -179,10 +179,12 @@ def oracle_bn_act_bwd(x, ga, gamma, beta, mask, relu, groups, means, invstds):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("n,c,h,w,groups", [(4, 16, 12, 10, 2), (2, 32, 7, 5, 1), (6, 8, 9, 16, 2), (2, 128, 4, 6, 1), (4, 64, 16, 16, 2), (2, 512, 6, 6, 2), (4, 2048, 4, 4, 2), (2, 256, 8, 12, 1)])
+@pytest.mark.parametrize("n,c,h,w,groups", [(4, 16, 12, 10, 2), (2, 32, 7, 5, 1), (6, 8, 9, 16, 2), (2, 128, 4, 6, 1), (4, 64, 16, 16, 2), (2, 512, 6, 6, 2), (4, 2048, 4, 4, 2), (2, 256, 8, 12, 1),
+                                              (8, 64, 32, 32, 2), (16, 64, 64, 64, 2), (6, 16, 40, 24, 1)])
 def test_bn_relu_dropout_pool_vs_oracle(dtype, n, c, h, w, groups):
     """BatchNorm2d(train) + ReLU + Dropout2d mask + 2x2 max-pool and its backward: odd sizes, two groups (the shared encoder
-    BN sees date 0 then date 1: running statistics updated twice), masks with zeros."""
+    BN sees date 0 then date 1: running statistics updated twice), masks with zeros.  The three largest cases give the reductions
+    multi-block grids (64 ... 2048 blocks)."""
     rng = np.random.default_rng(n * 100 + c + h)
     x = rq(1.5 * rng.standard_normal((n, c, h, w)) + 0.3, dtype)
     gamma, beta = (1 + 0.1 * rng.standard_normal(c)).astype(np.float32), (0.1 * rng.standard_normal(c)).astype(np.float32)
