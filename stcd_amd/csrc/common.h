@@ -185,6 +185,18 @@ struct ConvEpi {
 int launch_conv_gemm(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvGemmPlan& gp, const void* in, const void* wf,
                    const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0 = 0,
                    float s1_scale = BN_FS1, float s2_scale = BN_FS2, const ConvEpi* epi = nullptr);
+// 3x3 stride-1 convolutions of wide layers on large maps (Ci % 64 == 0, Co % 128 == 0): resident 18 x 18 x 64-channel halo, the
+// filter streamed per (chunk, tap) stage; 16 x 16-pixel x 128/256-channel block tiles, persistent blocks (kernels_conv_halo.hip).
+// Reads the CiB = 64 fragment image (the one k_conv_gemm reads); ConvEpi as k_conv_gemm; no fused BN statistics.
+struct ConvHaloPlan {
+    int NH = 0;            // 128-channel halves of the block's output slice (1: 4 waves, 2: 8 waves)
+    int nslices = 0, P = 0, blocks = 0, lds_bytes = 0;
+    bool ok = false;
+};
+ConvHaloPlan conv_halo_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p);
+int launch_conv_halo(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvHaloPlan& hp, const void* in, const void* wf,
+                     const float* bias, void* out, hipStream_t s, const ConvEpi* epi = nullptr);
+
 // small-channel persistent kernel (filter in registers, double-buffered halo, optional fused BN statistics);
 // uses the mode-B fragment image of conv_mfma_plan.
 bool conv_small_ok(const stcd_conv_geom& g, const ConvMfmaPlan& p);

@@ -59,6 +59,7 @@ struct ConvOp {
     bool small = false;                  // eligible for the small-channel persistent kernel
     ConvResPlan res; int res_groups = 1; // resident-filter persistent kernel (3x3 stride 1, Ci % 32 == 0)
     ConvGemmPlan gemm;                    // 1x1 convs with Ci % 64 == 0, Co % 64 == 0: tiled GEMM
+    ConvHaloPlan halo;                    // wide 3x3 layers on large maps: resident halo, streamed filter (opt-in, STCD_HALO_KERNEL=1)
 };
 struct WgradOp {
     stcd_conv_geom g{};
@@ -475,6 +476,11 @@ static void pick_gemm_or_res(const stcd_engine& e, ConvOp& op, const stcd_conv_g
     if (op.res.ok && !(mode == 2 || (mode == 1 && op.res.NT == 1))) return;
     op.gemm = conv_gemm_plan(g, op.plan, groups);
     if (op.gemm.ok) op.res = ConvResPlan();
+    // opt-in (measured 0.93 - 1.03 of k_conv_gemm on ChangeFormer's 256 -> 256 layers): layers that take the GEMM kernel,
+    // carry no fused BatchNorm statistics (groups == 1 callers that pass none) and fill the chip with 16 x 16 tiles
+    static const bool halo_on = [] { const char* v = getenv("STCD_HALO_KERNEL"); return v && v[0] == '1'; }();
+    op.halo = ConvHaloPlan();
+    if (halo_on && op.gemm.ok && (int64_t)g.n * ((g.hm + 15) / 16) * ((g.wm + 15) / 16) >= 512) op.halo = conv_halo_plan(g, op.plan);
 }
 
 // weight-gradient plan of one launch: the GEMM kernel for one-tap launches with >= 64 channels on both sides, else the tile kernel
@@ -952,7 +958,8 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     const bool small_path = !gemm_path && mfma_on(c.e) && op.small && op.wf >= 0 && c.e.use_small;
     const bool res_path = !gemm_path && !small_path && mfma_on(c.e) && op.res.ok && op.wf >= 0 && !nchw;
     const bool mfma_path = !small_path && !res_path && mfma_on(c.e) && op.plan.ok && op.wf >= 0;
-    if (gemm_path) snprintf(kname, sizeof(kname), "k_conv_gemm<%d>", op.gemm.W);
+    if (gemm_path && op.halo.ok && !(stat_groups > 0 && stat_acc)) snprintf(kname, sizeof(kname), "k_conv_halo");
+    else if (gemm_path) snprintf(kname, sizeof(kname), "k_conv_gemm<%d>", op.gemm.W);
     else if (res_path) snprintf(kname, sizeof(kname), "k_conv_res<%d, %d, %s>", op.res.NT, op.res.CW, op.res.single_halo ? "true" : "false");
     else if (small_path) snprintf(kname, sizeof(kname), "k_conv_small<1, %d>", (op.g.ntaps * op.g.ci + 31) / 32 <= 5 ? 5 : 9);
     else if (mfma_path) snprintf(kname, sizeof(kname), "k_conv_mfma<%d>", op.plan.NT);
@@ -960,6 +967,12 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     ProfScope prof(c, PC_CONV, fl, by, kname);
     if (stat_chunks) *stat_chunks = 0;
     if (epi_fused) *epi_fused = 0;
+    if (gemm_path && op.halo.ok && !(stat_groups > 0 && stat_acc)) {
+        if (launch_conv_halo(op.g, op.plan, op.halo, in, c.at(op.wf), bias, out, c.s, epi) == 0) {
+            if (epi_fused && epi) *epi_fused = 1;
+            return;
+        }
+    }
     if (gemm_path) {
         const bool want = stat_groups > 0 && stat_groups == op.res_groups && stat_acc;
         long long* sp = want ? stat_acc : nullptr;
@@ -2756,12 +2769,19 @@ int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, c
                  void* out, void* scratch, int64_t scratch_bytes, void* hip_stream) {
     if (check_geom(g)) return 1;
     STCD_CHECK(in && w && out, "null pointer argument");
-    if (impl == 1 || impl == 2) {
+    if (impl == 1 || impl == 2 || impl == 3) {
         STCD_CHECK(dtype == STCD_DTYPE_BF16, "the MFMA implementation is bf16 only");
         ConvMfmaPlan p = conv_mfma_plan(*g);
         STCD_CHECK(p.ok, "geometry not supported by the MFMA kernel");
         STCD_CHECK(scratch && scratch_bytes >= p.wf_elems * 2, "scratch too small for the fragment-order filter");
         launch_pack_frag(*g, p, w, g->ci, g->co, scratch, (hipStream_t)hip_stream);
+        if (impl == 3) {      // resident-halo / streamed-filter kernel of the wide 3x3 layers (Ci % 64 == 0, Co % 128 == 0)
+            const ConvHaloPlan hp = conv_halo_plan(*g, p);
+            STCD_CHECK(hp.ok, "geometry not supported by the resident-halo kernel (3x3 stride 1, Ci % 64 == 0, Co % 128 == 0)");
+            STCD_CHECK(launch_conv_halo(*g, p, hp, in, scratch, bias, out, (hipStream_t)hip_stream) == 0, "launch failed");
+            STCD_HIP(hipGetLastError());
+            return 0;
+        }
         if (impl == 1 && conv_small_ok(*g, p)) {
             STCD_CHECK(launch_conv_small(*g, in, scratch, bias, out, false, 1, nullptr, g->co, (hipStream_t)hip_stream) == 0,
                        "small-channel kernel rejected the geometry");
@@ -2786,7 +2806,7 @@ int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, c
         STCD_HIP(hipGetLastError());
         return 0;
     }
-    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA), 1 (MFMA, auto-selected kernel) or 2 (generic MFMA kernel)");
+    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA), 1 (MFMA, auto-selected kernel), 2 (generic MFMA kernel) or 3 (resident-halo kernel)");
     launch_conv_ref(dtype, *g, in, w, g->ci, g->co, bias, out, false, (hipStream_t)hip_stream);
     STCD_HIP(hipGetLastError());
     return 0;

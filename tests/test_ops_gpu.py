@@ -87,6 +87,32 @@ def test_conv3x3_mfma_vs_ref_vs_oracle(n, h, w, ci, co):
     np.testing.assert_allclose(outs[1].numpy(), outs[0].numpy(), rtol=2 ** -7, atol=2e-3)
 
 
+HALO_CASES = [(1, 16, 16, 128, 128), (1, 16, 16, 128, 256), (2, 20, 37, 128, 256), (1, 33, 16, 256, 128), (3, 48, 48, 256, 256),
+              (2, 8, 8, 128, 384), (1, 40, 24, 128, 512), (5, 128, 128, 128, 128), (9, 64, 64, 128, 256), (1, 24, 24, 384, 128)]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", HALO_CASES)
+def test_conv3x3_halo_kernel_vs_ref_vs_oracle(n, h, w, ci, co):
+    """k_conv_halo (impl 3: resident 18 x 18 x 64-channel halo, filter streamed per (chunk, tap) stage through a 3-deep LDS ring,
+    persistent 4-wave blocks of 16 x 16 pixels x 128 channels): ragged maps (masked border tiles), 2 ... 6 channel chunks, 1 ... 4
+    output-channel slices, and more tiles than blocks (5 x 128 x 128: 320 tiles over 256 blocks; 9 x 64 x 64 x 256 channels: 144
+    tiles over the 128 blocks of each slice -- the halo stream crosses tile boundaries)."""
+    rng = np.random.default_rng(ci * 1000 + co + h)
+    x = rnd(rng, n, h, w, ci).to(DEV)
+    wt = rnd(rng, 9, ci, co, scale=1.0 / np.sqrt(9 * ci)).float().to(DEV)
+    bias = torch.from_numpy(rng.standard_normal(co).astype(np.float32)).to(DEV)
+    g = geom(n, h, w, ci, ci, h, w, 1, h, w, 1, 0, 0, co, co, TAPS3)
+    outs = []
+    for impl in (0, 3):
+        out = torch.zeros(n, h, w, co, dtype=torch.bfloat16, device=DEV)
+        run_conv(impl, g, x, wt, bias, out)
+        outs.append(out.float().cpu())
+    w_ref = wt.cpu().numpy().reshape(3, 3, ci, co).transpose(3, 2, 0, 1)
+    ref = O.conv2d_fwd(x.float().cpu().numpy().transpose(0, 3, 1, 2), w_ref, bias.cpu().numpy(), 1).transpose(0, 2, 3, 1)
+    np.testing.assert_allclose(outs[1].numpy(), ref, rtol=2 ** -7, atol=2e-3, err_msg="halo kernel vs oracle")
+    np.testing.assert_allclose(outs[1].numpy(), outs[0].numpy(), rtol=2 ** -7, atol=2e-3, err_msg="halo kernel vs reference kernel")
+
+
 WGRAD_CASES = [(2, 40, 24, 192, 96), (1, 16, 16, 320, 32), (2, 16, 16, 8, 16), (2, 16, 32, 16, 16), (1, 24, 16, 16, 32), (2, 16, 16, 32, 32), (2, 8, 16, 64, 64),
                (1, 16, 16, 64, 128), (1, 8, 16, 128, 128), (1, 8, 16, 256, 128), (1, 16, 16, 48, 16), (1, 16, 16, 96, 32),
                (2, 16, 16, 16, 2), (1, 20, 18, 16, 16), (1, 9, 11, 64, 64), (4, 32, 32, 16, 16)]
