@@ -46,6 +46,10 @@ extern "C" {
 #define STCD_ARCH_SEGCD_R34 6  /* encoder_name="resnet34":  BasicBlock  [3, 4, 6, 3]  */
 #define STCD_ARCH_SEGCD_R101 7 /* encoder_name="resnet101": Bottleneck  [3, 4, 23, 3] */
 #define STCD_ARCH_SEGCD_R152 8 /* encoder_name="resnet152": Bottleneck  [3, 8, 36, 3] */
+/* "Unet" -> Unet, the FC-EF network of the same paper (models/Unet.py:10-154; define_G name "Unet", models/networks.py:144-145): ONE
+ * encoder stream over cat(x1, x2) (conv11 takes 2 * in_ch channels, in_ch <= 4), skips = the stream's own activations, decoder and
+ * state_dict layout of SiamUnet_diff; forward returns the logits tensor. */
+#define STCD_ARCH_FCEF 9
 /* smp.UnetSeg (decoders/unet/model.py:109-171), the single-image ResNet UNet train_sup.py:303 trains: the same encoder /
  * decoder / head on ONE image batch (x2 of stcd_forward is ignored; BatchNorm over the whole batch; logits [batch, label_ch,
  * H, W]).  STCD_ARCH_UNETSEG + k, k = 0..4: resnet50, resnet18, resnet34, resnet101, resnet152 (the order of the ids above). */

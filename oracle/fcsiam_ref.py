@@ -6,6 +6,8 @@ Follows, without sharing code with, the reference models:
   * SiamUnet_diff  -- /root/reference/models/SiamUnet_diff.py:13-92 (layers), :94-181 (forward)
   * SiamUnet_conc  -- /root/reference/models/SiamUnet_conc.py:54,66,78,87 (decoder widths), :149-172 (concat skips)
   * SiamUnet_sub   -- /root/reference/models/SiamUnet_sub.py:150-180 (signed skips, list return)
+  * Unet (FC-EF)   -- /root/reference/models/Unet.py:10-91 (layers: conv11 takes 2 * input_nbr channels), :93-154 (one stream over
+                      cat(x1, x2), skips = the stream's own activations)
 
 The network is written as a table walk with every non-conv op restated explicitly
 (transposed convs as flipped/transposed direct convs, batch-norm from its defining
@@ -13,7 +15,7 @@ sums, dropout as an explicit per-(n,c) scale), so that agreement with the refere
 (tests/golden) is a real check of the semantics the HIP engine implements.
 Backward comes from CPU autograd over these explicit ops.
 
-Parity status: pinned by tests/golden/g2_*.npz, g3_*.npz, g4_*.npz, g6_*.npz.
+Parity status: pinned by tests/golden/g2_*.npz, g3_*.npz, g4_*.npz, g6_*.npz (FC-EF: g2_fcef_*.npz, g19_fcef_step.npz).
 """
 from __future__ import annotations
 
@@ -42,7 +44,7 @@ DECODER = (
     ("upconv2", 32, (("22d", "cat", 32), ("21d", 32, 16))),
     ("upconv1", 16, (("12d", "cat", 16), ("11d", 16, None))),  # 11d: -> label_nbr, no BN
 )
-ARCHS = ("diff", "conc", "sub")
+ARCHS = ("diff", "conc", "sub", "fcef")
 
 
 def skip_channels(arch: str, c: int) -> int:
@@ -67,7 +69,7 @@ def param_specs(arch: str, in_ch: int, label: int):
 
     for stage in ENCODER:
         for sfx, ci, co in stage:
-            ci = in_ch if ci is None else ci
+            ci = (2 * in_ch if arch == "fcef" else in_ch) if ci is None else ci
             specs.append((f"conv{sfx}.weight", (co, ci, 3, 3), "conv_w"))
             specs.append((f"conv{sfx}.bias", (co,), "conv_b"))
             bn(f"bn{sfx}", co)
@@ -140,7 +142,7 @@ def synth_masks(arch: str, batch: int, seed: int, p: float = DROP_P):
     rng = np.random.default_rng(seed)
     masks = OrderedDict()
     for name, c, where in dropout_layers(arch):
-        n = 2 * batch if where == "enc" else batch
+        n = 2 * batch if (where == "enc" and arch != "fcef") else batch
         keep = (rng.random((n, c)) >= p).astype(np.float32) / (1.0 - p)
         masks[name] = torch.from_numpy(keep)
     return masks
@@ -225,7 +227,8 @@ def forward(arch, st, x1, x2, training=False, masks=None):
     B = x1.shape[0]
     skips = []
     bott = None
-    for t, x in enumerate((x1, x2)):
+    streams = (torch.cat((x1, x2), 1),) if arch == "fcef" else (x1, x2)      # Unet.py:94
+    for t, x in enumerate(streams):
         feats = []
         for stage in ENCODER:
             for sfx, _, _ in stage:
@@ -237,10 +240,12 @@ def forward(arch, st, x1, x2, training=False, masks=None):
         bott = x  # T2's pooled map overwrites T1's (SiamUnet_diff.py:119 then :143)
     x = bott
     for lvl, (up, c, convs) in zip((3, 2, 1, 0), DECODER):
-        f1, f2 = skips[0][lvl], skips[1][lvl]
+        f1, f2 = skips[0][lvl], skips[-1][lvl]
         x = convT3x3_s2(x, st[f"{up}.weight"], st[f"{up}.bias"])
         x = pad_to(x, f1)
-        if arch == "diff":
+        if arch == "fcef":
+            x = torch.cat((x, f1), 1)                    # Unet.py:128
+        elif arch == "diff":
             x = torch.cat((x, torch.abs(f1 - f2)), 1)   # SiamUnet_diff.py:150
         elif arch == "sub":
             x = torch.cat((x, f2 - f1), 1)               # SiamUnet_sub.py:150

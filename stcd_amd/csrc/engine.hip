@@ -388,14 +388,19 @@ static const DecSpec DEC[4] = {
     {"upconv1", 16, 2, {"12d", "11d", nullptr}, {16, -1, 0}},   // 11d -> label_nbr, no BN
 };
 
+// FC-EF (`Unet`, models/Unet.py:93-154): the FC-Siam-conc plan with ONE encoder stream over cat(x1, x2) -- every encoder tensor holds
+// B images in one BatchNorm group, the skips are the stream's own activations, written straight into the concat buffers
+static inline int fc_dates(const stcd_engine& e) { return e.arch == STCD_ARCH_FCEF ? 1 : 2; }
+static inline bool fc_concat_skips(const stcd_engine& e) { return e.arch == STCD_ARCH_CONC || e.arch == STCD_ARCH_FCEF; }
+
 static void build_fcsiam_tables(stcd_engine& e) {
     // registration order of SiamUnet_*.__init__ (SiamUnet_diff.py:18-90): conv, bn per layer; upconv before its stage
     for (int s = 0; s < 4; ++s)
         for (int j = 0; j < ENC_STAGE_CONVS[s]; ++j) {
             std::string sfx = std::to_string(s + 1) + std::to_string(j + 1);
-            int cin = j == 0 ? (s == 0 ? e.in_ch : ENC_C[s - 1]) : ENC_C[s];
+            int cin = j == 0 ? (s == 0 ? (e.arch == STCD_ARCH_FCEF ? 2 * e.in_ch : e.in_ch) : ENC_C[s - 1]) : ENC_C[s];
             add_conv(e, "conv" + sfx, K_CONV3, cin, ENC_C[s], !(s == 0 && j == 0));
-            add_bn(e, "bn" + sfx, ENC_C[s], 2);
+            add_bn(e, "bn" + sfx, ENC_C[s], fc_dates(e));
         }
     e.enc_param_end = e.param_floats;
     for (int k = 0; k < 4; ++k) {
@@ -651,6 +656,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
 
 static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     const int64_t T = (int64_t)dsize(e.dt);
+    const int ND = fc_dates(e);            // encoder streams (dates) stacked in the batch dimension
     e.enc.clear(); e.dec.clear(); e.ups.clear(); e.drops.clear();
     e.drop_floats = 0;
     e.Hs[0] = H; e.Ws[0] = W;
@@ -664,14 +670,14 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     };
     auto plain = [&](int N, int h, int w, int C) { TRef t; t.off = ws.take((int64_t)N * h * w * C * T); t.ld = C; return t; };
 
-    e.X0 = plain(2 * B, H, W, 8);
+    e.X0 = plain(ND * B, H, W, 8);
     // concat buffers first (conc keeps its skips inside them)
     for (int s = 0; s < 4; ++s) {
         int Cd = ENC_C[s] + (e.arch == STCD_ARCH_CONC ? 2 : 1) * ENC_C[s];
         e.D[s] = plain(B, e.Hs[s], e.Ws[s], Cd);
         e.dD[s] = plain(B, e.Hs[s], e.Ws[s], Cd);
-        e.P[s] = plain(2 * B, e.Hs[s + 1], e.Ws[s + 1], ENC_C[s]);
-        e.dP[s] = plain(2 * B, e.Hs[s + 1], e.Ws[s + 1], ENC_C[s]);
+        e.P[s] = plain(ND * B, e.Hs[s + 1], e.Ws[s + 1], ENC_C[s]);
+        e.dP[s] = plain(ND * B, e.Hs[s + 1], e.Ws[s + 1], ENC_C[s]);
     }
     // ---- zero arena, directly behind dP[3] (whose date-0 half must read as zero: the reference's T1 bottleneck pool is
     //      dead work, SiamUnet_diff.py:119 overwritten at :143; the date-1 half is rewritten by upconv4's data gradient):
@@ -697,25 +703,25 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             Cbrd L;
             L.conv = conv_index(e, "conv" + sfx);
             L.bn = bn_index(e, "bn" + sfx);
-            L.drop = add_drop("do" + sfx, 2 * B, C);
-            L.N = 2 * B; L.H = h; L.W = w; L.groups = 2; L.npg = B;
+            L.drop = add_drop("do" + sfx, ND * B, C);
+            L.N = ND * B; L.H = h; L.W = w; L.groups = ND; L.npg = B;
             const bool first = j == 0, last = j == ENC_STAGE_CONVS[s] - 1;
             if (first && s == 0) { L.in = e.X0; L.K = 8; }
             else if (first) { L.in = e.P[s - 1]; L.K = ENC_C[s - 1]; }
             else { L.in.off = e.enc.back().A.off; L.in.ld = C; L.K = C; }
-            L.Y = plain(2 * B, h, w, C);
-            if (last && e.arch == STCD_ARCH_CONC) {
+            L.Y = plain(ND * B, h, w, C);
+            if (last && fc_concat_skips(e)) {
                 L.A.off = e.D[s].off + C * T; L.A.ld = e.D[s].ld; L.A.goff = C;
                 L.dA.off = e.dD[s].off + C * T; L.dA.ld = e.dD[s].ld; L.dA.goff = C;
-                L.dY = plain(2 * B, h, w, C);
+                L.dY = plain(ND * B, h, w, C);
             } else {
-                TRef a = plain(2 * B, h, w, C), da = plain(2 * B, h, w, C);
+                TRef a = plain(ND * B, h, w, C), da = plain(ND * B, h, w, C);
                 L.A.off = a.off; L.A.ld = C; L.A.goff = (int64_t)B * h * w * C;
                 L.dA.off = da.off; L.dA.ld = C; L.dA.goff = L.A.goff;
                 L.dY = da;   // in place
             }
             if (last) { L.pool = true; L.P = e.P[s]; L.dPool = e.dP[s]; }
-            if (last && e.arch != STCD_ARCH_CONC) { L.fuse_dst.off = e.D[s].off + C * T; L.fuse_dst.ld = e.D[s].ld; }
+            if (last && !fc_concat_skips(e)) { L.fuse_dst.off = e.D[s].off + C * T; L.fuse_dst.ld = e.D[s].ld; }
             if (first && s == 0) L.has_dIn = false;
             else if (first) { L.has_dIn = true; L.dIn = e.dP[s - 1]; }
             else { L.has_dIn = true; L.dIn.off = e.enc.back().dA.off; L.dIn.ld = C; }
@@ -724,8 +730,9 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         }
     }
     // ---- decoder
-    TRef prevA = {e.P[3].off + (int64_t)B * e.Hs[4] * e.Ws[4] * ENC_C[3] * T, ENC_C[3]};    // T2 half of the last pool
-    TRef prevdA = {e.dP[3].off + (int64_t)B * e.Hs[4] * e.Ws[4] * ENC_C[3] * T, ENC_C[3]};
+    // T2 half of the last pool (FC-EF: the one stream's)
+    TRef prevA = {e.P[3].off + (int64_t)(fc_dates(e) - 1) * B * e.Hs[4] * e.Ws[4] * ENC_C[3] * T, ENC_C[3]};
+    TRef prevdA = {e.dP[3].off + (int64_t)(fc_dates(e) - 1) * B * e.Hs[4] * e.Ws[4] * ENC_C[3] * T, ENC_C[3]};
     for (int k = 0; k < 4; ++k) {
         const DecSpec& d = DEC[k];
         const int s = 3 - k, h = e.Hs[s], w = e.Ws[s];
@@ -1216,7 +1223,7 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
     }
     if (pack_all_weights(c, training != 0)) return 1;
     if (training) STCD_HIP(hipMemsetAsync(c.at(e.zero_begin), 0, e.zero_end - e.zero_begin, s));   // the step's ONE workspace memset
-    launch_in_pack(dt, x1, x2, c.at(e.X0.off), B, e.in_ch, e.H, e.W, s);
+    launch_in_pack(dt, x1, x2, c.at(e.X0.off), B, e.in_ch, e.H, e.W, s, e.arch == STCD_ARCH_FCEF ? 0 : 2);      // 0: cat(x1, x2) along the channels
     for (auto& L : e.enc) cbrd_forward(c, L, bn_running, training != 0);
     size_t di = 0;
     for (int k = 0; k < 4; ++k) {
@@ -1224,7 +1231,7 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
         const int s_ = U.level, C = ENC_C[s_];
         upconv_forward(c, U);
         const Cbrd& skip = e.enc[SKIP_IDX[s_]];
-        if (e.arch != STCD_ARCH_CONC && !(e.use_act_fuse && skip.fuse_dst.off >= 0)) {
+        if (!fc_concat_skips(e) && !(e.use_act_fuse && skip.fuse_dst.off >= 0)) {
             ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.0 * B * e.Hs[s_] * e.Ws[s_] * C * (double)T);
             launch_fuse(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(skip.A.off), skip.A.ld, skip.A.goff,
                         c.at<char>(e.D[s_].off) + C * T, e.D[s_].ld, B, (int64_t)e.Hs[s_] * e.Ws[s_], C, s);
@@ -1262,7 +1269,7 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
             const int s_ = U.level, C = ENC_C[s_];
             upconv_backward(c, U);
             const Cbrd& skip = e.enc[SKIP_IDX[s_]];
-            if (e.arch != STCD_ARCH_CONC && !e.use_skip_fused) {
+            if (!fc_concat_skips(e) && !e.use_skip_fused) {
                 ProfScope ps(c, PC_POOL_FUSE, 0.0, (e.arch == STCD_ARCH_DIFF ? 5.0 : 3.0) * B * e.Hs[s_] * e.Ws[s_] * C * (double)T);
                 launch_fuse_bwd(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(skip.A.off), skip.A.ld, skip.A.goff,
                                 c.at<char>(e.dD[s_].off) + C * T, e.dD[s_].ld, c.at(skip.dA.off), skip.dA.ld, skip.dA.goff, B,
@@ -1276,7 +1283,7 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
         for (int li = (int)e.enc.size() - 1; li >= 0; --li) {
             const Cbrd& L = e.enc[li];
             int skip_chunks = 0;
-            if (L.pool && e.arch != STCD_ARCH_CONC && e.use_skip_fused) {
+            if (L.pool && !fc_concat_skips(e) && e.use_skip_fused) {
                 // pool gradient + skip-fusion gradient + BN partial sums of the level's last conv in one pass
                 const int C = e.convs[L.conv].cout;
                 int lvl = 0;
@@ -2473,7 +2480,8 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
         cfg.in_ch = in_ch; cfg.out_ch = label_ch;
         return stcd_create_changeformer(&cfg, dtype, out);
     }
-    STCD_CHECK((arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD_R152) || is_unetseg(arch) || is_ffctlcd(arch), "unknown arch");
+    STCD_CHECK((arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD_R152) || arch == STCD_ARCH_FCEF || is_unetseg(arch) || is_ffctlcd(arch), "unknown arch");
+    STCD_CHECK(arch != STCD_ARCH_FCEF || in_ch <= 4, "FC-EF concatenates the two dates along the channels: in_ch must be <= 4");
     STCD_CHECK(in_ch >= 1 && in_ch <= 8, "in_ch must be in [1,8]");
     STCD_CHECK(label_ch >= 1 && label_ch <= 8, "label_ch must be in [1,8]");
     STCD_CHECK(dtype == STCD_DTYPE_F32 || dtype == STCD_DTYPE_BF16, "unknown dtype");

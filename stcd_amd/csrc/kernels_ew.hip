@@ -57,23 +57,32 @@ struct GV {
 // ------------------------------------------------------------------ pack / unpack at the NCHW fp32 boundary
 template <typename T>
 __global__ void k_in_pack(const float* __restrict__ x1, const float* __restrict__ x2, T* __restrict__ X, int B, int cin,
-                          int64_t HW, int64_t total) {
+                          int64_t HW, int64_t total, int concat) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int n = (int)(i / HW);
     int64_t p = i - (int64_t)n * HW;
-    const float* src = (n < B ? x1 + (int64_t)n * cin * HW : x2 + (int64_t)(n - B) * cin * HW) + p;
     float v[8];
+    if (concat) {       // image n = cat(x1[n], x2[n]) along the channels (FC-EF, Unet.py:94)
+        const float* s1 = x1 + (int64_t)n * cin * HW + p;
+        const float* s2 = x2 + (int64_t)n * cin * HW + p;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) v[c] = c < cin ? src[(int64_t)c * HW] : 0.f;
+        for (int c = 0; c < 8; ++c) v[c] = c < cin ? s1[(int64_t)c * HW] : c < 2 * cin ? s2[(int64_t)(c - cin) * HW] : 0.f;
+    } else {
+        const float* src = (n < B ? x1 + (int64_t)n * cin * HW : x2 + (int64_t)(n - B) * cin * HW) + p;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = c < cin ? src[(int64_t)c * HW] : 0.f;
+    }
     store8<T>(X + i * 8, v);
 }
 
-// dates = 2: images [x1; x2] (2B of them); dates = 1: x1 alone (single-image networks: x2 is not read)
+// dates = 2: images [x1; x2] (2B of them); dates = 1: x1 alone (single-image networks: x2 is not read); dates = 0: B images of
+// cat(x1, x2) along the channels (2 * cin <= 8)
 void launch_in_pack(int dt, const float* x1, const float* x2, void* X, int B, int cin, int H, int W, hipStream_t s, int dates) {
-    int64_t HW = (int64_t)H * W, n = (int64_t)dates * B * HW;
-    if (dt == BF16) k_in_pack<bf16><<<cdiv(n, 256), 256, 0, s>>>(x1, x2, (bf16*)X, B, cin, HW, n);
-    else k_in_pack<float><<<cdiv(n, 256), 256, 0, s>>>(x1, x2, (float*)X, B, cin, HW, n);
+    const int concat = dates == 0 ? 1 : 0;
+    int64_t HW = (int64_t)H * W, n = (int64_t)(concat ? 1 : dates) * B * HW;
+    if (dt == BF16) k_in_pack<bf16><<<cdiv(n, 256), 256, 0, s>>>(x1, x2, (bf16*)X, B, cin, HW, n, concat);
+    else k_in_pack<float><<<cdiv(n, 256), 256, 0, s>>>(x1, x2, (float*)X, B, cin, HW, n, concat);
 }
 
 template <typename T>

@@ -327,7 +327,7 @@ class _FCSiam(HipChangeDetector):
         self.input_nbr = input_nbr
         for stage in _ENC:
             for sfx, ci, co in stage:
-                ci = input_nbr if ci is None else ci
+                ci = (2 * input_nbr if self.ARCH == "fcef" else input_nbr) if ci is None else ci
                 setattr(self, f"conv{sfx}", nn.Conv2d(ci, co, kernel_size=3, padding=1))
                 setattr(self, f"bn{sfx}", nn.BatchNorm2d(co))
                 setattr(self, f"do{sfx}", nn.Dropout2d(p=0.2))
@@ -359,6 +359,12 @@ class SiamUnet_sub(_FCSiam):
     """Signed skips f2 - f1; returns a one-element list like the reference (SiamUnet_sub.py:150,177-180)."""
     ARCH = "sub"
     RETURNS_LIST = True
+
+
+class Unet(_FCSiam):
+    """FC-EF (models/Unet.py:10-154): ONE encoder stream over cat(x1, x2) (conv11 takes 2 * input_nbr channels), skips = the
+    stream's own activations (Unet.py:128,136,144,151), SiamUnet_diff's decoder; returns the logits tensor."""
+    ARCH = "fcef"
 
 
 class _NestedBlockHolder(nn.Module):

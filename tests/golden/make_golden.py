@@ -37,13 +37,14 @@ from models.SiamUnet_diff import SiamUnet_diff      # noqa: E402  (reference)
 from models.SiamUnet_conc import SiamUnet_conc      # noqa: E402
 from models.SiamUnet_sub import SiamUnet_sub        # noqa: E402
 from models.SNUNet import SNUNet_ECAM               # noqa: E402
+from models.Unet import Unet as RefUnet             # noqa: E402  (FC-EF)
 from models import losses as ref_losses             # noqa: E402
 
 from oracle import fcsiam_ref, snunet_ref           # noqa: E402  (only for synth_state / synth_masks)
 from stcd_amd import synth                          # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
-REF_CLS = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub}
+REF_CLS = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub, "fcef": RefUnet}
 torch.set_num_threads(8)
 
 
@@ -186,8 +187,8 @@ def g1_ops():
 
 # ------------------------------------------------------------------------------ G2
 
-def g2_fcsiam():
-    for arch in ("diff", "conc", "sub"):
+def g2_fcsiam(archs=("diff", "conc", "sub")):
+    for arch in archs:
         for label in (1, 2):
             print(f"G2 {arch} label={label}")
             seed = 200 + 10 * fcsiam_ref.ARCHS.index(arch) + label
@@ -369,12 +370,12 @@ def g6_odd():
 
 
 # ------------------------------------------------------------------------------ G7
-def g7_train128():
+def g7_train128(archs=("diff", "conc", "snunet")):
     """Train-mode step at 2 x 128 x 128 (bottleneck BatchNorm over 2*8*8 samples instead of G2's 2*2*2): the vectors the
     bf16 production path is held to -- logits, loss and every parameter's (sampled) gradient of diff / conc / SNUNet."""
-    for arch in ("diff", "conc", "snunet"):
+    for arch in archs:
         print(f"G7 {arch} 128x128")
-        seed = 700 + ("diff", "conc", "snunet").index(arch)
+        seed = 700 + ("diff", "conc", "snunet", "fcef").index(arch)
         d = {"seed": seed}
         x1, x2 = rand_pair(seed + 1, 2, 128, 128)
         rng = np.random.default_rng(seed + 4)
@@ -400,6 +401,13 @@ def g7_train128():
 
 
 # ------------------------------------------------------------------------------ G8
+def g19_fcef():
+    """FC-EF (`Unet`, models/Unet.py): the G2 pair (eval + train step with masks, label 1 and 2, 2 x 32 x 32) and the G7 step
+    (2 x 128 x 128), from the reference's own class."""
+    g2_fcsiam(("fcef",))
+    g7_train128(("fcef",))
+
+
 def g8_contrastive():
     """contrastive_loss of /root/reference/train_stcd.py:334-385.  The module cannot be imported (argparse at import time,
     pytorch_grad_cam / smp / timm absent), so the reference's OWN function is compiled from its file (ast: that one
@@ -653,9 +661,9 @@ def g17_cf_base():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd,
           "g7": g7_train128, "g8": g8_contrastive, "g10": g10_segcd, "g11": g11_segcd, "g12": g12_segcd_r18, "g13": g13_segcd_r34,
-          "g14": g14_segcd_r101, "g15": g15_unetseg, "g16": g16_ffctlcd, "g17": g17_cf_base, "g18": g18_segcd_wide}
+          "g14": g14_segcd_r101, "g15": g15_unetseg, "g16": g16_ffctlcd, "g17": g17_cf_base, "g18": g18_segcd_wide, "g19": g19_fcef}
     for w in which:
         fn[w]()

@@ -106,7 +106,7 @@ def test_two_rank_bf16_buckets_accumulate_in_fp32():
 # the reducer: the two slices must be disjoint, cover the flat gradient buffer, stage 0 must hold exactly the decoder's
 # tensors (final first, so its collective overlaps the encoder's backward), and a 2-rank run over those slices must
 # deliver the mean everywhere -- also with a trainer-shaped epoch metric all-reduce.
-ARCHES = [("diff", 0), ("conc", 1), ("sub", 2), ("snunet", 3), ("segcd", 4), ("segcd_resnet18", 5), ("segcd_resnet101", 7),
+ARCHES = [("diff", 0), ("conc", 1), ("sub", 2), ("fcef", 9), ("snunet", 3), ("segcd", 4), ("segcd_resnet18", 5), ("segcd_resnet101", 7),
           ("unetseg_resnet34", 18), ("ffctlcd_resnet50", 32), ("changeformer", 64)]
 SINGLE_STAGE = ("snunet", "segcd", "unetseg", "ffctlcd")
 
