@@ -139,6 +139,11 @@ uint32_t stcd_cf_site_seed(uint64_t seed, int site);
 /* change the element-wise dropout rates of a ChangeFormer engine (re-run stcd_configure afterwards); DropPath rates are fixed at
  * creation (they are a per-block schedule) */
 int stcd_cf_set_drop_rates(stcd_engine* e, float drop_rate, float attn_drop, float diff_drop);
+/* multi_scale_train (models/trainer.py:300-309: the loss is a weighted sum over ALL five predictions): on != 0 makes stcd_backward
+ * propagate the gradients of the four auxiliary maps too -- `grad_logits` then carries d(loss)/d(p_c4 ... p_c1, cp) in the output
+ * layout of stcd_cf_output_info (make_prediction, models/ChangeFormer.py:1151-1157: conv - ReLU - BatchNorm - conv per scale).  Off
+ * (the default, multi_scale_train == "False", trainer.py:311): only cp's gradient is read. */
+int stcd_cf_set_aux_backward(stcd_engine* e, int on);
 
 /* ---- parameter / buffer enumeration in the reference's registration order (state_dict compatibility,
  *      /root/reference/models/trainer.py:138,183; basic_model.py:35) ---- */

@@ -262,13 +262,18 @@ class ChangeFormerV6(HipChangeDetector):
         return [flat[off:off + B * L * h * w].view(B, L, h, w) for off, h, w in self._engine.cf_outputs()]
 
     def _merge_grads(self, flat, grads):
-        if any(g is not None for g in grads[:4]):
-            raise StcdError("ChangeFormer: only the last output (cp) is differentiated by the engine (the reference's default loss, "
-                            "trainer.py:311); gradients into the auxiliary maps p_c4..p_c1 (multi_scale_train) are not supported")
+        """Gradients of the five outputs in the engine's output layout.  A gradient into p_c4 .. p_c1 (the reference's
+        multi_scale_train loss, trainer.py:300-309) switches the auxiliary heads' backward on for this step."""
+        aux = any(g is not None for g in grads[:4])
+        if aux != getattr(self, "_aux_bwd", False):
+            self._engine.cf_set_aux_backward(aux)
+            self._aux_bwd = aux
         g = torch.zeros_like(flat)
-        if grads[4] is not None:
-            off, h, w = self._engine.cf_outputs()[4]
-            g[off:off + grads[4].numel()].copy_(grads[4].reshape(-1))
+        outs = self._engine.cf_outputs()
+        for i in (range(5) if aux else (4,)):
+            if grads[i] is not None:
+                off = outs[i][0]
+                g[off:off + grads[i].numel()].copy_(grads[i].reshape(-1))
         return g
 
     def _wrap_output(self, out, B):

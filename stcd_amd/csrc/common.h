@@ -522,5 +522,9 @@ void launch_axpby(int dt, float alpha, const void* x, int ldx, float beta, const
 // fp32 NCHW [n, C, H, W] maps of the auxiliary prediction heads (ChangeFormer.py:1151-1157: ReLU - BatchNorm2d(C) - Conv3x3(C -> C), C <= 8)
 void launch_aux_head(const float* y, float* out, const float* bn_w, const float* bn_b, float* running_mean, float* running_var,
                      const float* w, const float* b, float* stat, int n, int C, int H, int W, int training, hipStream_t s);
+// backward of the same head given g = d(loss)/d(out): conv3's filter / bias gradients, BatchNorm's, and dy = d(loss)/d(y) (fp32 NCHW);
+// stat as the forward left it (scale, shift at [2c], mean, invstd at [16 + 2c]); dz / dy / sums: scratch of y's size / 16 floats
+void launch_aux_head_bwd(const float* y, const float* stat, const float* g, const float* w3, float* dz, float* dy, float* sums, float* dw3,
+                         float* db3, float* dgamma, float* dbeta, int n, int C, int H, int W, hipStream_t s);
 
 }  // namespace stcd

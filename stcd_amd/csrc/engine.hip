@@ -2452,6 +2452,11 @@ int stcd_cf_site_get(const stcd_engine* e, int i, stcd_cf_site* out) {
     return 0;
 }
 uint32_t stcd_cf_site_seed(uint64_t seed, int site) { return cf_site_seed(seed, site); }
+int stcd_cf_set_aux_backward(stcd_engine* e, int on) {
+    STCD_CHECK(e && e->cf, "not a ChangeFormer engine");
+    e->cf->aux_bwd = on != 0;
+    return 0;
+}
 int stcd_cf_set_drop_rates(stcd_engine* e, float drop_rate, float attn_drop, float diff_drop) {
     STCD_CHECK(e && e->cf, "not a ChangeFormer engine");
     for (float p : {drop_rate, attn_drop, diff_drop}) STCD_CHECK(p >= 0.f && p < 1.f, "drop rates must be in [0,1)");

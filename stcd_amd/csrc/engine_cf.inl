@@ -54,6 +54,10 @@ struct CfDiff {                 // linear_c + conv_diff + make_prediction of one
     // auxiliary head
     int aux_conv0 = -1, aux_bn = -1; int64_t aux_w3 = 0, aux_b3 = 0;
     ConvOp aux_fwd; int64_t aux_y = -1, aux_stat = -1; int64_t out_off = 0;
+    // its backward (multi_scale_train): fp32 scratch of the small maps, the packed gradient of the first conv's output, that conv's
+    // weight / data gradient launches, a temporary for the feature gradient it adds to c.g
+    ConvOp aux_dgr; WgradOp aux_wg;
+    int64_t aux_dz = -1, aux_dy = -1, aux_sums = -1, aux_G = -1, aux_dtmp = -1, aux_bias_acc = -1;
 };
 struct CfUp {                   // ConvTranspose2d(D, D, 4, stride 2, padding 1): 4 sub-pixel phases of 2x2 taps
     int conv[4] = {-1, -1, -1, -1};
@@ -71,6 +75,7 @@ struct CfPlan {
     float drop = 0.1f, attn_drop = 0.1f, drop_path = 0.1f, diff_drop = 0.6f;
     CfStage st[4];
     CfDiff df[4];               // index 0: scale 4 ... index 3: scale 1 (forward order)
+    bool aux_bwd = false;       // propagate the gradients of p_c4 ... p_c1 too (stcd_cf_set_aux_backward)
     CfGemm fuse; CfBN fuse_bn; CfT fcat, fy, fa;
     CfUp up2, up1; CfRes res2, res1;
     int head_conv = -1; ConvOp head_fwd, head_dgr; WgradOp head_wg;
@@ -170,7 +175,7 @@ static void build_cf_tables(stcd_engine& e) {
     for (int k = 0; k < 4; ++k) {
         CfDiff& F = P.df[k];
         const std::string n = d + "make_pred_c" + std::to_string(F.s);
-        F.aux_conv0 = add_conv(e, n + ".0", K_CONV3, D, e.label, false);
+        F.aux_conv0 = add_conv(e, n + ".0", K_CONV3, D, e.label, true);
         F.aux_bn = add_bn(e, n + ".2", e.label, 1);
         add_param(e, n + ".3.weight", {e.label, e.label, 3, 3}, &F.aux_w3);
         add_param(e, n + ".3.bias", {e.label}, &F.aux_b3);
@@ -230,6 +235,7 @@ static int configure_cf(stcd_engine& e, int B, int H, int W) {
     e.conv_ops.clear(); e.wgrad_ops.clear(); e.slab_floats = 0;
     e.ws_tensors.clear();
     P.sites.clear();
+    std::vector<CfDiff*> aux_pending;      // the auxiliary heads' backward launches are bound once the zero arena exists
     Bump ws;
     auto mk = [&](int n, int h, int w, int c, bool grad = true) {
         CfT t; t.n = n; t.h = h; t.w = w; t.c = c;
@@ -409,6 +415,15 @@ static int configure_cf(stcd_engine& e, int B, int H, int W) {
         F.aux_y = ws.take((int64_t)B * e.label * F.h * F.w * 4);
         F.aux_stat = ws.take(64 * 4);
         bind_conv(F.aux_fwd, geom3(B, F.h, F.w, D, F.c.v.ld, e.label, e.label), F.aux_conv0, false, 0, D, e.label);
+        {       // backward of the head (runs when stcd_cf_set_aux_backward is on; its weight-gradient job is part of the stage's grouped
+                // launch either way and reads aux_G, which lives in the zero arena: an all-zero gradient without it)
+            const ConvW& cv0 = e.convs[F.aux_conv0];
+            F.aux_dz = ws.take((int64_t)B * e.label * F.h * F.w * 4); F.aux_dy = ws.take((int64_t)B * e.label * F.h * F.w * 4);
+            F.aux_sums = ws.take(64 * 4);
+            F.aux_dtmp = ws.take((int64_t)B * F.h * F.w * D * T);
+            aux_pending.push_back(&F);
+            (void)cv0;
+        }
         F.out_off = out_off; out_off += (int64_t)B * e.label * F.h * F.w;
         const std::string dn = "dec.c" + std::to_string(F.s);
         recT(dn + ".lo", F.lo); recT(dn + ".cat", F.cat); recT(dn + ".ya", F.ya); recT(dn + ".aa", F.aa); recT(dn + ".yb", F.yb); recT(dn + ".c", F.c);
@@ -472,7 +487,14 @@ static int configure_cf(stcd_engine& e, int B, int H, int W) {
         for (CfBN* bn : {&P.df[k].bna, &P.df[k].bnb}) { bn->facc = ws.take(bn_acc_bytes(2, D)); bn->bacc = ws.take(bn_acc_bytes(2, D)); }
     P.fuse_bn.facc = ws.take(bn_acc_bytes(2, D)); P.fuse_bn.bacc = ws.take(bn_acc_bytes(2, D));
     e.final_bias_acc = ws.take(bn_acc_bytes(1, 8));
+    for (CfDiff* Fp : aux_pending) { Fp->aux_bias_acc = ws.take(bn_acc_bytes(1, 8)); Fp->aux_G = ws.take((int64_t)B * Fp->h * Fp->w * 8 * T); }
     e.zero_end = ws.cur;
+    for (CfDiff* Fp : aux_pending) {       // (bound OUTSIDE the arena: bind_conv carves the launch's fragment-order filter image from `ws`)
+        CfDiff& F = *Fp;
+        const ConvW& cv0 = e.convs[F.aux_conv0];
+        bind_wgrad(F.aux_wg, geom3(B, F.h, F.w, D, F.c.v.ld, e.label, 8), F.aux_conv0, F.c.v.off, F.aux_G, 0);
+        bind_conv(F.aux_dgr, geom3(B, F.h, F.w, cv0.dgrad.kpad, 8, D, D), F.aux_conv0, true, 0, e.label, D);
+    }
     e.scratch8 = ws.take(256);
     e.masks = ws.take(256);
     P.scratch_floats = scratch_floats; P.scratch = ws.take(scratch_floats * 4);
@@ -493,6 +515,10 @@ static int configure_cf(stcd_engine& e, int B, int H, int W) {
     {
         BiasJob jb{}; jb.acc_off = e.final_bias_acc; jb.out_off = e.convs[P.head_conv].b_off; jb.C = 8; jb.valid = e.label; jb.scale = BN_BS;
         e.bias_jobs.push_back(jb);
+        for (int k = 0; k < 4; ++k) {       // the auxiliary heads' first-conv biases (zero unless the aux backward runs)
+            BiasJob ja{}; ja.acc_off = P.df[k].aux_bias_acc; ja.out_off = e.convs[P.df[k].aux_conv0].b_off; ja.C = 8; ja.valid = e.label; ja.scale = BN_BS;
+            e.bias_jobs.push_back(ja);
+        }
         e.bias_jobs_off = ws.take((int64_t)e.bias_jobs.size() * sizeof(BiasJob) + 16);
     }
     build_pack_jobs(e, ws);
@@ -756,8 +782,9 @@ static int forward_cf(stcd_engine& e, const float* x1, const float* x2, const fl
     return 0;
 }
 
-// grad_logits: gradient of the LAST output (cp, [B, label, H, W]) at offset cp_off of the output layout; the auxiliary heads'
-// gradients are not propagated (the reference's default loss uses G_pred[-1] only: trainer.py:311, multi_scale_train == "False")
+// grad_logits: gradients in the OUTPUT layout (p_c4, p_c3, p_c2, p_c1, cp back to back).  cp's is always propagated; the auxiliary
+// heads' only with stcd_cf_set_aux_backward(e, 1) (the reference's default loss uses G_pred[-1] alone: trainer.py:311; with
+// multi_scale_train == "True" it is a weighted sum over all five maps, :300-309)
 static int backward_cf(stcd_engine& e, const float* grad_logits, const float* params, float* grads, void* workspace, int stage,
                        hipStream_t s) {
     Ctx c{e, (char*)workspace, params, grads, s};
@@ -785,6 +812,16 @@ static int backward_cf(stcd_engine& e, const float* grad_logits, const float* pa
             if (k < 3) {
                 const CfDiff& Nx = P.df[k + 1];
                 launch_bilinear_bwd(dt, c.at(Nx.c.g.off), Nx.c.g.ld, c.at(F.c.g.off), F.c.g.ld, B, F.h, F.w, Nx.h, Nx.w, D, 1, s);
+            }
+            if (P.aux_bwd) {       // + the gradient arriving through the scale's auxiliary prediction head (trainer.py:300-309)
+                const BnP& bp = e.bns[F.aux_bn];
+                launch_aux_head_bwd(c.at<float>(F.aux_y), c.at<float>(F.aux_stat), grad_logits + F.out_off, params + F.aux_w3, c.at<float>(F.aux_dz),
+                                    c.at<float>(F.aux_dy), c.at<float>(F.aux_sums), grads + F.aux_w3, grads + F.aux_b3, grads + bp.g_off,
+                                    grads + bp.b_off, B, e.label, F.h, F.w, s);
+                launch_gout_pack(dt, c.at<float>(F.aux_dy), c.at(F.aux_G), B, e.label, F.h, F.w, s, c.at<long long>(F.aux_bias_acc));
+                exec_wgrad(c, F.aux_wg, c.at(F.c.v.off), c.at(F.aux_G));
+                exec_conv(c, F.aux_dgr, c.at(F.aux_G), nullptr, c.at(F.aux_dtmp), false);
+                launch_slice(dt, c.at(F.c.g.off), F.c.g.ld, c.at(F.aux_dtmp), D, rows, D, 1, s);
             }
             launch_dropout_ew(dt, c.at(F.c.g.off), F.c.g.ld, c.at(F.bb.g.off), D, rows, D, cf_site(e, F.site0 + 1, P.diff_drop, true), s);
             cf_bn_backward(c, F.bnb, F.bb.g, F.zb.v, F.zb.g);

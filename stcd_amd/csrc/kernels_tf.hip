@@ -1221,6 +1221,8 @@ k_aux_stats(const float* __restrict__ y, const float* __restrict__ bn_w, const f
             const float inv = 1.f / sqrtf(var + 1e-5f);
             stat[2 * c] = bn_w[c] * inv;
             stat[2 * c + 1] = bn_b[c] - mean * bn_w[c] * inv;
+            stat[16 + 2 * c] = mean;           // for the backward (launch_aux_head_bwd)
+            stat[16 + 2 * c + 1] = inv;
         }
     }
 }
@@ -1248,6 +1250,92 @@ void launch_aux_head(const float* y, float* out, const float* bn_w, const float*
     k_aux_stats<<<1, 1024, 0, s>>>(y, bn_w, bn_b, running_mean, running_var, stat, n, C, (int64_t)H * W, training);
     const int64_t total = (int64_t)n * C * H * W;
     k_aux_conv<<<cdiv(total, 256), 256, 0, s>>>(y, stat, w, b, out, C, H, W, total);
+}
+
+// ---- backward of the auxiliary head (multi_scale_train, models/trainer.py:300-309): everything on the tiny fp32 NCHW maps, in a
+//      fixed summation order (one block per reduced value, double-precision tree): conv3's data / filter / bias gradients, the
+//      BatchNorm backward with batch statistics, the ReLU gate.  dy = gradient of the first conv's output (the engine packs it and
+//      runs that conv's weight / data gradient on the MFMA kernels).
+// dz[n, ci, q] = sum_{co, k} g[n, co, q - (k - 1)] * w3[co][ci][k]
+__global__ void __launch_bounds__(256)
+k_aux_bwd_dz(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dz, int C, int H, int W, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % W), yy = (int)((idx / W) % H), ci = (int)((idx / ((int64_t)W * H)) % C), n = (int)(idx / ((int64_t)W * H * C));
+    float acc = 0.f;
+    for (int co = 0; co < C; ++co) {
+        const float* p = g + ((int64_t)n * C + co) * H * W;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const int oy = yy - (ky - 1), ox = x - (kx - 1);
+                if ((unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W) acc += p[(int64_t)oy * W + ox] * w[((co * C + ci) * 3 + ky) * 3 + kx];
+            }
+    }
+    dz[idx] = acc;
+}
+// block b < C*C*9: dw3[co][ci][ky][kx] = sum g[n, co, p] * z[n, ci, p + k - 1] (z = relu(y)*sc + sh inside the map, 0 outside);
+// C*C*9 <= b < C*C*9 + C: db3[co] = sum g;  then per channel c: S1 = sum dz, S2 = sum dz * rhat (rhat = (relu(y) - mean) * inv) ->
+// dbeta, dgamma and sums[2c], sums[2c + 1] for the elementwise pass
+__global__ void __launch_bounds__(256)
+k_aux_bwd_reduce(const float* __restrict__ y, const float* __restrict__ stat, const float* __restrict__ g, const float* __restrict__ dz,
+                 float* __restrict__ dw3, float* __restrict__ db3, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                 float* __restrict__ sums, int n, int C, int H, int W) {
+    __shared__ double r1[256], r2[256];
+    const int b = blockIdx.x, nw = C * C * 9;
+    const int64_t HW = (int64_t)H * W, tot = (int64_t)n * HW;
+    double a1 = 0.0, a2 = 0.0;
+    if (b < nw) {
+        const int kx = b % 3, ky = (b / 3) % 3, ci = (b / 9) % C, co = b / (9 * C);
+        const float sc = stat[2 * ci], sh = stat[2 * ci + 1];
+        for (int64_t i = threadIdx.x; i < tot; i += 256) {
+            const int img = (int)(i / HW);
+            const int64_t p = i - (int64_t)img * HW;
+            const int py = (int)(p / W) + ky - 1, px = (int)(p % W) + kx - 1;
+            if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W)
+                a1 += (double)g[((int64_t)img * C + co) * HW + p] * (double)(fmaxf(y[((int64_t)img * C + ci) * HW + (int64_t)py * W + px], 0.f) * sc + sh);
+        }
+    } else if (b < nw + C) {
+        const int co = b - nw;
+        for (int64_t i = threadIdx.x; i < tot; i += 256) { const int img = (int)(i / HW); a1 += (double)g[((int64_t)img * C + co) * HW + (i - (int64_t)img * HW)]; }
+    } else {
+        const int c = b - nw - C;
+        const float mean = stat[16 + 2 * c], inv = stat[16 + 2 * c + 1];
+        for (int64_t i = threadIdx.x; i < tot; i += 256) {
+            const int img = (int)(i / HW);
+            const int64_t at = ((int64_t)img * C + c) * HW + (i - (int64_t)img * HW);
+            const double d = dz[at];
+            a1 += d; a2 += d * (double)((fmaxf(y[at], 0.f) - mean) * inv);
+        }
+    }
+    r1[threadIdx.x] = a1; r2[threadIdx.x] = a2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (b < nw) dw3[b] = (float)r1[0];
+        else if (b < nw + C) db3[b - nw] = (float)r1[0];
+        else { const int c = b - nw - C; dbeta[c] = (float)r1[0]; dgamma[c] = (float)r2[0]; sums[2 * c] = (float)(r1[0] / (double)tot); sums[2 * c + 1] = (float)(r2[0] / (double)tot); }
+    }
+}
+// dy = (y > 0) ? gamma * inv * (dz - mean(dz) - rhat * mean(dz * rhat)) : 0
+__global__ void __launch_bounds__(256)
+k_aux_bwd_dy(const float* __restrict__ y, const float* __restrict__ stat, const float* __restrict__ dz, const float* __restrict__ sums,
+             float* __restrict__ dy, int C, int64_t HW, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)((idx / HW) % C);
+    const float v = y[idx], mean = stat[16 + 2 * c], inv = stat[16 + 2 * c + 1];
+    const float rhat = (fmaxf(v, 0.f) - mean) * inv;
+    dy[idx] = v > 0.f ? stat[2 * c] * (dz[idx] - sums[2 * c] - rhat * sums[2 * c + 1]) : 0.f;
+}
+void launch_aux_head_bwd(const float* y, const float* stat, const float* g, const float* w3, float* dz, float* dy, float* sums, float* dw3,
+                         float* db3, float* dgamma, float* dbeta, int n, int C, int H, int W, hipStream_t s) {
+    const int64_t total = (int64_t)n * C * H * W;
+    k_aux_bwd_dz<<<cdiv(total, 256), 256, 0, s>>>(g, w3, dz, C, H, W, total);
+    k_aux_bwd_reduce<<<C * C * 9 + 2 * C, 256, 0, s>>>(y, stat, g, dz, dw3, db3, dgamma, dbeta, sums, n, C, H, W);
+    k_aux_bwd_dy<<<cdiv(total, 256), 256, 0, s>>>(y, stat, dz, sums, dy, C, (int64_t)H * W, total);
 }
 
 }  // namespace stcd
