@@ -142,7 +142,8 @@ int stcd_cf_set_drop_rates(stcd_engine* e, float drop_rate, float attn_drop, flo
 /* multi_scale_train (models/trainer.py:300-309: the loss is a weighted sum over ALL five predictions): on != 0 makes stcd_backward
  * propagate the gradients of the four auxiliary maps too -- `grad_logits` then carries d(loss)/d(p_c4 ... p_c1, cp) in the output
  * layout of stcd_cf_output_info (make_prediction, models/ChangeFormer.py:1151-1157: conv - ReLU - BatchNorm - conv per scale).  Off
- * (the default, multi_scale_train == "False", trainer.py:311): only cp's gradient is read. */
+ * (the default, multi_scale_train == "False", trainer.py:311): only cp's gradient is read and the heads' backward launches are not
+ * part of the plan.  Changing the setting invalidates the plan: call stcd_configure (and re-query stcd_workspace_bytes) afterwards. */
 int stcd_cf_set_aux_backward(stcd_engine* e, int on);
 
 /* ---- parameter / buffer enumeration in the reference's registration order (state_dict compatibility,

@@ -261,16 +261,22 @@ class ChangeFormerV6(HipChangeDetector):
         L = self._engine.label_ch
         return [flat[off:off + B * L * h * w].view(B, L, h, w) for off, h, w in self._engine.cf_outputs()]
 
+    def set_multi_scale_train(self, on: bool = True):
+        """The reference's `multi_scale_train == "True"` (models/trainer.py:300-309: the loss is a weighted sum over all five
+        predictions): plan the backward of the four auxiliary heads as well.  Off by default, as in the reference (the heads'
+        weight-gradient jobs and scratch maps are then not part of the step at all)."""
+        self._engine.cf_set_aux_backward(bool(on))
+        self._aux_bwd = bool(on)
+
     def _merge_grads(self, flat, grads):
-        """Gradients of the five outputs in the engine's output layout.  A gradient into p_c4 .. p_c1 (the reference's
-        multi_scale_train loss, trainer.py:300-309) switches the auxiliary heads' backward on for this step."""
+        """Gradients of the five outputs in the engine's output layout."""
         aux = any(g is not None for g in grads[:4])
-        if aux != getattr(self, "_aux_bwd", False):
-            self._engine.cf_set_aux_backward(aux)
-            self._aux_bwd = aux
+        if aux and not getattr(self, "_aux_bwd", False):
+            raise StcdError("ChangeFormer: a gradient arrived for the auxiliary maps p_c4..p_c1 (a multi-scale loss, trainer.py:300-309) but "
+                            "the engine was planned for the default cp-only loss: call model.set_multi_scale_train(True) before the step")
         g = torch.zeros_like(flat)
         outs = self._engine.cf_outputs()
-        for i in (range(5) if aux else (4,)):
+        for i in range(5):
             if grads[i] is not None:
                 off = outs[i][0]
                 g[off:off + grads[i].numel()].copy_(grads[i].reshape(-1))

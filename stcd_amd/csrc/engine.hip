@@ -2454,6 +2454,7 @@ int stcd_cf_site_get(const stcd_engine* e, int i, stcd_cf_site* out) {
 uint32_t stcd_cf_site_seed(uint64_t seed, int site) { return cf_site_seed(seed, site); }
 int stcd_cf_set_aux_backward(stcd_engine* e, int on) {
     STCD_CHECK(e && e->cf, "not a ChangeFormer engine");
+    if (e->cf->aux_bwd != (on != 0)) e->configured = false;      // the heads' backward launches and scratch are part of the plan
     e->cf->aux_bwd = on != 0;
     return 0;
 }

@@ -415,8 +415,7 @@ static int configure_cf(stcd_engine& e, int B, int H, int W) {
         F.aux_y = ws.take((int64_t)B * e.label * F.h * F.w * 4);
         F.aux_stat = ws.take(64 * 4);
         bind_conv(F.aux_fwd, geom3(B, F.h, F.w, D, F.c.v.ld, e.label, e.label), F.aux_conv0, false, 0, D, e.label);
-        {       // backward of the head (runs when stcd_cf_set_aux_backward is on; its weight-gradient job is part of the stage's grouped
-                // launch either way and reads aux_G, which lives in the zero arena: an all-zero gradient without it)
+        if (P.aux_bwd) {       // backward of the head: planned only with stcd_cf_set_aux_backward (multi_scale_train)
             const ConvW& cv0 = e.convs[F.aux_conv0];
             F.aux_dz = ws.take((int64_t)B * e.label * F.h * F.w * 4); F.aux_dy = ws.take((int64_t)B * e.label * F.h * F.w * 4);
             F.aux_sums = ws.take(64 * 4);
@@ -515,7 +514,7 @@ static int configure_cf(stcd_engine& e, int B, int H, int W) {
     {
         BiasJob jb{}; jb.acc_off = e.final_bias_acc; jb.out_off = e.convs[P.head_conv].b_off; jb.C = 8; jb.valid = e.label; jb.scale = BN_BS;
         e.bias_jobs.push_back(jb);
-        for (int k = 0; k < 4; ++k) {       // the auxiliary heads' first-conv biases (zero unless the aux backward runs)
+        for (int k = 0; k < 4 && P.aux_bwd; ++k) {       // the auxiliary heads' first-conv biases
             BiasJob ja{}; ja.acc_off = P.df[k].aux_bias_acc; ja.out_off = e.convs[P.df[k].aux_conv0].b_off; ja.C = 8; ja.valid = e.label; ja.scale = BN_BS;
             e.bias_jobs.push_back(ja);
         }

@@ -151,9 +151,11 @@ class Engine:
 
     def cf_set_drop_rates(self, drop_rate: float, attn_drop: float, diff_drop: float):
         _lib.check(self._l.stcd_cf_set_drop_rates(self._h, C.c_float(drop_rate), C.c_float(attn_drop), C.c_float(diff_drop)))
+        self.shape = None
 
     def cf_set_aux_backward(self, on: bool):
-        """ChangeFormer: propagate the gradients of the four auxiliary prediction maps too (multi_scale_train)."""
+        """ChangeFormer: plan and run the backward of the four auxiliary prediction heads too (multi_scale_train); takes effect at
+        the next configure (the workspace plan changes)."""
         _lib.check(self._l.stcd_cf_set_aux_backward(self._h, 1 if on else 0))
         self.shape = None
 

@@ -9,6 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import changeformer_ref as R
+from stcd_amd._lib import StcdError
 from stcd_amd.changeformer import ChangeFormerV6
 from tests import _util
 
@@ -172,11 +173,15 @@ def test_multi_scale_training_step_matches_the_oracle(cfg_name, B, H, W, out_ch)
     """multi_scale_train (trainer.py:300-309): a weighted loss over ALL five predictions, so the four auxiliary heads
     (make_prediction, ChangeFormer.py:1151-1157) carry gradients: their own conv / BatchNorm parameters and the extra term they add to
     every scale's change feature.  fp32 engine vs the fp64 oracle, every parameter's gradient per tensor -- the bars of the
-    single-output test; then a plain cp-only step on the same module must switch the auxiliary backward off again (their
-    gradients exactly zero)."""
+    single-output test.  Without `set_multi_scale_train(True)` such a loss is refused; switched off again, a cp-only step leaves
+    the heads' gradients exactly zero."""
     ocfg, st, m = build(cfg_name, "fp32", out_ch)
     x1, x2, tgt = data(B, H, W, out_ch)
     m.train()
+    with pytest.raises(StcdError, match="set_multi_scale_train"):       # planned for the default loss: loud, not silently dropped
+        multi_scale_loss(m(x1.to(DEV), x2.to(DEV)), tgt.to(DEV)).backward()
+    m.zero_grad(set_to_none=False)
+    m.set_multi_scale_train(True)
     m.set_seed(77)
     outs = m(x1.to(DEV), x2.to(DEV))
     loss = multi_scale_loss(outs, tgt.to(DEV))
@@ -210,8 +215,9 @@ def test_multi_scale_training_step_matches_the_oracle(cfg_name, B, H, W, out_ch)
     assert seen_aux >= 12, seen_aux          # 4 heads x (conv weight, BatchNorm weight / bias, conv weight / bias ...)
     assert not bad, f"{len(bad)} tensors off: " + "; ".join(bad[:12])
     _util.ACHIEVED[f"changeformer-{cfg_name}-fp32 multi-scale loss {B}x{H}x{W} out{out_ch}"] = worst
-    # back to the default loss: the auxiliary backward switches itself off
+    # back to the default plan: the heads take no part in the backward, their gradients stay exactly zero
     m.zero_grad(set_to_none=False)
+    m.set_multi_scale_train(False)
     m.set_seed(78)
     loss_fn(m(x1.to(DEV), x2.to(DEV))[-1], tgt.to(DEV)).backward()
     for name, p in m.named_parameters():
@@ -228,6 +234,7 @@ def test_bf16_multi_scale_step_tracks_the_fp32_engine():
         _, _, m = build("tiny", dtype)
         x1, x2, tgt = data(2, 64, 64, 2)
         m.train()
+        m.set_multi_scale_train(True)
         m.set_seed(9)
         multi_scale_loss(m(x1.to(DEV), x2.to(DEV)), tgt.to(DEV)).backward()
         res[dtype] = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}

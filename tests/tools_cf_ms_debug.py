@@ -9,7 +9,7 @@ for which in ("cp", "ms"):
     for dtype in ("fp32", "bf16"):
         _, _, m = build("tiny", dtype)
         x1, x2, tgt = data(2, 64, 64, 2)
-        m.train(); m.set_seed(9)
+        m.train(); m.set_multi_scale_train(which == "ms"); m.set_seed(9)
         outs = m(x1.to(DEV), x2.to(DEV))
         (multi_scale_loss(outs, tgt.to(DEV)) if which == "ms" else loss_fn(outs[-1], tgt.to(DEV))).backward()
         res[dtype] = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
