@@ -123,6 +123,8 @@ class CDTrainer:
         self.shuffle_AB = getattr(args, "shuffle_AB", False)
         self.multi_scale_train = getattr(args, "multi_scale_train", "False")
         self.multi_scale_infer = getattr(args, "multi_scale_infer", "False")
+        if self.multi_scale_train == "True" and hasattr(self.net_G, "set_multi_scale_train"):
+            self.net_G.set_multi_scale_train(True)      # ChangeFormer: plan the auxiliary heads' backward (trainer.py:300-309)
         self.weights = tuple(getattr(args, "multi_pred_weights", (1.0,)))
         if args.loss == "ce":                # trainer.py:92-114
             self._pxl_loss = losses.cross_entropy

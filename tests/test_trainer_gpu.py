@@ -39,6 +39,28 @@ def _args(tmp, **kw):
     return NS(**d)
 
 
+def test_cdtrainer_changeformer_with_the_multi_scale_loss(tmp_path):
+    """The reference's ChangeFormer training configuration through the CDTrainer mirror: net_G ChangeFormerV6 (five outputs),
+    multi_scale_train == "True" with the reference's default weights (loss over all five maps, models/trainer.py:300-309),
+    multi_scale_infer == "True" (prediction = sum of the resized maps, :288-295).  The loss falls over two epochs and the auxiliary
+    heads learn (their weights move)."""
+    from stcd_amd.trainer import CDTrainer
+
+    torch.manual_seed(0)
+    loaders = {"train": torch.utils.data.DataLoader(PairSet(8, 64, 1, True), batch_size=4, shuffle=False),
+               "val": torch.utils.data.DataLoader(PairSet(4, 64, 2, True), batch_size=4)}
+    args = _args(str(tmp_path), net_G="ChangeFormerV6", loss="ce", multi_scale_train="True", multi_scale_infer="True",
+                 multi_pred_weights=[0.5, 0.5, 0.5, 0.8, 1.0], lr=2e-4, max_epochs=3, embed_dim=64)
+    tr = CDTrainer(args, loaders)
+    before = {k: v.detach().clone() for k, v in tr.net_G.state_dict().items() if "make_pred_c3" in k and v.dtype.is_floating_point and "running" not in k}
+    tr.train_models()
+    assert len(tr.TRAIN_ACC) == 3 and np.isfinite(tr.TRAIN_ACC).all()
+    after = tr.net_G.state_dict()
+    assert before and all(not torch.equal(v, after[k]) for k, v in before.items())          # every tensor of the head moved
+    ck = torch.load(os.path.join(args.checkpoint_dir, "last_ckpt.pt"), weights_only=False)
+    assert any(k.startswith("TDec_x2.make_pred_c1.") for k in ck["model_G_state_dict"])
+
+
 @pytest.mark.parametrize("net,loss", [("SiamUnet_abs", "ce"), ("SiamUnet_sub", "ce")])
 def test_cdtrainer_epochs_checkpoints_resume_and_evaluator(tmp_path, net, loss):
     from stcd_amd.basic_model import CDEvaluator
