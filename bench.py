@@ -35,6 +35,8 @@ MFMA_F32_PEAK_TF = 157.3
 ALG_PER_PAIR_256 = {"diff": (25.37e9, 169e6), "sub": (25.37e9, 169e6), "conc": (28.99e9, 182e6), "snunet": (279.6e9, 1118e6),
                     # FC-EF (Unet): SiamUnet_diff's table with ONE encoder stream on 6 input channels (same accounting)
                     "fcef": (18.57e9, 122.9e6),
+                    # SiamUnet_cross_conc: SiamUnet_diff + a (pairwise depthwise 3x3, 3x3 C -> C) block on each of the 4 skips
+                    "xconc": (29.21e9, 228e6),
                     # SegCD(resnet50): same accounting from the layer table (oracle/segcd_ref.py block_specs / decoder_specs), both dates
                     "segcd": (127.65e9, 912.2e6)}
 
@@ -134,7 +136,7 @@ def changeformer_alg(H=512, W=512, out_ch=2, E=(64, 128, 320, 512), depths=(3, 3
     return 3.0 * fl, 3.0 * by
 
 
-NAMES = {"changeformer": "ChangeFormerV6", "diff": "SiamUnet_diff", "conc": "SiamUnet_conc", "sub": "SiamUnet_sub", "fcef": "Unet (FC-EF)", "snunet": "SNUNet_ECAM", "segcd": "SegCD-resnet50"}
+NAMES = {"changeformer": "ChangeFormerV6", "diff": "SiamUnet_diff", "conc": "SiamUnet_conc", "sub": "SiamUnet_sub", "fcef": "Unet (FC-EF)", "xconc": "SiamUnet_cross_conc", "snunet": "SNUNet_ECAM", "segcd": "SegCD-resnet50"}
 
 
 def parse():
@@ -142,7 +144,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub", "fcef", "snunet", "segcd", "unetseg", "ffctlcd", "changeformer"],
+    ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub", "fcef", "xconc", "snunet", "segcd", "unetseg", "ffctlcd", "changeformer"],
                     help="unetseg: the single-image UNet of train_sup.py (one 'pair' = one image); ffctlcd: SegCD's feature-level variant")
     ap.add_argument("--encoder", default="resnet50", choices=sorted(SEGCD_ENCODERS), help="--model segcd: the ResNet encoder")
     ap.add_argument("--batch", type=int, default=16, help="image pairs per GPU per step")
@@ -345,7 +347,7 @@ def main():
     from stcd_amd import synth
     from stcd_amd.ddp import FlatGradReducer, broadcast_parameters, init_distributed
     from stcd_amd.losses import bce_dice_with_logits, cross_entropy
-    from stcd_amd.modules import SiamUnet_conc, SiamUnet_diff, SiamUnet_sub, SNUNet_ECAM, Unet
+    from stcd_amd.modules import SiamUnet_conc, SiamUnet_cross_conc, SiamUnet_diff, SiamUnet_sub, SNUNet_ECAM, Unet
     from stcd_amd.optim import FlatAdamW
 
     rank, local_rank, world = init_distributed()
@@ -379,7 +381,7 @@ def main():
         NAMES["unetseg"] = "UnetSeg-" + args.encoder
         args.no_cpu_baseline = True
     else:
-        cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub, "fcef": Unet, "snunet": SNUNet_ECAM}[args.model]
+        cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub, "fcef": Unet, "xconc": SiamUnet_cross_conc, "snunet": SNUNet_ECAM}[args.model]
         model = cls(3, args.label, dtype=args.dtype).to(dev).train()
     broadcast_parameters(model)
     # torch.optim.AdamW semantics, one launch (weight_decay 0 == the Adam the SegCD script uses)

@@ -50,6 +50,10 @@ extern "C" {
  * encoder stream over cat(x1, x2) (conv11 takes 2 * in_ch channels, in_ch <= 4), skips = the stream's own activations, decoder and
  * state_dict layout of SiamUnet_diff; forward returns the logits tensor. */
 #define STCD_ARCH_FCEF 9
+/* "SiamUnet_cross_conc" -> SiamUnet_cross_conc (models/SiamUnet_crossconc.py:35-212; define_G name, models/networks.py:152-153): the
+ * FC-Siam encoder / decoder with a cross_conc block on every skip (:11-33: the two dates' channels interleaved into a grouped 3x3
+ * conv (C groups of 2 -> 1), BatchNorm, ReLU, a 3x3 conv C -> C, BatchNorm, ReLU); forward returns [logits]. */
+#define STCD_ARCH_XCONC 10
 /* smp.UnetSeg (decoders/unet/model.py:109-171), the single-image ResNet UNet train_sup.py:303 trains: the same encoder /
  * decoder / head on ONE image batch (x2 of stcd_forward is ignored; BatchNorm over the whole batch; logits [batch, label_ch,
  * H, W]).  STCD_ARCH_UNETSEG + k, k = 0..4: resnet50, resnet18, resnet34, resnet101, resnet152 (the order of the ids above). */

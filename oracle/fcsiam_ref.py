@@ -6,6 +6,8 @@ Follows, without sharing code with, the reference models:
   * SiamUnet_diff  -- /root/reference/models/SiamUnet_diff.py:13-92 (layers), :94-181 (forward)
   * SiamUnet_conc  -- /root/reference/models/SiamUnet_conc.py:54,66,78,87 (decoder widths), :149-172 (concat skips)
   * SiamUnet_sub   -- /root/reference/models/SiamUnet_sub.py:150-180 (signed skips, list return)
+  * SiamUnet_cross_conc -- /root/reference/models/SiamUnet_crossconc.py:11-33 (cross_conc block), :119-122 (one per level), :180-204
+                      (skips = cross_conc(f1, f2)); list return
   * Unet (FC-EF)   -- /root/reference/models/Unet.py:10-91 (layers: conv11 takes 2 * input_nbr channels), :93-154 (one stream over
                       cat(x1, x2), skips = the stream's own activations)
 
@@ -15,7 +17,7 @@ sums, dropout as an explicit per-(n,c) scale), so that agreement with the refere
 (tests/golden) is a real check of the semantics the HIP engine implements.
 Backward comes from CPU autograd over these explicit ops.
 
-Parity status: pinned by tests/golden/g2_*.npz, g3_*.npz, g4_*.npz, g6_*.npz (FC-EF: g2_fcef_*.npz, g19_fcef_step.npz).
+Parity status: pinned by tests/golden/g2_*.npz, g3_*.npz, g4_*.npz, g6_*.npz (FC-EF: g2_fcef_*.npz, g7_fcef_128.npz; cross_conc: g2_xconc_*.npz, g7_xconc_128.npz).
 """
 from __future__ import annotations
 
@@ -44,7 +46,7 @@ DECODER = (
     ("upconv2", 32, (("22d", "cat", 32), ("21d", 32, 16))),
     ("upconv1", 16, (("12d", "cat", 16), ("11d", 16, None))),  # 11d: -> label_nbr, no BN
 )
-ARCHS = ("diff", "conc", "sub", "fcef")
+ARCHS = ("diff", "conc", "sub", "fcef", "xconc")
 
 
 def skip_channels(arch: str, c: int) -> int:
@@ -83,6 +85,14 @@ def param_specs(arch: str, in_ch: int, label: int):
             specs.append((f"conv{sfx}.bias", (co,), "convT_b"))
             if sfx != "11d":
                 bn(f"bn{sfx}", co)
+    if arch == "xconc":      # cross_conc1..4 (SiamUnet_crossconc.py:119-122), registered after the decoder
+        for l, c in enumerate((16, 32, 64, 128), 1):
+            specs.append((f"cross_conc{l}.diff.0.weight", (c, 2, 3, 3), "conv_w"))       # Conv2d(2c, c, 3, groups=c)
+            specs.append((f"cross_conc{l}.diff.0.bias", (c,), "conv_b"))
+            bn(f"cross_conc{l}.diff.1", c)
+            specs.append((f"cross_conc{l}.conv_res.0.weight", (c, c, 3, 3), "conv_w"))
+            specs.append((f"cross_conc{l}.conv_res.0.bias", (c,), "conv_b"))
+            bn(f"cross_conc{l}.conv_res.1", c)
     return specs
 
 
@@ -218,6 +228,24 @@ def _cbrd(x, st, sfx, training, mask, conv):
     return a
 
 
+def _cross_conc(st, l, f1, f2, training):
+    """cross_conc.forward (SiamUnet_crossconc.py:24-33): channels interleaved (0::2 = date 1, 1::2 = date 2), grouped 3x3 conv with one
+    group per channel pair, BatchNorm, ReLU, 3x3 conv, BatchNorm, ReLU."""
+    n, c, h, w = f1.shape
+    pair = torch.stack((f1, f2), 2).reshape(n, 2 * c, h, w)
+    p = f"cross_conc{l}."
+    y = F.conv2d(pair, st[p + "diff.0.weight"], st[p + "diff.0.bias"], padding=1, groups=c)
+    z = batchnorm(y, st[p + "diff.1.weight"], st[p + "diff.1.bias"], st[p + "diff.1.running_mean"], st[p + "diff.1.running_var"], training)
+    if training:
+        st[p + "diff.1.num_batches_tracked"] += 1
+    y2 = conv3x3(torch.relu(z), st[p + "conv_res.0.weight"], st[p + "conv_res.0.bias"])
+    z2 = batchnorm(y2, st[p + "conv_res.1.weight"], st[p + "conv_res.1.bias"], st[p + "conv_res.1.running_mean"],
+                   st[p + "conv_res.1.running_var"], training)
+    if training:
+        st[p + "conv_res.1.num_batches_tracked"] += 1
+    return torch.relu(z2)
+
+
 def forward(arch, st, x1, x2, training=False, masks=None):
     """Returns logits [B,label,H,W] (tensor for every arch; the reference's list
     wrapping for 'sub' (SiamUnet_sub.py:177-180) is a boundary concern).
@@ -243,7 +271,9 @@ def forward(arch, st, x1, x2, training=False, masks=None):
         f1, f2 = skips[0][lvl], skips[-1][lvl]
         x = convT3x3_s2(x, st[f"{up}.weight"], st[f"{up}.bias"])
         x = pad_to(x, f1)
-        if arch == "fcef":
+        if arch == "xconc":
+            x = torch.cat((x, _cross_conc(st, lvl + 1, f1, f2, training)), 1)   # SiamUnet_crossconc.py:180
+        elif arch == "fcef":
             x = torch.cat((x, f1), 1)                    # Unet.py:128
         elif arch == "diff":
             x = torch.cat((x, torch.abs(f1 - f2)), 1)   # SiamUnet_diff.py:150

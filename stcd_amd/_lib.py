@@ -18,11 +18,12 @@ LIB_PATH = os.path.join(_HERE, "libstcd_hip.so")
 ARCH_DIFF, ARCH_CONC, ARCH_SUB, ARCH_SNUNET, ARCH_SEGCD = 0, 1, 2, 3, 4
 ARCH_SEGCD_R18, ARCH_SEGCD_R34, ARCH_SEGCD_R101, ARCH_SEGCD_R152 = 5, 6, 7, 8
 ARCH_FCEF = 9              # Unet (FC-EF)
+ARCH_XCONC = 10            # SiamUnet_cross_conc
 ARCH_UNETSEG = 16          # + 0..4: resnet50, resnet18, resnet34, resnet101, resnet152
 ARCH_FFCTLCD = 32          # + 0..4, same order
 ARCH_CHANGEFORMER = 64     # ChangeFormerV6
 DTYPE_F32, DTYPE_BF16 = 0, 1
-ARCH_IDS = {"diff": ARCH_DIFF, "conc": ARCH_CONC, "sub": ARCH_SUB, "fcef": ARCH_FCEF, "snunet": ARCH_SNUNET, "segcd": ARCH_SEGCD,
+ARCH_IDS = {"diff": ARCH_DIFF, "conc": ARCH_CONC, "sub": ARCH_SUB, "fcef": ARCH_FCEF, "xconc": ARCH_XCONC, "snunet": ARCH_SNUNET, "segcd": ARCH_SEGCD,
             "segcd_resnet50": ARCH_SEGCD, "segcd_resnet18": ARCH_SEGCD_R18, "segcd_resnet34": ARCH_SEGCD_R34,
             "segcd_resnet101": ARCH_SEGCD_R101, "segcd_resnet152": ARCH_SEGCD_R152,
             "unetseg_resnet50": ARCH_UNETSEG, "unetseg_resnet18": ARCH_UNETSEG + 1, "unetseg_resnet34": ARCH_UNETSEG + 2,

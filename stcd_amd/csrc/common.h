@@ -357,6 +357,15 @@ void launch_bn_bwd_apply(int dt, const void* dA, int ldda, int64_t da_goff, void
                          int npg, int64_t HW, int relu, hipStream_t s, const void* res = nullptr, int ldres = 0,
                          void* dZout = nullptr, int lddz = 0, const void* extra = nullptr, int ldex = 0,
                          float* dbeta_copy = nullptr);      // dbeta_copy: a second destination of d(beta) (SNUNet: conv1's bias gradient)
+// pairwise depthwise 3x3 convolution of SiamUnet_cross_conc's skip blocks (kernels_xconc.hip; SiamUnet_crossconc.py:14-18,24-33):
+// G[n, p, c] = b[c] + sum_t w[c][0][t] * A1[n, p + t, c] + w[c][1][t] * A2[n, p + t, c]; A1 / A2 (and dA1 / dA2) `goff` elements apart
+void launch_pairdw_fwd(int dt, const void* A, int lda, int64_t goff, void* G, int ldg, const float* w, const float* b, int B, int H,
+                       int W, int C, hipStream_t s);
+void launch_pairdw_bwd_data(int dt, const void* dG, int lddg, void* dA, int ldda, int64_t goff, const float* w, int B, int H, int W,
+                            int C, hipStream_t s);
+int64_t pairdw_partial_floats(int B, int H, int W, int C);
+void launch_pairdw_bwd_filter(int dt, const void* A, int lda, int64_t goff, const void* dG, int lddg, float* dw, float* partial, int B,
+                              int H, int W, int C, hipStream_t s);
 // dst[.., 0:C] (ld ldd) = or += src[.., 0:C] (ld lds): dense concatenation by copy, and its gradient scatter
 void launch_slice(int dt, void* dst, int ldd, const void* src, int lds, int64_t pixels, int C, int accumulate, hipStream_t s);
 // ECAM head of SNUNet (SNUNet.py:46-59,144-149); scratch layouts documented at the kernels (kernels_ew.hip)

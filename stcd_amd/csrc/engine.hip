@@ -94,6 +94,14 @@ struct Cbrd {                         // conv -> BN -> ReLU -> Dropout2d [-> poo
                                                                     // output (bias gradient of the transposed conv feeding it)
     TRef fuse_dst;                    // skip layers of diff / sub: the decoder's concat slice that receives |a1-a2| / a2-a1
 };
+struct XConc {                        // cross_conc skip block of SiamUnet_cross_conc (SiamUnet_crossconc.py:11-33): pairwise depthwise
+    int level = 0, C = 0;             // conv -> BN -> ReLU, then conv3x3 C -> C -> BN -> ReLU (the Cbrd `res`, no dropout) into the concat slice
+    int64_t w_off = 0, b_off = 0;     // diff.0 weight [C][2][3][3] / bias in the flat parameters
+    int bn1 = -1;
+    TRef G, dG, R, dR;                // pairwise-conv output (+ gradient), its BN + ReLU (+ gradient)
+    int64_t stat1 = -1, facc1 = -1, bacc1 = -1, part = -1;
+    Cbrd res;
+};
 struct UpConv {
     int conv = -1, level = 0;
     int N = 0, h = 0, w = 0, Ho = 0, Wo = 0, C = 0;   // input h x w, concat buffer Ho x Wo
@@ -181,6 +189,7 @@ struct stcd_engine_impl {
     std::vector<NBlock> sn_blocks;
     std::vector<SnUp> sn_ups;
     std::vector<int> sn_order;                               // forward order of blocks (index into sn_blocks)
+    std::vector<XConc> xc;                                   // SiamUnet_cross_conc: one block per level (index = level 0..3)
     int sn_final = -1;
     int64_t sn_w[4] = {0, 0, 0, 0};                          // ca.fc1, ca.fc2, ca1.fc1, ca1.fc2 offsets in the flat params
     TRef snE, sndE, snZ, sndZ;
@@ -392,6 +401,7 @@ static const DecSpec DEC[4] = {
 // B images in one BatchNorm group, the skips are the stream's own activations, written straight into the concat buffers
 static inline int fc_dates(const stcd_engine& e) { return e.arch == STCD_ARCH_FCEF ? 1 : 2; }
 static inline bool fc_concat_skips(const stcd_engine& e) { return e.arch == STCD_ARCH_CONC || e.arch == STCD_ARCH_FCEF; }
+static inline bool fc_cross(const stcd_engine& e) { return e.arch == STCD_ARCH_XCONC; }
 
 static void build_fcsiam_tables(stcd_engine& e) {
     // registration order of SiamUnet_*.__init__ (SiamUnet_diff.py:18-90): conv, bn per layer; upconv before its stage
@@ -413,6 +423,19 @@ static void build_fcsiam_tables(stcd_engine& e) {
             add_conv(e, std::string("conv") + d.sfx[j], K_CONVT3_S1, cin, cout, true);
             if (d.cout[j] >= 0) add_bn(e, std::string("bn") + d.sfx[j], cout, 1);
             cin = cout;
+        }
+    }
+    if (fc_cross(e)) {      // SiamUnet_crossconc.py:119-122: cross_conc1..4 registered after the decoder, each diff.0 / diff.1 / conv_res.0 / conv_res.1
+        e.xc.assign(4, XConc());
+        for (int l = 0; l < 4; ++l) {
+            XConc& X = e.xc[l];
+            const std::string n = "cross_conc" + std::to_string(l + 1);
+            X.level = l; X.C = ENC_C[l];
+            add_param(e, n + ".diff.0.weight", {X.C, 2, 3, 3}, &X.w_off);
+            add_param(e, n + ".diff.0.bias", {X.C}, &X.b_off);
+            X.bn1 = add_bn(e, n + ".diff.1", X.C, 1);
+            X.res.conv = add_conv(e, n + ".conv_res.0", K_CONV3, X.C, X.C, true);
+            X.res.bn = add_bn(e, n + ".conv_res.1", X.C, 1);
         }
     }
 }
@@ -691,6 +714,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         arena_bytes += r256(bn_acc_bytes(1, DEC[k].C));
     }
     arena_bytes += r256(bn_acc_bytes(1, 8));
+    if (fc_cross(e)) for (int s = 0; s < 4; ++s) arena_bytes += 4 * r256(bn_acc_bytes(1, ENC_C[s]));      // two BatchNorms per cross_conc block
     e.zero_begin = e.dP[3].off;
     Bump za;
     za.cur = ws.take(arena_bytes);
@@ -721,7 +745,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
                 L.dY = da;   // in place
             }
             if (last) { L.pool = true; L.P = e.P[s]; L.dPool = e.dP[s]; }
-            if (last && !fc_concat_skips(e)) { L.fuse_dst.off = e.D[s].off + C * T; L.fuse_dst.ld = e.D[s].ld; }
+            if (last && !fc_concat_skips(e) && !fc_cross(e)) { L.fuse_dst.off = e.D[s].off + C * T; L.fuse_dst.ld = e.D[s].ld; }
             if (first && s == 0) L.has_dIn = false;
             else if (first) { L.has_dIn = true; L.dIn = e.dP[s - 1]; }
             else { L.has_dIn = true; L.dIn.off = e.enc.back().dA.off; L.dIn.ld = C; }
@@ -768,7 +792,29 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             prevA = a; prevdA = da;
         }
     }
+    if (fc_cross(e)) {      // the cross_conc block of every level: pairwise depthwise conv + BN + ReLU, then a dropout-free Cbrd whose
+        for (int s = 0; s < 4; ++s) {       // activation IS the skip slice of the level's concat buffer
+            XConc& X = e.xc[s];
+            const int C = ENC_C[s], h = e.Hs[s], w = e.Ws[s];
+            X.G = plain(B, h, w, C); X.dG = plain(B, h, w, C); X.R = plain(B, h, w, C); X.dR = plain(B, h, w, C);
+            X.stat1 = ws.take((int64_t)4 * C * 4);
+            X.part = ws.take(pairdw_partial_floats(B, h, w, C) * 4);
+            Cbrd& L = X.res;
+            L.drop = -1; L.N = B; L.H = h; L.W = w; L.groups = 1; L.npg = B;
+            L.in = X.R; L.K = C;
+            L.Y = plain(B, h, w, C);
+            L.A.off = e.D[s].off + C * T; L.A.ld = e.D[s].ld; L.A.goff = 0;
+            L.dA.off = e.dD[s].off + C * T; L.dA.ld = e.dD[s].ld; L.dA.goff = 0;
+            L.dY = plain(B, h, w, C);
+            L.has_dIn = true; L.dIn = X.dR;
+            L.stat = ws.take((int64_t)4 * C * 4);
+        }
+    }
     e.G = plain(B, H, W, 8);
+    for (auto& X : e.xc) {
+        X.facc1 = za.take(bn_acc_bytes(1, X.C)); X.bacc1 = za.take(bn_acc_bytes(1, X.C));
+        X.res.facc = za.take(bn_acc_bytes(1, X.C)); X.res.bacc = za.take(bn_acc_bytes(1, X.C));
+    }
     for (auto& L : e.enc) { L.facc = za.take(bn_acc_bytes(L.groups, e.convs[L.conv].cout)); L.bacc = za.take(bn_acc_bytes(L.groups, e.convs[L.conv].cout)); }
     for (auto& L : e.dec) { L.facc = za.take(bn_acc_bytes(L.groups, e.convs[L.conv].cout)); L.bacc = za.take(bn_acc_bytes(L.groups, e.convs[L.conv].cout)); }
     for (auto& U : e.ups) U.bias_acc = za.take(bn_acc_bytes(1, U.C));
@@ -821,6 +867,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     };
     for (auto& L : e.enc) bind_cbrd(L);
     for (auto& L : e.dec) bind_cbrd(L);
+    for (auto& X : e.xc) bind_cbrd(X.res);
     for (auto& U : e.ups) {
         const ConvW& cv = e.convs[U.conv];
         for (int ph = 0; ph < 4; ++ph) {
@@ -1136,7 +1183,7 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     a.A = c.at(L.A.off); a.lda = L.A.ld; a.a_group_off = L.A.goff;
     a.P = L.pool ? c.at(L.P.off) : nullptr; a.ldp = L.P.ld;
     a.stat = stat;
-    a.mask = (training && e.drop_p > 0.f) ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
+    a.mask = (training && e.drop_p > 0.f && L.drop >= 0) ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
     a.C = C; a.groups = L.groups; a.npg = L.npg; a.H = L.H; a.W = L.W; a.relu = 1;
     // the activation kernel derives scale / shift itself: from the accumulators in training mode, from the running statistics in
     // eval mode (no finalize / prepare launch either way)
@@ -1160,7 +1207,7 @@ static void cbrd_backward(const Ctx& c, const Cbrd& L, int skip_chunks = 0) {
     const int C = cv.cout;
     const int64_t HW = (int64_t)L.H * L.W, ppg = (int64_t)L.npg * HW;
     const float* stat = c.at<float>(L.stat);
-    const float* mask = e.drop_p > 0.f ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
+    const float* mask = (e.drop_p > 0.f && L.drop >= 0) ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
     long long* bacc = c.at<long long>(L.bacc);
     const double act_bytes = (double)L.N * HW * C * (double)dsize(e.dt);
     (void)ppg;
@@ -1211,6 +1258,47 @@ static void upconv_backward(const Ctx& c, const UpConv& U) {
     exec_conv(c, U.dgr, c.at(U.dOut.off), nullptr, c.at(U.dIn.off), false);
 }
 
+// cross_conc block (SiamUnet_crossconc.py:24-33): skip slice of the level's concat buffer = relu(bn(conv(relu(bn(pairdw(x1, x2))))))
+static void xconc_forward(const Ctx& c, const XConc& X, const Cbrd& skip, float* bn_running, bool training) {
+    stcd_engine& e = c.e;
+    const BnP& bn = e.bns[X.bn1];
+    const int C = X.C, B = X.res.N, h = X.res.H, w = X.res.W;
+    {
+        ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.0 * B * h * w * C * (double)dsize(e.dt), "k_pairdw_fwd");
+        launch_pairdw_fwd(e.dt, c.at(skip.A.off), skip.A.ld, skip.A.goff, c.at(X.G.off), X.G.ld, c.params + X.w_off, c.params + X.b_off, B, h, w, C, c.s);
+    }
+    if (training) launch_bn_stats(e.dt, c.at(X.G.off), X.G.ld, C, 1, (int64_t)B * h * w, c.at<long long>(X.facc1), c.s);
+    BnActArgs a;
+    a.Y = c.at(X.G.off); a.ldy = X.G.ld;
+    a.A = c.at(X.R.off); a.lda = X.R.ld; a.a_group_off = 0;
+    a.P = nullptr; a.ldp = 0;
+    a.stat = c.at<float>(X.stat1);
+    a.mask = nullptr;
+    a.C = C; a.groups = 1; a.npg = B; a.H = h; a.W = w; a.relu = 1;
+    a.facc = training ? c.at<long long>(X.facc1) : nullptr;
+    a.gamma = c.params + bn.g_off; a.beta = c.params + bn.b_off;
+    a.running_mean = bn_running + bn.run_off; a.running_var = bn_running + bn.run_off + C;
+    launch_bn_act(e.dt, a, c.s);
+    cbrd_forward(c, X.res, bn_running, training);
+}
+// its backward: writes the gradient of BOTH dates' skip activations (the pool gradient is accumulated onto them in the encoder stage)
+static void xconc_backward(const Ctx& c, const XConc& X, const Cbrd& skip) {
+    stcd_engine& e = c.e;
+    const BnP& bn = e.bns[X.bn1];
+    const int C = X.C, B = X.res.N, h = X.res.H, w = X.res.W;
+    const int64_t HW = (int64_t)h * w;
+    cbrd_backward(c, X.res);                       // BN-backward of conv_res, its weight gradient, data gradient -> dR
+    launch_bn_bwd_reduce(e.dt, c.at(X.dR.off), X.dR.ld, 0, c.at(X.G.off), X.G.ld, c.at<float>(X.stat1), nullptr, C, 1, B, HW, 1,
+                         c.at<long long>(X.bacc1), c.s);
+    launch_bn_bwd_apply(e.dt, c.at(X.dR.off), X.dR.ld, 0, c.at(X.dG.off), X.dG.ld, c.at(X.G.off), X.G.ld, c.at<float>(X.stat1),
+                        c.at<long long>(X.bacc1), c.grads + bn.g_off, c.grads + bn.b_off, nullptr, C, 1, B, HW, 1, c.s);
+    ProfScope ps(c, PC_POOL_FUSE, 0.0, 6.0 * B * h * w * C * (double)dsize(e.dt), "k_pairdw_bwd");
+    launch_pairdw_bwd_data(e.dt, c.at(X.dG.off), X.dG.ld, c.at(skip.dA.off), skip.dA.ld, skip.dA.goff, c.params + X.w_off, B, h, w, C, c.s);
+    launch_pairdw_bwd_filter(e.dt, c.at(skip.A.off), skip.A.ld, skip.A.goff, c.at(X.dG.off), X.dG.ld, c.grads + X.w_off, c.at<float>(X.part),
+                             B, h, w, C, c.s);
+    // (diff.0's bias sits in front of a train-mode BatchNorm: its gradient is exactly zero and stays zero)
+}
+
 static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, const float* params, float* bn_running,
                           const float* masks, uint64_t seed, int training, float* logits, void* workspace, hipStream_t s) {
     Ctx c{e, (char*)workspace, params, nullptr, s};
@@ -1231,7 +1319,8 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
         const int s_ = U.level, C = ENC_C[s_];
         upconv_forward(c, U);
         const Cbrd& skip = e.enc[SKIP_IDX[s_]];
-        if (!fc_concat_skips(e) && !(e.use_act_fuse && skip.fuse_dst.off >= 0)) {
+        if (fc_cross(e)) xconc_forward(c, e.xc[s_], skip, bn_running, training != 0);
+        else if (!fc_concat_skips(e) && !(e.use_act_fuse && skip.fuse_dst.off >= 0)) {
             ProfScope ps(c, PC_POOL_FUSE, 0.0, 3.0 * B * e.Hs[s_] * e.Ws[s_] * C * (double)T);
             launch_fuse(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(skip.A.off), skip.A.ld, skip.A.goff,
                         c.at<char>(e.D[s_].off) + C * T, e.D[s_].ld, B, (int64_t)e.Hs[s_] * e.Ws[s_], C, s);
@@ -1269,7 +1358,8 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
             const int s_ = U.level, C = ENC_C[s_];
             upconv_backward(c, U);
             const Cbrd& skip = e.enc[SKIP_IDX[s_]];
-            if (!fc_concat_skips(e) && !e.use_skip_fused) {
+            if (fc_cross(e)) xconc_backward(c, e.xc[s_], skip);
+            else if (!fc_concat_skips(e) && !e.use_skip_fused) {
                 ProfScope ps(c, PC_POOL_FUSE, 0.0, (e.arch == STCD_ARCH_DIFF ? 5.0 : 3.0) * B * e.Hs[s_] * e.Ws[s_] * C * (double)T);
                 launch_fuse_bwd(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(skip.A.off), skip.A.ld, skip.A.goff,
                                 c.at<char>(e.dD[s_].off) + C * T, e.dD[s_].ld, c.at(skip.dA.off), skip.dA.ld, skip.dA.goff, B,
@@ -1283,7 +1373,7 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
         for (int li = (int)e.enc.size() - 1; li >= 0; --li) {
             const Cbrd& L = e.enc[li];
             int skip_chunks = 0;
-            if (L.pool && !fc_concat_skips(e) && e.use_skip_fused) {
+            if (L.pool && !fc_concat_skips(e) && !fc_cross(e) && e.use_skip_fused) {
                 // pool gradient + skip-fusion gradient + BN partial sums of the level's last conv in one pass
                 const int C = e.convs[L.conv].cout;
                 int lvl = 0;
@@ -2486,7 +2576,7 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
         cfg.in_ch = in_ch; cfg.out_ch = label_ch;
         return stcd_create_changeformer(&cfg, dtype, out);
     }
-    STCD_CHECK((arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD_R152) || arch == STCD_ARCH_FCEF || is_unetseg(arch) || is_ffctlcd(arch), "unknown arch");
+    STCD_CHECK((arch >= STCD_ARCH_DIFF && arch <= STCD_ARCH_SEGCD_R152) || arch == STCD_ARCH_FCEF || arch == STCD_ARCH_XCONC || is_unetseg(arch) || is_ffctlcd(arch), "unknown arch");
     STCD_CHECK(arch != STCD_ARCH_FCEF || in_ch <= 4, "FC-EF concatenates the two dates along the channels: in_ch must be <= 4");
     STCD_CHECK(in_ch >= 1 && in_ch <= 8, "in_ch must be in [1,8]");
     STCD_CHECK(label_ch >= 1 && label_ch <= 8, "label_ch must be in [1,8]");

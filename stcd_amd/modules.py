@@ -319,6 +319,18 @@ class HipChangeDetector(nn.Module):
         return [out] if self.RETURNS_LIST else out
 
 
+class _CrossConcHolder(nn.Module):
+    """Parameter holder of the reference's `cross_conc` block (SiamUnet_crossconc.py:11-22); the engine runs it."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.diff = nn.Sequential(nn.Conv2d(in_channels, in_channels // 2, kernel_size=3, padding=1, stride=1, groups=in_channels // 2),
+                                  nn.BatchNorm2d(in_channels // 2), nn.ReLU())
+        self.conv_res = nn.Sequential(nn.Conv2d(in_channels // 2, out_channels, kernel_size=3, padding=1, stride=1), nn.BatchNorm2d(out_channels))
+        self.act = nn.ReLU()
+
+
 class _FCSiam(HipChangeDetector):
     """Layer holders in the reference's registration order (SiamUnet_diff.py:18-90)."""
 
@@ -342,6 +354,9 @@ class _FCSiam(HipChangeDetector):
                     setattr(self, f"do{sfx}", nn.Dropout2d(p=0.2))
                 ci = co_
         self.sm = nn.LogSoftmax(dim=1)   # present (unused) in the reference too: SiamUnet_diff.py:92
+        if self.ARCH == "xconc":         # SiamUnet_crossconc.py:119-122
+            for l, c in enumerate((16, 32, 64, 128), 1):
+                setattr(self, f"cross_conc{l}", _CrossConcHolder(2 * c, c))
         self._check_layout()
 
 
@@ -358,6 +373,13 @@ class SiamUnet_conc(_FCSiam):
 class SiamUnet_sub(_FCSiam):
     """Signed skips f2 - f1; returns a one-element list like the reference (SiamUnet_sub.py:150,177-180)."""
     ARCH = "sub"
+    RETURNS_LIST = True
+
+
+class SiamUnet_cross_conc(_FCSiam):
+    """FC-Siam with a `cross_conc` block on every skip (SiamUnet_crossconc.py:35-212): cat(upsampled, cross_conc_l(f1, f2)); returns a
+    one-element list like the reference (:206-208)."""
+    ARCH = "xconc"
     RETURNS_LIST = True
 
 

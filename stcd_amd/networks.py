@@ -8,15 +8,16 @@ import torch
 from torch.nn import init
 from torch.optim import lr_scheduler
 
-from .modules import SiamUnet_conc, SiamUnet_diff, SiamUnet_sub, Unet
+from .modules import SiamUnet_conc, SiamUnet_cross_conc, SiamUnet_diff, SiamUnet_sub, Unet
 
 _ON_PATH = {
     "Unet": lambda n: Unet(input_nbr=3, label_nbr=n),                     # networks.py:144-145 (FC-EF)
     "SiamUnet_abs": lambda n: SiamUnet_diff(input_nbr=3, label_nbr=n),    # networks.py:148-149
     "SiamUnet_conc": lambda n: SiamUnet_conc(input_nbr=3, label_nbr=n),   # :150-151
     "SiamUnet_sub": lambda n: SiamUnet_sub(input_nbr=3, label_nbr=n),     # :146-147
+    "SiamUnet_cross_conc": lambda n: SiamUnet_cross_conc(input_nbr=3, label_nbr=n),   # :152-153
 }
-_OFF_PATH = ("SiamUnet_cross_conc", "DTCDSCN", "IFNet", "base_resnet18", "base_transformer_pos_s4",
+_OFF_PATH = ("DTCDSCN", "IFNet", "base_resnet18", "base_transformer_pos_s4",
              "base_transformer_pos_s4_dd8", "base_transformer_pos_s4_dd8_dedim8", "ChangeFormerV1", "ChangeFormerV2",
              "ChangeFormerV3", "ChangeFormerV4", "ChangeFormerV5", "ChangeGNNV1", "ChangeGNNV2",
              "ChangeGNNV2_sub", "ChangeGNNV2_abs", "ChangeGNNV2_conc", "GNN")

@@ -22,6 +22,8 @@ def zero_grad_by_construction(name):
     batch mean); autograd reports rounding noise, the engine reports 0."""
     if re.fullmatch(r"conv\d\dd?\.bias", name):
         return name != "conv11d.bias"
+    if re.fullmatch(r"cross_conc\d\.(diff|conv_res)\.0\.bias", name):      # SiamUnet_cross_conc: both convs of the block feed a BatchNorm
+        return True
     return name.endswith(".conv2.bias")
 
 

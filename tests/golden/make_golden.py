@@ -38,13 +38,14 @@ from models.SiamUnet_conc import SiamUnet_conc      # noqa: E402
 from models.SiamUnet_sub import SiamUnet_sub        # noqa: E402
 from models.SNUNet import SNUNet_ECAM               # noqa: E402
 from models.Unet import Unet as RefUnet             # noqa: E402  (FC-EF)
+from models.SiamUnet_crossconc import SiamUnet_cross_conc as RefXConc   # noqa: E402
 from models import losses as ref_losses             # noqa: E402
 
 from oracle import fcsiam_ref, snunet_ref           # noqa: E402  (only for synth_state / synth_masks)
 from stcd_amd import synth                          # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
-REF_CLS = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub, "fcef": RefUnet}
+REF_CLS = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub, "fcef": RefUnet, "xconc": RefXConc}
 torch.set_num_threads(8)
 
 
@@ -375,7 +376,7 @@ def g7_train128(archs=("diff", "conc", "snunet")):
     bf16 production path is held to -- logits, loss and every parameter's (sampled) gradient of diff / conc / SNUNet."""
     for arch in archs:
         print(f"G7 {arch} 128x128")
-        seed = 700 + ("diff", "conc", "snunet", "fcef").index(arch)
+        seed = 700 + ("diff", "conc", "snunet", "fcef", "xconc").index(arch)
         d = {"seed": seed}
         x1, x2 = rand_pair(seed + 1, 2, 128, 128)
         rng = np.random.default_rng(seed + 4)
@@ -406,6 +407,12 @@ def g19_fcef():
     (2 x 128 x 128), from the reference's own class."""
     g2_fcsiam(("fcef",))
     g7_train128(("fcef",))
+
+
+def g20_xconc():
+    """SiamUnet_cross_conc (models/SiamUnet_crossconc.py): the G2 pair and the G7 step from the reference's own class."""
+    g2_fcsiam(("xconc",))
+    g7_train128(("xconc",))
 
 
 def g8_contrastive():
@@ -661,9 +668,9 @@ def g17_cf_base():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
     fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd,
           "g7": g7_train128, "g8": g8_contrastive, "g10": g10_segcd, "g11": g11_segcd, "g12": g12_segcd_r18, "g13": g13_segcd_r34,
-          "g14": g14_segcd_r101, "g15": g15_unetseg, "g16": g16_ffctlcd, "g17": g17_cf_base, "g18": g18_segcd_wide, "g19": g19_fcef}
+          "g14": g14_segcd_r101, "g15": g15_unetseg, "g16": g16_ffctlcd, "g17": g17_cf_base, "g18": g18_segcd_wide, "g19": g19_fcef, "g20": g20_xconc}
     for w in which:
         fn[w]()

@@ -106,7 +106,7 @@ def test_two_rank_bf16_buckets_accumulate_in_fp32():
 # the reducer: the two slices must be disjoint, cover the flat gradient buffer, stage 0 must hold exactly the decoder's
 # tensors (final first, so its collective overlaps the encoder's backward), and a 2-rank run over those slices must
 # deliver the mean everywhere -- also with a trainer-shaped epoch metric all-reduce.
-ARCHES = [("diff", 0), ("conc", 1), ("sub", 2), ("fcef", 9), ("snunet", 3), ("segcd", 4), ("segcd_resnet18", 5), ("segcd_resnet101", 7),
+ARCHES = [("diff", 0), ("conc", 1), ("sub", 2), ("fcef", 9), ("xconc", 10), ("snunet", 3), ("segcd", 4), ("segcd_resnet18", 5), ("segcd_resnet101", 7),
           ("unetseg_resnet34", 18), ("ffctlcd_resnet50", 32), ("changeformer", 64)]
 SINGLE_STAGE = ("snunet", "segcd", "unetseg", "ffctlcd")
 
@@ -129,7 +129,7 @@ def test_stage_ranges_partition_the_gradient_buffer(arch, _id):
         in1 = s1[0] <= off and off + numel <= s1[1]
         assert in0 != in1, name
         if not arch.startswith(SINGLE_STAGE):
-            dec = name.startswith("TDec_x2.") if arch == "changeformer" else (name.split(".")[0].endswith("d") or name.startswith("upconv"))
+            dec = name.startswith("TDec_x2.") if arch == "changeformer" else (name.split(".")[0].endswith("d") or name.startswith(("upconv", "cross_conc")))
             assert in0 == dec, f"{name}: stage 0 must finalise exactly the decoder's gradients"
     if arch.startswith(SINGLE_STAGE):
         assert s1[1] - s1[0] == 0                                         # single-stage plan: everything final after stage 0

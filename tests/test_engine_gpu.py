@@ -6,11 +6,11 @@ import pytest
 import torch
 
 from oracle import fcsiam_ref as R
-from stcd_amd.modules import SiamUnet_conc, SiamUnet_diff, SiamUnet_sub, Unet
+from stcd_amd.modules import SiamUnet_conc, SiamUnet_cross_conc, SiamUnet_diff, SiamUnet_sub, Unet
 from tests._util import check_grad, rel_l2_cos, t
 
 pytestmark = pytest.mark.gpu
-CLS = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub, "fcef": Unet}
+CLS = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "sub": SiamUnet_sub, "fcef": Unet, "xconc": SiamUnet_cross_conc}
 DEV = "cuda:0"
 
 
@@ -28,7 +28,7 @@ def loss_fn(label, logits, tgt):
     return bce + dice
 
 
-@pytest.mark.parametrize("arch", ["diff", "conc", "sub", "fcef"])
+@pytest.mark.parametrize("arch", ["diff", "conc", "sub", "fcef", "xconc"])
 @pytest.mark.parametrize("label", [1, 2])
 def test_fp32_matches_reference_vectors(golden, arch, label):
     g = golden(f"g2_{arch}_{label}.npz")
@@ -74,7 +74,7 @@ def test_fp32_odd_size_replication_pad(golden, arch):
     np.testing.assert_allclose(out, g[f"{arch}/logits"], rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("arch", ["diff", "conc", "sub", "fcef"])
+@pytest.mark.parametrize("arch", ["diff", "conc", "sub", "fcef", "xconc"])
 def test_fp32_odd_size_backward_matches_oracle(arch):
     """ReplicationPad2d branch in training (36x44 -> pool chain 18x22, 9x11, 4x5, 2x2: two padded levels)."""
     seed, label = 77, 2
@@ -443,7 +443,7 @@ def test_full_size_properties_other_configs_bf16(arch):
 # |a-b| fusion) median 0.987, worst 0.952.  The bounds sit just under the measured values: what they catch is a wrong
 # term, not rounding (the exact-arithmetic checks of the same kernels are the fp32 runs above and the per-op tests).
 BF16_LOGIT_ERR, BF16_LOSS_ERR = 6e-2, 2e-2
-BF16_GRAD = {"diff": (0.72, 0.80), "conc": (0.72, 0.80), "snunet": (0.94, 0.36), "fcef": (0.72, 0.80)}     # (min cosine, max relative l2) per tensor
+BF16_GRAD = {"diff": (0.72, 0.80), "conc": (0.72, 0.80), "snunet": (0.94, 0.36), "fcef": (0.72, 0.80), "xconc": (0.70, 0.82)}      # (xconc: two more BatchNorm-ed layers on every skip; measured 0.7198 / 0.761)     # (min cosine, max relative l2) per tensor
 
 
 def _g7_inputs(g, arch):
@@ -460,7 +460,7 @@ def _g7_inputs(g, arch):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("arch", ["diff", "conc", "snunet", "fcef"])
+@pytest.mark.parametrize("arch", ["diff", "conc", "snunet", "fcef", "xconc"])
 def test_train_step_128_tracks_reference_vectors(golden, arch, dtype):
     """G7: one train-mode step at 2 x 128 x 128 against the reference's logits, loss and EVERY parameter's gradient.
     fp32 engine: logits 1e-3, loss 1e-4, per-tensor relative l2 <= 2e-2 / cosine >= 0.9995.

@@ -14,7 +14,7 @@ from stcd_amd.train_loop import Poly
 
 def test_define_G_registry_and_errors():
     for name, cls in (("SiamUnet_abs", "SiamUnet_diff"), ("SiamUnet_conc", "SiamUnet_conc"), ("SiamUnet_sub", "SiamUnet_sub"),
-                      ("SNUNet", "SNUNet_ECAM"), ("Unet", "Unet")):
+                      ("SNUNet", "SNUNet_ECAM"), ("Unet", "Unet"), ("SiamUnet_cross_conc", "SiamUnet_cross_conc")):
         m = define_G(NS(net_G=name, n_class=2))
         assert type(m).__name__ == cls
     with pytest.raises(NotImplementedError, match="not recognized"):

@@ -33,6 +33,8 @@ def _zero_grad_by_construction(name):
     (BN subtracts the batch mean); what autograd reports is rounding noise."""
     if re.fullmatch(r"conv\d\dd?\.bias", name):
         return name != "conv11d.bias"
+    if re.fullmatch(r"cross_conc\d\.(diff|conv_res)\.0\.bias", name):
+        return True
     return name.endswith(".conv2.bias")
 
 
@@ -54,7 +56,7 @@ def _loss(label, logits, tgt):
     return R.cd_loss(torch.sigmoid(logits), tgt.float().unsqueeze(1))
 
 
-@pytest.mark.parametrize("arch", ["diff", "conc", "sub", "fcef"])
+@pytest.mark.parametrize("arch", ["diff", "conc", "sub", "fcef", "xconc"])
 @pytest.mark.parametrize("label", [1, 2])
 def test_fcsiam_eval_and_train_step(golden, arch, label):
     g = golden(f"g2_{arch}_{label}.npz")
@@ -143,7 +145,7 @@ def test_metrics_against_sklearn_vectors(golden):
     assert abs(sc["oa"].item() - float(g["oa"])) < 1e-12
 
 
-@pytest.mark.parametrize("arch", ["diff", "conc", "snunet", "fcef"])
+@pytest.mark.parametrize("arch", ["diff", "conc", "snunet", "fcef", "xconc"])
 def test_train_step_128_against_reference_vectors(golden, arch):
     """G7: the train-mode step at 2 x 128 x 128 the bf16 production path is measured against (tests/test_engine_gpu.py)."""
     g = golden(f"g7_{arch}_128.npz")
