@@ -346,6 +346,14 @@ int stcd_op_maxpool_bwd(int dtype, const stcd_map_geom* g, const void* a, int ld
  * pool / dpool are [n, h/2, w/2, c]; idx (n*(h/2)*(w/2)*c bytes) receives / provides the winning window position of every element */
 int stcd_op_maxpool3(int dtype, const stcd_map_geom* g, const void* a, int lda, void* pool, int ldp, void* idx, void* hip_stream);
 int stcd_op_maxpool3_bwd(int dtype, const stcd_map_geom* g, const void* idx, const void* dpool, int ldp, void* da, int ldda, void* hip_stream);
+/* cross_conc's grouped 3x3 convolution (models/SiamUnet_crossconc.py:14-18,24-29: the two dates' channels interleaved, one group per
+ * channel pair) on the two dates as they sit stacked in the batch dimension (g->groups == 2, a: [2 * n, h, w, c]; out / dout: [n, h, w, c];
+ * w: the reference tensor [c][2][3][3], b: [c] or NULL); the backward writes both dates' gradients (da like a) and dw. */
+int64_t stcd_op_pairdw_scratch_bytes(const stcd_map_geom* g);
+int stcd_op_pairdw(int dtype, const stcd_map_geom* g, const void* a, int lda, const float* w, const float* b, void* out, int ldo,
+                   void* hip_stream);
+int stcd_op_pairdw_bwd(int dtype, const stcd_map_geom* g, const void* a, int lda, const void* dout, int lddo, const float* w, void* da,
+                       int ldda, float* dw, void* scratch, int64_t scratch_bytes, void* hip_stream);
 int stcd_op_fuse(int dtype, int mode, const stcd_map_geom* g, const void* a, int lda, void* d, int ldd, void* hip_stream);
 int stcd_op_fuse_bwd(int dtype, int mode, const stcd_map_geom* g, const void* a, int lda, const void* dd, int ldd, void* da, int ldda,
                      void* hip_stream);

@@ -136,6 +136,9 @@ _PROTOS = {
     "stcd_op_maxpool_bwd": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
     "stcd_op_maxpool3": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _vp, _i, _vp, _vp]),
     "stcd_op_maxpool3_bwd": (_i, [_i, C.POINTER(MapGeom), _vp, _vp, _i, _vp, _i, _vp]),
+    "stcd_op_pairdw_scratch_bytes": (_i64, [C.POINTER(MapGeom)]),
+    "stcd_op_pairdw": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "stcd_op_pairdw_bwd": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i64, _vp]),
     "stcd_op_fuse": (_i, [_i, _i, C.POINTER(MapGeom), _vp, _i, _vp, _i, _vp]),
     "stcd_op_fuse_bwd": (_i, [_i, _i, C.POINTER(MapGeom), _vp, _i, _vp, _i, _vp, _i, _vp]),
     "stcd_op_rep_pad": (_i, [_i, C.POINTER(MapGeom), _vp, _i, _i, _i, _vp]),

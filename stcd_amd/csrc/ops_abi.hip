@@ -154,6 +154,32 @@ int stcd_op_fuse(int dtype, int mode, const stcd_map_geom* g, const void* a, int
     return 0;
 }
 
+int64_t stcd_op_pairdw_scratch_bytes(const stcd_map_geom* g) {
+    if (!g || g->n < 2 || g->c < 8) return 0;
+    return pairdw_partial_floats(g->n / 2, g->h, g->w, g->c) * 4 + 256;
+}
+int stcd_op_pairdw(int dtype, const stcd_map_geom* g, const void* a, int lda, const float* w, const float* b, void* out, int ldo,
+                   void* hip_stream) {
+    if (check_map(g)) return 1;
+    STCD_CHECK(g->groups == 2 && a && w && out, "bad argument (groups must be 2: the two dates stacked in the batch dimension)");
+    const int n = g->n / 2;
+    launch_pairdw_fwd(dtype, a, lda, (int64_t)n * g->h * g->w * lda, out, ldo, w, b, n, g->h, g->w, g->c, (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+int stcd_op_pairdw_bwd(int dtype, const stcd_map_geom* g, const void* a, int lda, const void* dout, int lddo, const float* w, void* da,
+                       int ldda, float* dw, void* scratch, int64_t scratch_bytes, void* hip_stream) {
+    if (check_map(g)) return 1;
+    STCD_CHECK(g->groups == 2 && a && dout && w && da && dw && scratch, "bad argument (groups must be 2)");
+    STCD_CHECK(scratch_bytes >= stcd_op_pairdw_scratch_bytes(g), "scratch too small");
+    const int n = g->n / 2;
+    launch_pairdw_bwd_data(dtype, dout, lddo, da, ldda, (int64_t)n * g->h * g->w * ldda, w, n, g->h, g->w, g->c, (hipStream_t)hip_stream);
+    launch_pairdw_bwd_filter(dtype, a, lda, (int64_t)n * g->h * g->w * lda, dout, lddo, dw, (float*)scratch, n, g->h, g->w, g->c,
+                             (hipStream_t)hip_stream);
+    STCD_HIP(hipGetLastError());
+    return 0;
+}
+
 int stcd_op_fuse_bwd(int dtype, int mode, const stcd_map_geom* g, const void* a, int lda, const void* dd, int ldd, void* da, int ldda,
                      void* hip_stream) {
     if (check_map(g)) return 1;

@@ -398,3 +398,42 @@ def test_stem_maxpool3_and_gradient_vs_torch(dtype, n, c, h, w):
     _lib.check(l.stcd_op_maxpool3_bwd(DT[dtype][0], C.byref(g), P(idx), P(nhwc(gp, dtype)), ld, P(dA), ld, stream()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(nchw(dA, c), rq(xt.grad.cpu().numpy(), dtype), **SUM_TOL[dtype])   # up to 4 windows summed per pixel
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("n,c,h,w", [(2, 16, 12, 10), (1, 32, 7, 5), (3, 8, 16, 16), (2, 128, 8, 8), (2, 16, 64, 64), (1, 64, 33, 17)])
+def test_pairwise_depthwise_conv_vs_torch(dtype, n, c, h, w):
+    """cross_conc's Conv2d(2C, C, 3, padding=1, groups=C) on the channel-interleaved pair (SiamUnet_crossconc.py:14-18,24-29) as the
+    engine runs it -- on the two dates stacked in the batch dimension, nothing interleaved in memory -- against torch's grouped
+    convolution of the interleaved tensor: forward, both dates' data gradients, the filter gradient; odd maps, 1 ... 16 channel blocks,
+    multi-chunk filter-gradient grids."""
+    rng = np.random.default_rng(c * 100 + h + n)
+    x1, x2 = rq(rng.standard_normal((n, c, h, w)), dtype), rq(rng.standard_normal((n, c, h, w)), dtype)
+    wt = (rng.standard_normal((c, 2, 3, 3)) / 3).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(c)).astype(np.float32)
+    gy = rq(rng.standard_normal((n, c, h, w)), dtype)
+    # torch reference on the interleaved tensor (fp64: the fixed point both dtypes are compared with)
+    t1, t2 = torch.from_numpy(x1).double().requires_grad_(True), torch.from_numpy(x2).double().requires_grad_(True)
+    tw = torch.from_numpy(wt).double().requires_grad_(True)
+    inter = torch.stack((t1, t2), 2).reshape(n, 2 * c, h, w)
+    y = torch.nn.functional.conv2d(inter, tw, torch.from_numpy(bias).double(), padding=1, groups=c)
+    y.backward(torch.from_numpy(gy).double())
+    geo = mg(2 * n, h, w, c, 2)
+    A = nhwc(np.concatenate([x1, x2]), dtype, ld=c)
+    out = torch.zeros(n, h, w, c, dtype=A.dtype, device=DEV)
+    l = _lib.lib()
+    W_, B_ = f32(wt), f32(bias)
+    _lib.check(l.stcd_op_pairdw(DT[dtype][0], C.byref(geo), P(A), c, P(W_), P(B_), P(out), c, stream()))
+    np.testing.assert_allclose(nchw(out, c), y.detach().numpy(), **TOL[dtype])
+    dO = nhwc(gy, dtype, ld=c)
+    dA = torch.full_like(A, float("nan"))
+    dw = torch.full((c, 2, 3, 3), float("nan"), dtype=torch.float32, device=DEV)
+    nb = l.stcd_op_pairdw_scratch_bytes(C.byref(geo))
+    sc = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    _lib.check(l.stcd_op_pairdw_bwd(DT[dtype][0], C.byref(geo), P(A), c, P(dO), c, P(W_), P(dA), c, P(dw), P(sc), nb, stream()))
+    torch.cuda.synchronize()
+    got = nchw(dA, c)
+    np.testing.assert_allclose(got[:n], t1.grad.numpy(), **TOL[dtype])
+    np.testing.assert_allclose(got[n:], t2.grad.numpy(), **TOL[dtype])
+    scale = float(tw.grad.abs().max())
+    np.testing.assert_allclose(dw.cpu().numpy() / scale, tw.grad.numpy() / scale, rtol=0, atol=2e-5 if dtype == "fp32" else 2e-5)
