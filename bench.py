@@ -448,6 +448,7 @@ def main():
         loss = step()
     enqueue_s = time.perf_counter() - t0          # host time to enqueue the timed steps (the GPU may still be running them)
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0        # this rank's own K steps (before it waits for the others at the barrier)
     barrier()
     elapsed = time.perf_counter() - t0
     gc_guard.close()
@@ -456,7 +457,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     last_loss = loss.item()
-    my_rate = args.batch * args.steps / elapsed
+    my_rate = args.batch * args.steps / own_elapsed
     rank_rates = [my_rate]
     if world > 1:      # self-check of the first multi-GPU run: every rank's own pairs/s and the collective backend in use
         rr = torch.tensor([0.0] * world, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")

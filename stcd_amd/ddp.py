@@ -26,11 +26,17 @@ def init_distributed(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # STCD_DDP_REHEARSAL=1: a multi-rank launch on a box with FEWER GPUs than ranks (the one-GPU development boxes): the ranks share
+    # the cards round-robin and meet over gloo (RCCL cannot put two ranks on one device).  Everything above the transport -- the
+    # launch contract, barriers, the reducer's hook protocol, rank-0 reporting -- runs as it will on a real node.
+    rehearsal = os.environ.get("STCD_DDP_REHEARSAL") == "1"
     if torch.cuda.is_available():
+        if rehearsal:
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = "nccl" if (torch.cuda.is_available() and not rehearsal) else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
