@@ -197,6 +197,17 @@ ConvHaloPlan conv_halo_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p);
 int launch_conv_halo(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvHaloPlan& hp, const void* in, const void* wf,
                      const float* bias, void* out, hipStream_t s, const ConvEpi* epi = nullptr);
 
+// Wide layers on large maps (Ci % 64 == 0, Co % 256 == 0, an even number >= 4 of (chunk, tap) K-tiles) as an implicit GEMM on a
+// 256 x 256 block tile staged by LDS-DMA with counted vmcnt (8 waves, 4 phases per K-tile; kernels_conv_dma.hip).  Reads the
+// CiB = 64 fragment image; ConvEpi as k_conv_gemm; one BatchNorm group, no fused statistics.
+struct ConvDmaPlan {
+    int tiles_m = 0, tiles_n = 0, blocks = 0, lds_bytes = 0;
+    bool ok = false;
+};
+ConvDmaPlan conv_dma_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p);
+int launch_conv_dma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvDmaPlan& dp, const void* in, const void* wf,
+                    const float* bias, void* out, hipStream_t s, const ConvEpi* epi = nullptr);
+
 // small-channel persistent kernel (filter in registers, double-buffered halo, optional fused BN statistics);
 // uses the mode-B fragment image of conv_mfma_plan.
 bool conv_small_ok(const stcd_conv_geom& g, const ConvMfmaPlan& p);

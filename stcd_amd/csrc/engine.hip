@@ -59,6 +59,7 @@ struct ConvOp {
     bool small = false;                  // eligible for the small-channel persistent kernel
     ConvResPlan res; int res_groups = 1; // resident-filter persistent kernel (3x3 stride 1, Ci % 32 == 0)
     ConvGemmPlan gemm;                    // 1x1 convs with Ci % 64 == 0, Co % 64 == 0: tiled GEMM
+    ConvDmaPlan dma;                      // wide layers on large maps: 256 x 256 implicit-GEMM tile staged by LDS-DMA (kernels_conv_dma.hip)
     ConvHaloPlan halo;                    // wide 3x3 layers on large maps: resident halo, streamed filter (opt-in, STCD_HALO_KERNEL=1)
 };
 struct WgradOp {
@@ -508,6 +509,9 @@ static void pick_gemm_or_res(const stcd_engine& e, ConvOp& op, const stcd_conv_g
     // carry no fused BatchNorm statistics (groups == 1 callers that pass none) and fill the chip with 16 x 16 tiles
     static const bool halo_on = [] { const char* v = getenv("STCD_HALO_KERNEL"); return v && v[0] == '1'; }();
     op.halo = ConvHaloPlan();
+    // the LDS-DMA kernel takes the layers it fits once they fill the chip with 256-position tiles (ChangeFormer's decoder head)
+    op.dma = ConvDmaPlan();
+    if (op.gemm.ok && (int64_t)g.n * g.hm * g.wm >= 256 * 192) op.dma = conv_dma_plan(g, op.plan);
     if (halo_on && op.gemm.ok && (int64_t)g.n * ((g.hm + 15) / 16) * ((g.wm + 15) / 16) >= 512) op.halo = conv_halo_plan(g, op.plan);
 }
 
@@ -1012,7 +1016,9 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     const bool small_path = !gemm_path && mfma_on(c.e) && op.small && op.wf >= 0 && c.e.use_small;
     const bool res_path = !gemm_path && !small_path && mfma_on(c.e) && op.res.ok && op.wf >= 0 && !nchw;
     const bool mfma_path = !small_path && !res_path && mfma_on(c.e) && op.plan.ok && op.wf >= 0;
-    if (gemm_path && op.halo.ok && !(stat_groups > 0 && stat_acc)) snprintf(kname, sizeof(kname), "k_conv_halo");
+    const bool dma_path = gemm_path && op.dma.ok && op.res_groups == 1 && !(stat_groups > 0 && stat_acc);
+    if (dma_path) snprintf(kname, sizeof(kname), "k_conv_dma");
+    else if (gemm_path && op.halo.ok && !(stat_groups > 0 && stat_acc)) snprintf(kname, sizeof(kname), "k_conv_halo");
     else if (gemm_path) snprintf(kname, sizeof(kname), "k_conv_gemm<%d>", op.gemm.W);
     else if (res_path) snprintf(kname, sizeof(kname), "k_conv_res<%d, %d, %s>", op.res.NT, op.res.CW, op.res.single_halo ? "true" : "false");
     else if (small_path) snprintf(kname, sizeof(kname), "k_conv_small<1, %d>", (op.g.ntaps * op.g.ci + 31) / 32 <= 5 ? 5 : 9);
@@ -1021,6 +1027,10 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     ProfScope prof(c, PC_CONV, fl, by, kname);
     if (stat_chunks) *stat_chunks = 0;
     if (epi_fused) *epi_fused = 0;
+    if (dma_path && launch_conv_dma(op.g, op.plan, op.dma, in, c.at(op.wf), bias, out, c.s, epi) == 0) {
+        if (epi_fused && epi) *epi_fused = 1;
+        return;
+    }
     if (gemm_path && op.halo.ok && !(stat_groups > 0 && stat_acc)) {
         if (launch_conv_halo(op.g, op.plan, op.halo, in, c.at(op.wf), bias, out, c.s, epi) == 0) {
             if (epi_fused && epi) *epi_fused = 1;
@@ -2873,7 +2883,7 @@ int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, c
                  void* out, void* scratch, int64_t scratch_bytes, void* hip_stream) {
     if (check_geom(g)) return 1;
     STCD_CHECK(in && w && out, "null pointer argument");
-    if (impl == 1 || impl == 2 || impl == 3) {
+    if (impl == 1 || impl == 2 || impl == 3 || impl == 6) {
         STCD_CHECK(dtype == STCD_DTYPE_BF16, "the MFMA implementation is bf16 only");
         ConvMfmaPlan p = conv_mfma_plan(*g);
         STCD_CHECK(p.ok, "geometry not supported by the MFMA kernel");
@@ -2883,6 +2893,13 @@ int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, c
             const ConvHaloPlan hp = conv_halo_plan(*g, p);
             STCD_CHECK(hp.ok, "geometry not supported by the resident-halo kernel (3x3 stride 1, Ci % 64 == 0, Co % 128 == 0)");
             STCD_CHECK(launch_conv_halo(*g, p, hp, in, scratch, bias, out, (hipStream_t)hip_stream) == 0, "launch failed");
+            STCD_HIP(hipGetLastError());
+            return 0;
+        }
+        if (impl == 6) {      // 256 x 256 implicit-GEMM tile staged by LDS-DMA (Ci % 64 == 0, Co % 256 == 0, an even number >= 4 of K-tiles)
+            const ConvDmaPlan dp = conv_dma_plan(*g, p);
+            STCD_CHECK(dp.ok, "geometry not supported by the LDS-DMA kernel (Ci % 64 == 0, Co % 256 == 0, (Ci / 64) * taps even and >= 4)");
+            STCD_CHECK(launch_conv_dma(*g, p, dp, in, scratch, bias, out, (hipStream_t)hip_stream) == 0, "launch failed");
             STCD_HIP(hipGetLastError());
             return 0;
         }
@@ -2910,7 +2927,7 @@ int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, c
         STCD_HIP(hipGetLastError());
         return 0;
     }
-    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA), 1 (MFMA, auto-selected kernel), 2 (generic MFMA kernel) or 3 (resident-halo kernel)");
+    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA), 1 (MFMA, auto-selected kernel), 2 (generic MFMA kernel), 3 (resident-halo kernel) or 6 (LDS-DMA kernel)");
     launch_conv_ref(dtype, *g, in, w, g->ci, g->co, bias, out, false, (hipStream_t)hip_stream);
     STCD_HIP(hipGetLastError());
     return 0;

@@ -456,6 +456,56 @@ def test_tap_list_gemm_kernel(n, h, w, ci, co, stride, taps):
         assert (outs[impl] - want).abs().max().item() <= tol, impl
 
 
+# the LDS-DMA kernel (k_conv_dma, impl=6: 256 positions x 256 channels per 8-wave block, (chunk, tap) K-tiles staged by
+# `buffer_load ... lds` with counted vmcnt, two wave rows one barrier apart): ChangeFormer's 256 -> 256 3x3 layers and the
+# 4-tap phases of its 4x4 stride-2 transposed convolutions (scatter at out_stride 2), ragged position counts (partial last
+# tile: masked rows read zeros and are not stored), 1 ... 3 channel tiles, 4 ... 54 K-tiles, more tiles than CUs, and maps one
+# tile row wide / narrower than a tile (taps of one tile reach three image rows or several images).  Every border tap of every
+# case checks the zero fill of an out-of-range DMA.
+DMA_CASES = [  # n, h, w, ci, co, out_stride, (oy0, ox0), taps
+    (1, 16, 16, 128, 256, 1, (0, 0), TAPS3), (2, 20, 37, 128, 256, 1, (0, 0), TAPS3), (1, 33, 16, 256, 512, 1, (0, 0), TAPS3),
+    (3, 48, 48, 256, 256, 1, (0, 0), TAPS3), (5, 128, 128, 128, 256, 1, (0, 0), TAPS3), (2, 64, 64, 384, 768, 1, (0, 0), TAPS3),
+    (2, 24, 40, 256, 256, 2, (1, 0), [(0, 0), (0, 1), (1, 0), (1, 1)]), (2, 24, 40, 256, 256, 2, (0, 1), [(0, 0), (0, -1), (-1, 0), (-1, -1)]),
+    (3, 17, 19, 256, 256, 1, (0, 0), [(0, 0)]), (1, 8, 8, 512, 256, 1, (0, 0), [(0, 0), (0, 1)]), (1, 300, 7, 64, 256, 1, (0, 0), TAPS3 + []),
+]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,so,o0,taps", DMA_CASES)
+def test_lds_dma_conv_kernel(n, h, w, ci, co, so, o0, taps):
+    if (ci // 64) * len(taps) % 2 or (ci // 64) * len(taps) < 4:
+        pytest.skip("K-tile count must be even and >= 4")
+    rng = np.random.default_rng(ci + co + h + len(taps))
+    ho, wo = h * so, w * so
+    x = rnd(rng, n, h, w, ci).to(DEV)
+    wt = rnd(rng, len(taps), ci, co, scale=1.0 / np.sqrt(len(taps) * ci)).float().to(DEV)
+    bias = torch.from_numpy(rng.standard_normal(co).astype(np.float32)).to(DEV)
+    g = geom(n, h, w, ci, ci, h, w, 1, ho, wo, so, o0[0], o0[1], co, co, taps)
+    outs = {}
+    for impl in (6, 2):
+        out = torch.full((n, ho, wo, co), 7.0, dtype=torch.bfloat16, device=DEV)
+        run_conv(impl, g, x, wt, bias, out)
+        outs[impl] = out.double()
+    want = bias.double().view(1, 1, 1, co).expand(n, h, w, co).clone()
+    xd = x.double()
+    for t, (dy, dx) in enumerate(taps):                       # out(y, x) += X(y + dy, x + dx) . W[t]   (zero outside the image)
+        ys = torch.arange(h, device=DEV) + dy
+        xs = torch.arange(w, device=DEV) + dx
+        oky, okx = (ys >= 0) & (ys < h), (xs >= 0) & (xs < w)
+        sub = xd[:, ys.clamp(0, h - 1)][:, :, xs.clamp(0, w - 1)] * (oky.view(1, -1, 1, 1) & okx.view(1, 1, -1, 1))
+        want += (sub.reshape(-1, ci) @ wt[t].double()).reshape(n, h, w, co)
+    tol = 2.0 ** -7 * want.abs().max().item()
+    for impl in (6, 2):
+        got = outs[impl][:, o0[0]::so, o0[1]::so]
+        assert (got - want).abs().max().item() <= tol, impl
+        if so == 2:                                           # positions the scatter must not touch
+            untouched = outs[impl].clone()
+            untouched[:, o0[0]::2, o0[1]::2] = 7.0
+            assert torch.equal(untouched, torch.full_like(untouched, 7.0))
+    # same operands, same fp32 accumulation order per output (chunk-major, tap, k): the two MFMA kernels agree to the last bit
+    # wherever neither rounds differently -- allow one bf16 ulp
+    assert (outs[6] - outs[2]).abs().max().item() <= tol
+
+
 # one-tap weight gradients on the position-GEMM kernel (impl=3): 1x1 convs, stride-2 1x1 (in_stride 2), the phases of a 2x2
 # stride-2 transposed conv (dY read at stride 2 from phase (py, px)), ragged position counts and channel counts that are not
 # multiples of the 64 / 128 tile -- against an fp64 matmul of the same bf16 operands and the reference kernel (impl=0)
