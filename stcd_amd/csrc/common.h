@@ -219,6 +219,7 @@ struct WgradMfmaPlan {
     int64_t slab_floats = 0;
     int wi_valid = 0;      // > 0: columns of the input that exist (a strided VIEW passes a virtual width: see configure_segcd)
     int gemm = 0;          // > 0: one-tap launch on k_wgrad_gemm<gemm> (32*gemm x 32*gemm channel tile), gx = position slices
+    int dma = 0;           // 1: k_wgrad_dma (256 x 256 channel tile per (split, tap) block, LDS-DMA staging), gx = position splits, gy = taps
     bool ok = false;
 };
 WgradMfmaPlan wgrad_mfma_plan(const stcd_conv_geom& g, int kpad, int wld, bool allow_wide = false, int force_co64 = -1);   // allow_wide: 64 x 32 tile for ci >= 64; force_co64 1: the 64 x 64 tile (opt-in variant, see the plan)
@@ -241,6 +242,7 @@ struct WgradJob {
     int start;                             // first block of the job inside a grouped launch
     int lds_bytes;
     int wi_valid;                          // input columns >= wi_valid read as zero (== g.wi for a plain tensor)
+    int dma_L, dma_nk;                     // k_wgrad_dma: positions per split (a multiple of 64), K-tiles per block (even)
     int pad_;
 };
 // one-tap weight gradients with Ci, Co >= 64 (1x1 convs, the phases of 2x2 stride-2 transposed convs): dW = X^T . dY as a GEMM
@@ -249,6 +251,13 @@ WgradMfmaPlan wgrad_gemm_plan(const stcd_conv_geom& g, int kpad, int wld);
 WgradJob wgrad_gemm_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t in_off, int64_t dout_off, int64_t slab_off,
                              int kpad, int wld);
 int launch_wgrad_gemm_group(int W, const WgradJob* jobs_dev, int njobs, int total_blocks, const char* base, hipStream_t s);
+// weight gradient of wide stride-1 tap-list layers (Ci % 256 == 0, Co % 256 == 0, maps >= 64 wide) on the LDS-DMA pipeline
+// (kernels_wgrad_dma.hip): block = (position split, tap, 256 x 256 channel tile); S splits -> S slabs [tap][ci][co]
+WgradMfmaPlan wgrad_dma_plan(const stcd_conv_geom& g, int kpad, int wld);
+void wgrad_dma_set_split(WgradMfmaPlan& p, const stcd_conv_geom& g, int S, int kpad, int wld);
+WgradJob wgrad_dma_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t in_off, int64_t dout_off, int64_t slab_off,
+                            int kpad, int wld);
+int launch_wgrad_dma_group(const WgradJob* jobs_dev, int njobs, int total_blocks, const char* base, hipStream_t s);
 WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t in_off, int64_t dout_off, int64_t slab_off,
                         int kpad, int wld);
 int wgrad_variant_slots(int WCI, int NTW, bool t9, int lds_bytes);   // resident blocks of that kernel variant on the chip

@@ -76,6 +76,7 @@ struct WgradOp {
 struct WgradGroup {                      // all launches of one kernel variant in one backward stage
     int WCI = 1, NTW = 1; bool t9 = false;
     int gemm = 0;                        // > 0: k_wgrad_gemm<gemm> group (one-tap launches; WCI / NTW / t9 unused)
+    int dma = 0;                         // 1: k_wgrad_dma group (256 x 256 channel tiles, LDS-DMA staging; splits chosen for the group)
     std::vector<WgradJob> jobs;
     int total_blocks = 0, lds_bytes = 0;
     int64_t table_off = -1;
@@ -525,6 +526,11 @@ static WgradMfmaPlan pick_wgrad_plan(const stcd_engine& e, const stcd_conv_geom&
     }
     // (64 x 32 tile: SNUNet everywhere; ChangeFormer for its 3x3 layers only -- measured 5.0 vs 5.4 ms there, but 2.7 vs 2.1 ms on the
     //  4-tap phases of its transposed convs)
+    // ChangeFormer's 256 -> 256 3x3 layers on 256^2 / 512^2 maps: the LDS-DMA kernel (measured: DESIGN.md section 4)
+    if (e.use_wgroup && g.ntaps == 9 && (int64_t)g.n * g.hm * g.wm >= 65536) {
+        WgradMfmaPlan p = wgrad_dma_plan(g, kpad, wld);
+        if (p.ok) return p;
+    }
     return wgrad_mfma_plan(g, kpad, wld, e.arch == STCD_ARCH_SNUNET || (e.cf && g.ntaps == 9));
 }
 
@@ -543,17 +549,45 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                 std::vector<WgradGroup>& gs = e.wgroups[op->stage];
                 size_t gi = 0;
                 for (; gi < gs.size(); ++gi)
-                    if (gs[gi].gemm == op->plan.gemm && gs[gi].WCI == op->plan.WCI && gs[gi].NTW == op->plan.NTW && gs[gi].t9 == t9) break;
-                if (gi == gs.size()) { WgradGroup g; g.WCI = op->plan.WCI; g.NTW = op->plan.NTW; g.t9 = t9; g.gemm = op->plan.gemm; gs.push_back(g); }
+                    if (gs[gi].gemm == op->plan.gemm && gs[gi].dma == op->plan.dma && gs[gi].WCI == op->plan.WCI && gs[gi].NTW == op->plan.NTW && gs[gi].t9 == t9) break;
+                if (gi == gs.size()) { WgradGroup g; g.WCI = op->plan.WCI; g.NTW = op->plan.NTW; g.t9 = t9; g.gemm = op->plan.gemm; g.dma = op->plan.dma; gs.push_back(g); }
                 op->grouped = true;
             }
             for (int st = 0; st < 2; ++st)
                 for (WgradGroup& G : e.wgroups[st]) {
                     if (G.gemm) { G.lds_bytes = 2 * 2 * G.gemm * (64 * 64 + 8 * 32); continue; }     // gx fixed by wgrad_gemm_plan
+                    if (G.dma) {
+                        // one block per CU and ONE round: the smallest split length (in 64-position K-tiles) whose blocks -- (split, tap,
+                        // channel tile) over all layers of the group -- fit the 256 CUs; every block then walks about the same K
+                        G.lds_bytes = 128 * 1024;
+                        std::vector<WgradOp*> dops;
+                        for (WgradOp* op : e.wgrad_ops)
+                            if (op->grouped && op->stage == st && op->plan.dma && (op->g.ntaps == 9) == G.t9) dops.push_back(op);
+                        auto blocks_at = [&](int64_t kt) {
+                            int64_t b = 0;
+                            for (WgradOp* op : dops) {
+                                const int64_t M = (int64_t)op->g.n * op->g.hi * op->g.wi;
+                                b += ((M + kt * 64 - 1) / (kt * 64)) * op->plan.gy * op->plan.gz;
+                            }
+                            return b;
+                        };
+                        int64_t lo = 1, hi = 1;
+                        while (blocks_at(hi) > 256) hi *= 2;
+                        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (blocks_at(mid) <= 256) hi = mid; else lo = mid + 1; }
+                        for (WgradOp* op : dops) {
+                            const ConvW& cv = e.convs[op->conv];
+                            const int64_t M = (int64_t)op->g.n * op->g.hi * op->g.wi;
+                            int64_t S = (M + lo * 64 - 1) / (lo * 64);
+                            const int64_t slab_bytes = (int64_t)op->g.ntaps * cv.fwd.kpad * cv.fwd.wld * 4;
+                            S = std::min<int64_t>(S, std::max<int64_t>(1, ((int64_t)64 << 20) / slab_bytes));
+                            wgrad_dma_set_split(op->plan, op->g, (int)S, cv.fwd.kpad, cv.fwd.wld);
+                        }
+                        continue;
+                    }
                     std::vector<WgradOp*> ops;
                     int64_t W = 0;
                     for (WgradOp* op : e.wgrad_ops)
-                        if (op->grouped && op->stage == st && !op->plan.gemm && op->plan.WCI == G.WCI && op->plan.NTW == G.NTW && (op->g.ntaps == 9) == G.t9) {
+                        if (op->grouped && op->stage == st && !op->plan.gemm && !op->plan.dma && op->plan.WCI == G.WCI && op->plan.NTW == G.NTW && (op->g.ntaps == 9) == G.t9) {
                             ops.push_back(op);
                             const int64_t ntiles = (int64_t)op->g.n * ((op->g.wm + 15) / 16) * ((op->g.hm + 7) / 8);
                             W += ntiles * op->plan.gy * op->plan.gz;
@@ -585,8 +619,9 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
             if (op->grouped) {
                 const bool t9 = op->g.ntaps == 9;
                 for (WgradGroup& G : e.wgroups[op->stage])
-                    if (G.gemm == op->plan.gemm && G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9) {
-                        WgradJob j = op->plan.gemm ? wgrad_gemm_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
+                    if (G.gemm == op->plan.gemm && G.dma == op->plan.dma && G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9) {
+                        WgradJob j = op->plan.dma ? wgrad_dma_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
+                                   : op->plan.gemm ? wgrad_gemm_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
                                                    : wgrad_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld);
                         j.start = G.total_blocks;
                         G.total_blocks += j.gx * j.gy * j.gz;
@@ -1155,9 +1190,14 @@ static void reduce_stage(const Ctx& c, int stage) {
     stcd_engine& e = c.e;
     for (const WgradGroup& G : e.wgroups[stage]) {
         char kname[64];
-        if (G.gemm) snprintf(kname, sizeof(kname), "k_wgrad_gemm<%d>", G.gemm);
+        if (G.dma) snprintf(kname, sizeof(kname), "k_wgrad_dma");
+        else if (G.gemm) snprintf(kname, sizeof(kname), "k_wgrad_gemm<%d>", G.gemm);
         else snprintf(kname, sizeof(kname), "k_wgrad_group<%d, %d, %s>", G.WCI, G.NTW, G.t9 ? "true" : "false");
         ProfScope prof(c, PC_WGRAD, G.flops, G.bytes, kname);
+        if (G.dma) {
+            launch_wgrad_dma_group(c.at<WgradJob>(G.table_off), (int)G.jobs.size(), G.total_blocks, c.ws, c.s);
+            continue;
+        }
         if (G.gemm) {
             launch_wgrad_gemm_group(G.gemm, c.at<WgradJob>(G.table_off), (int)G.jobs.size(), G.total_blocks, c.ws, c.s);
             continue;
@@ -2872,12 +2912,19 @@ static int check_geom(const stcd_conv_geom* g) {
                "output positions exceed the output buffer");
     return 0;
 }
+// split count of a stand-alone k_wgrad_dma launch (stcd_op_wgrad impl 7): one round of blocks over the 256 CUs, >= 8 K-tiles per block
+static int op_dma_splits(const stcd_conv_geom& g, const WgradMfmaPlan& p) {
+    const int64_t M = (int64_t)g.n * g.hi * g.wi;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(256 / std::max(1, p.gy * p.gz), M / 512));
+}
 int64_t stcd_op_scratch_bytes(const stcd_conv_geom* g) {
     if (!g) return 0;
     ConvMfmaPlan p = conv_mfma_plan(*g);
     WgradMfmaPlan w = wgrad_mfma_plan(*g, g->ci, g->co), ww = wgrad_mfma_plan(*g, g->ci, g->co, true);
     WgradMfmaPlan wg = wgrad_gemm_plan(*g, g->ci, g->co);
-    return std::max<int64_t>(p.wf_elems * 2, std::max(std::max(w.slab_floats, ww.slab_floats), wg.ok ? wg.slab_floats : 0) * 4) + 1024;
+    WgradMfmaPlan wd = wgrad_dma_plan(*g, g->ci, g->co);
+    if (wd.ok) wgrad_dma_set_split(wd, *g, op_dma_splits(*g, wd), g->ci, g->co);
+    return std::max<int64_t>(p.wf_elems * 2, std::max(std::max(std::max(w.slab_floats, ww.slab_floats), wg.ok ? wg.slab_floats : 0), wd.ok ? wd.slab_floats : 0) * 4) + 1024;
 }
 int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, const float* w, const float* bias,
                  void* out, void* scratch, int64_t scratch_bytes, void* hip_stream) {
@@ -2946,6 +2993,21 @@ int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, 
         STCD_HIP(hipGetLastError());
         return 0;
     }
+    if (impl == 7) {      // the LDS-DMA kernel: 256 x 256 channel tile per (position split, tap) block (ChangeFormer's 256 -> 256 3x3 layers)
+        STCD_CHECK(dtype == STCD_DTYPE_BF16, "the MFMA implementation is bf16 only");
+        WgradMfmaPlan p = wgrad_dma_plan(*g, g->ci, g->co);
+        STCD_CHECK(p.ok, "geometry not supported by the LDS-DMA weight-gradient kernel (stride 1, full map >= 64 wide, Ci % 256 == 0, Co % 256 == 0)");
+        wgrad_dma_set_split(p, *g, op_dma_splits(*g, p), g->ci, g->co);
+        const int64_t table = (p.slab_floats * 4 + 255) & ~(int64_t)255;
+        STCD_CHECK(scratch && scratch_bytes >= table + (int64_t)sizeof(WgradJob), "scratch too small for the partial slabs + job table");
+        WgradJob j = wgrad_dma_make_job(*g, p, (int64_t)(intptr_t)in, (int64_t)(intptr_t)dout, (int64_t)(intptr_t)scratch, g->ci, g->co);
+        STCD_HIP(hipMemcpyAsync((char*)scratch + table, &j, sizeof(j), hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+        STCD_HIP(hipStreamSynchronize((hipStream_t)hip_stream));       // `j` is a stack object
+        launch_wgrad_dma_group((const WgradJob*)((char*)scratch + table), 1, p.gx * p.gy * p.gz, nullptr, (hipStream_t)hip_stream);
+        launch_reduce_dw((const float*)scratch, p.gx, *g, g->ci, g->co, g->ci, g->co, nullptr, dw, (hipStream_t)hip_stream);
+        STCD_HIP(hipGetLastError());
+        return 0;
+    }
     if (impl == 3) {      // one-tap launches on the position-GEMM kernel (the engine's choice for Ci, Co >= 64)
         STCD_CHECK(dtype == STCD_DTYPE_BF16, "the MFMA implementation is bf16 only");
         WgradMfmaPlan p = wgrad_gemm_plan(*g, g->ci, g->co);
@@ -2960,7 +3022,7 @@ int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, 
         STCD_HIP(hipGetLastError());
         return 0;
     }
-    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA), 1 / 4 (MFMA tile kernel, 4: wide tile allowed) or 3 (MFMA position-GEMM kernel)");
+    STCD_CHECK(impl == 0, "impl must be 0 (reference FMA), 1 / 4 (MFMA tile kernel, 4: wide tile allowed), 3 (MFMA position-GEMM kernel) or 7 (LDS-DMA kernel)");
     STCD_HIP(hipMemsetAsync(dw, 0, (size_t)g->ntaps * g->ci * g->co * 4, (hipStream_t)hip_stream));
     launch_wgrad_ref(dtype, *g, in, dout, dw, g->ci, g->co, (hipStream_t)hip_stream);
     STCD_HIP(hipGetLastError());

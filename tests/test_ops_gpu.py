@@ -139,6 +139,43 @@ def test_wgrad_mfma_vs_ref_vs_oracle(n, h, w, ci, co):
         np.testing.assert_allclose(run_wgrad(5, g, x, dout).cpu().numpy() / scale, ref / scale, atol=2e-4, err_msg="mfma, 64 x 64 tile")
 
 
+# the LDS-DMA weight-gradient kernel (k_wgrad_dma, impl=7: block = (position split, tap, 256 x 256 channel tile), K-tiles of 64
+# positions staged by `buffer_load ... lds`, transposed fragment reads): against an fp64 einsum of the same bf16 operands -- map
+# widths that do and do not divide 64 (the per-row (y, x) carry), ragged split ends (positions not a multiple of 64: zero rows),
+# several images (rows at the image seam must not see the neighbour image through a +-1 tap), 2 x 1 / 1 x 2 channel tiles, wider
+# pixel pitches than channel counts, and the 4-tap lists of the transposed-conv phases.
+WDMA_CASES = [  # n, h, w, ci, co, ldi, ldo, taps
+    (1, 64, 64, 256, 256, 256, 256, TAPS3), (2, 33, 67, 256, 256, 256, 256, TAPS3), (3, 16, 100, 256, 256, 320, 264, TAPS3),
+    (1, 40, 64, 512, 256, 512, 256, TAPS3), (2, 24, 72, 256, 512, 256, 512, TAPS3), (2, 48, 96, 256, 256, 256, 256, [(0, 0), (0, 1), (1, 0), (1, 1)]),
+    (4, 128, 128, 256, 256, 256, 256, TAPS3),
+]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,ldi,ldo,taps", WDMA_CASES)
+def test_lds_dma_wgrad_kernel(n, h, w, ci, co, ldi, ldo, taps):
+    rng = np.random.default_rng(ci + co + h + w)
+    x = torch.zeros(n, h, w, ldi, dtype=torch.bfloat16, device=DEV)
+    x[..., :ci] = rnd(rng, n, h, w, ci).to(DEV)
+    x[..., ci:] = 3.0                                          # channels beyond Ci belong to another tensor: must not be read
+    dout = torch.zeros(n, h, w, ldo, dtype=torch.bfloat16, device=DEV)
+    dout[..., :co] = rnd(rng, n, h, w, co).to(DEV)
+    dout[..., co:] = 5.0
+    g = geom(n, h, w, ci, ldi, h, w, 1, h, w, 1, 0, 0, co, ldo, taps)
+    dw = run_wgrad(7, g, x, dout).double()
+    xd, dd = x[..., :ci].double(), dout[..., :co].double()
+    want = torch.zeros(len(taps), ci, co, dtype=torch.float64, device=DEV)
+    for t, (dy, dx) in enumerate(taps):                        # dW[t] = sum X(y + dy, x + dx)^T dY(y, x) over the positions whose tap is inside
+        ys, xs = torch.arange(h, device=DEV) + dy, torch.arange(w, device=DEV) + dx
+        oky, okx = (ys >= 0) & (ys < h), (xs >= 0) & (xs < w)
+        sub = xd[:, ys.clamp(0, h - 1)][:, :, xs.clamp(0, w - 1)] * (oky.view(1, -1, 1, 1) & okx.view(1, 1, -1, 1))
+        want[t] = sub.reshape(-1, ci).T @ dd.reshape(-1, co)
+    scale = want.abs().max().item()
+    assert (dw - want).abs().max().item() / scale <= 2e-5      # fp32 accumulation over <= 65536 positions per slab, then a slab sum
+    if taps is TAPS3 and n * h * w <= 16384:
+        ref = run_wgrad(0, geom(n, h, w, ci, ldi, h, w, 1, h, w, 1, 0, 0, co, ldo, taps), x, dout).double()
+        assert (dw - ref).abs().max().item() / scale <= 2e-4
+
+
 def up_phase_taps(py, px):
     return [(dy, dx) for dy in range(py + 1) for dx in range(px + 1)]
 

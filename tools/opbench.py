@@ -46,6 +46,7 @@ def main():
     which = os.environ.get("OPBENCH_KIND", "conv,wgrad").split(",")
     global IMPL
     IMPL = int(os.environ.get("OPBENCH_IMPL", "1"))
+    WIMPL = int(os.environ.get("OPBENCH_WIMPL", "1"))
     for case in (sys.argv[1:] or DEFAULT):
         name, spec = case.split("=")
         n, h, w, ci, co = [int(v) for v in spec.split(",")[:5]]
@@ -66,7 +67,7 @@ def main():
                                                          C.c_void_p(out.data_ptr()), C.c_void_p(scratch.data_ptr()), nb, st)))
             print(f"{name:6s} conv  {us:8.1f} us  {flops / us / 1e6:8.1f} TFLOP/s  {byts / us / 1e3:8.1f} GB/s   (incl. filter repack launch)")
         if "wgrad" in which:
-            us = timeit(lambda: _lib.check(l.stcd_op_wgrad(1, 1, C.byref(g), C.c_void_p(x.data_ptr()), C.c_void_p(dout.data_ptr()),
+            us = timeit(lambda: _lib.check(l.stcd_op_wgrad(1, WIMPL, C.byref(g), C.c_void_p(x.data_ptr()), C.c_void_p(dout.data_ptr()),
                                                           C.c_void_p(dw.data_ptr()), C.c_void_p(scratch.data_ptr()), nb, st)))
             print(f"{name:6s} wgrad {us:8.1f} us  {flops / us / 1e6:8.1f} TFLOP/s  {byts / us / 1e3:8.1f} GB/s   (incl. slab reduce launch)")
 
