@@ -527,7 +527,7 @@ static WgradMfmaPlan pick_wgrad_plan(const stcd_engine& e, const stcd_conv_geom&
     // (64 x 32 tile: SNUNet everywhere; ChangeFormer for its 3x3 layers only -- measured 5.0 vs 5.4 ms there, but 2.7 vs 2.1 ms on the
     //  4-tap phases of its transposed convs)
     // ChangeFormer's 256 -> 256 3x3 layers on 256^2 / 512^2 maps: the LDS-DMA kernel (measured: DESIGN.md section 4)
-    if (e.use_wgroup && g.ntaps == 9 && (int64_t)g.n * g.hm * g.wm >= 65536) {
+    if (e.use_wgroup && (g.ntaps == 9 || (e.cf && g.ntaps == 4)) && (int64_t)g.n * g.hm * g.wm >= 65536) {
         WgradMfmaPlan p = wgrad_dma_plan(g, kpad, wld);
         if (p.ok) return p;
     }
@@ -545,7 +545,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
         if (e.use_wgroup) {
             for (WgradOp* op : e.wgrad_ops) {
                 if (!op->plan.ok) continue;
-                const bool t9 = op->g.ntaps == 9;
+                const bool t9 = !op->plan.dma && op->g.ntaps == 9;      // (one LDS-DMA group per stage, whatever the tap count)
                 std::vector<WgradGroup>& gs = e.wgroups[op->stage];
                 size_t gi = 0;
                 for (; gi < gs.size(); ++gi)
@@ -562,7 +562,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                         G.lds_bytes = 128 * 1024;
                         std::vector<WgradOp*> dops;
                         for (WgradOp* op : e.wgrad_ops)
-                            if (op->grouped && op->stage == st && op->plan.dma && (op->g.ntaps == 9) == G.t9) dops.push_back(op);
+                            if (op->grouped && op->stage == st && op->plan.dma) dops.push_back(op);
                         auto blocks_at = [&](int64_t kt) {
                             int64_t b = 0;
                             for (WgradOp* op : dops) {
@@ -617,7 +617,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
             const ConvW& cv = e.convs[op->conv];
             op->slab = ws.take(op->plan.slab_floats * 4);
             if (op->grouped) {
-                const bool t9 = op->g.ntaps == 9;
+                const bool t9 = !op->plan.dma && op->g.ntaps == 9;      // (one LDS-DMA group per stage, whatever the tap count)
                 for (WgradGroup& G : e.wgroups[op->stage])
                     if (G.gemm == op->plan.gemm && G.dma == op->plan.dma && G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9) {
                         WgradJob j = op->plan.dma ? wgrad_dma_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)

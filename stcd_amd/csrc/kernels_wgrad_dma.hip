@@ -18,6 +18,9 @@
 //   * positions map linearly to pixels (stride 1, full map), so a DMA's address is base + (pos + tap shift) * pitch: only the
 //     VALIDITY of a row needs (y, x), which each thread carries incrementally for its two rows (64 positions per K-tile).
 //     Rows past the split's end, and taps outside the image, get a voffset past num_records: the DMA writes zeros.
+//   * dY may be a strided view (the sub-pixel phases of a stride-2 transposed convolution read dY at (so*y + oy0, so*x + ox0)):
+//     its row offset is then not linear in the position, so each thread carries the global row index R = n*h + y of its two rows
+//     and forms  R * (so*wo*pitch) + x * (so*pitch)  per K-tile (two multiply-adds per row).
 //   * the loop runs an even number of K-tiles in steady state to its end (the K-tiles it stages past the range are zeros that
 //     nobody reads), then drains.
 #include <algorithm>
@@ -86,7 +89,7 @@ k_wgrad_dma(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
 
     // ---- staging plan: DMA instruction i of wave w covers positions 4 * (2w + i) .. + 3 of the K-tile (lane >> 4), physical chunk
     //      lane & 15 -> logical chunk (lane & 15) ^ swz(pos)
-    int py[2], px[2];                                    // (y, x) of the thread's two rows in the K-tile being staged
+    int py[2], px[2], pr[2];                             // (y, x) and global row index n*h + y of the thread's two rows in the K-tile being staged
     unsigned xvo[2], yvo[2];                             // their byte offsets inside a K-tile (X / dY), channel part included
     int prow[2];
 #pragma unroll
@@ -96,9 +99,9 @@ k_wgrad_dma(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
         const int c16 = (lane & 15) ^ sw;
         prow[i] = pos;
         xvo[i] = (unsigned)((pos * ldi + (c16 >> 3) * 128 + (c16 & 7) * 8) * 2);
-        yvo[i] = (unsigned)((pos * ldo + (c16 >> 2) * 64 + (c16 & 3) * 8) * 2);
+        yvo[i] = (unsigned)((((int64_t)a.g.oy0 * a.g.wo + a.g.ox0) * ldo + (c16 >> 2) * 64 + (c16 & 3) * 8) * 2);
         const int p = P0 + pos;
-        px[i] = p % wi; py[i] = (p / wi) % hi_;
+        px[i] = p % wi; pr[i] = p / wi; py[i] = pr[i] % hi_;
     }
     const int dq = 64 / wi, dr = 64 - dq * wi;           // a K-tile advances (y, x) by (dq, dr) with at most one carry each
     const unsigned lead = (unsigned)((wi + 1) * ldi * 2);
@@ -110,8 +113,9 @@ k_wgrad_dma(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
         const_cast<char*>(reinterpret_cast<const char*>(a_dout)), (short)0, (int)a.dout_bytes, 0x00020000);
     // scalar byte offsets of the staged K-tile's first position (X: tap shift and `lead` included)
     unsigned sx = (unsigned)(((int64_t)P0 + tdy * wi + tdx) * ldi * 2 + ci0 * 2) + lead;
-    unsigned sy = (unsigned)((int64_t)P0 * ldo * 2 + co0 * 2);
-    const unsigned dsx = (unsigned)(64 * ldi * 2), dsy = (unsigned)(64 * ldo * 2);
+    const unsigned sy = (unsigned)(co0 * 2);
+    const unsigned dsx = (unsigned)(64 * ldi * 2);
+    const unsigned yrow_b = (unsigned)(a.g.out_stride * a.g.wo * ldo * 2), ycol_b = (unsigned)(a.g.out_stride * ldo * 2);
     int pk = P0;                                         // first position of the staged K-tile
     unsigned xv[2], yv[2];                               // voffsets of the staged K-tile (valid rows) or past num_records
 #define WD_STATE()                                                                                                     \
@@ -120,15 +124,15 @@ k_wgrad_dma(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
             const bool inr_ = pk + prow[i] < Pend;                                                                     \
             const bool okx_ = inr_ && (unsigned)(py[i] + tdy) < (unsigned)hi_ && (unsigned)(px[i] + tdx) < (unsigned)wi; \
             xv[i] = okx_ ? xvo[i] : 0x80000000u;                                                                       \
-            yv[i] = inr_ ? yvo[i] : 0x80000000u;                                                                       \
+            yv[i] = inr_ ? yvo[i] + (unsigned)pr[i] * yrow_b + (unsigned)px[i] * ycol_b : 0x80000000u;                 \
         }                                                                                                              \
     } while (0)
 #define WD_ADVANCE()                                                                                                   \
     do {                                                                                                               \
-        pk += 64; sx += dsx; sy += dsy;                                                                                \
+        pk += 64; sx += dsx;                                                                                           \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-            px[i] += dr; py[i] += dq;                                                                                  \
-            if (px[i] >= wi) { px[i] -= wi; ++py[i]; }                                                                 \
+            px[i] += dr; py[i] += dq; pr[i] += dq;                                                                     \
+            if (px[i] >= wi) { px[i] -= wi; ++py[i]; ++pr[i]; }                                                        \
             if (py[i] >= hi_) py[i] -= hi_;                                                                            \
         }                                                                                                              \
         WD_STATE();                                                                                                    \
@@ -279,18 +283,20 @@ static bool wgrad_dma_enabled() {
     return on;
 }
 
-// ok: stride-1 full-map tap list, Ci % 256 == 0, Co % 256 == 0, maps at least 64 wide and 2 high, taps within +-1 ... (the lead of the
+// ok: stride-1 full-map tap list (dY plain or the (oy0, ox0) phase of a map twice as large), Ci % 256 == 0, Co % 256 == 0, maps at least 64 wide and 2 high, taps within +-1 ... (the lead of the
 // X descriptor is one row + one pixel).  gx (the split count) is set by the caller (wgrad_dma_set_split).
 WgradMfmaPlan wgrad_dma_plan(const stcd_conv_geom& g, int kpad, int wld) {
     WgradMfmaPlan p;
     if (!wgrad_dma_enabled()) return p;
-    if (g.in_stride != 1 || g.out_stride != 1 || g.oy0 != 0 || g.ox0 != 0 || g.hm != g.hi || g.wm != g.wi || g.ho != g.hi || g.wo != g.wi) return p;
+    if (g.in_stride != 1 || g.hm != g.hi || g.wm != g.wi) return p;
+    if (g.out_stride < 1 || g.out_stride > 2 || g.ho != g.out_stride * g.hi || g.wo != g.out_stride * g.wi || g.oy0 < 0 || g.ox0 < 0 ||
+        g.oy0 >= g.out_stride || g.ox0 >= g.out_stride) return p;
     if (g.ci % 256 != 0 || g.co % 256 != 0 || kpad != g.ci || wld != g.co || g.ldi % 8 != 0 || g.ldo % 8 != 0 || g.ldi < g.ci || g.ldo < g.co) return p;
     if (g.wi < 64 || g.hi < 2 || g.ntaps < 1) return p;
     for (int t = 0; t < g.ntaps; ++t)
         if (g.dy[t] < -1 || g.dy[t] > 1 || g.dx[t] < -1 || g.dx[t] > 1) return p;
     const int64_t M = (int64_t)g.n * g.hi * g.wi;
-    if ((M + 2 * g.wi + 256) * g.ldi * 2 >= ((int64_t)1 << 31) || (M + 256) * g.ldo * 2 >= ((int64_t)1 << 31)) return p;
+    if ((M + 2 * g.wi + 256) * g.ldi * 2 >= ((int64_t)1 << 31) || ((int64_t)g.n * g.ho * g.wo + 256) * g.ldo * 2 >= ((int64_t)1 << 31)) return p;
     p.dma = 1;
     p.gy = g.ntaps; p.gz = (g.ci / 256) * (g.co / 256);
     p.ok = true;
@@ -319,7 +325,7 @@ WgradJob wgrad_dma_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int
     a.dma_nk = (a.dma_L / 64 + 1) & ~1;
     a.co_valid = g.co;
     a.in_bytes = (unsigned)(M * g.ldi * 2);
-    a.dout_bytes = (unsigned)(M * g.ldo * 2);
+    a.dout_bytes = (unsigned)((int64_t)g.n * g.ho * g.wo * g.ldo * 2);
     a.gx = p.gx; a.gy = p.gy; a.gz = p.gz; a.start = 0;
     a.wi_valid = g.wi;
     a.lds_bytes = 8 * WD_HT;

@@ -144,24 +144,28 @@ def test_wgrad_mfma_vs_ref_vs_oracle(n, h, w, ci, co):
 # widths that do and do not divide 64 (the per-row (y, x) carry), ragged split ends (positions not a multiple of 64: zero rows),
 # several images (rows at the image seam must not see the neighbour image through a +-1 tap), 2 x 1 / 1 x 2 channel tiles, wider
 # pixel pitches than channel counts, and the 4-tap lists of the transposed-conv phases.
-WDMA_CASES = [  # n, h, w, ci, co, ldi, ldo, taps
-    (1, 64, 64, 256, 256, 256, 256, TAPS3), (2, 33, 67, 256, 256, 256, 256, TAPS3), (3, 16, 100, 256, 256, 320, 264, TAPS3),
-    (1, 40, 64, 512, 256, 512, 256, TAPS3), (2, 24, 72, 256, 512, 256, 512, TAPS3), (2, 48, 96, 256, 256, 256, 256, [(0, 0), (0, 1), (1, 0), (1, 1)]),
-    (4, 128, 128, 256, 256, 256, 256, TAPS3),
+WDMA_CASES = [  # n, h, w, ci, co, ldi, ldo, taps, out_stride, (oy0, ox0)
+    (1, 64, 64, 256, 256, 256, 256, TAPS3, 1, (0, 0)), (2, 33, 67, 256, 256, 256, 256, TAPS3, 1, (0, 0)), (3, 16, 100, 256, 256, 320, 264, TAPS3, 1, (0, 0)),
+    (1, 40, 64, 512, 256, 512, 256, TAPS3, 1, (0, 0)), (2, 24, 72, 256, 512, 256, 512, TAPS3, 1, (0, 0)),
+    (2, 48, 96, 256, 256, 256, 256, [(0, 0), (0, 1), (1, 0), (1, 1)], 1, (0, 0)), (4, 128, 128, 256, 256, 256, 256, TAPS3, 1, (0, 0)),
+    # the sub-pixel phases of a stride-2 transposed convolution: dY is the (oy0, ox0) phase of a map twice as large
+    (2, 40, 72, 256, 256, 256, 256, [(0, 0), (0, 1), (1, 0), (1, 1)], 2, (1, 1)), (3, 21, 64, 256, 256, 256, 272, [(0, 0), (0, -1), (-1, 0), (-1, -1)], 2, (0, 1)),
+    (1, 64, 64, 256, 256, 256, 256, [(0, 0), (1, 0)], 2, (1, 0)),
 ]
 
 
-@pytest.mark.parametrize("n,h,w,ci,co,ldi,ldo,taps", WDMA_CASES)
-def test_lds_dma_wgrad_kernel(n, h, w, ci, co, ldi, ldo, taps):
+@pytest.mark.parametrize("n,h,w,ci,co,ldi,ldo,taps,so,o0", WDMA_CASES)
+def test_lds_dma_wgrad_kernel(n, h, w, ci, co, ldi, ldo, taps, so, o0):
     rng = np.random.default_rng(ci + co + h + w)
     x = torch.zeros(n, h, w, ldi, dtype=torch.bfloat16, device=DEV)
     x[..., :ci] = rnd(rng, n, h, w, ci).to(DEV)
     x[..., ci:] = 3.0                                          # channels beyond Ci belong to another tensor: must not be read
-    dout = torch.zeros(n, h, w, ldo, dtype=torch.bfloat16, device=DEV)
-    dout[..., :co] = rnd(rng, n, h, w, co).to(DEV)
-    dout[..., co:] = 5.0
-    g = geom(n, h, w, ci, ldi, h, w, 1, h, w, 1, 0, 0, co, ldo, taps)
-    dw = run_wgrad(7, g, x, dout).double()
+    dfull = torch.zeros(n, h * so, w * so, ldo, dtype=torch.bfloat16, device=DEV)
+    dfull[..., :co] = rnd(rng, n, h * so, w * so, co).to(DEV)  # the other phases hold data too: they must not be read
+    dfull[..., co:] = 5.0
+    g = geom(n, h, w, ci, ldi, h, w, 1, h * so, w * so, so, o0[0], o0[1], co, ldo, taps)
+    dw = run_wgrad(7, g, x, dfull).double()
+    dout = dfull[:, o0[0]::so, o0[1]::so]
     xd, dd = x[..., :ci].double(), dout[..., :co].double()
     want = torch.zeros(len(taps), ci, co, dtype=torch.float64, device=DEV)
     for t, (dy, dx) in enumerate(taps):                        # dW[t] = sum X(y + dy, x + dx)^T dY(y, x) over the positions whose tap is inside
@@ -172,7 +176,7 @@ def test_lds_dma_wgrad_kernel(n, h, w, ci, co, ldi, ldo, taps):
     scale = want.abs().max().item()
     assert (dw - want).abs().max().item() / scale <= 2e-5      # fp32 accumulation over <= 65536 positions per slab, then a slab sum
     if taps is TAPS3 and n * h * w <= 16384:
-        ref = run_wgrad(0, geom(n, h, w, ci, ldi, h, w, 1, h, w, 1, 0, 0, co, ldo, taps), x, dout).double()
+        ref = run_wgrad(0, geom(n, h, w, ci, ldi, h, w, 1, h, w, 1, 0, 0, co, ldo, taps), x, dfull).double()
         assert (dw - ref).abs().max().item() / scale <= 2e-4
 
 
