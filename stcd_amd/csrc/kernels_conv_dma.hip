@@ -38,12 +38,14 @@ namespace stcd {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct ConvDmaArgs {
     stcd_conv_geom g;
     const bf16* in; const bf16* wf; const float* bias; bf16* out;
     int NTtot, nk;                 // n-tiles of the fragment image; K-tiles = (Ci / 64) * ntaps (even, >= 4)
     unsigned lead, in_bytes;       // the X descriptor starts `lead` bytes before the tensor (most negative tap offset)
+    unsigned out_bytes;
     int M;                         // positions
     int tiles_m, tiles_n;
     unsigned long long tapbits;    // 6 bits per tap: (dy + 3) | (dx + 3) << 3 -- decoded with scalar shifts, no memory access in the loop
@@ -54,7 +56,7 @@ struct ConvDmaArgs {
 };
 
 constexpr int DM_HT = 16384;                                   // bytes of a half-tile
-constexpr int DM_OPITCH = 256 * 2 + 16;                        // out-tile row pitch (bytes)
+constexpr int DM_SCR = 16 * 144;                               // bytes of one wave's epilogue scratch (16 rows x 128 B, pitch 144)
 #define DM_A(H_, SLOT_) ((((SLOT_) * 2 + (H_)) * DM_HT))
 #define DM_B(H_, SLOT_) ((4 * DM_HT + ((SLOT_) * 2 + (H_)) * DM_HT))
 #define DM_LDS(P_) ((__attribute__((address_space(3))) void*)(P_))
@@ -66,83 +68,85 @@ k_conv_dma(const ConvDmaArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, r = lane & 15;
     const int wr = wid >> 2, wc = wid & 3;
-    // block -> tile: the blocks of one XCD (ids congruent mod 8) take a CONTIGUOUS range of tiles, so the rows neighbouring
-    // tiles share (the +-1 image-row taps) and the filter meet in that XCD's L2 (bijective form of the remap)
-    int tile;
-    {
-        const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-        tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    }
-    const int nt = tile % a.tiles_n, mt = tile / a.tiles_n;
-    const int m0 = mt * 256, nf0 = nt * 16;
+    // PERSISTENT blocks (one per CU).  In round j block b plays the virtual block B = j * nblk + b of a one-tile-per-block grid whose
+    // blocks are dealt round-robin over the 8 XCDs (XCD = B mod 8 = b mod 8 as nblk is a multiple of 8, or the only round): XCD x
+    // owns a CONTIGUOUS range of tiles (bijective split of ntiles over the 8 XCDs) and walks it front to back, 32 neighbouring
+    // tiles at a time -- the rows neighbouring tiles share (the +-1 image-row taps), this round's and the last one's, and the
+    // filter meet in that XCD's L2.
+    const int nblk = gridDim.x, ntiles = a.tiles_m * a.tiles_n;
+    int vb = blockIdx.x;                                   // virtual block id
+    const int xq = ntiles >> 3, xr = ntiles & 7;
+#define DM_TILE_OF(B_) ((((B_) & 7) < xr ? ((B_) & 7) * (xq + 1) : xr * (xq + 1) + (((B_) & 7) - xr) * xq) + ((B_) >> 3))
+    int tile = DM_TILE_OF(vb);
 
     // ---- staging plan.  A: DMA instruction (h, i) of wave w moves rows rho = (2w + i) * 8 + (lane >> 3) of half-tile h, physical
     //      16-B chunk lane & 7; tile row of rho = (rho >> 6) * 128 + h * 64 + (rho & 63).
-    unsigned xoff[2][2], xmask[2][2];
-    {
-        const int ntaps = a.g.ntaps;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int rho = (wid * 2 + i) * 8 + (lane >> 3);
-                const int trow = (rho >> 6) * 128 + h * 64 + (rho & 63);
-                const int lc = (lane & 7) ^ ((rho >> 1) & 7);
-                const int m = m0 + trow;
-                unsigned off = 0x80000000u, mask = 0;
-                if (m < a.M) {
-                    const int x = m % a.g.wm, t = m / a.g.wm, y = t % a.g.hm, n = t / a.g.hm;
-                    const int yi = y * a.g.in_stride, xi = x * a.g.in_stride;
-                    off = (unsigned)(((((int64_t)n * a.g.hi + yi) * a.g.wi + xi) * a.g.ldi + lc * 8) * 2) + a.lead;
-                    for (int tp = 0; tp < ntaps; ++tp) {
-                        const int dy = (int)((a.tapbits >> (6 * tp)) & 7) - 3, dx = (int)((a.tapbits >> (6 * tp + 3)) & 7) - 3;
-                        if ((unsigned)(yi + dy) < (unsigned)a.g.hi && (unsigned)(xi + dx) < (unsigned)a.g.wi) mask |= 1u << tp;
-                    }
-                }
-                xoff[h][i] = off; xmask[h][i] = mask;
-            }
-    }
+    const int ntaps = a.g.ntaps;
+#define DM_DECODE(TILE_)                                                                                               \
+    do {                                                                                                               \
+        const int m0_ = ((TILE_) / a.tiles_n) * 256;                                                                   \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                            \
+                const int rho = (wid * 2 + i) * 8 + (lane >> 3);                                                       \
+                const int trow = (rho >> 6) * 128 + h * 64 + (rho & 63);                                               \
+                const int lc = (lane & 7) ^ ((rho >> 1) & 7);                                                          \
+                const int m = m0_ + trow;                                                                              \
+                unsigned off = 0x80000000u;                                                                            \
+                int yx = (int)0xC000C000;                  /* far outside every image: all taps of a masked row read zeros */ \
+                if (m < a.M) {                                                                                         \
+                    const int x = m % a.g.wm, t = m / a.g.wm, y = t % a.g.hm, n = t / a.g.hm;                          \
+                    const int yi = y * a.g.in_stride, xi = x * a.g.in_stride;                                          \
+                    off = (unsigned)(((((int64_t)n * a.g.hi + yi) * a.g.wi + xi) * a.g.ldi + lc * 8) * 2) + a.lead;    \
+                    yx = (yi << 16) | xi;                                                                              \
+                }                                                                                                      \
+                xoff[h][i] = off; xyx[h][i] = yx;                                                                      \
+            }                                                                                                          \
+    } while (0)
+    unsigned xoff[2][2]; int xyx[2][2];                  // byte offset of the row's centre pixel (+ lead), packed (y, x) of it
     // B: DMA instruction (h, i) of wave w moves fragment piece pi = 2w + i of half-tile h: k-step pi >> 3, wave column (pi & 7) >> 1,
-    //    fragment h * 2 + (pi & 1) of that column
-    unsigned woff[2][2];
+    //    fragment h * 2 + (pi & 1) of that column (the tile's first n-fragment goes into the scalar offset)
+    unsigned woff[2];                                    // (half-tile h: two n-fragments = 2 KB further, in the scalar offset)
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pi = wid * 2 + i, ks = pi >> 3, f8 = pi & 7;
-            const int ntile = (f8 >> 1) * 4 + h * 2 + (f8 & 1);
-            woff[h][i] = (unsigned)(((ks * a.NTtot + nf0 + ntile) * 64 + lane) * 16);
-        }
+    for (int i = 0; i < 2; ++i) {
+        const int pi = wid * 2 + i, ks = pi >> 3, f8 = pi & 7;
+        const int ntile = (f8 >> 1) * 4 + (f8 & 1);
+        woff[i] = (unsigned)(((ks * a.NTtot + ntile) * 64 + lane) * 16);
+    }
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(a.in)) - a.lead, (short)0, (int)(a.in_bytes + a.lead), 0x00020000);
     const unsigned wstep = (unsigned)(2 * a.NTtot * 1024);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(a.wf)), (short)0, (int)((unsigned)a.nk * wstep), 0x00020000);
-    const int ntaps = a.g.ntaps;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(a.out), (short)0, (int)a.out_bytes, 0x00020000);
     const int wi_ldi2 = a.g.wi * a.g.ldi * 2, ldi2 = a.g.ldi * 2;
+    int nt = tile % a.tiles_n, m0 = (tile / a.tiles_n) * 256;
 
 #define DM_STAGE_A(H_, SLOT_, CC_, TT_)                                                                                \
     do {                                                                                                               \
-        const int tt_ = __builtin_amdgcn_readfirstlane(TT_);                                                                                       \
+        const int tt_ = __builtin_amdgcn_readfirstlane(TT_);                                                           \
         const int tdy_ = (int)((a.tapbits >> (6 * tt_)) & 7) - 3, tdx_ = (int)((a.tapbits >> (6 * tt_ + 3)) & 7) - 3;  \
         const unsigned toff_ = (unsigned)(tdy_ * wi_ldi2 + tdx_ * ldi2);                                               \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-            const unsigned vo_ = ((xmask[H_][i] >> tt_) & 1u) ? xoff[H_][i] + toff_ : 0x80000000u;                     \
+            const bool ok_ = (unsigned)((xyx[H_][i] >> 16) + tdy_) < (unsigned)a.g.hi &&                               \
+                             (unsigned)((int)(short)(xyx[H_][i] & 0xffff) + tdx_) < (unsigned)a.g.wi;                  \
+            const unsigned vo_ = ok_ ? xoff[H_][i] + toff_ : 0x80000000u;                                              \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, DM_LDS(smem + DM_A(H_, SLOT_) + (wid * 2 + i) * 1024), 16,   \
-                                                     (int)vo_, __builtin_amdgcn_readfirstlane((CC_) * 128), 0, 0);                                     \
+                                                     (int)vo_, __builtin_amdgcn_readfirstlane((CC_) * 128), 0, 0);     \
         }                                                                                                              \
     } while (0)
 #define DM_STAGE_B(H_, SLOT_, KT_)                                                                                     \
     do {                                                                                                               \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, DM_LDS(smem + DM_B(H_, SLOT_) + (wid * 2 + i) * 1024), 16,   \
-                                                     (int)woff[H_][i], __builtin_amdgcn_readfirstlane((int)((unsigned)(KT_) * wstep)), 0, 0);          \
+                                                     (int)woff[i],                                                     \
+                                                     __builtin_amdgcn_readfirstlane((int)((unsigned)(KT_) * wstep + (unsigned)nt * 16384u + (H_) * 2048u)), 0, 0); \
     } while (0)
 
     // ---- fragment read plan
     const int sw = (r >> 1) & 7;
     const int va0 = (wr * 64 + r) * 128 + ((q ^ sw) * 16), va1 = (wr * 64 + r) * 128 + (((4 + q) ^ sw) * 16);
-    const int vb = (wc * 2 * 64 + lane) * 16;
+    const int vbo = (wc * 2 * 64 + lane) * 16;
     bf16x8 af[2][4], b0f[2][2], b1f[2][2];
     f32x4 acc[8][4];
 #pragma unroll
@@ -160,7 +164,7 @@ k_conv_dma(const ConvDmaArgs a) {
     do {                                                                                                               \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
             _Pragma("unroll") for (int nn = 0; nn < 2; ++nn)                                                           \
-                BF_[ks][nn] = *reinterpret_cast<const bf16x8*>(smem + DM_B(H_, SLOT_) + vb + (ks * 8 + nn) * 1024);    \
+                BF_[ks][nn] = *reinterpret_cast<const bf16x8*>(smem + DM_B(H_, SLOT_) + vbo + (ks * 8 + nn) * 1024);    \
     } while (0)
 #define DM_MMA(HA_, HB_, BF_)                                                                                          \
     do {                                                                                                               \
@@ -216,93 +220,146 @@ k_conv_dma(const ConvDmaArgs a) {
         DM_BAR();                                                                                                      \
         c1 = c2_; t1 = t2_; ++kt;                                                                                      \
     } while (0)
+    // the first 14 DMA instructions of a tile: K-tile 0 and B0, A0, B1 of K-tile 1 (the loop's first phase stages A1 of K-tile 1)
+    int kt, c1, t1;
+#define DM_PROLOGUE()                                                                                                  \
+    do {                                                                                                               \
+        kt = 0; c1 = 0; t1 = 1;                                                                                        \
+        if (t1 == ntaps) { t1 = 0; c1 = 1; }                                                                           \
+        DM_STAGE_B(0, 0, 0);                                                                                           \
+        DM_STAGE_A(0, 0, 0, 0);                                                                                        \
+        DM_STAGE_B(1, 0, 0);                                                                                           \
+        DM_STAGE_A(1, 0, 0, 0);                                                                                        \
+        DM_STAGE_B(0, 1, 1);                                                                                           \
+        DM_STAGE_A(0, 1, c1, t1);                                                                                      \
+        DM_STAGE_B(1, 1, 1);                                                                                           \
+    } while (0)
 
-    // ---- prologue: K-tile 0 and B0, A0, B1 of K-tile 1 (the loop's first phase stages A1 of K-tile 1)
-    int kt = 0;                                  // K-tile being multiplied
-    int c1 = 0, t1 = 1;                          // (chunk, tap) of K-tile kt + 1
-    if (t1 == ntaps) { t1 = 0; c1 = 1; }
-    DM_STAGE_B(0, 0, 0);
-    DM_STAGE_A(0, 0, 0, 0);
-    DM_STAGE_B(1, 0, 0);
-    DM_STAGE_A(1, 0, 0, 0);
-    DM_STAGE_B(0, 1, 1);
-    DM_STAGE_A(0, 1, c1, t1);
-    DM_STAGE_B(1, 1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    DM_BAR();
-    if (wr == 1) DM_BAR();                       // wave row 1 runs one barrier behind wave row 0
+    const bool plain_out = a.g.out_stride == 1 && a.g.ho == a.g.hm && a.g.wo == a.g.wm && a.g.oy0 == 0 && a.g.ox0 == 0;
+    // this wave's transposition scratch (16 rows x 128 B, pitch 144): LDS byte addresses of the lane's write and read slots
+    const unsigned scr0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + 8 * DM_HT + wid * DM_SCR;
+    const unsigned scr_w = scr0 + r * 144 + q * 8, scr_r = scr0 + (lane >> 3) * 144 + (lane & 7) * 16;
     const int nk = a.nk;
-    for (int it = 0; it < nk - 2; it += 2) {
-        DM_KTILE(0, 0);
-        DM_KTILE(1, 0);
+    // the bias goes to LDS once (an ordinary global load in the epilogue would make hipcc wait `vmcnt(0)`, i.e. for the next tile's DMAs)
+    {
+        float* const lb = reinterpret_cast<float*>(smem + 8 * DM_HT + 8 * DM_SCR);
+        for (int i = tid; i < a.g.co; i += 512) lb[i] = a.bias ? a.bias[i] : 0.f;
+        __syncthreads();
     }
-    DM_KTILE(0, 1);
-    DM_KTILE(1, 2);
-    if (wr == 0) DM_BAR();
+    const unsigned bias_r = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + 8 * DM_HT + 8 * DM_SCR + (wc * 64 + 4 * q) * 4;
+    DM_DECODE(tile);
+    DM_PROLOGUE();
+    bool first = true;
+    for (;;) {
+        const int nvb = vb + nblk;
+        const bool has_next = nvb < ntiles;
+        const int ntile = has_next ? DM_TILE_OF(nvb) : tile;
+        // K-tile 0 has landed: all but the 6 youngest DMAs -- and, from the second tile on, the 16 stores of the previous tile's
+        // epilogue, which were issued behind this tile's first DMAs (vmcnt counts loads, stores and DMAs together, in order)
+        if (first) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        DM_BAR();
+        if (wr == 1) DM_BAR();                       // wave row 1 runs one barrier behind wave row 0
+        for (int it = 0; it < nk - 2; it += 2) {
+            DM_KTILE(0, 0);
+            DM_KTILE(1, 0);
+        }
+        DM_KTILE(0, 1);
+        DM_KTILE(1, 2);
+        if (wr == 0) DM_BAR();
+        // every staging slot is dead: the next tile's first DMAs go out before this tile's epilogue
+        const int em0 = m0, ent = nt;
+        if (has_next) {
+            DM_DECODE(ntile);
+            nt = ntile % a.tiles_n; m0 = (ntile / a.tiles_n) * 256;
+            DM_PROLOGUE();
+        }
+        // ---- epilogue: bias, ReLU, rounding; every wave passes its 128 x 64 sub-tile through its OWN scratch in strips of 16
+        //      rows and stores complete 128-B row segments (8 rows per instruction); exactly 16 store instructions per lane and
+        //      tile -- a row past the last position gets a voffset past num_records and is dropped by the hardware.
+        {
+            f32x4 bv[4];
+            {
+                const unsigned ba = bias_r + (unsigned)ent * 1024u;
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\tds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]), "=&v"(bv[3]) : "v"(ba) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int prow = lane >> 3, piece = lane & 7;
+            int mrow = em0 + wr * 128 + prow;                        // position of this lane's first output row; the others are +8 apart
+            int ox = 0, oy = 0, on = 0;
+            if (!plain_out) { ox = mrow % a.g.wm; const int t = mrow / a.g.wm; oy = t % a.g.hm; on = t / a.g.hm; }
+            const int cbase = ent * 256 + wc * 64 + piece * 8;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[m][n][j] + bv[n][j];
+                        if (a.relu) v[j] = fmaxf(v[j], 0.f);
+                        acc[m][n][j] = 0.f;
+                    }
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    // (inline asm: an LDS access hipcc can see gets `s_waitcnt vmcnt(0)` in front of it while the next tile's DMAs fly)
+                    asm volatile("ds_write_b64 %0, %1" :: "v"(scr_w + n * 32), "v"(pk) : "memory");
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    u32x4 pkv;
+                    if (k == 0) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pkv) : "v"(scr_r) : "memory");
+                    else asm volatile("ds_read_b128 %0, %1 offset:1152\n\ts_waitcnt lgkmcnt(0)" : "=v"(pkv) : "v"(scr_r) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    uint4 pk = make_uint4(pkv[0], pkv[1], pkv[2], pkv[3]);
+                    const bool valid = mrow < a.M;
+                    int64_t opix = mrow;
+                    if (!plain_out) opix = ((int64_t)on * a.g.ho + oy * a.g.out_stride + a.g.oy0) * a.g.wo + ox * a.g.out_stride + a.g.ox0;
+                    if (!valid) opix = 0;
+                    if (a.gate || a.res) {      // the rounded conv output, gated and / or combined with a residual, rounded once more
+                        float v8[8];
+                        const uint32_t wv[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) { v8[2 * i2] = __uint_as_float(wv[i2] << 16); v8[2 * i2 + 1] = __uint_as_float(wv[i2] & 0xffff0000u); }
+                        if (a.gate) {
+                            float g8[8];
+                            load8(a.gate + opix * a.ldg + cbase, g8);
+#pragma unroll
+                            for (int i2 = 0; i2 < 8; ++i2) v8[i2] = g8[i2] > 0.f ? v8[i2] : 0.f;
+                        }
+                        if (a.res) {
+                            float r8[8];
+                            load8(a.res + opix * a.ldr + cbase, r8);
+#pragma unroll
+                            for (int i2 = 0; i2 < 8; ++i2) v8[i2] = a.alpha * v8[i2] + a.beta * r8[i2];
+                        }
+                        pk.x = pack_bf16x2(v8[0], v8[1]); pk.y = pack_bf16x2(v8[2], v8[3]);
+                        pk.z = pack_bf16x2(v8[4], v8[5]); pk.w = pack_bf16x2(v8[6], v8[7]);
+                    }
+                    const unsigned vo = valid ? (unsigned)((opix * a.g.ldo + cbase) * 2) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk.x, pk.y, pk.z, pk.w}, ors, vo, 0, 0);
+                    // the lane's next row: 8 positions on
+                    mrow += 8;
+                    if (!plain_out) {
+                        ox += 8;
+                        if (ox >= a.g.wm) { ox -= a.g.wm; ++oy; if (oy >= a.g.hm) { oy = 0; ++on; } }      // (the plan requires wm >= 8)
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = ntile; vb = nvb; first = false;
+    }
 #undef DM_KTILE
 #undef DM_MMA
 #undef DM_READ_A
 #undef DM_READ_B
 #undef DM_STAGE_A
 #undef DM_STAGE_B
-
-    // ---- epilogue: bias, ReLU, rounding; the tile goes to LDS [256 rows][256 channels] (pitch DM_OPITCH)
-    char* const ot = smem;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int cl = wc * 64 + n * 16 + 4 * q;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) { const float4 b4 = *reinterpret_cast<const float4*>(a.bias + nt * 256 + cl); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int row = wr * 128 + m * 16 + r;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = acc[m][n][j] + bv[j];
-                if (a.relu) v[j] = fmaxf(v[j], 0.f);
-            }
-            uint2 pk;
-            pk.x = pack_bf16x2(v[0], v[1]);
-            pk.y = pack_bf16x2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(ot + row * DM_OPITCH + cl * 2) = pk;
-        }
-    }
-    __syncthreads();
-    const bool plain_out = a.g.out_stride == 1 && a.g.ho == a.g.hm && a.g.wo == a.g.wm && a.g.oy0 == 0 && a.g.ox0 == 0;
-#pragma unroll 4
-    for (int p = 0; p < 16; ++p) {
-        const int i = tid + p * 512, row = i >> 5, c8 = i & 31, m = m0 + row;
-        if (m < a.M) {
-            int64_t opix = m;
-            if (!plain_out) {
-                const int x = m % a.g.wm, t = m / a.g.wm, y = t % a.g.hm, n = t / a.g.hm;
-                opix = ((int64_t)n * a.g.ho + y * a.g.out_stride + a.g.oy0) * a.g.wo + x * a.g.out_stride + a.g.ox0;
-            }
-            uint4 pk = *reinterpret_cast<const uint4*>(ot + row * DM_OPITCH + c8 * 16);
-            if (a.gate || a.res) {      // the rounded conv output, gated and / or combined with a residual, rounded once more
-                float v8[8];
-                const uint32_t wv[4] = {pk.x, pk.y, pk.z, pk.w};
-#pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) { v8[2 * i2] = __uint_as_float(wv[i2] << 16); v8[2 * i2 + 1] = __uint_as_float(wv[i2] & 0xffff0000u); }
-                if (a.gate) {
-                    float g8[8];
-                    load8(a.gate + opix * a.ldg + nt * 256 + c8 * 8, g8);
-#pragma unroll
-                    for (int i2 = 0; i2 < 8; ++i2) v8[i2] = g8[i2] > 0.f ? v8[i2] : 0.f;
-                }
-                if (a.res) {
-                    float r8[8];
-                    load8(a.res + opix * a.ldr + nt * 256 + c8 * 8, r8);
-#pragma unroll
-                    for (int i2 = 0; i2 < 8; ++i2) v8[i2] = a.alpha * v8[i2] + a.beta * r8[i2];
-                }
-                pk.x = pack_bf16x2(v8[0], v8[1]); pk.y = pack_bf16x2(v8[2], v8[3]);
-                pk.z = pack_bf16x2(v8[4], v8[5]); pk.w = pack_bf16x2(v8[6], v8[7]);
-            }
-            *reinterpret_cast<uint4*>(a.out + opix * a.g.ldo + nt * 256 + c8 * 8) = pk;
-        }
-    }
+#undef DM_PROLOGUE
+#undef DM_DECODE
 }
 
 static bool conv_dma_enabled() {
@@ -325,8 +382,11 @@ ConvDmaPlan conv_dma_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p) {
     if (M >= ((int64_t)1 << 31)) return dp;
     dp.tiles_m = (int)((M + 255) / 256);
     dp.tiles_n = g.co / 256;
-    dp.blocks = dp.tiles_m * dp.tiles_n;
-    dp.lds_bytes = std::max(8 * DM_HT, 256 * DM_OPITCH);
+    if (g.wm < 8) return dp;
+    if (((int64_t)g.n * g.ho * g.wo + 8) * g.ldo * 2 >= ((int64_t)1 << 31)) return dp;      // 32-bit buffer offsets of the output stores
+    dp.blocks = std::min(dp.tiles_m * dp.tiles_n, 256);       // persistent: one block per CU (a multiple of 8, or a single round)
+    if (g.co > 2048) return dp;                               // the bias copy in LDS
+    dp.lds_bytes = 8 * DM_HT + 8 * DM_SCR + g.co * 4;
     dp.ok = true;
     return dp;
 }
@@ -340,6 +400,7 @@ int launch_conv_dma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvDm
     a.NTtot = p.NTtot; a.nk = (g.ci / 64) * g.ntaps;
     a.lead = (unsigned)((3 * g.wi + 3) * g.ldi * 2);
     a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
+    a.out_bytes = (unsigned)((int64_t)g.n * g.ho * g.wo * g.ldo * 2);
     a.M = g.n * g.hm * g.wm;
     a.tiles_m = dp.tiles_m; a.tiles_n = dp.tiles_n;
     a.tapbits = 0;
