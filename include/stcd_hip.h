@@ -303,12 +303,17 @@ typedef struct stcd_conv_geom {
 
 /* w: fp32 [ntaps][ci][co]; bias: fp32 [co] or NULL; impl: 0 = reference FMA kernel, 1 = MFMA, the kernel the engine would
  * pick (bf16 only: small-channel persistent kernel, resident-filter kernel, tap-list GEMM kernel, else the generic one),
- * 2 = generic MFMA kernel */
+ * 2 = generic MFMA kernel, 3 = resident-halo kernel (wide 3x3 layers, opt-in in the engine), 6 = LDS-DMA kernel (Ci % 64 == 0,
+ * Co % 256 == 0, an even number >= 4 of (64-channel chunk, tap) K-tiles: 256 positions x 256 channels per persistent 8-wave block,
+ * `buffer_load ... lds` staging with counted vmcnt -- what the engine runs for ChangeFormer's 256 -> 256 decoder-head layers,
+ * /root/reference/models/ChangeFormerBaseNetworks.py:85-120) */
 int stcd_op_conv(int dtype, int impl, const stcd_conv_geom* g, const void* in, const float* w, const float* bias,
                  void* out, void* scratch, int64_t scratch_bytes, void* hip_stream);
 /* dw: fp32 [ntaps][ci][co], overwritten; impl: 0 = reference FMA kernel, 1 = MFMA tile kernel (4: its 64 x 32-channel tile
  * allowed for Ci >= 64, as the SNUNet engine runs it; 5: its 64 x 64-channel tile, an opt-in variant), 3 = MFMA position-GEMM kernel
- * (one tap, Ci >= 64, Co >= 64: what the engine runs for 1x1 convs and the phases of 2x2 stride-2 transposed convs) */
+ * (one tap, Ci >= 64, Co >= 64: what the engine runs for 1x1 convs and the phases of 2x2 stride-2 transposed convs),
+ * 7 = LDS-DMA kernel (stride-1 full-map tap lists with Ci % 256 == 0, Co % 256 == 0, maps >= 64 wide; dY plain or one sub-pixel
+ * phase of a map twice as large: block = (position split, tap, 256 x 256 channel tile) -- ChangeFormer's decoder-head layers) */
 int stcd_op_wgrad(int dtype, int impl, const stcd_conv_geom* g, const void* in, const void* dout, float* dw,
                   void* scratch, int64_t scratch_bytes, void* hip_stream);
 int64_t stcd_op_scratch_bytes(const stcd_conv_geom* g);
