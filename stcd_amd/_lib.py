@@ -91,6 +91,7 @@ _PROTOS = {
     "stcd_cf_site_seed": (C.c_uint32, [C.c_uint64, _i]),
     "stcd_cf_set_drop_rates": (_i, [_vp, _f, _f, _f]),
     "stcd_cf_set_aux_backward": (_i, [_vp, _i]),
+    "stcd_set_wgrad_side": (_i, [_vp, _i]),
     "stcd_num_params": (_i, [_vp]),
     "stcd_param_info": (_i, [_vp, _i, C.POINTER(TensorInfo)]),
     "stcd_param_floats": (_i64, [_vp]),

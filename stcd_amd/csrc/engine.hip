@@ -252,6 +252,11 @@ struct stcd_engine_impl {
     std::vector<BiasJob> bias_jobs; int64_t bias_jobs_off = -1;
     int64_t masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
     int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1, use_act_fuse = 1, use_gemm = 1;
+    // FC-Siam backward: the decoder's grouped weight gradients (+ slab reduce, bias finish) run on a low-priority side stream beside
+    // the encoder's backward chain on the caller's stream; their grids get 1 / wg_side_div of the planner's block budget so that the
+    // chain's blocks find free slots (wgrad_side_stream)
+    int wg_side_on = 1, wg_side_div = 4;
+    hipStream_t wg_side = nullptr; hipEvent_t wg_fork = nullptr, wg_join = nullptr; int wg_side_dev = -1;
 };
 
 }  // namespace stcd
@@ -404,6 +409,9 @@ static const DecSpec DEC[4] = {
 static inline int fc_dates(const stcd_engine& e) { return e.arch == STCD_ARCH_FCEF ? 1 : 2; }
 static inline bool fc_concat_skips(const stcd_engine& e) { return e.arch == STCD_ARCH_CONC || e.arch == STCD_ARCH_FCEF; }
 static inline bool fc_cross(const stcd_engine& e) { return e.arch == STCD_ARCH_XCONC; }
+static inline bool fc_family(const stcd_engine& e) {      // the engines backward_fcsiam runs
+    return e.arch == STCD_ARCH_DIFF || e.arch == STCD_ARCH_CONC || e.arch == STCD_ARCH_SUB || e.arch == STCD_ARCH_FCEF || e.arch == STCD_ARCH_XCONC;
+}
 
 static void build_fcsiam_tables(stcd_engine& e) {
     // registration order of SiamUnet_*.__init__ (SiamUnet_diff.py:18-90): conv, bn per layer; upconv before its stage
@@ -597,7 +605,9 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                         WgradJob j = wgrad_make_job(op->g, op->plan, 0, 0, 0, cv.fwd.kpad, cv.fwd.wld);
                         G.lds_bytes = std::max(G.lds_bytes, j.lds_bytes);
                     }
-                    const int slots = wgrad_variant_slots(G.WCI, G.NTW, G.t9, G.lds_bytes);
+                    int slots = wgrad_variant_slots(G.WCI, G.NTW, G.t9, G.lds_bytes);
+                    // stage 0 of the FC-Siam family runs beside stage 1's chain on a side stream: its grids leave room for the chain's blocks
+                    if (st == 0 && e.wg_side_on && e.wg_side_div > 1 && fc_family(e)) slots = std::max(64, slots / e.wg_side_div);
                     const int64_t rounds = e.wgroup_rounds;
                     const int64_t tpb = std::max<int64_t>(e.wgroup_min_tiles, (W + rounds * slots - 1) / (rounds * slots));
                     for (WgradOp* op : ops) {
@@ -1385,9 +1395,38 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
     return 0;
 }
 
+// The side stream of the decoder's weight gradients (FC-Siam family, both backward stages in one call): created on first use, lowest
+// priority.  nullptr: switched off (STCD_WGRAD_SIDE=0), or the caller's stream is being captured into a graph (a captured step stays on
+// one stream).  MEASURED (MI355X, SiamUnet_diff 16 x 256^2): serial 2.281-2.289 ms; side stream with the planner's full grids 2.265
+// (the grouped launches fill every CU: the chain's kernels queue behind them); with a quarter of the block budget for stage 0's
+// groups (fewer, longer blocks: fewer slabs too) 2.223-2.235 ms.  A CU-masked stream (hipExtStreamCreateWithCUMask, any mask
+// including all CUs) cost 0.8-1.7 ms per step on this stack and was dropped.
+static hipStream_t wgrad_side_stream(stcd_engine& e, hipStream_t s) {
+    if (!e.wg_side_on || !e.use_wgroup || !mfma_on(e)) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cap != hipStreamCaptureStatusNone) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (e.wg_side && e.wg_side_dev == dev) return e.wg_side;
+    if (e.wg_side) return nullptr;                      // created on another device: stay serial there
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // (least, greatest)
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_lo) != hipSuccess) { (void)hipGetLastError(); e.wg_side_on = 0; return nullptr; }
+    if (hipEventCreateWithFlags(&e.wg_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e.wg_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipStreamDestroy(st); e.wg_side_on = 0; return nullptr;
+    }
+    e.wg_side = st; e.wg_side_dev = dev;
+    return st;
+}
+
 static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float* params, float* grads, void* workspace,
                            int stage, hipStream_t s) {
     Ctx c{e, (char*)workspace, params, grads, s};
+    // both stages in one call (no gradient all-reduce between them): stage 0's weight gradients only read stored tensors and write
+    // their own slabs / gradient entries, so they can run beside stage 1's chain
+    hipStream_t side = stage < 0 ? wgrad_side_stream(e, s) : nullptr;
     const int B = e.B, dt = e.dt;
     const int64_t T = (int64_t)dsize(dt);
     static const int SKIP_IDX[4] = {1, 3, 6, 9};
@@ -1416,8 +1455,17 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
                                 (int64_t)e.Hs[s_] * e.Ws[s_], C, s);
             }
         }
-        reduce_stage(c, 0);
-        launch_bias_finish(c.at<BiasJob>(e.bias_jobs_off), (int)e.bias_jobs.size(), c.ws, c.grads, s);
+        if (side) {
+            STCD_HIP(hipEventRecord(e.wg_fork, s));
+            STCD_HIP(hipStreamWaitEvent(side, e.wg_fork, 0));
+            Ctx cs{e, (char*)workspace, params, grads, side};
+            reduce_stage(cs, 0);
+            launch_bias_finish(c.at<BiasJob>(e.bias_jobs_off), (int)e.bias_jobs.size(), c.ws, c.grads, side);
+            STCD_HIP(hipEventRecord(e.wg_join, side));
+        } else {
+            reduce_stage(c, 0);
+            launch_bias_finish(c.at<BiasJob>(e.bias_jobs_off), (int)e.bias_jobs.size(), c.ws, c.grads, s);
+        }
     }
     if (stage < 0 || stage == 1) {
         for (int li = (int)e.enc.size() - 1; li >= 0; --li) {
@@ -1443,6 +1491,7 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
             cbrd_backward(c, L, skip_chunks);
         }
         reduce_stage(c, 1);
+        if (side) STCD_HIP(hipStreamWaitEvent(s, e.wg_join, 0));
     }
     STCD_HIP(hipGetLastError());
     return 0;
@@ -2536,6 +2585,10 @@ static void engine_env_switches(stcd_engine* e) {
     e->use_act_fuse = !(env && env[0] == '1');
     env = getenv("STCD_NO_SKIP_FUSED");
     e->use_skip_fused = !(env && env[0] == '1');
+    env = getenv("STCD_WGRAD_SIDE");              // 0: the decoder's weight gradients stay on the caller's stream
+    if (env) e->wg_side_on = atoi(env) != 0;
+    env = getenv("STCD_WGRAD_SIDE_DIV");          // share of the planner's block budget for stage 0's grouped grids: 1 / div
+    if (env && atoi(env) > 0) e->wg_side_div = atoi(env);
     env = getenv("STCD_WGRAD_ROUNDS");
     if (env && atoi(env) > 0) e->wgroup_rounds = atoi(env);
     env = getenv("STCD_WGRAD_MIN_TILES");
@@ -2598,6 +2651,12 @@ int stcd_cf_set_aux_backward(stcd_engine* e, int on) {
     e->cf->aux_bwd = on != 0;
     return 0;
 }
+int stcd_set_wgrad_side(stcd_engine* e, int on) {
+    STCD_CHECK(e, "null engine");
+    if ((e->wg_side_on != 0) != (on != 0)) e->configured = false;        // the block budget of stage 0's grouped grids is part of the plan
+    e->wg_side_on = on != 0;
+    return 0;
+}
 int stcd_cf_set_drop_rates(stcd_engine* e, float drop_rate, float attn_drop, float diff_drop) {
     STCD_CHECK(e && e->cf, "not a ChangeFormer engine");
     for (float p : {drop_rate, attn_drop, diff_drop}) STCD_CHECK(p >= 0.f && p < 1.f, "drop rates must be in [0,1)");
@@ -2640,7 +2699,10 @@ int stcd_create(int arch, int in_ch, int label_ch, int dtype, stcd_engine** out)
     *out = e.release();
     return 0;
 }
-void stcd_destroy(stcd_engine* e) { delete e; }
+void stcd_destroy(stcd_engine* e) {
+    if (e && e->wg_side) { (void)hipStreamSynchronize(e->wg_side); (void)hipStreamDestroy(e->wg_side); (void)hipEventDestroy(e->wg_fork); (void)hipEventDestroy(e->wg_join); }
+    delete e;
+}
 
 int stcd_num_params(const stcd_engine* e) { return e ? (int)e->params.size() : 0; }
 int stcd_param_info(const stcd_engine* e, int i, stcd_tensor_info* info) {

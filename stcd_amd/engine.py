@@ -159,6 +159,13 @@ class Engine:
         _lib.check(self._l.stcd_cf_set_aux_backward(self._h, 1 if on else 0))
         self.shape = None
 
+    def set_wgrad_side(self, on: bool):
+        """FC-Siam family: run the decoder's weight gradients on the engine's side stream beside the encoder's backward chain
+        (single-call backward only).  Off for data-parallel training, whose staged backward keeps everything on one stream; the
+        plan is rebuilt by the next forward."""
+        _lib.check(self._l.stcd_set_wgrad_side(self._h, 1 if on else 0))
+        self.shape = None
+
     def pack_masks(self, masks: dict, device) -> torch.Tensor:
         """name -> [rows, C] tensors (oracle convention) into the engine's flat mask buffer."""
         flat = torch.empty(self.dropout_floats, dtype=torch.float32, device=device)

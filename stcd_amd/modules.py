@@ -121,7 +121,22 @@ class HipChangeDetector(nn.Module):
         self._next_masks: Optional[torch.Tensor] = None
         self._seed = int(os.environ.get("STCD_DROPOUT_SEED", "1337"))
         self._steps = 0
-        self.grad_stage_hook: Optional[Callable[[int, torch.Tensor], None]] = None
+        self._grad_stage_hook: Optional[Callable[[int, torch.Tensor], None]] = None
+
+    @property
+    def grad_stage_hook(self) -> Optional[Callable[[int, torch.Tensor], None]]:
+        """hook(stage, flat_gradient_slice), called when that slice is final (stcd_amd.ddp.FlatGradReducer).  With a hook the
+        backward runs as two staged calls on ONE stream, so the engine's side stream for the decoder's weight gradients (and the
+        smaller grids planned for it) is switched off: the plan is rebuilt by the next forward."""
+        return self._grad_stage_hook
+
+    @grad_stage_hook.setter
+    def grad_stage_hook(self, hook):
+        changed = (hook is None) != (self._grad_stage_hook is None)
+        self._grad_stage_hook = hook
+        eng = getattr(self, "_engine", None)
+        if changed and eng is not None and hasattr(eng, "set_wgrad_side"):
+            eng.set_wgrad_side(hook is None)
 
     # ------------------------------------------------------------------ parameter plumbing
     def _check_layout(self):

@@ -234,6 +234,7 @@ class GraphedTrainStep:
                             "set_dropout_p(0) first, or train it eagerly")
         if inner.grad_stage_hook is not None:
             raise StcdError("a data-parallel gradient hook is installed: collectives are not captured; use the eager step")
+        inner._engine.set_wgrad_side(False)                  # a captured step stays on one stream: plan the FC-Siam decoder's weight gradients for it
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self._x = [t.detach().clone() for t in example_inputs]
         self._y = example_target.detach().clone()

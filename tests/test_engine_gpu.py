@@ -608,3 +608,56 @@ def test_fcsiam_every_layer_in_place(arch, dtype, B, H, W):
             a = torch.relu((y - mu) * torch.rsqrt(var + 1e-5) * bn.weight.detach().view(1, -1, 1, 1) + bn.bias.detach().view(1, -1, 1, 1))
             chk("bn+relu", name, nchw(ws[f"{name}.A.g{gi}"]), a, 5e-6 if dtype == "fp32" else 4e-3)
     print(f"SiamUnet_{arch} {dtype} B={B} {H}x{W} layer-local worst relative l2: " + ", ".join(f"{k} {v[0]:.1e} ({v[1]})" for k, v in worst.items()))
+
+
+@pytest.mark.parametrize("arch", ["diff", "conc", "fcef"])
+def test_side_stream_weight_gradients_are_deterministic_and_match_the_serial_plan(arch):
+    """FC-Siam backward in one call: the decoder's grouped weight gradients run on the engine's low-priority side stream beside the
+    encoder's chain (stcd_set_wgrad_side, on by default) with a quarter of the planner's block budget.  (1) Race screen: the launches
+    differ from pass to pass only by the order of the float atomics that finish the slab sums of many-slab layers (1e-7), so 12
+    backward passes of one state / batch at the headline size must agree with the first to 1e-5 per tensor, with allocator / cache
+    noise in between -- a weight gradient read before its dY is final, or a slab summed before it is written, is an error of the
+    order of 1 / slabs.  (2) The same gradients from the serial plan (stcd_set_wgrad_side(0): more K-split slabs, i.e.
+    another fp32 summation order over bf16 products) agree to fp32 summation noise, tensor by tensor."""
+    torch.manual_seed(3)
+    B, H, W = 16, 256, 256
+    cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "fcef": Unet}[arch]
+    x1 = torch.randn(B, 3, H, W, device=DEV); x2 = torch.randn(B, 3, H, W, device=DEV)
+    tgt = (torch.rand(B, H, W, device=DEV) < 0.2).long()
+    st = R.synth_state(arch, 3, 2, 5)
+
+    def grads(side, reps):
+        m = cls(3, 2, dtype="bf16")
+        m.load_state_dict(st)
+        m.to(DEV).train()
+        m._engine.set_wgrad_side(side)
+        outs = []
+        junk = torch.empty(96 << 20, dtype=torch.uint8, device=DEV)
+        for it in range(reps):
+            m.zero_grad(set_to_none=False)
+            m._steps = 0                                     # the same dropout masks every pass
+            out = m(x1, x2)
+            out = out[-1] if isinstance(out, (list, tuple)) else out
+            torch.nn.functional.cross_entropy(out, tgt).backward()
+            outs.append(m._flat_grads.clone())
+            if it % 2:
+                junk.fill_(it)
+        torch.cuda.synchronize()
+        return outs
+
+    on = grads(True, 12)
+    off = grads(False, 1)[0]
+    infos = cls(3, 2, dtype="bf16")._engine.params
+    worst = [0.0, 0.0]
+    for info in infos:
+        sl = slice(info.offset, info.offset + info.numel)
+        a = on[0][sl].double()
+        for k, g in enumerate(on[1:], 1):
+            rel = float((g[sl].double() - a).norm() / (a.norm() + 1e-30))
+            worst[0] = max(worst[0], rel)
+            assert rel <= 1e-5, f"{arch} {info.name}: backward pass {k} differs from pass 0 by rel-l2 {rel:.2e} with the side stream on"
+        b = off[sl].double()
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        worst[1] = max(worst[1], rel)
+        assert rel <= 2e-5, f"{arch} {info.name}: side-stream plan vs serial plan rel-l2 {rel:.2e}"
+    print(f"{arch}: worst rel-l2 between passes {worst[0]:.2e}, side-stream plan vs serial plan {worst[1]:.2e}")
