@@ -70,6 +70,7 @@ struct WgradOp {
     int stage = 0;
     int64_t in_off = -1, dout_off = -1;  // workspace offsets of X and dY (grouped launch at the end of the stage)
     bool grouped = false;
+    int group = -1;                      // index of its WgradGroup inside e.wgroups[stage]
     bool own_taps = false;               // filter taps (ky, kx) of this launch given here instead of conv.fwd.ky/kx[tap0 + t]
     int8_t oky[9] = {0}, okx[9] = {0};   // (the 7x7 stem: 49 taps spread over 7 launches)
 };
@@ -81,6 +82,7 @@ struct WgradGroup {                      // all launches of one kernel variant i
     int total_blocks = 0, lds_bytes = 0;
     int64_t table_off = -1;
     double flops = 0.0, bytes = 0.0;
+    int seen = 0; bool launched = false;  // run time: members whose operands exist so far in this backward; the grid went out
 };
 
 struct Cbrd {                         // conv -> BN -> ReLU -> Dropout2d [-> pool]
@@ -256,6 +258,7 @@ struct stcd_engine_impl {
     // the encoder's backward chain on the caller's stream; their grids get 1 / wg_side_div of the planner's block budget so that the
     // chain's blocks find free slots (wgrad_side_stream)
     int wg_side_on = 1, wg_side_div = 4;
+    bool wg_early = false; hipStream_t wg_cur_side = nullptr;      // set by backward_fcsiam for the duration of a call (exec_wgrad)
     hipStream_t wg_side = nullptr; hipEvent_t wg_fork = nullptr, wg_join = nullptr; int wg_side_dev = -1;
 };
 
@@ -607,6 +610,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                     }
                     int slots = wgrad_variant_slots(G.WCI, G.NTW, G.t9, G.lds_bytes);
                     // stage 0 of the FC-Siam family runs beside stage 1's chain on a side stream: its grids leave room for the chain's blocks
+                    // (stage 1's groups keep the full budget: half cost 2 %, a quarter 7 %)
                     if (st == 0 && e.wg_side_on && e.wg_side_div > 1 && fc_family(e)) slots = std::max(64, slots / e.wg_side_div);
                     const int64_t rounds = e.wgroup_rounds;
                     const int64_t tpb = std::max<int64_t>(e.wgroup_min_tiles, (W + rounds * slots - 1) / (rounds * slots));
@@ -630,6 +634,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                 const bool t9 = !op->plan.dma && op->g.ntaps == 9;      // (one LDS-DMA group per stage, whatever the tap count)
                 for (WgradGroup& G : e.wgroups[op->stage])
                     if (G.gemm == op->plan.gemm && G.dma == op->plan.dma && G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9) {
+                        op->group = (int)(&G - e.wgroups[op->stage].data());
                         WgradJob j = op->plan.dma ? wgrad_dma_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
                                    : op->plan.gemm ? wgrad_gemm_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
                                                    : wgrad_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld);
@@ -1135,6 +1140,7 @@ static bool exec_conv_x4(const Ctx& c, const ConvOp ops[4], const void* in, cons
 }
 
 // weight gradient of one launch, delivered straight into the reference-layout gradient tensor
+static void wgroup_member_ready(const Ctx& c, const WgradOp& op);
 static void exec_wgrad(const Ctx& c, const WgradOp& op, const void* in, const void* dout) {
     const ConvW& cv = c.e.convs[op.conv];
     PackSpec sub = cv.fwd;                 // this launch's taps of the filter
@@ -1145,7 +1151,10 @@ static void exec_wgrad(const Ctx& c, const WgradOp& op, const void* in, const vo
     }
     double fl, by;
     conv_work(c.e, op.g, op.kreal, op.nreal, &fl, &by);
-    if (mfma_on(c.e) && op.plan.ok && op.grouped) return;    // runs in the stage's grouped launch (wgrad_stage)
+    if (mfma_on(c.e) && op.plan.ok && op.grouped) {          // runs in the stage's grouped launch (reduce_stage, or early: wgroup_member_ready)
+        if (c.e.wg_early) wgroup_member_ready(c, op);
+        return;
+    }
     if (mfma_on(c.e) && op.plan.ok) {
         int rc;
         {
@@ -1196,25 +1205,51 @@ static int pack_all_weights(const Ctx& c, bool with_dgrad) {
     return 0;
 }
 
-static void reduce_stage(const Ctx& c, int stage) {
-    stcd_engine& e = c.e;
-    for (const WgradGroup& G : e.wgroups[stage]) {
+static void launch_wgroup(const Ctx& c, WgradGroup& G) {
+    {
         char kname[64];
         if (G.dma) snprintf(kname, sizeof(kname), "k_wgrad_dma");
         else if (G.gemm) snprintf(kname, sizeof(kname), "k_wgrad_gemm<%d>", G.gemm);
         else snprintf(kname, sizeof(kname), "k_wgrad_group<%d, %d, %s>", G.WCI, G.NTW, G.t9 ? "true" : "false");
         ProfScope prof(c, PC_WGRAD, G.flops, G.bytes, kname);
+        G.launched = true;
         if (G.dma) {
             launch_wgrad_dma_group(c.at<WgradJob>(G.table_off), (int)G.jobs.size(), G.total_blocks, c.ws, c.s);
-            continue;
+            return;
         }
         if (G.gemm) {
             launch_wgrad_gemm_group(G.gemm, c.at<WgradJob>(G.table_off), (int)G.jobs.size(), G.total_blocks, c.ws, c.s);
-            continue;
+            return;
         }
         if (launch_wgrad_group(G.WCI, G.NTW, G.t9, c.at<WgradJob>(G.table_off), (int)G.jobs.size(), G.total_blocks, G.lds_bytes,
                                c.ws, c.s) != 0)
             set_error("grouped weight-gradient launch exceeds the LDS budget");
+    }
+}
+
+// FC-Siam backward with early launches (e.wg_early): a member's operands (X stored by the forward, dY final) exist when the chain
+// calls exec_wgrad for it; the group's grid goes out with its LAST member -- on the side stream, behind an event of the chain's
+// stream, when there is one -- instead of at the end of the stage
+static void wgroup_member_ready(const Ctx& c, const WgradOp& op) {
+    stcd_engine& e = c.e;
+    if (op.group < 0 || op.group >= (int)e.wgroups[op.stage].size()) return;
+    WgradGroup& G = e.wgroups[op.stage][op.group];
+    if (++G.seen < (int)G.jobs.size() || G.launched) return;
+    if (e.wg_cur_side) {
+        if (hipEventRecord(e.wg_fork, c.s) != hipSuccess || hipStreamWaitEvent(e.wg_cur_side, e.wg_fork, 0) != hipSuccess) { set_error("side-stream fork failed"); return; }
+        Ctx cs{e, c.ws, c.params, c.grads, e.wg_cur_side};
+        launch_wgroup(cs, G);
+    } else {
+        launch_wgroup(c, G);
+    }
+}
+
+// the stage's groups that have not gone out yet, then the batched slab reduction; resets the groups' run-time state
+static void reduce_stage(const Ctx& c, int stage) {
+    stcd_engine& e = c.e;
+    for (WgradGroup& G : e.wgroups[stage]) {
+        if (!G.launched) launch_wgroup(c, G);
+        G.launched = false; G.seen = 0;
     }
     if (e.rjobs[stage].empty()) return;
     ProfScope prof(c, PC_PACK, 0.0, 0.0, "k_reduce_jobs");
@@ -1427,6 +1462,15 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
     // both stages in one call (no gradient all-reduce between them): stage 0's weight gradients only read stored tensors and write
     // their own slabs / gradient entries, so they can run beside stage 1's chain
     hipStream_t side = stage < 0 ? wgrad_side_stream(e, s) : nullptr;
+    static const bool early_on = [] { const char* v = getenv("STCD_WGRAD_EARLY"); return !(v && v[0] == '0'); }();
+    struct EarlyScope {      // exec_wgrad sends a group out with its last member for the duration of this call
+        stcd_engine& e;
+        EarlyScope(stcd_engine& e_, bool on, hipStream_t sd) : e(e_) { e.wg_early = on; e.wg_cur_side = sd; }
+        ~EarlyScope() { e.wg_early = false; e.wg_cur_side = nullptr; }
+    } early_scope(e, early_on && mfma_on(e) && e.use_wgroup, side);
+    for (int st = 0; st < 2; ++st)
+        if (stage < 0 || stage == st)
+            for (WgradGroup& G : e.wgroups[st]) { G.seen = 0; G.launched = false; }      // (a failed call may have left them set)
     const int B = e.B, dt = e.dt;
     const int64_t T = (int64_t)dsize(dt);
     static const int SKIP_IDX[4] = {1, 3, 6, 9};
@@ -1490,8 +1534,16 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
             }
             cbrd_backward(c, L, skip_chunks);
         }
-        reduce_stage(c, 1);
-        if (side) STCD_HIP(hipStreamWaitEvent(s, e.wg_join, 0));
+        if (side) {
+            STCD_HIP(hipEventRecord(e.wg_fork, s));
+            STCD_HIP(hipStreamWaitEvent(side, e.wg_fork, 0));
+            Ctx cs{e, (char*)workspace, params, grads, side};
+            reduce_stage(cs, 1);
+            STCD_HIP(hipEventRecord(e.wg_join, side));
+            STCD_HIP(hipStreamWaitEvent(s, e.wg_join, 0));
+        } else {
+            reduce_stage(c, 1);
+        }
     }
     STCD_HIP(hipGetLastError());
     return 0;
