@@ -583,8 +583,11 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                             return b;
                         };
                         int64_t lo = 1, hi = 1;
-                        while (blocks_at(hi) > 256) hi *= 2;
-                        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (blocks_at(mid) <= 256) hi = mid; else lo = mid + 1; }
+                        // (STCD_WGRAD_DMA_BLOCKS: fewer than one block per CU leaves whole CUs to the kernels of the backward chain the
+                        //  group runs beside -- its blocks fill the register file of the CUs they sit on)
+                        static const int dma_blocks = [] { const char* v = getenv("STCD_WGRAD_DMA_BLOCKS"); return v && atoi(v) > 0 ? atoi(v) : 256; }();
+                        while (blocks_at(hi) > dma_blocks) hi *= 2;
+                        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (blocks_at(mid) <= dma_blocks) hi = mid; else lo = mid + 1; }
                         for (WgradOp* op : dops) {
                             const ConvW& cv = e.convs[op->conv];
                             const int64_t M = (int64_t)op->g.n * op->g.hi * op->g.wi;
@@ -1456,6 +1459,12 @@ static hipStream_t wgrad_side_stream(stcd_engine& e, hipStream_t s) {
     return st;
 }
 
+struct EarlyScope {      // exec_wgrad sends a group out with its last member for the duration of a backward call
+    stcd_engine& e;
+    EarlyScope(stcd_engine& e_, bool on, hipStream_t sd) : e(e_) { e.wg_early = on; e.wg_cur_side = sd; }
+    ~EarlyScope() { e.wg_early = false; e.wg_cur_side = nullptr; }
+};
+
 static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float* params, float* grads, void* workspace,
                            int stage, hipStream_t s) {
     Ctx c{e, (char*)workspace, params, grads, s};
@@ -1463,11 +1472,7 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
     // their own slabs / gradient entries, so they can run beside stage 1's chain
     hipStream_t side = stage < 0 ? wgrad_side_stream(e, s) : nullptr;
     static const bool early_on = [] { const char* v = getenv("STCD_WGRAD_EARLY"); return !(v && v[0] == '0'); }();
-    struct EarlyScope {      // exec_wgrad sends a group out with its last member for the duration of this call
-        stcd_engine& e;
-        EarlyScope(stcd_engine& e_, bool on, hipStream_t sd) : e(e_) { e.wg_early = on; e.wg_cur_side = sd; }
-        ~EarlyScope() { e.wg_early = false; e.wg_cur_side = nullptr; }
-    } early_scope(e, early_on && mfma_on(e) && e.use_wgroup, side);
+    EarlyScope early_scope(e, early_on && mfma_on(e) && e.use_wgroup, side);
     for (int st = 0; st < 2; ++st)
         if (stage < 0 || stage == st)
             for (WgradGroup& G : e.wgroups[st]) { G.seen = 0; G.launched = false; }      // (a failed call may have left them set)

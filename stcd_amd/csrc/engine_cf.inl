@@ -791,6 +791,14 @@ static int backward_cf(stcd_engine& e, const float* grad_logits, const float* pa
     const int B = e.B, N2 = 2 * B, dt = e.dt, D = P.D;
     const int64_t T = (int64_t)dsize(dt);
     const int h1 = P.st[0].h, w1 = P.st[0].w;
+    // both stages in one call: the grouped weight gradients go out with their last member on the engine's side stream (the head's
+    // LDS-DMA group right after the second up-sampling layer's backward) and run beside the rest of the chain
+    static const bool cf_side = [] { const char* v = getenv("STCD_CF_SIDE"); return v && v[0] == '1'; }();
+    hipStream_t side = (stage < 0 && cf_side) ? wgrad_side_stream(e, s) : nullptr;
+    EarlyScope early_scope(e, side != nullptr, side);
+    for (int st = 0; st < 2; ++st)
+        if (stage < 0 || stage == st)
+            for (WgradGroup& G : e.wgroups[st]) { G.seen = 0; G.launched = false; }
     if (stage <= 0) {
         STCD_HIP(hipMemsetAsync(grads, 0, e.param_floats * 4, s));
         if (!mfma_on(e)) STCD_HIP(hipMemsetAsync(c.at(e.dwe_begin), 0, e.dwe_end - e.dwe_begin, s));
@@ -834,9 +842,19 @@ static int backward_cf(stcd_engine& e, const float* grad_logits, const float* pa
             launch_slice(dt, c.at<char>(F.lo.g.off) + rows * D * T, D, c.at<char>(F.cat.g.off) + D * T, 2 * D, rows, D, 0, s);
             cf_gemm_bwd(c, F.lin);                 // -> d(stage output) (written; the next stage's patch embedding accumulates)
         }
-        reduce_stage(c, 0);
-        cf_colsum_stage(c, 0);
-        launch_bias_finish(c.at<BiasJob>(e.bias_jobs_off), (int)e.bias_jobs.size(), c.ws, c.grads, s);
+        if (side) {
+            STCD_HIP(hipEventRecord(e.wg_fork, s));
+            STCD_HIP(hipStreamWaitEvent(side, e.wg_fork, 0));
+            Ctx cs{e, (char*)workspace, params, grads, side};
+            reduce_stage(cs, 0);
+            cf_colsum_stage(cs, 0);
+            launch_bias_finish(c.at<BiasJob>(e.bias_jobs_off), (int)e.bias_jobs.size(), c.ws, c.grads, side);
+            STCD_HIP(hipEventRecord(e.wg_join, side));
+        } else {
+            reduce_stage(c, 0);
+            cf_colsum_stage(c, 0);
+            launch_bias_finish(c.at<BiasJob>(e.bias_jobs_off), (int)e.bias_jobs.size(), c.ws, c.grads, s);
+        }
     }
     if (stage < 0 || stage == 1) {
         for (int si = 3; si >= 0; --si) {
@@ -851,8 +869,18 @@ static int backward_cf(stcd_engine& e, const float* grad_logits, const float* pa
                 launch_col2im(dt, c.at(S.col.g.off), S.Kp, c.at(S.in_g.off), S.in_ld, N2, S.hin, S.win, S.cin, S.k, S.stride, S.k / 2, S.h, S.w, 1, s);
             }
         }
-        reduce_stage(c, 1);
-        cf_colsum_stage(c, 1);
+        if (side) {
+            STCD_HIP(hipEventRecord(e.wg_fork, s));
+            STCD_HIP(hipStreamWaitEvent(side, e.wg_fork, 0));
+            Ctx cs{e, (char*)workspace, params, grads, side};
+            reduce_stage(cs, 1);
+            cf_colsum_stage(cs, 1);
+            STCD_HIP(hipEventRecord(e.wg_join, side));
+            STCD_HIP(hipStreamWaitEvent(s, e.wg_join, 0));
+        } else {
+            reduce_stage(c, 1);
+            cf_colsum_stage(c, 1);
+        }
     }
     STCD_HIP(hipGetLastError());
     return 0;
