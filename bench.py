@@ -552,7 +552,7 @@ def main():
             "other_bound_frac": round(min(hbm_frac, mfma_frac), 4),
             "class_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in prof.items()},
             "kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("STCD_BENCH_TOP_KERNELS", "8"))]},
-            "instrumented_ms_per_step": round(tot_ms / nprof, 4),
+            "instrumented_ms_per_step": round(tot_ms / nprof, 4),     # (instrumented steps run on ONE stream: no side-stream overlap)
             "launches_per_step_all_kernels": sum(v["launches"] for v in kern.values()) // nprof,
             "step": step_roof,
         }

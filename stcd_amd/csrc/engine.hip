@@ -1441,6 +1441,7 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
 // including all CUs) cost 0.8-1.7 ms per step on this stack and was dropped.
 static hipStream_t wgrad_side_stream(stcd_engine& e, hipStream_t s) {
     if (!e.wg_side_on || !e.use_wgroup || !mfma_on(e)) return nullptr;
+    if (e.prof.on) return nullptr;                      // instrumented steps (stcd_profile_enable) time every kernel ALONE: same plan, one stream
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (cap != hipStreamCaptureStatusNone) return nullptr;
