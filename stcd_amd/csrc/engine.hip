@@ -71,8 +71,6 @@ struct WgradOp {
     int64_t in_off = -1, dout_off = -1;  // workspace offsets of X and dY (grouped launch at the end of the stage)
     bool grouped = false;
     int group = -1;                      // index of its WgradGroup inside e.wgroups[stage]
-    int bucket = 0;                      // ops of one kernel variant with different buckets get separate groups (SNUNet: a quarter of the
-                                         // backward order, so a group's grid can go out when the chain has passed its last member)
     bool own_taps = false;               // filter taps (ky, kx) of this launch given here instead of conv.fwd.ky/kx[tap0 + t]
     int8_t oky[9] = {0}, okx[9] = {0};   // (the 7x7 stem: 49 taps spread over 7 launches)
 };
@@ -84,7 +82,6 @@ struct WgradGroup {                      // all launches of one kernel variant i
     int total_blocks = 0, lds_bytes = 0;
     int64_t table_off = -1;
     double flops = 0.0, bytes = 0.0;
-    int bucket = 0;
     int seen = 0; bool launched = false;  // run time: members whose operands exist so far in this backward; the grid went out
 };
 
@@ -548,7 +545,6 @@ static WgradMfmaPlan pick_wgrad_plan(const stcd_engine& e, const stcd_conv_geom&
     return wgrad_mfma_plan(g, kpad, wld, e.arch == STCD_ARCH_SNUNET || (e.cf && g.ntaps == 9));
 }
 
-static int sn_side_mode();
 static void build_pack_jobs(stcd_engine& e, Bump& ws) {
     // ---- per-launch slab regions + the batched reduce job tables (MFMA path only)
     for (int st = 0; st < 2; ++st) { e.rjobs[st].clear(); e.rjobs_total[st] = 0; }
@@ -564,8 +560,8 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                 std::vector<WgradGroup>& gs = e.wgroups[op->stage];
                 size_t gi = 0;
                 for (; gi < gs.size(); ++gi)
-                    if (gs[gi].gemm == op->plan.gemm && gs[gi].dma == op->plan.dma && gs[gi].WCI == op->plan.WCI && gs[gi].NTW == op->plan.NTW && gs[gi].t9 == t9 && gs[gi].bucket == op->bucket) break;
-                if (gi == gs.size()) { WgradGroup g; g.WCI = op->plan.WCI; g.NTW = op->plan.NTW; g.t9 = t9; g.gemm = op->plan.gemm; g.dma = op->plan.dma; g.bucket = op->bucket; gs.push_back(g); }
+                    if (gs[gi].gemm == op->plan.gemm && gs[gi].dma == op->plan.dma && gs[gi].WCI == op->plan.WCI && gs[gi].NTW == op->plan.NTW && gs[gi].t9 == t9) break;
+                if (gi == gs.size()) { WgradGroup g; g.WCI = op->plan.WCI; g.NTW = op->plan.NTW; g.t9 = t9; g.gemm = op->plan.gemm; g.dma = op->plan.dma; gs.push_back(g); }
                 op->grouped = true;
             }
             for (int st = 0; st < 2; ++st)
@@ -577,7 +573,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                         G.lds_bytes = 128 * 1024;
                         std::vector<WgradOp*> dops;
                         for (WgradOp* op : e.wgrad_ops)
-                            if (op->grouped && op->stage == st && op->plan.dma && op->bucket == G.bucket) dops.push_back(op);
+                            if (op->grouped && op->stage == st && op->plan.dma) dops.push_back(op);
                         auto blocks_at = [&](int64_t kt) {
                             int64_t b = 0;
                             for (WgradOp* op : dops) {
@@ -605,7 +601,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                     std::vector<WgradOp*> ops;
                     int64_t W = 0;
                     for (WgradOp* op : e.wgrad_ops)
-                        if (op->grouped && op->stage == st && op->bucket == G.bucket && !op->plan.gemm && !op->plan.dma && op->plan.WCI == G.WCI && op->plan.NTW == G.NTW && (op->g.ntaps == 9) == G.t9) {
+                        if (op->grouped && op->stage == st && !op->plan.gemm && !op->plan.dma && op->plan.WCI == G.WCI && op->plan.NTW == G.NTW && (op->g.ntaps == 9) == G.t9) {
                             ops.push_back(op);
                             const int64_t ntiles = (int64_t)op->g.n * ((op->g.wm + 15) / 16) * ((op->g.hm + 7) / 8);
                             W += ntiles * op->plan.gy * op->plan.gz;
@@ -619,8 +615,6 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                     // stage 0 of the FC-Siam family runs beside stage 1's chain on a side stream: its grids leave room for the chain's blocks
                     // (stage 1's groups keep the full budget: half cost 2 %, a quarter 7 %)
                     if (st == 0 && e.wg_side_on && e.wg_side_div > 1 && fc_family(e)) slots = std::max(64, slots / e.wg_side_div);
-                    static const int sn_div = [] { const char* v = getenv("STCD_SN_SIDE_DIV"); return v ? atoi(v) : 1; }();
-                    if (e.arch == STCD_ARCH_SNUNET && sn_side_mode() && sn_div > 1) slots = std::max(64, slots / sn_div);
                     const int64_t rounds = e.wgroup_rounds;
                     const int64_t tpb = std::max<int64_t>(e.wgroup_min_tiles, (W + rounds * slots - 1) / (rounds * slots));
                     for (WgradOp* op : ops) {
@@ -642,7 +636,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
             if (op->grouped) {
                 const bool t9 = !op->plan.dma && op->g.ntaps == 9;      // (one LDS-DMA group per stage, whatever the tap count)
                 for (WgradGroup& G : e.wgroups[op->stage])
-                    if (G.gemm == op->plan.gemm && G.dma == op->plan.dma && G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9 && G.bucket == op->bucket) {
+                    if (G.gemm == op->plan.gemm && G.dma == op->plan.dma && G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9) {
                         op->group = (int)(&G - e.wgroups[op->stage].data());
                         WgradJob j = op->plan.dma ? wgrad_dma_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
                                    : op->plan.gemm ? wgrad_gemm_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
@@ -740,12 +734,6 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
     }
 }
 
-// STCD_SN_SIDE: SNUNet's grouped weight gradients in <n> buckets of the backward order, each going out with its last member on the
-// engine's side stream (experiment)
-static int sn_side_mode() {
-    static const int m = [] { const char* v = getenv("STCD_SN_SIDE"); return v ? atoi(v) : 0; }();
-    return m;
-}
 static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     const int64_t T = (int64_t)dsize(e.dt);
     const int ND = fc_dates(e);            // encoder streams (dates) stacked in the batch dimension
@@ -1807,16 +1795,6 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
         if (e.dt == BF16) op.plan = pick_wgrad_plan(e, g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
         e.wgrad_ops.push_back(&op);
     };
-    if (sn_side_mode() > 0) {      // bucket = quarter (n-th part) of the BACKWARD order the block sits in
-        const int nb = (int)e.sn_order.size(), parts = sn_side_mode();
-        for (int oi = 0; oi < nb; ++oi) {
-            NBlock& b = e.sn_blocks[e.sn_order[oi]];
-            const int bk = ((nb - 1 - oi) * parts) / nb;
-            b.w1.bucket = b.w2.bucket = bk;
-            if (b.up >= 0) for (int ph = 0; ph < 4; ++ph) e.sn_ups[b.up].wg[ph].bucket = bk;
-        }
-        e.sn_final_wg.bucket = 0;
-    }
     for (auto& b : e.sn_blocks) {
         const ConvW& c1 = e.convs[b.c1];
         const ConvW& c2 = e.convs[b.c2];
@@ -2022,8 +2000,12 @@ static int backward_snunet(stcd_engine& e, const float* grad_logits, const float
                            hipStream_t s) {
     if (stage == 1) return 0;            // single-stage plan: everything is final after stage 0 / -1
     Ctx c{e, (char*)workspace, params, grads, s};
-    hipStream_t side = (stage < 0 && sn_side_mode() > 0) ? wgrad_side_stream(e, s) : nullptr;
-    EarlyScope early_scope(e, side != nullptr, side);
+    // single call, no gradient hook: the grouped weight gradients go out with their last member on the engine's side stream (the
+    // groups whose members all sit deep in the backward order -- the GEMM groups, the 32 x 32 tile group -- run beside the rest of
+    // the chain: 13.22 -> 12.80 ms; cutting the groups into buckets of the backward order, or smaller grids, added nothing)
+    hipStream_t side = stage < 0 ? wgrad_side_stream(e, s) : nullptr;
+    static const bool early_on = [] { const char* v = getenv("STCD_WGRAD_EARLY"); return !(v && v[0] == '0'); }();
+    EarlyScope early_scope(e, early_on && mfma_on(e) && e.use_wgroup, side);
     for (WgradGroup& G : e.wgroups[0]) { G.seen = 0; G.launched = false; }
     const int dt = e.dt, B = e.B;
     const int64_t T = (int64_t)dsize(dt);

@@ -610,7 +610,7 @@ def test_fcsiam_every_layer_in_place(arch, dtype, B, H, W):
     print(f"SiamUnet_{arch} {dtype} B={B} {H}x{W} layer-local worst relative l2: " + ", ".join(f"{k} {v[0]:.1e} ({v[1]})" for k, v in worst.items()))
 
 
-@pytest.mark.parametrize("arch", ["diff", "conc", "fcef"])
+@pytest.mark.parametrize("arch", ["diff", "conc", "fcef", "snunet"])
 def test_side_stream_weight_gradients_are_deterministic_and_match_the_serial_plan(arch):
     """FC-Siam backward in one call: the decoder's grouped weight gradients run on the engine's low-priority side stream beside the
     encoder's chain (stcd_set_wgrad_side, on by default) with a quarter of the planner's block budget.  (1) Race screen: the launches
@@ -621,10 +621,13 @@ def test_side_stream_weight_gradients_are_deterministic_and_match_the_serial_pla
     another fp32 summation order over bf16 products) agree to fp32 summation noise, tensor by tensor."""
     torch.manual_seed(3)
     B, H, W = 16, 256, 256
-    cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "fcef": Unet}[arch]
+    if arch == "snunet":      # one backward stage: the groups whose members sit deep in the backward order run beside the rest of the chain
+        from oracle import snunet_ref as S
+        from stcd_amd.modules import SNUNet_ECAM
+    cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "fcef": Unet}[arch] if arch != "snunet" else SNUNet_ECAM
     x1 = torch.randn(B, 3, H, W, device=DEV); x2 = torch.randn(B, 3, H, W, device=DEV)
     tgt = (torch.rand(B, H, W, device=DEV) < 0.2).long()
-    st = R.synth_state(arch, 3, 2, 5)
+    st = R.synth_state(arch, 3, 2, 5) if arch != "snunet" else S.synth_state(3, 2, 5)
 
     def grads(side, reps):
         m = cls(3, 2, dtype="bf16")
