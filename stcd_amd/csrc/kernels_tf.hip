@@ -836,9 +836,104 @@ k_dwgelu_fwd(const T* __restrict__ h, T* __restrict__ u, T* __restrict__ a, cons
     store8(u + pix * Ch + c0, acc);
     store8(a + pix * Ch + c0, o);
 }
+// The same, a thread = 8 channels x a strip of DW_P pixels of one row: the 72 filter values are loaded once per strip and every
+// input piece serves up to three outputs (18 + 18 load instructions per 4 pixels instead of 4 x 27); branch-free (a neighbour outside
+// the map re-reads a clamped address and is zeroed by a select), so all loads of a strip are in flight together.  Same tap order
+// per output (dy major, dx minor) as the pixel kernel.  MEASURED: DESIGN.md section 3b.
+constexpr int DW_P = 4;
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256)
+k_dw_strip(const T* __restrict__ src, T* __restrict__ u, T* __restrict__ a, const float* __restrict__ w, const float* __restrict__ b, int H, int W,
+           int WS, int Ch, int64_t total, DropSite drop) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int np = Ch >> 3, piece = (int)(idx % np);
+    const int64_t strip = idx / np;
+    const int xs = (int)(strip % WS);
+    const int64_t row = strip / WS;                       // n * H + y
+    const int y = (int)(row % H), x0 = xs * DW_P, c0 = piece * 8;
+    float wv[72], acc[DW_P][8];
+    {
+        const float4* wp = reinterpret_cast<const float4*>(w + (int64_t)c0 * 9);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) { const float4 t = wp[k]; wv[4 * k] = t.x; wv[4 * k + 1] = t.y; wv[4 * k + 2] = t.z; wv[4 * k + 3] = t.w; }
+        float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (!BWD) load8(b + c0, b8);
+#pragma unroll
+        for (int p = 0; p < DW_P; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[p][j] = b8[j];
+    }
+    // forward: out(x) += in(y + dy, x + dx) w[dy][dx];  backward (data): dh(x) += g(y - dy, x - dx) w[dy][dx]
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) {
+        const int dy = t3 - 1, yy = BWD ? y - dy : y + dy;
+        const bool yok = (unsigned)yy < (unsigned)H;
+        const int64_t rbase = (row + (yok ? yy - y : 0)) * W;
+        uint4 raw[DW_P + 2];
+#pragma unroll
+        for (int c = 0; c < DW_P + 2; ++c) {             // columns x0 - 1 .. x0 + DW_P
+            const int xx = x0 - 1 + c;
+            const int xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            if constexpr (sizeof(T) == 2) raw[c] = *reinterpret_cast<const uint4*>(src + (rbase + xc) * Ch + c0);
+        }
+#pragma unroll
+        for (int c = 0; c < DW_P + 2; ++c) {
+            const int xx = x0 - 1 + c;
+            const bool ok = yok && (unsigned)xx < (unsigned)W;
+            float v[8];
+            if constexpr (sizeof(T) == 2) {
+                const uint32_t wd[4] = {raw[c].x, raw[c].y, raw[c].z, raw[c].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(wd[i] << 16); v[2 * i + 1] = __uint_as_float(wd[i] & 0xffff0000u); }
+            } else {
+                const int xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                load8(src + (rbase + xc) * Ch + c0, v);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ok ? v[j] : 0.f;
+            // this column is tap dx = (c - 1) - p of output p (forward), dx = p - (c - 1) (backward): in increasing dx per output
+#pragma unroll
+            for (int p = 0; p < DW_P; ++p) {
+                const int dx = BWD ? p - (c - 1) : (c - 1) - p;
+                if (dx >= -1 && dx <= 1) {
+                    const int t = (dy + 1) * 3 + dx + 1;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[p][j] += v[j] * wv[j * 9 + t];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < DW_P; ++p) {
+        if (x0 + p >= W) break;
+        const int64_t pix = row * W + x0 + p;
+        if (BWD) {
+            store8(u + pix * Ch + c0, acc[p]);
+        } else {
+            float o[8];
+            const uint32_t e0 = (uint32_t)(pix * Ch + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = gelu_f(round_as<T>(acc[p][j])) * cf_keep(e0 + j, drop);
+            store8(u + pix * Ch + c0, acc[p]);
+            store8(a + pix * Ch + c0, o);
+        }
+    }
+}
+static bool dw_strip_on() {
+    static const bool on = [] { const char* e = getenv("STCD_NO_DW_STRIP"); return !(e && e[0] == '1'); }();
+    return on;
+}
 void launch_dwgelu_fwd(int dt, const void* h, void* u, void* a, const float* w, const float* b, int n, int H, int W, int Ch,
                        DropSite drop, hipStream_t s) {
     const int64_t total = (int64_t)n * H * W * (Ch / 8);
+    if (dw_strip_on() && W >= DW_P) {
+        const int WS = (W + DW_P - 1) / DW_P;
+        const int64_t tot = (int64_t)n * H * WS * (Ch / 8);
+        if (dt == BF16) k_dw_strip<bf16, false><<<cdiv(tot, 256), 256, 0, s>>>((const bf16*)h, (bf16*)u, (bf16*)a, w, b, H, W, WS, Ch, tot, drop);
+        else k_dw_strip<float, false><<<cdiv(tot, 256), 256, 0, s>>>((const float*)h, (float*)u, (float*)a, w, b, H, W, WS, Ch, tot, drop);
+        return;
+    }
     if (dt == BF16) k_dwgelu_fwd<bf16><<<cdiv(total, 256), 256, 0, s>>>((const bf16*)h, (bf16*)u, (bf16*)a, w, b, H, W, Ch, total, drop);
     else k_dwgelu_fwd<float><<<cdiv(total, 256), 256, 0, s>>>((const float*)h, (float*)u, (float*)a, w, b, H, W, Ch, total, drop);
 }
@@ -928,6 +1023,78 @@ k_dw_bwd_filter(const T* __restrict__ g, const T* __restrict__ h, float* __restr
         __syncthreads();
     }
 }
+// The same over strips of DW_P pixels of one row (as k_dw_strip: every h piece serves up to three taps of the strip's pixels, no
+// branches around the loads): 6 + 3 x 6 load instructions per 4 pixels instead of 4 x 10.  A block's slice = DW_PPB / DW_P strips.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_dw_bwd_filter_strip(const T* __restrict__ g, const T* __restrict__ h, float* __restrict__ partial, int H, int W, int WS, int Ch, int64_t nstrips) {
+    __shared__ float red[256 * 8];
+    const int pl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + pl) * 8;
+    const bool cok = c0 < Ch;
+    constexpr int SPB = DW_PPB / DW_P;
+    const int64_t s0 = (int64_t)blockIdx.y * SPB, s1 = s0 + SPB < nstrips ? s0 + SPB : nstrips;
+    float acc[10][8];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    if (cok)
+        for (int64_t st = s0 + rl; st < s1; st += 32) {
+            const int xs = (int)(st % WS);
+            const int64_t row = st / WS;
+            const int y = (int)(row % H), x0 = xs * DW_P;
+            float gv[DW_P][8];
+#pragma unroll
+            for (int p = 0; p < DW_P; ++p) {
+                const bool ok = x0 + p < W;
+                load8(g + (row * W + (ok ? x0 + p : x0)) * Ch + c0, gv[p]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { gv[p][j] = ok ? gv[p][j] : 0.f; acc[9][j] += gv[p][j]; }
+            }
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const int dy = t3 - 1;
+                const bool yok = (unsigned)(y + dy) < (unsigned)H;
+                const int64_t rbase = (row + (yok ? dy : 0)) * W;
+                float hv[DW_P + 2][8];
+#pragma unroll
+                for (int c = 0; c < DW_P + 2; ++c) {
+                    const int xx = x0 - 1 + c;
+                    const int xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                    load8(h + (rbase + xc) * Ch + c0, hv[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < DW_P + 2; ++c) {
+                    const int xx = x0 - 1 + c;
+                    const bool ok = yok && (unsigned)xx < (unsigned)W;
+#pragma unroll
+                    for (int p = 0; p < DW_P; ++p) {
+                        const int dx = (c - 1) - p;          // dw[dy][dx] += g(x0 + p) h(y + dy, x0 + p + dx)
+                        if (dx >= -1 && dx <= 1) {
+                            const int t = (dy + 1) * 3 + dx + 1;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[t][j] += ok ? gv[p][j] * hv[c][j] : 0.f;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[t][j];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int p2 = threadIdx.x >> 3, j = threadIdx.x & 7;
+            float s = 0.f;
+            for (int r = 0; r < 32; ++r) s += red[(r * 8 + p2) * 8 + j];
+            const int c = (blockIdx.x * 8 + p2) * 8 + j;
+            if (c < Ch) partial[((int64_t)blockIdx.y * Ch + c) * 10 + t] = s;
+        }
+        __syncthreads();
+    }
+}
 __global__ void k_dw_filter_finish(const float* __restrict__ partial, int nblk, int Ch, float* __restrict__ dw, float* __restrict__ db) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Ch * 10) return;
@@ -937,8 +1104,9 @@ __global__ void k_dw_filter_finish(const float* __restrict__ partial, int nblk, 
     if (t < 9) dw[c * 9 + t] = s; else db[c] = s;
 }
 int64_t dwgelu_bwd_scratch_floats(int n, int H, int W, int Ch) {
-    const int64_t npix = (int64_t)n * H * W;
-    return ((npix + DW_PPB - 1) / DW_PPB) * Ch * 10 + 16;
+    const int64_t npix = (int64_t)n * H * W, nstrips = (int64_t)n * H * ((W + DW_P - 1) / DW_P);
+    const int64_t slices = std::max((npix + DW_PPB - 1) / DW_PPB, (nstrips + DW_PPB / DW_P - 1) / (DW_PPB / DW_P));
+    return slices * Ch * 10 + 16;
 }
 void launch_dwgelu_bwd(int dt, const void* h, const void* u, void* da, void* dh, const float* w, float* dw, float* db, float* scratch,
                        int n, int H, int W, int Ch, DropSite drop, hipStream_t s) {
@@ -948,12 +1116,25 @@ void launch_dwgelu_bwd(int dt, const void* h, const void* u, void* da, void* dh,
 #define DW_B(T_)                                                                                                              \
     do {                                                                                                                      \
         k_dwgelu_bwd_gate<T_><<<cdiv(total, 256), 256, 0, s>>>((const T_*)u, (T_*)da, total, drop);                            \
-        k_dw_bwd_data<T_><<<cdiv(total, 256), 256, 0, s>>>((const T_*)da, (T_*)dh, w, H, W, Ch, total);                        \
-        k_dw_bwd_filter<T_><<<gf, 256, 0, s>>>((const T_*)da, (const T_*)h, scratch, H, W, Ch, npix);                          \
+        if (dw_strip_on() && W >= DW_P) {                                                                                     \
+            const int WS_ = (W + DW_P - 1) / DW_P;                                                                                \
+            const int64_t tot_ = (int64_t)n * H * WS_ * (Ch / 8);                                                                 \
+            k_dw_strip<T_, true><<<cdiv(tot_, 256), 256, 0, s>>>((const T_*)da, (T_*)dh, nullptr, w, nullptr, H, W, WS_, Ch, tot_, drop); \
+        } else                                                                                                                    \
+            k_dw_bwd_data<T_><<<cdiv(total, 256), 256, 0, s>>>((const T_*)da, (T_*)dh, w, H, W, Ch, total);                        \
+        if (dw_strip_on() && W >= DW_P) {                                                                                     \
+            const int WS_ = (W + DW_P - 1) / DW_P;                                                                                \
+            dim3 gfs(cdiv(Ch, 64), (unsigned)pbs);                                                                                \
+            k_dw_bwd_filter_strip<T_><<<gfs, 256, 0, s>>>((const T_*)da, (const T_*)h, scratch, H, W, WS_, Ch, nstrips);           \
+        } else                                                                                                                    \
+            k_dw_bwd_filter<T_><<<gf, 256, 0, s>>>((const T_*)da, (const T_*)h, scratch, H, W, Ch, npix);                          \
     } while (0)
+    const int64_t nstrips = (int64_t)n * H * ((W + DW_P - 1) / DW_P);
+    const int pbs = (int)((nstrips + DW_PPB / DW_P - 1) / (DW_PPB / DW_P));
+    const bool strip = dw_strip_on() && W >= DW_P;
     if (dt == BF16) DW_B(bf16); else DW_B(float);
 #undef DW_B
-    k_dw_filter_finish<<<cdiv(Ch * 10, 256), 256, 0, s>>>(scratch, pb, Ch, dw, db);
+    k_dw_filter_finish<<<cdiv(Ch * 10, 256), 256, 0, s>>>(scratch, strip ? pbs : pb, Ch, dw, db);
 }
 
 // ------------------------------------------------------------------------------------------------ residual + dropout + DropPath
