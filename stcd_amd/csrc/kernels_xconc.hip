@@ -7,8 +7,6 @@
 // i.e. two depthwise convolutions added up -- HBM-bound elementwise work: thread = (pixel, 8 channels), 16-B accesses on the NHWC
 // maps as they sit in the engine (the two dates `goff` elements apart), nothing interleaved in memory.  Backward: the two data
 // gradients in one pass, the filter gradient as per-block partials (fixed summation order) + a finish launch.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace stcd {
@@ -91,75 +89,6 @@ k_pairdw_bwd_data(const T* __restrict__ dG, int lddg, T* __restrict__ dA, int ld
     store8<T>(dA + goff + pix * ldda + c0, d2);
 }
 
-// Forward and data gradient over strips of XC_P pixels of one row (thread = 8 channels x XC_P pixels): every input piece serves up
-// to three outputs and the 18 filter rows are read from LDS once per strip -- 2 x 18 (forward) / 18 (backward) global loads per 4
-// pixels instead of 4 x 18 / 4 x 9, branch-free (a neighbour outside the map re-reads a clamped address and is zeroed by a select).
-// The forward keeps the pixel kernel's tap order per output (ky major, kx minor; date 1 then date 2 inside a tap); the data gradient
-// walks a row's taps in the opposite column order (fp32 summation order only).
-constexpr int XC_P = 4;
-template <typename T, bool BWD>
-__global__ void __launch_bounds__(256)
-k_pairdw_strip(const T* __restrict__ X, int ldx, int64_t goff, T* __restrict__ O, int ldo, int64_t ogoff, const float* __restrict__ w,
-               const float* __restrict__ b, int H, int W, int WS, int C, int64_t total) {
-    extern __shared__ float wl[];                        // [18][C]
-    pairdw_stage_weights(wl, w, C);
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int cb = C >> 3;
-    const int c0 = (int)(idx % cb) * 8;
-    const int64_t strip = idx / cb;
-    const int xs = (int)(strip % WS);
-    const int64_t row = strip / WS;                      // n * H + y
-    const int y = (int)(row % H), x0 = xs * XC_P;
-    float o1[XC_P][8], o2[XC_P][8];                      // forward: o1 = G; backward: o1 / o2 = the two dates' data gradients
-#pragma unroll
-    for (int p = 0; p < XC_P; ++p)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { o1[p][j] = (!BWD && b) ? b[c0 + j] : 0.f; o2[p][j] = 0.f; }
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int yy = BWD ? y - (ky - 1) : y + (ky - 1);
-        const bool yok = (unsigned)yy < (unsigned)H;
-        const int64_t rbase = (row + (yok ? yy - y : 0)) * W;
-        float v1[XC_P + 2][8], v2[XC_P + 2][8];
-#pragma unroll
-        for (int c = 0; c < XC_P + 2; ++c) {
-            const int xx = x0 - 1 + c, xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-            load8<T>(X + (rbase + xc) * ldx + c0, v1[c]);
-            if (!BWD) load8<T>(X + goff + (rbase + xc) * ldx + c0, v2[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < XC_P + 2; ++c) {
-            const int xx = x0 - 1 + c;
-            const bool ok = yok && (unsigned)xx < (unsigned)W;
-#pragma unroll
-            for (int p = 0; p < XC_P; ++p) {
-                const int kx = BWD ? p - (c - 1) + 1 : (c - 1) - p + 1;          // tap column of this input column for output p
-                if (kx >= 0 && kx <= 2) {
-                    const float* w1 = wl + (ky * 3 + kx) * C + c0;
-                    const float* w2 = w1 + 9 * C;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (BWD) { o1[p][j] += ok ? w1[j] * v1[c][j] : 0.f; o2[p][j] += ok ? w2[j] * v1[c][j] : 0.f; }
-                        else o1[p][j] += ok ? w1[j] * v1[c][j] + w2[j] * v2[c][j] : 0.f;
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < XC_P; ++p) {
-        if (x0 + p >= W) break;
-        const int64_t pix = row * W + x0 + p;
-        store8<T>(O + pix * ldo + c0, o1[p]);
-        if (BWD) store8<T>(O + ogoff + pix * ldo + c0, o2[p]);
-    }
-}
-static bool pairdw_strip_on() {
-    static const bool on = [] { const char* e = getenv("STCD_NO_DW_STRIP"); return !(e && e[0] == '1'); }();
-    return on;
-}
-
 // filter gradient: block (channel block cb, pixel chunk ch) -> partial[(ch * CB + cb)][18][8]; dw[c][d][t] = sum over pixels of
 // dG[p][c] * A_d[p + t][c]
 template <typename T>
@@ -227,26 +156,12 @@ int64_t pairdw_partial_floats(int B, int H, int W, int C) { return (int64_t)pair
 void launch_pairdw_fwd(int dt, const void* A, int lda, int64_t goff, void* G, int ldg, const float* w, const float* b, int B, int H,
                        int W, int C, hipStream_t s) {
     const int64_t total = (int64_t)B * H * W * (C / 8);
-    if (pairdw_strip_on() && W >= XC_P) {
-        const int WS = (W + XC_P - 1) / XC_P;
-        const int64_t tot = (int64_t)B * H * WS * (C / 8);
-        if (dt == BF16) k_pairdw_strip<bf16, false><<<xc_cdiv(tot, 256), 256, (size_t)C * 18 * 4, s>>>((const bf16*)A, lda, goff, (bf16*)G, ldg, 0, w, b, H, W, WS, C, tot);
-        else k_pairdw_strip<float, false><<<xc_cdiv(tot, 256), 256, (size_t)C * 18 * 4, s>>>((const float*)A, lda, goff, (float*)G, ldg, 0, w, b, H, W, WS, C, tot);
-        return;
-    }
     if (dt == BF16) k_pairdw_fwd<bf16><<<xc_cdiv(total, 256), 256, (size_t)C * 18 * 4, s>>>((const bf16*)A, lda, goff, (bf16*)G, ldg, w, b, H, W, C, total);
     else k_pairdw_fwd<float><<<xc_cdiv(total, 256), 256, (size_t)C * 18 * 4, s>>>((const float*)A, lda, goff, (float*)G, ldg, w, b, H, W, C, total);
 }
 void launch_pairdw_bwd_data(int dt, const void* dG, int lddg, void* dA, int ldda, int64_t goff, const float* w, int B, int H, int W,
                             int C, hipStream_t s) {
     const int64_t total = (int64_t)B * H * W * (C / 8);
-    if (pairdw_strip_on() && W >= XC_P) {
-        const int WS = (W + XC_P - 1) / XC_P;
-        const int64_t tot = (int64_t)B * H * WS * (C / 8);
-        if (dt == BF16) k_pairdw_strip<bf16, true><<<xc_cdiv(tot, 256), 256, (size_t)C * 18 * 4, s>>>((const bf16*)dG, lddg, 0, (bf16*)dA, ldda, goff, w, nullptr, H, W, WS, C, tot);
-        else k_pairdw_strip<float, true><<<xc_cdiv(tot, 256), 256, (size_t)C * 18 * 4, s>>>((const float*)dG, lddg, 0, (float*)dA, ldda, goff, w, nullptr, H, W, WS, C, tot);
-        return;
-    }
     if (dt == BF16) k_pairdw_bwd_data<bf16><<<xc_cdiv(total, 256), 256, (size_t)C * 18 * 4, s>>>((const bf16*)dG, lddg, (bf16*)dA, ldda, goff, w, H, W, C, total);
     else k_pairdw_bwd_data<float><<<xc_cdiv(total, 256), 256, (size_t)C * 18 * 4, s>>>((const float*)dG, lddg, (float*)dA, ldda, goff, w, H, W, C, total);
 }
