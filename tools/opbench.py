@@ -3,6 +3,7 @@
 
   python tools/opbench.py [case ...]        cases: name=n,h,w,ci,co[,stride]   e.g. c128=32,32,32,128,128
 Prints per-case MFMA-kernel time (HIP events, median of 20) with achieved TFLOP/s and GB/s.
+  OPBENCH_KIND=conv|wgrad, OPBENCH_IMPL=<stcd_op_conv impl: 1 auto, 6 LDS-DMA ...>, OPBENCH_WIMPL=<stcd_op_wgrad impl: 1, 4, 7 LDS-DMA ...>
 """
 import ctypes as C
 import sys, os
