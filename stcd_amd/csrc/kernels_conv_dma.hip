@@ -38,6 +38,7 @@
 //     tile (a row past the end is dropped by the range check), so the next tile's first wait is `vmcnt(22)`: all but the 6
 //     youngest DMAs and the 16 stores behind them.
 //   * MEASURED (MI355X, random data, 4 x 512 x 512 x 256 -> 256, filter repack included): 1005 us = 1231 TFLOP/s (k_conv_gemm: 1686 us);
+//     without the s_setprio pair around the MFMA clusters 1056-1069 us (-5 %);
 //     time against the K-tile count puts the loop at ~1500-1600 TFLOP/s and the per-tile fixed cost at ~11 us, of which the
 //     output stores are 2.4-3.3 us (STCD_DMA_DBG=1).
 #include <algorithm>
