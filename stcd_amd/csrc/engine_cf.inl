@@ -793,7 +793,7 @@ static int backward_cf(stcd_engine& e, const float* grad_logits, const float* pa
     const int h1 = P.st[0].h, w1 = P.st[0].w;
     // both stages in one call: the grouped weight gradients go out with their last member on the engine's side stream (the head's
     // LDS-DMA group right after the second up-sampling layer's backward) and run beside the rest of the chain
-    static const bool cf_side = [] { const char* v = getenv("STCD_CF_SIDE"); return v && v[0] == '1'; }();
+    static const bool cf_side = [] { const char* v = getenv("STCD_CF_SIDE"); return !(v && v[0] == '0'); }();
     hipStream_t side = (stage < 0 && cf_side) ? wgrad_side_stream(e, s) : nullptr;
     EarlyScope early_scope(e, side != nullptr, side);
     for (int st = 0; st < 2; ++st)

@@ -610,7 +610,7 @@ def test_fcsiam_every_layer_in_place(arch, dtype, B, H, W):
     print(f"SiamUnet_{arch} {dtype} B={B} {H}x{W} layer-local worst relative l2: " + ", ".join(f"{k} {v[0]:.1e} ({v[1]})" for k, v in worst.items()))
 
 
-@pytest.mark.parametrize("arch", ["diff", "conc", "fcef", "snunet"])
+@pytest.mark.parametrize("arch", ["diff", "conc", "fcef", "snunet", "changeformer"])
 def test_side_stream_weight_gradients_are_deterministic_and_match_the_serial_plan(arch):
     """FC-Siam backward in one call: the decoder's grouped weight gradients run on the engine's low-priority side stream beside the
     encoder's chain (stcd_set_wgrad_side, on by default) with a quarter of the planner's block budget.  (1) Race screen: the launches
@@ -621,13 +621,19 @@ def test_side_stream_weight_gradients_are_deterministic_and_match_the_serial_pla
     another fp32 summation order over bf16 products) agree to fp32 summation noise, tensor by tensor."""
     torch.manual_seed(3)
     B, H, W = 16, 256, 256
+    if arch == "changeformer":  # V6 at 4 x 512^2 (BASELINE.json configs[4] per GPU): the head's k_wgrad_dma group (192 blocks beside the chain
+        B, H, W = 4, 512, 512   # instead of 256 alone) goes out after the second up-sampling layer's backward
+        from stcd_amd.changeformer import ChangeFormerV6
     if arch == "snunet":      # one backward stage: the groups whose members sit deep in the backward order run beside the rest of the chain
         from oracle import snunet_ref as S
         from stcd_amd.modules import SNUNet_ECAM
-    cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "fcef": Unet}[arch] if arch != "snunet" else SNUNet_ECAM
+    cls = {"diff": SiamUnet_diff, "conc": SiamUnet_conc, "fcef": Unet}.get(arch) or (SNUNet_ECAM if arch == "snunet" else ChangeFormerV6)
     x1 = torch.randn(B, 3, H, W, device=DEV); x2 = torch.randn(B, 3, H, W, device=DEV)
     tgt = (torch.rand(B, H, W, device=DEV) < 0.2).long()
-    st = R.synth_state(arch, 3, 2, 5) if arch != "snunet" else S.synth_state(3, 2, 5)
+    st = None if arch == "changeformer" else (R.synth_state(arch, 3, 2, 5) if arch != "snunet" else S.synth_state(3, 2, 5))
+    if st is None:            # its own (seeded) initialisation; every engine below loads the same state
+        torch.manual_seed(11)
+        st = {k: v.clone() for k, v in cls(3, 2, dtype="bf16").state_dict().items()}
 
     def grads(side, reps):
         m = cls(3, 2, dtype="bf16")
@@ -638,7 +644,7 @@ def test_side_stream_weight_gradients_are_deterministic_and_match_the_serial_pla
         junk = torch.empty(96 << 20, dtype=torch.uint8, device=DEV)
         for it in range(reps):
             m.zero_grad(set_to_none=False)
-            m._steps = 0                                     # the same dropout masks every pass
+            m._steps = 0                                     # the same dropout masks every pass (ChangeFormer: the same hash seed)
             out = m(x1, x2)
             out = out[-1] if isinstance(out, (list, tuple)) else out
             torch.nn.functional.cross_entropy(out, tgt).backward()
@@ -662,5 +668,5 @@ def test_side_stream_weight_gradients_are_deterministic_and_match_the_serial_pla
         b = off[sl].double()
         rel = float((a - b).norm() / (b.norm() + 1e-30))
         worst[1] = max(worst[1], rel)
-        assert rel <= 2e-5, f"{arch} {info.name}: side-stream plan vs serial plan rel-l2 {rel:.2e}"
+        assert rel <= (2e-5 if arch != "changeformer" else 1e-4), f"{arch} {info.name}: side-stream plan vs serial plan rel-l2 {rel:.2e}"
     print(f"{arch}: worst rel-l2 between passes {worst[0]:.2e}, side-stream plan vs serial plan {worst[1]:.2e}")
