@@ -149,10 +149,10 @@ int stcd_cf_set_drop_rates(stcd_engine* e, float drop_rate, float attn_drop, flo
  * (the default, multi_scale_train == "False", trainer.py:311): only cp's gradient is read and the heads' backward launches are not
  * part of the plan.  Changing the setting invalidates the plan: call stcd_configure (and re-query stcd_workspace_bytes) afterwards. */
 int stcd_cf_set_aux_backward(stcd_engine* e, int on);
-/* FC-Siam family (SiamUnet_diff / _conc / _sub / _cross_conc, Unet) and SNUNet_ECAM: with the whole backward in ONE stcd_backward call
+/* FC-Siam family (SiamUnet_diff / _conc / _sub / _cross_conc, Unet), SNUNet_ECAM and ChangeFormerV6: with the whole backward in ONE stcd_backward call
  * (stage -1) the grouped weight gradients go out as soon as their last operand exists, on a low-priority side stream of the engine
- * beside the rest of the backward chain, and are joined before the call's work on `hip_stream` ends; the FC-Siam decoder's grids are
- * planned smaller for that.  on == 0 plans and runs them on the caller's
+ * beside the rest of the backward chain, and are joined before the call's work on `hip_stream` ends; the FC-Siam decoder's grids and
+ * ChangeFormer's LDS-DMA group are planned smaller for that.  on == 0 plans and runs them on the caller's
  * stream -- what a data-parallel caller wants, which calls stage 0 and stage 1 separately to all-reduce the decoder's gradients
  * (nn.DataParallel's role in /root/reference/models/networks.py:85-116) in between (staged calls never use the side stream).  Default on
  * (environment STCD_WGRAD_SIDE=0: off).  Changing the setting invalidates the plan: call stcd_configure afterwards. */
