@@ -269,7 +269,7 @@ def test_f1_parity_with_statistics_over_reference_seeds(dtype):
     print(f"{dtype}: engine {np.round(eng, 2)} reference {np.round(ref, 2)} difference {d:+.3f} pt, 2 SE {2 * se:.3f} pt")
     assert abs(d) <= max(0.2, 2 * se), f"engine and reference differ by {d:+.2f} pt over {K} seeds (95 % interval +-{2 * se:.2f} pt)"
     if K >= 3:     # the interval is informative, and the engine's seed-to-seed scatter is of the reference's size
-        # (three runs of this test at K = 9 / 10: -0.17 +- 0.45, +0.16 +- 0.43, +0.38 +- 0.85 pt -- the engine's own run-to-run scatter, from
+        # (four runs of this test at K = 9 / 10: -0.17 +- 0.45, +0.16 +- 0.43, +0.38 +- 0.85, -0.36 +- 0.81 pt -- the engine's own run-to-run scatter, from
         #  the float atomics of its slab sums, moves single seeds by up to 3 pt; 1.5 pt leaves room for two such seeds in one run)
         assert 2 * se <= 1.5, f"per-seed differences scatter too much to support a parity claim: {np.round(eng - ref, 2)}"
         assert eng.std(ddof=1) <= 3.0 * max(ref.std(ddof=1), 0.3)
