@@ -274,7 +274,8 @@ struct ReduceJob {
     int gx, ntaps, K, N, kpad, wld;
     int ks, kn_major;          // reference index map of the launch's taps (as PackSpec)
     int8_t ky[9], kx[9];
-    int8_t tiled, pad_[5];     // 1: block = (32 co x TK ci x taps tile, part), LDS-transposed stores; 0: thread = (output, part)
+    int8_t tiled, parts, pad_[4]; // tiled 1: block = (32 co x TK ci x taps tile), all slabs, LDS-transposed stores; 0: thread = (output, part),
+                               // `parts` (power of two <= 64) threads of one block per output, summed in index order (deterministic)
 };
 void launch_reduce_jobs(const ReduceJob* jobs_dev, int njobs, int64_t total, const char* ws, float* grads, hipStream_t s);
 // out = sum of the gx slabs; ps == nullptr: engine layout [tap][kpad][wld], else scattered into the reference layout
@@ -406,14 +407,17 @@ void launch_skip_bwd(int dt, int mode, const void* A, int lda, int64_t a_goff, c
                      const void* dP, int ldp, void* dA, int ldda, int64_t da_goff, const float* stat, const float* mask, int B,
                      int H, int W, int C, long long* bacc, hipStream_t s);
 // db[c] = sum over pixels of dY[.., c]  (db zeroed by caller; atomics)
-void launch_bias_grad(int dt, const void* dY, int ld, int64_t pixels, int C, float* db, hipStream_t s);
+// acc_i (bf16 mode): int64 accumulator [BN_REP][1][2][C] at scale BN_BS (zeroed by the caller, converted by k_bias_finish); nullptr: float atomics into db
+void launch_bias_grad(int dt, const void* dY, int ld, int64_t pixels, int C, float* db, hipStream_t s, long long* acc_i = nullptr);
 // masks from a counter hash: mask[i] = (u(seed, i) >= p) / (1-p)
 void launch_dropout_gen(float* mask, int64_t n, uint64_t seed, float p, hipStream_t s);
 void launch_fill(float* p, int64_t n, float v, hipStream_t s);
 
 // ---- ResNet-50 UNet (SegCD) specific kernels (kernels_ew.hip)
 void launch_stem_fwd(int dt, const void* X, const float* w, void* Y, int N, int H, int W, int cin, int Co, hipStream_t s);
-void launch_stem_wgrad(int dt, const void* X, const void* dY, float* dW, int N, int H, int W, int cin, int Co, hipStream_t s);
+// part: scratch of stem_wgrad_part_floats() floats (per-chunk partial filters, summed in chunk order by a finish launch)
+int64_t stem_wgrad_part_floats(int N, int H, int W, int cin, int Co);
+void launch_stem_wgrad(int dt, const void* X, const void* dY, float* dW, int N, int H, int W, int cin, int Co, hipStream_t s, float* part);
 // idx: [N, H/2, W/2, C] bytes, the winning window position 0..8 of every pooled element (nullable in the forward: inference)
 void launch_maxpool3(int dt, const void* A, int lda, void* P, int ldp, int N, int H, int W, int C, hipStream_t s, unsigned char* idx = nullptr);
 void launch_maxpool3_bwd(int dt, const unsigned char* idx, const void* dP, int ldp, void* dA, int ldda, int N, int H, int W, int C,

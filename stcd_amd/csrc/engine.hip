@@ -214,6 +214,7 @@ struct stcd_engine_impl {
     std::vector<std::array<int, 2>> g_dec;                   // (conv1, conv2) per decoder block
     TRef gP0, gdP0, gX3, gdX3, gFuseTmp;
     int64_t g_pool_idx = -1;                                  // winners of the stem's 3x3 max-pool (bytes)
+    int64_t g_stem_part = -1;                                 // k_stem_wgrad's per-chunk partial filters (fp32 / non-MFMA path: fixed-order finish)
     int64_t g_raw3 = -1, g_draw3 = -1;
     ConvOp g_head_fwd, g_head_dgr; WgradOp g_head_wg;
     int arch = 0, in_ch = 3, label = 2, dt = F32;
@@ -662,18 +663,18 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                 j.kx[t] = op->own_taps ? op->okx[t] : cv.fwd.kx[op->tap0 + t];
             }
             j.tiled = (int64_t)j.ntaps * j.K * j.N >= 512 * 1024;     // measured: the tiled form pays from ~0.5 M weights per launch
-            if (!j.tiled) {   // index space: parts x outputs (padded to whole waves); <= 32 slabs per part
-                const int64_t outs_pad = ((int64_t)j.ntaps * j.K * j.N + 63) & ~(int64_t)63;
-                const int parts = (j.gx + 31) / 32;
-                j.count = outs_pad * parts;
-            } else {   // index space: one block (256 threads) per (tile of 32 co x TK ci x taps, part of <= 32 slabs): see k_reduce_jobs
-                const int TK = j.ntaps == 1 ? 32 : 16;
+            if (!j.tiled) {   // index space: blocks of (256 / parts) outputs x parts threads; <= 32 slabs per part where 64 parts allow
+                const int64_t outs = (int64_t)j.ntaps * j.K * j.N;
+                int parts = 1;
+                while (parts < 64 && parts * 32 < j.gx) parts *= 2;
+                j.parts = (int8_t)parts;
+                const int64_t OUTS = 256 / parts;
+                j.count = ((outs + OUTS - 1) / OUTS) * 256;
+            } else {   // index space: one block (256 threads) per tile of 32 co x TK ci x taps, all slabs (>= 0.5 M weights: the 32 / 64 MB
+                const int TK = j.ntaps == 1 ? 32 : 16;                 // slab caps leave <= 32 of them): see k_reduce_jobs
                 const int64_t ntiles = (int64_t)((j.N + 31) / 32) * ((j.K + TK - 1) / TK);
-                // <= 32 slabs per part; layers with few tiles and many slabs (16-channel layers: 1 tile, > 100 slabs) get shorter
-                // parts (>= 4 slabs) so the job still spreads over ~128 blocks
-                const int64_t spp = std::min<int64_t>(32, std::max<int64_t>(4, ntiles * j.gx / 128));
-                const int parts = (int)((j.gx + spp - 1) / spp);
-                j.count = ntiles * parts * 256;
+                j.parts = 1;
+                j.count = ntiles * 256;
             }
             j.start = cur[op->stage];
             cur[op->stage] += (j.count + 255) & ~(int64_t)255;     // block-aligned: one job per block
@@ -974,6 +975,8 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             if (e.dt == BF16 && e.use_mfma && nb > 0 && L.has_dIn && L.dIn.off == U.dOut.off && L.dgr.res.ok && L.dgr.wf >= 0 && even) {
                 U.bias_fused = true;
                 L.dgr_sum_acc = U.bias_acc; L.dgr_sum_c0 = 0; L.dgr_sum_C = U.C;
+            }
+            if (e.dt == BF16) {     // fused or not, the bf16 path sums the bias gradient in the integer accumulator (deterministic)
                 BiasJob jb{}; jb.acc_off = U.bias_acc; jb.out_off = e.convs[U.conv].b_off; jb.C = U.C; jb.valid = U.C; jb.scale = BN_BS;
                 e.bias_jobs.push_back(jb);
             }
@@ -1347,13 +1350,14 @@ static void upconv_backward(const Ctx& c, const UpConv& U) {
     if (U.bias_fused && mfma_on(e)) {
         // summed by the data-gradient launch that produced dOut; converted by k_bias_finish at the end of the stage
     } else if (2 * U.h == U.Ho && 2 * U.w == U.Wo) {
-        launch_bias_grad(e.dt, c.at(U.dOut.off), U.dOut.ld, (int64_t)U.N * U.Ho * U.Wo, U.C, c.grads + cv.b_off, c.s);
+        launch_bias_grad(e.dt, c.at(U.dOut.off), U.dOut.ld, (int64_t)U.N * U.Ho * U.Wo, U.C, c.grads + cv.b_off, c.s,
+                         e.dt == BF16 ? c.at<long long>(U.bias_acc) : nullptr);
     } else {
         const int64_t T = (int64_t)dsize(e.dt);
         for (int n = 0; n < U.N; ++n)
             for (int y = 0; y < 2 * U.h; ++y)
                 launch_bias_grad(e.dt, c.at<char>(U.dOut.off) + ((int64_t)(n * U.Ho + y) * U.Wo) * U.dOut.ld * T, U.dOut.ld,
-                                 2 * U.w, U.C, c.grads + cv.b_off, c.s);
+                                 2 * U.w, U.C, c.grads + cv.b_off, c.s, e.dt == BF16 ? c.at<long long>(U.bias_acc) : nullptr);
     }
     for (int ph = 0; ph < 4; ++ph) exec_wgrad(c, U.wg[ph], c.at(U.in.off), c.at(U.dOut.off));
     exec_conv(c, U.dgr, c.at(U.dOut.off), nullptr, c.at(U.dIn.off), false);
@@ -1849,6 +1853,8 @@ static int configure_snunet(stcd_engine& e, int B, int H, int W) {
         if (e.dt == BF16 && e.use_mfma && b.dIn.off >= 0 && b.d1.res.ok && b.d1.wf >= 0) {
             u.bias_fused = true;
             b.d1_sum_acc = u.bias_acc; b.d1_sum_c0 = u.coff; b.d1_sum_C = u.C;
+        }
+        if (e.dt == BF16) {
             BiasJob jb{}; jb.acc_off = u.bias_acc; jb.out_off = e.convs[u.conv].b_off; jb.C = u.C; jb.valid = u.C; jb.scale = BN_BS;
             e.bias_jobs.push_back(jb);
         }
@@ -1973,7 +1979,8 @@ static void sn_up_backward(const Ctx& c, const SnUp& u) {
     const ConvW& cv = e.convs[u.conv];
     const int64_t T = (int64_t)dsize(e.dt);
     if (!(u.bias_fused && mfma_on(e)))
-        launch_bias_grad(e.dt, c.at(u.dOut.off), u.dOut.ld, (int64_t)u.N * 4 * u.h * u.w, u.C, c.grads + cv.b_off, c.s);
+        launch_bias_grad(e.dt, c.at(u.dOut.off), u.dOut.ld, (int64_t)u.N * 4 * u.h * u.w, u.C, c.grads + cv.b_off, c.s,
+                         e.dt == BF16 ? c.at<long long>(u.bias_acc) : nullptr);
     for (int ph = 0; ph < 4; ++ph) exec_wgrad(c, u.wg[ph], c.at(u.src.off), c.at(u.dOut.off));
     exec_conv(c, u.dgr, c.at(u.dOut.off), nullptr, c.at(u.tmp.off), false);     // summed into the lower block's dOut by ITS reduction
     (void)T;
@@ -2168,6 +2175,7 @@ static int configure_segcd(stcd_engine& e, int B, int H, int W) {
     { GStep st; st.kind = GS_LAYER; st.layer = e.g_stem; e.g_fwd.push_back(st); }
     e.gP0 = plain(N, H / 4, W / 4, 64); e.gdP0 = plain(N, H / 4, W / 4, 64);
     e.g_pool_idx = ws.take((int64_t)N * (H / 4) * (W / 4) * 64);
+    e.g_stem_part = ws.take(stem_wgrad_part_floats(N, H, W, e.in_ch, 64) * 4);
     { GStep st; st.kind = GS_MAXPOOL; st.src = S.A; st.dst = e.gP0; st.dsrc = S.dA; st.ddst = e.gdP0; st.N = N; st.h = H / 2; st.w = W / 2; st.C = 64; e.g_fwd.push_back(st); }
     TRef cur = e.gP0; int curC = 64, h = H / 4, w = W / 4, prev_out = -1;      // prev_out: layer whose A is `cur` (-1: the max-pool)
     std::vector<int> stage_out;                                               // L3 of the last block of layer1..4
@@ -2547,7 +2555,7 @@ static void glayer_backward(const Ctx& c, GLayer& L) {
     }
     if (L.kind == K_STEM7) {
         ProfScope ps(c, PC_WGRAD, 2.0 * L.N * HW * 49.0 * cv.cin * cv.cout, 0.0, "k_stem_wgrad");
-        launch_stem_wgrad(e.dt, c.at(L.in.off), c.at(L.dA.off), c.grads + cv.w_off, L.N, L.Hi, L.Wi, cv.cin, cv.cout, c.s);
+        launch_stem_wgrad(e.dt, c.at(L.in.off), c.at(L.dA.off), c.grads + cv.w_off, L.N, L.Hi, L.Wi, cv.cin, cv.cout, c.s, c.at<float>(e.g_stem_part));
         return;
     }
     for (int k = 0; k < L.nwg; ++k) exec_wgrad(c, L.wg[k], c.at(L.wg[k].in_off), c.at(L.dA.off));

@@ -58,7 +58,7 @@ struct ConvDmaArgs {
     int NTtot, nk;                 // n-tiles of the fragment image; K-tiles = (Ci / 64) * ntaps (even, >= 4)
     unsigned lead, in_bytes;       // the X descriptor starts `lead` bytes before the tensor (most negative tap offset)
     unsigned out_bytes;
-    int dbg;                       // development switches (STCD_DMA_DBG): 1 = drop every output store (sizes the store drain: 2.4 - 3.3 us of the ~11 us per tile)
+    int dbg;                       // development switches (STCD_DMA_DBG, compiled only with -DSTCD_DEV_SWITCHES): 1 = drop every output store (sizes the store drain: 2.4 - 3.3 us of the ~11 us per tile)
     int M;                         // positions
     int tiles_m, tiles_n;
     unsigned long long tapbits;    // 6 bits per tap: (dy + 3) | (dx + 3) << 3 -- decoded with scalar shifts, no memory access in the loop
@@ -327,7 +327,11 @@ k_conv_dma(const ConvDmaArgs a) {
                     else asm volatile("ds_read_b128 %0, %1 offset:1152\n\ts_waitcnt lgkmcnt(0)" : "=v"(pkv) : "v"(scr_r) : "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     uint4 pk = make_uint4(pkv[0], pkv[1], pkv[2], pkv[3]);
+#ifdef STCD_DEV_SWITCHES
                     const bool valid = mrow < a.M && !(a.dbg & 1);
+#else
+                    const bool valid = mrow < a.M;
+#endif
                     int64_t opix = mrow;
                     if (!plain_out) opix = ((int64_t)on * a.g.ho + oy * a.g.out_stride + a.g.oy0) * a.g.wo + ox * a.g.out_stride + a.g.ox0;
                     if (!valid) opix = 0;
@@ -415,7 +419,11 @@ int launch_conv_dma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvDm
     a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
     a.out_bytes = (unsigned)((int64_t)g.n * g.ho * g.wo * g.ldo * 2);
     a.M = g.n * g.hm * g.wm;
+#ifdef STCD_DEV_SWITCHES      // development builds only (make DEV=1): the shipped library never drops stores
     { static const int dbg = [] { const char* e = getenv("STCD_DMA_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+#else
+    a.dbg = 0;
+#endif
     a.tiles_m = dp.tiles_m; a.tiles_n = dp.tiles_n;
     a.tapbits = 0;
     for (int t = 0; t < g.ntaps; ++t)

@@ -746,15 +746,18 @@ k_reduce_dw(const float* __restrict__ slab, int gx, int64_t slab_stride, int nta
     }
 }
 
-// Block = (tile of 32 output channels x TK input channels x all taps of the launch, slab range "part"): the slabs are read as
-// rows of 32 consecutive floats (the slab's fast axis is the output channel), summed, passed through LDS and written in the
-// order of the REFERENCE-layout gradient tensor ([Cout][Cin][k][k]: the TK x k x k values of one output channel are contiguous;
-// transposed convs [Cin][Cout][k][k] likewise with the roles swapped).  The thread-per-output form wrote one float per 64-B line
-// (0.45 ms per SegCD step for 32.5 M weights).  A job with many slabs is cut into parts of <= 32 slabs that finish with float
-// atomicAdds (the gradient buffer is zeroed at the start of backward).
+// Block = (tile of 32 output channels x TK input channels x all taps of the launch): the slabs are read as rows of 32
+// consecutive floats (the slab's fast axis is the output channel), summed, passed through LDS and written in the order of the
+// REFERENCE-layout gradient tensor ([Cout][Cin][k][k]: the TK x k x k values of one output channel are contiguous; transposed
+// convs [Cin][Cout][k][k] likewise with the roles swapped).  The thread-per-output form wrote one float per 64-B line (0.45 ms
+// per SegCD step for 32.5 M weights).
+// DETERMINISTIC (round 4): every output is the sum of its slabs in ONE fixed order whatever the block schedule.  Small filters:
+// `parts` threads OF ONE BLOCK each sum a contiguous range of slabs (4 independent chains, fixed association) and thread 0 of the
+// output adds the parts in index order through LDS; tiled filters: one block walks all slabs of its tile.  Rounds 1-3 cut
+// many-slab jobs into parts of other blocks that met through float atomicAdd: two runs of one step differed by ~1e-6.
 __global__ void __launch_bounds__(256)
 k_reduce_jobs(const ReduceJob* __restrict__ jobs, int njobs, int64_t total, const char* __restrict__ ws, float* __restrict__ grads) {
-    __shared__ float tile[9 * 16 * 33];            // [tap][k][33] (ntaps > 1: TK = 16) or [32][33]
+    __shared__ float tile[9 * 16 * 33];            // [tap][k][33] (ntaps > 1: TK = 16) or [32][33]; small filters: [parts][outs] partials
     const int64_t i0 = (int64_t)blockIdx.x * blockDim.x;
     int lo = 0, hi = njobs - 1;            // block-uniform job (starts are 256-aligned)
     while (lo < hi) {
@@ -762,49 +765,20 @@ k_reduce_jobs(const ReduceJob* __restrict__ jobs, int njobs, int64_t total, cons
         if (jobs[mid].start <= i0) lo = mid; else hi = mid - 1;
     }
     const ReduceJob& jb = jobs[lo];
-    if (!jb.tiled) {       // small filters (L2-resident gradient tensor): one thread per output spreads a few thousand sums best
-        const int64_t e = i0 + threadIdx.x - jb.start;
-        if (e >= jb.count) return;
-        const int outs = jb.ntaps * jb.K * jb.N, outs_pad = (outs + 63) & ~63;
-        const int part = (int)(e / outs_pad), o = (int)(e - (int64_t)part * outs_pad);
-        if (o >= outs) return;
-        const int parts = (int)(jb.count / outs_pad);
+    if (!jb.tiled) {       // small filters (L2-resident gradient tensor): (output, part) threads spread a few thousand sums best
+        const int parts = jb.parts, OUTS = 256 / parts;                     // parts: power of two <= 64 (planner)
+        const int lb = (int)((i0 - jb.start) >> 8);
+        const int ol = threadIdx.x % OUTS, part = threadIdx.x / OUTS;
+        const int outs = jb.ntaps * jb.K * jb.N;
+        const int o = lb * OUTS + ol;
         const int chunk = (jb.gx + parts - 1) / parts;
         const int b0 = part * chunk, b1 = min(jb.gx, b0 + chunk);
-        const int n = o % jb.N, k = (o / jb.N) % jb.K, t = o / (jb.N * jb.K);
-        const float* p = reinterpret_cast<const float*>(ws + jb.slab_off) + ((int64_t)t * jb.kpad + k) * jb.wld + n;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int b = b0;
-        for (; b + 3 < b1; b += 4) {
-            a0 += p[(int64_t)b * jb.slab_stride];
-            a1 += p[(int64_t)(b + 1) * jb.slab_stride];
-            a2 += p[(int64_t)(b + 2) * jb.slab_stride];
-            a3 += p[(int64_t)(b + 3) * jb.slab_stride];
-        }
-        for (; b < b1; ++b) a0 += p[(int64_t)b * jb.slab_stride];
-        const float acc = (a0 + a1) + (a2 + a3);
-        const int64_t a_ = jb.kn_major ? ((int64_t)k * jb.N + n) : ((int64_t)n * jb.K + k);
-        float* dst = grads + jb.out_off + (a_ * jb.ks + jb.ky[t]) * jb.ks + jb.kx[t];
-        if (parts == 1) *dst = acc;
-        else atomicAdd(dst, acc);
-        return;
-    }
-    const int TK = jb.ntaps == 1 ? 32 : 16;
-    const int tiles_n = (jb.N + 31) >> 5, tiles_k = (jb.K + TK - 1) / TK, ntiles = tiles_n * tiles_k;
-    const int lb = (int)((i0 - jb.start) >> 8);
-    if (lb >= (int)(jb.count >> 8)) return;
-    const int part = lb / ntiles, t_ = lb - part * ntiles, tk = t_ / tiles_n, tn = t_ - tk * tiles_n;
-    const int parts = (int)(jb.count >> 8) / ntiles;
-    const int chunk = (jb.gx + parts - 1) / parts;
-    const int b0 = part * chunk, b1 = min(jb.gx, b0 + chunk);
-    const int TE = jb.ntaps * TK * 32;
-    const float* slab = reinterpret_cast<const float*>(ws + jb.slab_off);
-    for (int idx = threadIdx.x; idx < TE; idx += 256) {
-        const int nl = idx & 31, kl = (idx >> 5) % TK, t = idx / (32 * TK);
-        const int n = tn * 32 + nl, k = tk * TK + kl;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (n < jb.N && k < jb.K) {
-            const float* p = slab + ((int64_t)t * jb.kpad + k) * jb.wld + n;
+        int n = 0, k = 0, t = 0;
+        float acc = 0.f;
+        if (o < outs) {
+            n = o % jb.N; k = (o / jb.N) % jb.K; t = o / (jb.N * jb.K);
+            const float* p = reinterpret_cast<const float*>(ws + jb.slab_off) + ((int64_t)t * jb.kpad + k) * jb.wld + n;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             int b = b0;
             for (; b + 3 < b1; b += 4) {
                 a0 += p[(int64_t)b * jb.slab_stride];
@@ -813,6 +787,43 @@ k_reduce_jobs(const ReduceJob* __restrict__ jobs, int njobs, int64_t total, cons
                 a3 += p[(int64_t)(b + 3) * jb.slab_stride];
             }
             for (; b < b1; ++b) a0 += p[(int64_t)b * jb.slab_stride];
+            acc = (a0 + a1) + (a2 + a3);
+        }
+        if (parts > 1) {
+            tile[threadIdx.x] = acc;
+            __syncthreads();
+            if (part == 0) {
+                acc = tile[ol];
+                for (int q = 1; q < parts; ++q) acc += tile[q * OUTS + ol];      // fixed order
+            }
+        }
+        if (part == 0 && o < outs) {
+            const int64_t a_ = jb.kn_major ? ((int64_t)k * jb.N + n) : ((int64_t)n * jb.K + k);
+            grads[jb.out_off + (a_ * jb.ks + jb.ky[t]) * jb.ks + jb.kx[t]] = acc;
+        }
+        return;
+    }
+    const int TK = jb.ntaps == 1 ? 32 : 16;
+    const int tiles_n = (jb.N + 31) >> 5, tiles_k = (jb.K + TK - 1) / TK, ntiles = tiles_n * tiles_k;
+    const int lb = (int)((i0 - jb.start) >> 8);
+    if (lb >= ntiles) return;
+    const int tk = lb / tiles_n, tn = lb - tk * tiles_n;
+    const int TE = jb.ntaps * TK * 32;
+    const float* slab = reinterpret_cast<const float*>(ws + jb.slab_off);
+    for (int idx = threadIdx.x; idx < TE; idx += 256) {
+        const int nl = idx & 31, kl = (idx >> 5) % TK, t = idx / (32 * TK);
+        const int n = tn * 32 + nl, k = tk * TK + kl;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (n < jb.N && k < jb.K) {
+            const float* p = slab + ((int64_t)t * jb.kpad + k) * jb.wld + n;
+            int b = 0;
+            for (; b + 3 < jb.gx; b += 4) {
+                a0 += p[(int64_t)b * jb.slab_stride];
+                a1 += p[(int64_t)(b + 1) * jb.slab_stride];
+                a2 += p[(int64_t)(b + 2) * jb.slab_stride];
+                a3 += p[(int64_t)(b + 3) * jb.slab_stride];
+            }
+            for (; b < jb.gx; ++b) a0 += p[(int64_t)b * jb.slab_stride];
         }
         tile[(t * TK + kl) * 33 + nl] = (a0 + a1) + (a2 + a3);
     }
@@ -825,10 +836,7 @@ k_reduce_jobs(const ReduceJob* __restrict__ jobs, int njobs, int64_t total, cons
         const int n = tn * 32 + nl, k = tk * TK + kl;
         if (n >= jb.N || k >= jb.K) continue;
         const int64_t a_ = jb.kn_major ? ((int64_t)k * jb.N + n) : ((int64_t)n * jb.K + k);
-        float* dst = grads + jb.out_off + (a_ * jb.ks + jb.ky[t]) * jb.ks + jb.kx[t];
-        const float v = tile[(t * TK + kl) * 33 + nl];
-        if (parts == 1) *dst = v;
-        else atomicAdd(dst, v);
+        grads[jb.out_off + (a_ * jb.ks + jb.ky[t]) * jb.ks + jb.kx[t]] = tile[(t * TK + kl) * 33 + nl];
     }
 }
 void launch_reduce_jobs(const ReduceJob* jobs_dev, int njobs, int64_t total, const char* ws, float* grads, hipStream_t s) {

@@ -901,7 +901,7 @@ k_bn_bwd_apply(const T* __restrict__ dA, GV dav, T* __restrict__ dY, int lddy, c
 // ------------------------------------------------------------------ bias gradient (layers without a following BN)
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_bias_grad(const T* __restrict__ dY, int ld, int64_t pixels, int C, float* __restrict__ db) {
+k_bias_grad(const T* __restrict__ dY, int ld, int64_t pixels, int C, float* __restrict__ db, long long* __restrict__ acc_i) {
     __shared__ float red[256 * 8];
     const int cb = C >> 3, lanes = 256 / cb;
     const int mycb = threadIdx.x % cb, lane = threadIdx.x / cb;
@@ -931,11 +931,14 @@ k_bias_grad(const T* __restrict__ dY, int ld, int64_t pixels, int C, float* __re
     for (int c = threadIdx.x; c < C; c += 256) {
         float acc = 0.f;
         for (int l = 0; l < lanes; ++l) acc += red[(l * cb + (c >> 3)) * 8 + (c & 7)];
-        atomicAdd(db + c, acc);
+        // blocks meet in the 64-bit fixed-point accumulator of the BatchNorm sums (exact integer adds: the result does not depend
+        // on the block order; k_bias_finish converts) -- float atomicAdd (rounds 1-3) made two runs of one step differ
+        if (acc_i) bn_acc_add(acc_i, blockIdx.x, 1, C, 0, 0, c, acc, BN_BS);
+        else atomicAdd(db + c, acc);
     }
 }
 // parity (fp32) mode: one block per 8-channel group walks every pixel in a fixed order and tree-reduces in LDS, so the
-// result does not depend on scheduling (the production kernel above meets through float atomics)
+// result does not depend on scheduling (the bf16 kernel above meets in integer accumulators when given one)
 __global__ void __launch_bounds__(256)
 k_bias_grad_det(const float* __restrict__ dY, int ld, int64_t pixels, int C, float* __restrict__ db) {
     __shared__ double red[256];
@@ -950,7 +953,7 @@ k_bias_grad_det(const float* __restrict__ dY, int ld, int64_t pixels, int C, flo
     }
     if (threadIdx.x == 0) db[c] += (float)red[0];
 }
-void launch_bias_grad(int dt, const void* dY, int ld, int64_t pixels, int C, float* db, hipStream_t s) {
+void launch_bias_grad(int dt, const void* dY, int ld, int64_t pixels, int C, float* db, hipStream_t s, long long* acc_i) {
     if (dt != BF16) {
         k_bias_grad_det<<<C, 256, 0, s>>>((const float*)dY, ld, pixels, C, db);
         return;
@@ -958,8 +961,8 @@ void launch_bias_grad(int dt, const void* dY, int ld, int64_t pixels, int C, flo
     int lanes = 256 / (C / 8);
     int grid = (int)std::min<int64_t>(256, (pixels + 4 * lanes - 1) / (4 * lanes));   // <= 256 atomic adders per channel
     if (grid < 1) grid = 1;
-    if (dt == BF16) k_bias_grad<bf16><<<grid, 256, 0, s>>>((const bf16*)dY, ld, pixels, C, db);
-    else k_bias_grad<float><<<grid, 256, 0, s>>>((const float*)dY, ld, pixels, C, db);
+    if (dt == BF16) k_bias_grad<bf16><<<grid, 256, 0, s>>>((const bf16*)dY, ld, pixels, C, db, acc_i);
+    else k_bias_grad<float><<<grid, 256, 0, s>>>((const float*)dY, ld, pixels, C, db, acc_i);
 }
 
 // ------------------------------------------------------------------ dropout masks, fill
@@ -1201,47 +1204,81 @@ __global__ void k_ecam_sums_fin(const float* __restrict__ part, int nchunk, int 
 }
 
 // backward of the two channel-attention MLPs: from d att (= S1 for ca; folded S2 for ca1) to d avg / d max per channel
-// and the fc weight gradients (accumulated over n with atomics: tiny).  One block per (n, which).
+// and the fc weight gradients.  One block per MLP (`which`) walks the images in order, so the weight gradients are sums over n
+// in ONE fixed order (rounds 1-3: one block per (n, which) meeting through float atomics -- not reproducible run to run).
 __global__ void k_ecam_mlp_bwd(const float* __restrict__ pool, const float* __restrict__ att, const float* __restrict__ hid,
                                const float* __restrict__ sums, int C4, const float* __restrict__ w1a, const float* __restrict__ w2a,
                                const float* __restrict__ w1b, const float* __restrict__ w2b, float* __restrict__ gw1a,
                                float* __restrict__ gw2a, float* __restrict__ gw1b, float* __restrict__ gw2b,
-                               float* __restrict__ dpool) {
-    const int n = blockIdx.x, which = blockIdx.y, C1 = C4 / 4;
+                               float* __restrict__ dpool, int N) {
+    const int which = blockIdx.x, C1 = C4 / 4;
     const int C = which ? C1 : C4, Hd = which ? C1 / 4 : C4 / 16;
     const float* w1 = which ? w1b : w1a; const float* w2 = which ? w2b : w2a;
     float* gw1 = which ? gw1b : gw1a; float* gw2 = which ? gw2b : gw2a;
-    const float* avg = pool + (int64_t)n * 4 * C4 + (which ? 2 : 0) * C4;
-    const float* mx = avg + C4;
-    const float* a = att + ((int64_t)n * 2 + which) * C4;
-    const float* hrow = hid + ((int64_t)n * 2 + which) * 2 * 16;
     __shared__ float dpre[512];      // d(pre-sigmoid) per channel
     __shared__ float dh[2][16];
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float datt;
-        if (!which) datt = sums[((int64_t)n * 2 + 0) * C4 + c];
-        else datt = sums[((int64_t)n * 2 + 1) * C4 + c] + sums[((int64_t)n * 2 + 1) * C4 + c + C1] +
-                    sums[((int64_t)n * 2 + 1) * C4 + c + 2 * C1] + sums[((int64_t)n * 2 + 1) * C4 + c + 3 * C1];
-        dpre[c] = datt * a[c] * (1.f - a[c]);
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < 2 * Hd) {
-        const int k = threadIdx.x % Hd, src = threadIdx.x / Hd;
-        float g = 0.f;
-        for (int c = 0; c < C; ++c) g += dpre[c] * w2[c * Hd + k];
-        dh[src][k] = hrow[src * 16 + k] > 0.f ? g : 0.f;
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float da = 0.f, dm = 0.f;
-        for (int k = 0; k < Hd; ++k) {
-            da += dh[0][k] * w1[k * C + c];
-            dm += dh[1][k] * w1[k * C + c];
-            atomicAdd(&gw2[c * Hd + k], dpre[c] * (fmaxf(hrow[k], 0.f) + fmaxf(hrow[16 + k], 0.f)));
-            atomicAdd(&gw1[k * C + c], dh[0][k] * avg[c] + dh[1][k] * mx[c]);
+    // thread -> channels c = threadIdx.x, + blockDim.x, ...: at most 4 per thread (C <= 512, 128 threads); Hd <= 16 (hid rows)
+    float g1[4][16], g2[4][16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) g1[u][k] = g2[u][k] = 0.f;
+    const int lpp = (int)blockDim.x / (2 * Hd);     // lanes per (src, k) pair of the hidden-gradient sums (8 at Hd = 8)
+    const bool split = lpp >= 1 && (lpp & (lpp - 1)) == 0 && lpp <= 64 && lpp * 2 * Hd == (int)blockDim.x;
+    for (int n = 0; n < N; ++n) {
+        const float* avg = pool + (int64_t)n * 4 * C4 + (which ? 2 : 0) * C4;
+        const float* mx = avg + C4;
+        const float* a = att + ((int64_t)n * 2 + which) * C4;
+        const float* hrow = hid + ((int64_t)n * 2 + which) * 2 * 16;
+        __syncthreads();             // dpre / dh of the previous image are done with
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float datt;
+            if (!which) datt = sums[((int64_t)n * 2 + 0) * C4 + c];
+            else datt = sums[((int64_t)n * 2 + 1) * C4 + c] + sums[((int64_t)n * 2 + 1) * C4 + c + C1] +
+                        sums[((int64_t)n * 2 + 1) * C4 + c + 2 * C1] + sums[((int64_t)n * 2 + 1) * C4 + c + 3 * C1];
+            dpre[c] = datt * a[c] * (1.f - a[c]);
         }
-        dpool[((int64_t)n * 4 + (which ? 2 : 0)) * C4 + c] = da;
-        dpool[((int64_t)n * 4 + (which ? 3 : 1)) * C4 + c] = dm;
+        __syncthreads();
+        if (split) {                 // lpp lanes per pair, fixed strided partial sums + a fixed xor tree
+            const int pair = threadIdx.x / lpp, sub = threadIdx.x % lpp, k = pair % Hd, src = pair / Hd;
+            float g = 0.f;
+            for (int c = sub; c < C; c += lpp) g += dpre[c] * w2[c * Hd + k];
+            for (int o = 1; o < lpp; o <<= 1) g += __shfl_xor(g, o, 64);
+            if (sub == 0) dh[src][k] = hrow[src * 16 + k] > 0.f ? g : 0.f;
+        } else if ((int)threadIdx.x < 2 * Hd) {
+            const int k = threadIdx.x % Hd, src = threadIdx.x / Hd;
+            float g = 0.f;
+            for (int c = 0; c < C; ++c) g += dpre[c] * w2[c * Hd + k];
+            dh[src][k] = hrow[src * 16 + k] > 0.f ? g : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = threadIdx.x + u * blockDim.x;
+            if (c >= C) continue;
+            float da = 0.f, dm = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k >= Hd) continue;
+                da += dh[0][k] * w1[k * C + c];
+                dm += dh[1][k] * w1[k * C + c];
+                g2[u][k] += dpre[c] * (fmaxf(hrow[k], 0.f) + fmaxf(hrow[16 + k], 0.f));
+                g1[u][k] += dh[0][k] * avg[c] + dh[1][k] * mx[c];
+            }
+            dpool[((int64_t)n * 4 + (which ? 2 : 0)) * C4 + c] = da;
+            dpool[((int64_t)n * 4 + (which ? 3 : 1)) * C4 + c] = dm;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = threadIdx.x + u * blockDim.x;
+        if (c >= C) continue;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k >= Hd) continue;
+            gw2[c * Hd + k] = g2[u][k];
+            gw1[k * C + c] = g1[u][k];
+        }
     }
 }
 
@@ -1307,7 +1344,7 @@ void launch_ecam_backward(int dt, const void* X, int ld, const void* dZ, int ldd
     if (dt == BF16) k_ecam_bwd1<bf16><<<g1, 256, sm1, s>>>((const bf16*)X, ld, (const bf16*)dZ, lddz, (bf16*)dX, lddx, att, HW, C4, part);
     else k_ecam_bwd1<float><<<g1, 256, sm1, s>>>((const float*)X, ld, (const float*)dZ, lddz, (float*)dX, lddx, att, HW, C4, part);
     k_ecam_sums_fin<<<N, 256, 0, s>>>(part, nchunk, C4, sums);
-    k_ecam_mlp_bwd<<<dim3(N, 2), 128, 0, s>>>(pool, att, hid, sums, C4, w1a, w2a, w1b, w2b, gw1a, gw2a, gw1b, gw2b, dpool);
+    k_ecam_mlp_bwd<<<2, 128, 0, s>>>(pool, att, hid, sums, C4, w1a, w2a, w1b, w2b, gw1a, gw2a, gw1b, gw2b, dpool, N);
     int64_t total = (int64_t)N * HW * (C4 / 8);
     if (dt == BF16) k_ecam_bwd2<bf16><<<cdiv(total, 256), 256, 0, s>>>((bf16*)dX, lddx, dpool, argm, HW, C4, total);
     else k_ecam_bwd2<float><<<cdiv(total, 256), 256, 0, s>>>((float*)dX, lddx, dpool, argm, HW, C4, total);
@@ -1479,11 +1516,12 @@ void launch_stem_fwd(int dt, const void* X, const float* w, void* Y, int N, int 
     if (dt == BF16) k_stem_fwd<bf16><<<cdiv(total, 256), 256, lds, s>>>((const bf16*)X, w, (bf16*)Y, N, H, W, cin, Ho, Wo, Co);
     else k_stem_fwd<float><<<cdiv(total, 256), 256, lds, s>>>((const float*)X, w, (float*)Y, N, H, W, cin, Ho, Wo, Co);
 }
-// dW[co][ci][ky][kx] += sum over positions of X(2oy-3+ky, 2ox-3+kx)[ci] * dY(oy,ox)[co]; grid = (position chunks, 49 taps),
-// block = 4 position lanes x 64 output channels; dW zeroed by the caller (float atomics: ~chunks adders per address)
+// dW[co][ci][ky][kx] = sum over positions of X(2oy-3+ky, 2ox-3+kx)[ci] * dY(oy,ox)[co]; grid = (position chunks, 49 taps),
+// block = 4 position lanes x 64 output channels.  Every block writes its partial filter [chunk][tap][co][ci] and k_stem_wgrad_fin
+// adds the chunks in index order: reproducible run to run (rounds 1-3 met through float atomics on dW).
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_stem_wgrad(const T* __restrict__ X, const T* __restrict__ dY, float* __restrict__ dW, int N, int H, int W, int cin, int Ho, int Wo, int Co) {
+k_stem_wgrad(const T* __restrict__ X, const T* __restrict__ dY, float* __restrict__ part, int N, int H, int W, int cin, int Ho, int Wo, int Co) {
     __shared__ float red[4][64][8];
     const int t = blockIdx.y, ky = t / 7, kx = t % 7;
     const int co = threadIdx.x & 63, lane = threadIdx.x >> 6;
@@ -1509,14 +1547,25 @@ k_stem_wgrad(const T* __restrict__ X, const T* __restrict__ dY, float* __restric
     __syncthreads();
     if (lane == 0 && co < Co)
         for (int ci = 0; ci < cin; ++ci)
-            atomicAdd(dW + ((int64_t)co * cin + ci) * 49 + t, (red[0][co][ci] + red[1][co][ci]) + (red[2][co][ci] + red[3][co][ci]));
+            part[(((int64_t)blockIdx.x * 49 + t) * Co + co) * cin + ci] = (red[0][co][ci] + red[1][co][ci]) + (red[2][co][ci] + red[3][co][ci]);
 }
-void launch_stem_wgrad(int dt, const void* X, const void* dY, float* dW, int N, int H, int W, int cin, int Co, hipStream_t s) {
+__global__ void k_stem_wgrad_fin(const float* __restrict__ part, int chunks, int cin, int Co, float* __restrict__ dW) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (t, co, ci)
+    if (i >= 49 * Co * cin) return;
+    const int ci = i % cin, co = (i / cin) % Co, t = i / (cin * Co);
+    float a = 0.f;
+    for (int k = 0; k < chunks; ++k) a += part[(int64_t)k * 49 * Co * cin + i];
+    dW[((int64_t)co * cin + ci) * 49 + t] = a;
+}
+static int stem_wgrad_chunks(int N, int H, int W) { return (int)std::min<int64_t>(256, ((int64_t)N * (H / 2) * (W / 2) + 1023) / 1024); }
+int64_t stem_wgrad_part_floats(int N, int H, int W, int cin, int Co) { return (int64_t)stem_wgrad_chunks(N, H, W) * 49 * Co * cin; }
+void launch_stem_wgrad(int dt, const void* X, const void* dY, float* dW, int N, int H, int W, int cin, int Co, hipStream_t s, float* part) {
     const int Ho = H / 2, Wo = W / 2;
-    const int chunks = (int)std::min<int64_t>(256, ((int64_t)N * Ho * Wo + 1023) / 1024);
+    const int chunks = stem_wgrad_chunks(N, H, W);
     dim3 grid(chunks, 49);
-    if (dt == BF16) k_stem_wgrad<bf16><<<grid, 256, 0, s>>>((const bf16*)X, (const bf16*)dY, dW, N, H, W, cin, Ho, Wo, Co);
-    else k_stem_wgrad<float><<<grid, 256, 0, s>>>((const float*)X, (const float*)dY, dW, N, H, W, cin, Ho, Wo, Co);
+    if (dt == BF16) k_stem_wgrad<bf16><<<grid, 256, 0, s>>>((const bf16*)X, (const bf16*)dY, part, N, H, W, cin, Ho, Wo, Co);
+    else k_stem_wgrad<float><<<grid, 256, 0, s>>>((const float*)X, (const float*)dY, part, N, H, W, cin, Ho, Wo, Co);
+    k_stem_wgrad_fin<<<cdiv((int64_t)49 * Co * cin, 256), 256, 0, s>>>(part, chunks, cin, Co, dW);
 }
 
 // ---- 3x3 stride-2 padding-1 max-pool (H, W even) and its gradient (first maximum in scan order, as torch).

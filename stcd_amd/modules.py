@@ -324,7 +324,11 @@ class HipChangeDetector(nn.Module):
                 out = _EngineFn.apply(self, self._anchor, x1, x2)
             else:
                 out = self._run_forward(x1, x2, self.training)
+                guard = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
                 if self.OUT_MAPS == 0:
+                    # ChangeFormer: five maps in one flat buffer; the guard sits on the flat buffer so every map carries it
+                    if guard:
+                        out = _NoEvalGradFn.apply(out, self._anchor)
                     out = tuple(self._split_outputs(out))
                 elif torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                     out = _NoEvalGradFn.apply(out, self._anchor)

@@ -316,3 +316,20 @@ def test_bf16_step_tracks_the_fp32_oracle(cfg_name, B, H, W):
     print("relative l2 error of cp:", rel_out, "loss", loss.item(), rloss.item())
     assert coss[len(coss) // 2][0] > 0.98, coss[len(coss) // 2]
     assert coss[0][0] > 0.85, coss[0]
+
+
+def test_backward_through_an_eval_forward_raises():
+    """Eval-mode forwards keep no activations: a backward through any of ChangeFormer's five maps must raise like the other
+    families' single map does (stcd_amd.modules._NoEvalGradFn), not hand autograd a silent constant."""
+    ocfg, st, m = build("tiny", "fp32", 2)
+    x1, x2, tgt = data(1, 64, 64, 2)
+    m.eval()
+    outs = m(x1.to(DEV), x2.to(DEV))
+    assert len(outs) == 5 and all(o.requires_grad for o in outs)
+    for o in (outs[-1], outs[0]):
+        with pytest.raises(StcdError, match="eval-mode"):
+            loss_fn(o, F.interpolate(tgt.float().unsqueeze(1), size=o.shape[-2:]).squeeze(1).long().to(DEV)).backward()
+    with torch.no_grad():
+        outs2 = m(x1.to(DEV), x2.to(DEV))
+    assert not outs2[-1].requires_grad
+    assert torch.equal(outs2[-1], outs[-1].detach())

@@ -183,7 +183,7 @@ def test_example_script_runs_and_learns(monkeypatch, net):
 _F1_DATA = {}
 
 
-def _f1_run(g, dtype):
+def _f1_run(g, dtype, return_params=False):
     """One training run of the engine on a reference fixture's protocol (same initial weights, batch order, Dropout2d masks):
     -> (losses per step, validation F1 per epoch in points)."""
     from stcd_amd.losses import bce_dice_with_logits
@@ -221,6 +221,8 @@ def _f1_run(g, dtype):
             for i in range(0, n_va, 16):
                 met.add_logits(m(VA[i:i + 16], VB[i:i + 16]), VL[i:i + 16])
         f1s.append(float(met.F1score()[1]))
+    if return_params:
+        return torch.stack(losses_).cpu().numpy(), np.array(f1s) * 100, m._flat_params.detach().clone().cpu()
     return torch.stack(losses_).cpu().numpy(), np.array(f1s) * 100
 
 
@@ -239,9 +241,9 @@ def test_f1_parity_with_statistics_over_reference_seeds(dtype):
     (256 train / 64 val pairs of 256 x 256, 20 epochs, batch 16, Adam + Poly, sigmoid + cd_loss) that differ in the initial weights
     and the Dropout2d masks (tests/golden/g9_f1*.npz, made by tests/golden/make_f1_fixture.py from the reference's own class on
     the CPU), and the engine on the same K protocols.  Statistic: F1 of the change class on the validation slice, mean over the
-    last five epochs, per seed.  Asserted: the mean of the PAIRED per-seed differences lies inside its own 95 % interval around zero,
-    i.e. |mean_k(engine_k - reference_k)| <= max(0.2 pt, 2 standard errors), and that interval is itself narrower than 1.5 pt (K = 10: 0.4 ... 0.9 pt in three runs); and per seed the early trajectory still tracks the
-    reference (first 8 steps, epoch-mean losses).  The interval the data supports is printed as the achieved bar."""
+    last five epochs, per seed.  Asserted (bf16, K = 10): |mean_k(engine_k - reference_k)| <= 0.2 pt -- the engine is bit-reproducible
+    since round 4, so the statistic is one number per build; 2 standard errors of the seed sampling are printed beside it -- and per
+    seed the early trajectory still tracks the reference (first 8 steps, epoch-mean losses)."""
     from tests._util import ACHIEVED
     fixtures = _f1_fixtures()
     assert len(fixtures) >= 1
@@ -267,12 +269,37 @@ def test_f1_parity_with_statistics_over_reference_seeds(dtype):
     ACHIEVED[f"F1 parity {dtype}, K = {K} seeds: mean over seeds of the last-5-epoch mean F1, engine / reference (pt); difference {d:+.2f} pt, "
              f"95 % interval +-{2 * se:.2f} pt; per-seed sigma engine {eng.std(ddof=1) if K > 1 else 0:.2f} / reference {ref.std(ddof=1) if K > 1 else 0:.2f}"] = (eng.mean(), ref.mean())
     print(f"{dtype}: engine {np.round(eng, 2)} reference {np.round(ref, 2)} difference {d:+.3f} pt, 2 SE {2 * se:.3f} pt")
-    assert abs(d) <= max(0.2, 2 * se), f"engine and reference differ by {d:+.2f} pt over {K} seeds (95 % interval +-{2 * se:.2f} pt)"
+    # Round 4: the engine is bit-reproducible (fixed-order reductions), so this statistic is ONE number per build, not a sample of the
+    # engine's own scatter (rounds 1-3: four runs of the same ten seeds gave -0.17, +0.16, +0.38, -0.36 pt because float atomics
+    # finished the slab sums).  bf16 (the path the bench times), K = 10 paired seeds: |mean difference| <= F1_BAR_PT, the
+    # north_star's 0.2 pt; 2 SE (the seeds' sampling error, which no engine can shrink) is printed beside it.  fp32 runs three seeds
+    # on the reference kernels (minutes): its K = 3 mean cannot resolve 0.2 pt, so it keeps the interval form.
+    if dtype == "bf16" and K >= 10:
+        assert abs(d) <= F1_BAR_PT, f"engine and reference differ by {d:+.2f} pt over {K} seeds (bar {F1_BAR_PT} pt; 2 SE of the seed sampling {2 * se:.2f} pt)"
+    else:
+        assert abs(d) <= max(F1_BAR_PT, 2 * se), f"engine and reference differ by {d:+.2f} pt over {K} seeds (95 % interval +-{2 * se:.2f} pt)"
     if K >= 3:     # the interval is informative, and the engine's seed-to-seed scatter is of the reference's size
-        # (four runs of this test at K = 9 / 10: -0.17 +- 0.45, +0.16 +- 0.43, +0.38 +- 0.85, -0.36 +- 0.81 pt -- the engine's own run-to-run scatter, from
-        #  the float atomics of its slab sums, moves single seeds by up to 3 pt; 1.5 pt leaves room for two such seeds in one run)
         assert 2 * se <= 1.5, f"per-seed differences scatter too much to support a parity claim: {np.round(eng - ref, 2)}"
         assert eng.std(ddof=1) <= 3.0 * max(ref.std(ddof=1), 0.3)
+
+
+F1_BAR_PT = 0.2      # north_star: "F1 on a LEVIR-CD slice within 0.2 pt of the reference"
+
+
+def test_training_run_is_bit_reproducible():
+    """Two runs of ONE seed of the F1 protocol's first epochs (bf16 production path: MFMA kernels, grouped weight gradients on the side
+    stream, fused Adam) give bit-identical losses, validation F1 and final parameters: every reduction of the engine is fixed-order
+    (k_reduce_jobs sums slabs inside one block in index order; bias / BatchNorm sums meet in integer accumulators).  Rounds 1-3
+    finished many-slab weight gradients with float atomicAdd and two runs drifted apart by ~1 pt of F1 over 320 steps."""
+    g = dict(_f1_fixtures()[0])
+    g["epochs"] = np.int64(3)
+    runs = []
+    for _ in range(2):
+        losses_, f1, params = _f1_run(g, "bf16", return_params=True)
+        runs.append((losses_, f1, params))
+    assert np.array_equal(runs[0][0], runs[1][0]), np.abs(runs[0][0] - runs[1][0]).max()
+    assert np.array_equal(runs[0][1], runs[1][1])
+    assert torch.equal(runs[0][2], runs[1][2])
 
 
 @pytest.mark.parametrize("family", ["segcd", "snunet"])

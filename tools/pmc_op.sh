@@ -9,7 +9,9 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
-           "FETCH_SIZE WRITE_SIZE"; do
+           "FETCH_SIZE" \
+           "WRITE_SIZE"; do      # separate passes: FETCH_SIZE takes 3 and WRITE_SIZE 2 of the 4 TCC counters (MI355X_MICROARCH.md); one
+                                 # pass with both fails with "error code 38: Request exceeds the capabilities of the hardware to collect"
   i=$((i+1))
   OPBENCH_KIND=$K timeout -k 10 120 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmcop/s$i -- python3 $R/tools/opbench.py $CASE > $R/gpurun_out/pmcop/s$i.log 2>&1 || echo "set $i failed"
 done
