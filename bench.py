@@ -502,14 +502,29 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_roofline:
         eng = model._engine
-        nprof = 3
-        eng.profile_enable(True)
+        nprof = 5
+        # every instrumented step is read on its own and each kernel / class takes its MEDIAN over the steps, scaled back to nprof
+        # steps: the event pair of a launch also sees a host hiccup between its two records (round 4's first run: one 4-ms stall in one
+        # of three steps read as k_conv_res<2,32> = 1.59 ms per step, against 0.26 in the timed loop's rocprof trace)
+        per_step_k, per_step_c = [], []
         for _ in range(nprof):
+            eng.profile_enable(True)
             step()
-        torch.cuda.synchronize()
-        prof = eng.profile_read()
-        kern = eng.profile_kernels()
+            torch.cuda.synchronize()
+            per_step_c.append(eng.profile_read())
+            per_step_k.append(eng.profile_kernels())
         eng.profile_enable(False)
+
+        def _median_steps(runs):
+            out = {}
+            for k_ in runs[0]:
+                vals = sorted(r_[k_]["ms"] for r_ in runs if k_ in r_)
+                v0 = runs[0][k_]
+                out[k_] = {"ms": vals[len(vals) // 2] * nprof, "launches": v0["launches"] * nprof,
+                           "flops": v0["flops"] * nprof, "bytes": v0["bytes"] * nprof}
+            return out
+        prof = _median_steps(per_step_c)
+        kern = _median_steps(per_step_k)
         # the dominant KERNEL: template instantiations of one kernel (k_conv_res<2, 32, false>, <1, 64, false> ...) are ONE kernel
         # for this purpose -- merged by base name, so a kernel split over many instantiations cannot hide behind a smaller one
         merged = {}

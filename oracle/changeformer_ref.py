@@ -16,12 +16,18 @@ Restated from text; every function cites the lines it follows under /root/refere
                                                           the in-tree widths, not MiT-B0)
   ConvLayer / UpsampleConvLayer / ResidualBlock   ChangeFormerBaseNetworks.py:85-120
 
-PIN STATUS.  `models/ChangeFormer.py` cannot be imported in the authoring container (it imports `timm`, absent), so the
-encoder / decoder classes above are restated from the text only: **parity unpinned** for them.  What timm supplies is restated
-from its published definitions: `DropPath` (per-sample Bernoulli(keep) mask divided by keep), `trunc_normal_(std=.02)`
-(torch.nn.init.trunc_normal_ is the same algorithm), `to_2tuple`.  The three classes of `models/ChangeFormerBaseNetworks.py`
-the decoder head uses DO import, and tests/golden/g17_cf_base.npz holds their outputs and gradients (tests/golden/make_golden.py):
-`residual_block`, `upsample_conv` and `conv_layer` below are PINNED by it (tests/test_oracle_golden.py).
+PIN STATUS.  `models/ChangeFormer.py` cannot be imported in the authoring container (it imports `timm` at :10-11, absent).
+  * DECODER: PINNED (round 4).  `resize`, `MLP`, `conv_diff`, `make_prediction`, `DecoderTransformer_v3` and `DWConv` use none of
+    timm's names; tests/golden/make_golden.py (g21) compiles exactly those definitions from the reference's file by `ast` (the
+    recipe of G8; with the importable models.ChangeFormerBaseNetworks classes in the namespace) and stores outputs, every
+    gradient and the BatchNorm statistics of two feature pyramids (eval, train with Dropout p = 0, train with recorded masks):
+    `decoder`, `_conv_diff`, `_make_pred` and `dwconv_tokens` below are checked against tests/golden/g21_cf_decoder.npz at 1e-5
+    (tests/test_changeformer_cpu.py).  The three classes of `models/ChangeFormerBaseNetworks.py` are pinned by g17 as before.
+  * ENCODER: **parity unpinned**.  `OverlapPatchEmbed`, `Attention`, `Mlp`, `Block`, `EncoderTransformer_v3` call timm's
+    `trunc_normal_` / `to_2tuple` / `DropPath` at construction: they are restated from the text only, and what timm supplies is
+    restated from its published definitions -- `DropPath` (per-sample Bernoulli(keep) mask divided by keep),
+    `trunc_normal_(std=.02)` (torch.nn.init.trunc_normal_ is the same algorithm), `to_2tuple`.  No timm name is defined anywhere
+    in this repository.
 
 Randomness is explicit: every Dropout / DropPath site takes its mask from `masks` (name -> tensor already divided by keep),
 so the HIP engine and this file can be run on identical masks (`engine_masks` reproduces the engine's counter hash).
@@ -303,14 +309,19 @@ def attention(st, name, x, H, W, heads, sr, masks):
     return _m(masks, name + ".proj_drop", x)
 
 
+def dwconv_tokens(x, w, b, H, W):
+    """DWConv.forward (ChangeFormer.py:517-523): tokens [B, N, C] -> NCHW -> depth-wise 3x3 (padding 1, bias) -> tokens.
+    PINNED by tests/golden/g21_cf_decoder.npz (dw/*: the reference's own class, compiled from its file by ast)."""
+    B, N, Ch = x.shape
+    x = x.transpose(1, 2).reshape(B, Ch, H, W)
+    x = F.conv2d(x, w, b, padding=1, groups=Ch)
+    return x.flatten(2).transpose(1, 2)
+
+
 def mix_ffn(st, name, x, H, W, masks):
     """Mlp.forward + DWConv.forward (ChangeFormer.py:287-295, 517-523)."""
-    B, N, _ = x.shape
     x = F.linear(x, st[name + ".fc1.weight"], st[name + ".fc1.bias"])
-    Ch = x.shape[2]
-    x = x.transpose(1, 2).reshape(B, Ch, H, W)
-    x = F.conv2d(x, st[name + ".dwconv.dwconv.weight"], st[name + ".dwconv.dwconv.bias"], padding=1, groups=Ch)
-    x = x.flatten(2).transpose(1, 2)
+    x = dwconv_tokens(x, st[name + ".dwconv.dwconv.weight"], st[name + ".dwconv.dwconv.bias"], H, W)
     x = F.gelu(x)
     x = _m(masks, name + ".drop1", x)
     x = F.linear(x, st[name + ".fc2.weight"], st[name + ".fc2.bias"])

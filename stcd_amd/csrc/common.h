@@ -116,6 +116,91 @@ __device__ __forceinline__ double bn_acc_get(const long long* __restrict__ acc, 
     return (double)s / (double)scale;
 }
 
+// ---- consumer-side "finalize": every block of a kernel that APPLIES a BatchNorm derives the per-channel constants of all
+//      its channels from the integer accumulators (2*C*BN_REP loads per block) into an LDS table; block 0 also publishes
+//      them (stat, running statistics / dgamma, dbeta) for later kernels.  Same arithmetic as torch: biased variance for
+//      the normalisation, unbiased for running_var, momentum 0.1, double precision for the moments.
+// tab: [groups][2][C] = scale, shift.  Thread c handles channel c for all groups IN ORDER (the shared encoder BatchNorm
+// sees date 0 then date 1: /root/reference/models/SiamUnet_diff.py:99,123).
+__device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __restrict__ facc, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                             float* __restrict__ stat, int C, int groups, int64_t ppg, float momentum, float eps,
+                                             bool publish, int cbase = 0, int CS = 0, int g_first = 0) {
+    // channels [cbase, cbase + CS) only (CS == 0: all): wide layers give every block one 64-channel slab, so its prologue reads
+    // 64 channels' accumulators instead of up to 2048
+    if (CS == 0) CS = C;
+    for (int cl = threadIdx.x; cl < CS; cl += blockDim.x) {
+        const int c = cbase + cl;
+        if (facc) {
+            const float gam = gamma[c], bet = beta[c];
+            float rm = (publish && rmean) ? rmean[c] : 0.f, rv = (publish && rvar) ? rvar[c] : 0.f;
+            for (int gi = 0; gi < groups; ++gi) {      // the running statistics see the groups in the order the reference calls the
+                int g = gi + g_first;                   // BatchNorm on them: g_first, g_first + 1, ... (cyclic)
+                if (g >= groups) g -= groups;
+                const double s1 = bn_acc_get(facc, groups, C, g, 0, c, BN_FS1), s2 = bn_acc_get(facc, groups, C, g, 1, c, BN_FS2);
+                const double mean = s1 / (double)ppg;
+                double var = s2 / (double)ppg - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const double invstd = 1.0 / sqrt(var + (double)eps);
+                const float sc = (float)(gam * invstd), sh = (float)(bet - mean * gam * invstd);
+                tab[(g * 2 + 0) * CS + cl] = sc;
+                tab[(g * 2 + 1) * CS + cl] = sh;
+                if (publish) {
+                    float* st = stat + (int64_t)g * 4 * C;
+                    st[c] = (float)mean; st[C + c] = (float)invstd; st[2 * C + c] = sc; st[3 * C + c] = sh;
+                    const double unb = ppg > 1 ? var * ((double)ppg / (double)(ppg - 1)) : var;
+                    rm = (float)((1.0 - momentum) * rm + momentum * mean);
+                    rv = (float)((1.0 - momentum) * rv + momentum * unb);
+                }
+            }
+            if (publish && rmean) rmean[c] = rm;
+            if (publish && rvar) rvar[c] = rv;
+        } else if (gamma) {      // eval mode: the running statistics (read-only), the arithmetic of k_bn_eval_prepare -- no launch for it
+            const float invstd = 1.f / sqrtf(rvar[c] + eps);
+            const float sc = gamma[c] * invstd, sh = beta[c] - rmean[c] * gamma[c] * invstd;
+            for (int g = 0; g < groups; ++g) {
+                tab[(g * 2 + 0) * CS + cl] = sc;
+                tab[(g * 2 + 1) * CS + cl] = sh;
+            }
+        } else {
+            for (int g = 0; g < groups; ++g) {
+                tab[(g * 2 + 0) * CS + cl] = stat[(int64_t)g * 4 * C + 2 * C + c];
+                tab[(g * 2 + 1) * CS + cl] = stat[(int64_t)g * 4 * C + 3 * C + c];
+            }
+        }
+    }
+}
+
+// ---- "virtual activation" (round 4): the consumer of a conv -> BN -> ReLU -> Dropout2d layer reads the producer's RAW conv output
+//      Y and applies scale / shift / ReLU / mask while it stages its input tile, so the activation A is never written to HBM (one
+//      full-tensor pass and one launch less per layer; reference semantics: /root/reference/models/SiamUnet_diff.py:99-119).
+//      The arithmetic is k_bn_act's, bit for bit: A = round_bf16(max(y * sc + sh, 0) * mk).
+struct XfSrc {
+    const long long* facc = nullptr;   // training forward: the producer's statistics accumulators (bn_fwd_table); nullptr otherwise
+    const float* gamma = nullptr;      // forward (training / eval): affine parameters; nullptr: backward -- read the published `stat`
+    const float* beta = nullptr;
+    float* rmean = nullptr; float* rvar = nullptr;   // running statistics (updated by block 0 of the FORWARD consumer in training mode)
+    float* stat = nullptr;             // producer's [groups][4][C] (mean, invstd, scale, shift): published by block 0 when publish != 0
+    const float* mask = nullptr;       // Dropout2d factors [N][C] (0 or 1 / (1 - p)); nullptr: none
+    int C = 0, groups = 1, npg = 0, publish = 0;
+    long long ppg = 0;                 // values per channel and group
+    float momentum = 0.1f, eps = 1e-5f;
+    int on = 0;                        // 0: plain input tensor
+};
+// one 16-B piece (8 consecutive channels of one pixel); ok == false: a zero-filled border piece stays zero (the conv pads A, not Y)
+__device__ __forceinline__ uint4 xf_act8(const uint4 raw, const float (&sc)[8], const float (&sh)[8], const float (&mk)[8], const bool ok) {
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+        lo = fmaxf(fmaf(lo, sc[2 * i], sh[2 * i]), 0.f) * mk[2 * i];
+        hi = fmaxf(fmaf(hi, sc[2 * i + 1], sh[2 * i + 1]), 0.f) * mk[2 * i + 1];
+        o[i] = ok ? pack_bf16x2(lo, hi) : 0u;
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // ------------------------------------------------------------------ host launchers (kernels_*.hip)
 // All tensors NHWC with an explicit pixel stride ("ld", in elements); channel counts are multiples of 8.
 
@@ -161,7 +246,7 @@ struct ConvResPlan {
 ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups);
 int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvResPlan& rp, const void* in, const void* wf,
                     const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0 = 0,
-                    float s1_scale = BN_FS1, float s2_scale = BN_FS2);
+                    float s1_scale = BN_FS1, float s2_scale = BN_FS2, const XfSrc* xf = nullptr);
 // Tap-list convolutions with Ci % 64 == 0, Co % 64 == 0 as a tiled GEMM [positions x (taps * Ci)] . [(taps * Ci) x Co]: 128x128
 // or 64x64 block tiles staged through LDS in (64-channel chunk, tap) steps, fused bias + BN statistics, LDS-transposed 16-B
 // output stores.  1x1 convolutions of any stride, and the wide layers the resident-filter kernel cannot take.
@@ -213,7 +298,7 @@ int launch_conv_dma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvDm
 bool conv_small_ok(const stcd_conv_geom& g, const ConvMfmaPlan& p);
 int conv_small_blocks(const stcd_conv_geom& g, int groups);
 int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_modeB, const float* bias, void* out,
-                      bool out_nchw_f32, int groups, long long* stat_acc, int cpad, hipStream_t s);
+                      bool out_nchw_f32, int groups, long long* stat_acc, int cpad, hipStream_t s, const XfSrc* xf = nullptr);
 struct WgradMfmaPlan {
     int WCI = 1, NTW = 1, gx = 1, gy = 1, gz = 1;
     int64_t slab_floats = 0;
@@ -244,6 +329,10 @@ struct WgradJob {
     int wi_valid;                          // input columns >= wi_valid read as zero (== g.wi for a plain tensor)
     int dma_L, dma_nk;                     // k_wgrad_dma: positions per split (a multiple of 64), K-tiles per block (even)
     int pad_;
+    // X is a "virtual activation" (XfSrc): `in_off` addresses the producer's raw conv output, BN-affine + ReLU + Dropout2d are
+    // applied while the X tile is staged (k_wgrad_group only).  xf_C == 0: plain input.
+    int64_t xf_stat_off, xf_mask_off;      // producer's published [groups][4][C] table / Dropout2d factors [N][C] (-1: none); bytes from base
+    int xf_C, xf_groups, xf_npg, pad2_;
 };
 // one-tap weight gradients with Ci, Co >= 64 (1x1 convs, the phases of 2x2 stride-2 transposed convs): dW = X^T . dY as a GEMM
 // over positions, 128x128 / 64x64 channel tiles, positions split over gx blocks that each write one fp32 slab
@@ -260,6 +349,7 @@ WgradJob wgrad_dma_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int
 int launch_wgrad_dma_group(const WgradJob* jobs_dev, int njobs, int total_blocks, const char* base, hipStream_t s);
 WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t in_off, int64_t dout_off, int64_t slab_off,
                         int kpad, int wld);
+void wgrad_job_set_xf(WgradJob& a, int64_t stat_off, int64_t mask_off, int C, int groups, int npg);
 int wgrad_variant_slots(int WCI, int NTW, bool t9, int lds_bytes);   // resident blocks of that kernel variant on the chip
 int launch_wgrad_group(int WCI, int NTW, bool t9, const WgradJob* jobs_dev, int njobs, int total_blocks, int lds_bytes,
                        const char* base, hipStream_t s);

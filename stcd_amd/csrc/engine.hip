@@ -71,6 +71,8 @@ struct WgradOp {
     int64_t in_off = -1, dout_off = -1;  // workspace offsets of X and dY (grouped launch at the end of the stage)
     bool grouped = false;
     int group = -1;                      // index of its WgradGroup inside e.wgroups[stage]
+    // X is a virtual activation (the producer's raw conv output, transformed while staged: XfSrc / wgrad_job_set_xf); xf_C == 0: plain
+    int64_t xf_stat_off = -1, xf_mask_off = -1; int xf_C = 0, xf_groups = 1, xf_npg = 1;
     bool own_taps = false;               // filter taps (ky, kx) of this launch given here instead of conv.fwd.ky/kx[tap0 + t]
     int8_t oky[9] = {0}, okx[9] = {0};   // (the 7x7 stem: 49 taps spread over 7 launches)
 };
@@ -97,6 +99,10 @@ struct Cbrd {                         // conv -> BN -> ReLU -> Dropout2d [-> poo
     int64_t dgr_sum_acc = -1; int dgr_sum_c0 = 0, dgr_sum_C = 0;   // the data-gradient launch also sums a channel slice of its
                                                                     // output (bias gradient of the transposed conv feeding it)
     TRef fuse_dst;                    // skip layers of diff / sub: the decoder's concat slice that receives |a1-a2| / a2-a1
+    // "virtual activation" (round 4): virt = this layer's A is never written -- its ONE consumer (the next conv of the stage: forward
+    // launch and weight gradient) reads Y and applies scale / shift / ReLU / Dropout2d while staging (no k_bn_act launch, one tensor
+    // pass less); xsrc = the producer whose raw output this layer reads that way (nullptr: a materialised input)
+    bool virt = false; const Cbrd* xsrc = nullptr;
 };
 struct XConc {                        // cross_conc skip block of SiamUnet_cross_conc (SiamUnet_crossconc.py:11-33): pairwise depthwise
     int level = 0, C = 0;             // conv -> BN -> ReLU, then conv3x3 C -> C -> BN -> ReLU (the Cbrd `res`, no dropout) into the concat slice
@@ -235,6 +241,8 @@ struct stcd_engine_impl {
     std::vector<UpConv> ups;
     int final_conv = -1;
     ConvOp final_fwd, final_dgr; WgradOp final_wg;
+    const Cbrd* final_xsrc = nullptr;   // conv11d reads conv12d's raw output (virtual activation)
+    int use_virt = 1;                   // STCD_VIRT_ACT=0: every activation materialised (the round-3 plan)
     std::vector<ConvOp*> conv_ops;      // every ConvOp of the plan (weight-image packing walks this)
     int64_t slab = -1, slab_floats = 0;
     std::vector<WgradOp*> wgrad_ops;                    // every WgradOp of the plan
@@ -613,6 +621,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                     for (WgradOp* op : ops) {   // LDS need of the group = max over its jobs
                         const ConvW& cv = e.convs[op->conv];
                         WgradJob j = wgrad_make_job(op->g, op->plan, 0, 0, 0, cv.fwd.kpad, cv.fwd.wld);
+                        if (op->xf_C > 0) wgrad_job_set_xf(j, op->xf_stat_off, op->xf_mask_off, op->xf_C, op->xf_groups, op->xf_npg);
                         G.lds_bytes = std::max(G.lds_bytes, j.lds_bytes);
                     }
                     int slots = wgrad_variant_slots(G.WCI, G.NTW, G.t9, G.lds_bytes);
@@ -645,6 +654,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                         WgradJob j = op->plan.dma ? wgrad_dma_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
                                    : op->plan.gemm ? wgrad_gemm_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
                                                    : wgrad_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld);
+                        if (op->xf_C > 0 && !op->plan.dma && !op->plan.gemm) wgrad_job_set_xf(j, op->xf_stat_off, op->xf_mask_off, op->xf_C, op->xf_groups, op->xf_npg);
                         j.start = G.total_blocks;
                         G.total_blocks += j.gx * j.gy * j.gz;
                         G.jobs.push_back(j);
@@ -914,6 +924,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
                           int64_t dout_off) {
         op.g = g; op.conv = conv; op.tap0 = tap0; op.kreal = kreal; op.nreal = nreal;
         op.in_off = in_off; op.dout_off = dout_off; op.grouped = false;
+        op.xf_stat_off = op.xf_mask_off = -1; op.xf_C = 0; op.xf_groups = op.xf_npg = 1;
         op.plan = WgradMfmaPlan(); op.slab = -1;
         op.stage = e.convs[conv].w_off < e.enc_param_end ? 1 : 0;     // encoder filters are finalised by stage 1
         if (e.dt == BF16) op.plan = pick_wgrad_plan(e, g, e.convs[conv].fwd.kpad, e.convs[conv].fwd.wld);
@@ -957,6 +968,46 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     }
     e.slab = ws.take(e.slab_floats * 4);
 
+    // ---- virtual activations: a non-skip layer whose ONLY reader is the next conv of its stage hands that conv its raw output Y;
+    //      the conv's forward launch (k_conv_small / k_conv_res, XF variants) and its weight gradient (k_wgrad_group, job.xf_*)
+    //      apply BN-affine + ReLU + Dropout2d while staging.  Eligibility mirrors exec_conv / exec_wgrad's kernel choice, which is
+    //      fixed at configure time (the switches are read at stcd_create).
+    e.final_xsrc = nullptr;
+    for (auto& L : e.enc) { L.virt = false; L.xsrc = nullptr; }
+    for (auto& L : e.dec) { L.virt = false; L.xsrc = nullptr; }
+    if (e.use_virt && e.dt == BF16 && e.use_mfma && e.use_wgroup && !fc_cross(e)) {
+        auto fwd_ok = [&](const ConvOp& op, bool nchw) {
+            if (op.wf < 0 || (op.gemm.ok && !nchw)) return false;
+            if (op.small && e.use_small) return true;
+            return op.res.ok && !nchw && !op.res.single_halo;
+        };
+        auto wg_ok = [&](const WgradOp& op) { return op.plan.ok && !op.plan.gemm && !op.plan.dma; };
+        auto link = [&](Cbrd& P, ConvOp& cf, WgradOp& cw, bool nchw) {
+            if (P.pool || P.fuse_dst.off >= 0) return false;
+            if (!fwd_ok(cf, nchw) || !wg_ok(cw)) return false;
+            P.virt = true;
+            cw.in_off = P.Y.off;
+            cw.xf_stat_off = P.stat;
+            cw.xf_mask_off = (P.drop >= 0) ? e.masks + e.drops[P.drop].off * 4 : -1;
+            cw.xf_C = e.convs[P.conv].cout; cw.xf_groups = P.groups; cw.xf_npg = P.npg;
+            return true;
+        };
+        for (size_t i = 0; i + 1 < e.enc.size(); ++i) {
+            Cbrd& P = e.enc[i]; Cbrd& Cn = e.enc[i + 1];
+            if (Cn.in.off != P.A.off) continue;                       // (the next layer reads the pooled map: P is a skip layer)
+            if (link(P, Cn.fwd, Cn.wg, false)) { Cn.xsrc = &P; Cn.in.off = P.Y.off; Cn.in.ld = P.Y.ld; }
+        }
+        for (size_t i = 0; i < e.dec.size(); ++i) {
+            Cbrd& P = e.dec[i];
+            if (i + 1 < e.dec.size() && e.dec[i + 1].in.off == P.A.off) {
+                Cbrd& Cn = e.dec[i + 1];
+                if (link(P, Cn.fwd, Cn.wg, false)) { Cn.xsrc = &P; Cn.in.off = P.Y.off; Cn.in.ld = P.Y.ld; }
+            } else if (e.finalIn.off == P.A.off) {
+                if (link(P, e.final_fwd, e.final_wg, true)) { e.final_xsrc = &P; e.finalIn.off = P.Y.off; e.finalIn.ld = P.Y.ld; }
+            }
+        }
+    }
+
     // ---- bias gradients without a pass of their own: the transposed conv of stage k wrote channels [0, C) of the concat
     //      buffer, so its bias gradient is the per-channel sum of that slice of d(concat) -- which the data-gradient launch
     //      of the stage's first conv produces.  When that launch runs on the resident-filter kernel it sums the slice in its
@@ -999,9 +1050,10 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             r.offset_bytes = off; r.n = n; r.h = L.H; r.w = L.W; r.c = ch; r.ld = ld; r.dtype = e.dt;
             e.ws_tensors.push_back(r);
         };
-        rec("in", L.in.off, L.in.ld, L.N, L.K);
+        // "in.virt": the input is the producer's RAW conv output (virtual activation); the producer then records no A
+        rec(L.xsrc ? "in.virt" : "in", L.in.off, L.in.ld, L.N, L.K);
         rec("Y", L.Y.off, L.Y.ld, L.N, cv.cout);
-        for (int g = 0; g < L.groups; ++g) {
+        for (int g = 0; g < L.groups && !L.virt; ++g) {
             char sfx[8];
             snprintf(sfx, sizeof(sfx), "A.g%d", g);
             rec(sfx, L.A.off + g * L.A.goff * T, L.A.ld, L.npg, cv.cout);
@@ -1062,7 +1114,8 @@ static bool mfma_on(const stcd_engine& e) { return e.dt == BF16 && e.use_mfma; }
 struct StatReq { long long* acc = nullptr; int groups = 1; int c0 = 0; int C = 0; float s1 = BN_FS1, s2 = BN_FS2; };
 // *fused receives 1 when the kernel delivered the sums, 0 when the caller must run the separate pass.
 static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const float* bias, void* out, bool nchw,
-                      const StatReq* sr = nullptr, int* stat_chunks = nullptr, const ConvEpi* epi = nullptr, int* epi_fused = nullptr) {
+                      const StatReq* sr = nullptr, int* stat_chunks = nullptr, const ConvEpi* epi = nullptr, int* epi_fused = nullptr,
+                      const XfSrc* xf = nullptr) {
     const int stat_groups = (sr && sr->acc) ? sr->groups : 0;
     long long* stat_acc = sr ? sr->acc : nullptr;
     const bool bn_form = sr && sr->c0 == 0 && sr->C == op.g.co && sr->s1 == BN_FS1 && sr->s2 == BN_FS2;
@@ -1106,10 +1159,12 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
             return;
         }
     }
+    const bool xf_on = xf && xf->on;
     if (mfma_on(c.e) && op.small && op.wf >= 0 && c.e.use_small) {
-        const int groups = (stat_groups > 0 && bn_form) ? stat_groups : 1;
-        long long* sp = (stat_groups > 0 && bn_form) ? stat_acc : nullptr;
-        if (launch_conv_small(op.g, in, c.at(op.wf), bias, out, nchw, groups, sp, op.g.co, c.s) == 0) {
+        // (a virtual input partitions the tiles by the PRODUCER's BatchNorm groups, statistics or not: eval mode has none)
+        const int groups = xf_on ? xf->groups : (stat_groups > 0 && bn_form) ? stat_groups : 1;
+        long long* sp = (stat_groups > 0 && bn_form && stat_groups == groups) ? stat_acc : nullptr;
+        if (launch_conv_small(op.g, in, c.at(op.wf), bias, out, nchw, groups, sp, op.g.co, c.s, xf) == 0) {
             if (stat_chunks && sp) *stat_chunks = 1;
             return;
         }
@@ -1118,10 +1173,14 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
         const bool want = stat_groups > 0 && stat_groups == op.res_groups && stat_acc;
         long long* sp = want ? stat_acc : nullptr;
         if (launch_conv_res(op.g, op.plan, op.res, in, c.at(op.wf), bias, out, op.res_groups, sp, want ? sr->C : op.g.co, c.s,
-                            want ? sr->c0 : 0, want ? sr->s1 : BN_FS1, want ? sr->s2 : BN_FS2) == 0) {
+                            want ? sr->c0 : 0, want ? sr->s1 : BN_FS1, want ? sr->s2 : BN_FS2, xf) == 0) {
             if (stat_chunks && want) *stat_chunks = 1;
             return;
         }
+    }
+    if (xf_on) {     // planned at configure time for a kernel that applies the transform: nothing below can (and must not run on raw Y)
+        set_error("internal: a virtual-activation input reached a convolution kernel without the staging transform");
+        return;
     }
     if (mfma_on(c.e) && op.plan.ok && op.wf >= 0 &&
         launch_conv_mfma(op.g, op.plan, in, c.at(op.wf), bias, out, nchw, c.s) == 0)
@@ -1265,6 +1324,23 @@ static void reduce_stage(const Ctx& c, int stage) {
     launch_reduce_jobs(c.at<ReduceJob>(e.rjobs_off[stage]), (int)e.rjobs[stage].size(), e.rjobs_total[stage], c.ws, c.grads, c.s);
 }
 
+// the producer P as its consumer's staging transform sees it (XfSrc, common.h): training -> batch statistics from P's accumulators,
+// the consumer's block 0 publishes P.stat and updates the running statistics; eval -> the running statistics, nothing written
+static XfSrc xf_source(const Ctx& c, const Cbrd& P, float* bn_running, bool training) {
+    stcd_engine& e = c.e;
+    const BnP& bn = e.bns[P.bn];
+    XfSrc x;
+    x.C = e.convs[P.conv].cout; x.groups = P.groups; x.npg = P.npg; x.ppg = (long long)P.npg * P.H * P.W;
+    x.facc = training ? c.at<long long>(P.facc) : nullptr;
+    x.gamma = c.params + bn.g_off; x.beta = c.params + bn.b_off;
+    x.rmean = bn_running + bn.run_off; x.rvar = bn_running + bn.run_off + x.C;
+    x.stat = c.at<float>(P.stat);
+    x.mask = (training && e.drop_p > 0.f && P.drop >= 0) ? c.at<float>(e.masks) + e.drops[P.drop].off : nullptr;
+    x.publish = training ? 1 : 0;
+    x.on = 1;
+    return x;
+}
+
 static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool training) {
     stcd_engine& e = c.e;
     const ConvW& cv = e.convs[L.conv];
@@ -1272,7 +1348,9 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     const int C = cv.cout;
     int fused_chunks = 0;
     StatReq sr; sr.acc = training ? c.at<long long>(L.facc) : nullptr; sr.groups = L.groups; sr.C = C;
-    exec_conv(c, L.fwd, c.at(L.in.off), c.params + cv.b_off, c.at(L.Y.off), false, &sr, &fused_chunks);
+    XfSrc xf;
+    if (L.xsrc) xf = xf_source(c, *L.xsrc, bn_running, training);
+    exec_conv(c, L.fwd, c.at(L.in.off), c.params + cv.b_off, c.at(L.Y.off), false, &sr, &fused_chunks, nullptr, nullptr, L.xsrc ? &xf : nullptr);
     const int64_t ppg = (int64_t)L.npg * L.H * L.W;
     const double act_bytes = (double)L.N * L.H * L.W * C * (double)dsize(e.dt);
     float* stat = c.at<float>(L.stat);
@@ -1282,6 +1360,7 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
             launch_bn_stats(e.dt, c.at(L.Y.off), L.Y.ld, C, L.groups, ppg, c.at<long long>(L.facc), c.s);
         }
     }
+    if (L.virt) return;      // the consumer applies scale / shift / ReLU / Dropout2d while staging Y (and publishes the statistics)
     BnActArgs a;
     a.Y = c.at(L.Y.off); a.ldy = L.Y.ld;
     a.A = c.at(L.A.off); a.lda = L.A.ld; a.a_group_off = L.A.goff;
@@ -1435,7 +1514,12 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
             cbrd_forward(c, e.dec[di++], bn_running, training != 0);
         }
     }
-    exec_conv(c, e.final_fwd, c.at(e.finalIn.off), params + e.convs[e.final_conv].b_off, logits, true);
+    {
+        XfSrc xf;
+        if (e.final_xsrc) xf = xf_source(c, *e.final_xsrc, bn_running, training != 0);
+        exec_conv(c, e.final_fwd, c.at(e.finalIn.off), params + e.convs[e.final_conv].b_off, logits, true, nullptr, nullptr, nullptr, nullptr,
+                  e.final_xsrc ? &xf : nullptr);
+    }
     STCD_HIP(hipGetLastError());
     return 0;
 }
@@ -2671,6 +2755,8 @@ static void engine_env_switches(stcd_engine* e) {
     e->use_act_fuse = !(env && env[0] == '1');
     env = getenv("STCD_NO_SKIP_FUSED");
     e->use_skip_fused = !(env && env[0] == '1');
+    env = getenv("STCD_VIRT_ACT");                // 0: materialise every activation (k_bn_act per layer, the round-3 plan)
+    if (env) e->use_virt = atoi(env) != 0;
     env = getenv("STCD_WGRAD_SIDE");              // 0: the decoder's weight gradients stay on the caller's stream
     if (env) e->wg_side_on = atoi(env) != 0;
     env = getenv("STCD_WGRAD_SIDE_DIV");          // share of the planner's block budget for stage 0's grouped grids: 1 / div

@@ -557,9 +557,31 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(a_dout)), (short)0, (int)a.dout_bytes, 0x00020000);
     uint4 prex[MAXX], prey[NTW];
+    // X as a virtual activation (job.xf_C > 0; uniform per block): scale / shift table of the producer in LDS behind the two staging
+    // buffers, the fetched tile's validity bits, image group and Dropout2d factors ride with the loads, xf_act8 at the LDS store
+    const bool xf_on = a.xf_C > 0;
+    float* const xf_tab = reinterpret_cast<float*>(smem + 2 * buf_bytes);
+    const int xf_ch = min(ci0 + (tid % XCH) * 8, max(a.xf_C - 8, 0));        // (tid + p * 256) % XCH is the same for every piece p
+    unsigned xf_ok = 0; int xf_g = 0;
+    float4 xf_m0 = make_float4(1.f, 1.f, 1.f, 1.f), xf_m1 = xf_m0;
+    if (xf_on) {
+        const float* st = reinterpret_cast<const float*>(base + a.xf_stat_off);
+        for (int i = tid; i < a.xf_groups * 2 * a.xf_C; i += 256) {
+            const int c = i % a.xf_C, w = (i / a.xf_C) & 1, g_ = i / (2 * a.xf_C);
+            xf_tab[i] = st[((int64_t)g_ * 4 + 2 + w) * a.xf_C + c];
+        }
+        __syncthreads();
+    }
 #define WG_FETCH(N_, Y_, X_)                                                                                          \
     do {                                                                                                              \
         const int my0_ = (Y_) * 8, mx0_ = (X_) * 16;                                                                   \
+        if (xf_on) {                                                                                                  \
+            xf_ok = 0; xf_g = (N_) / a.xf_npg;                                                                        \
+            if (a.xf_mask_off >= 0) {                                                                                 \
+                const float4* mp_ = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base + a.xf_mask_off) + (int64_t)(N_) * a.xf_C + xf_ch); \
+                xf_m0 = mp_[0]; xf_m1 = mp_[1];                                                                       \
+            }                                                                                                         \
+        }                                                                                                             \
         const unsigned xs_ = (unsigned)(((((int64_t)(N_) * a.g.hi + my0_) * a.g.wi + mx0_) * a.g.ldi) * 2);            \
         const unsigned ys_ = (unsigned)(((((int64_t)(N_) * a.g.ho + my0_ * a.g.out_stride + a.g.oy0) * a.g.wo +        \
                                           mx0_ * a.g.out_stride + a.g.ox0) * a.g.ldo) * 2);                            \
@@ -568,6 +590,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
                 const bool ok_ = (unsigned)(my0_ + xa[p]) < (unsigned)a.g.hi && (unsigned)(mx0_ + xb[p]) < (unsigned)a.wi_valid; \
                 const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok_ ? (unsigned)xg[p] : 0x80000000u, xs_, 0); \
                 prex[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                     \
+                xf_ok |= ok_ ? (1u << p) : 0u;                                                                        \
             }                                                                                                         \
         }                                                                                                             \
         _Pragma("unroll") for (int q = 0; q < NTW; ++q) {                                                             \
@@ -578,6 +601,14 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
     } while (0)
 #define WG_STASH(BUF_)                                                                                                \
     do {                                                                                                              \
+        if (xf_on) {                                                                                                  \
+            float sc_[8], sh_[8];                                                                                     \
+            const float mk_[8] = {xf_m0.x, xf_m0.y, xf_m0.z, xf_m0.w, xf_m1.x, xf_m1.y, xf_m1.z, xf_m1.w};            \
+            const float* tb_ = xf_tab + (xf_g * 2) * a.xf_C + xf_ch;                                                  \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) { sc_[j] = tb_[j]; sh_[j] = tb_[a.xf_C + j]; }              \
+            _Pragma("unroll") for (int p = 0; p < MAXX; ++p)                                                          \
+                if (p < npx) prex[p] = xf_act8(prex[p], sc_, sh_, mk_, (xf_ok >> p) & 1u);                            \
+        }                                                                                                             \
         _Pragma("unroll") for (int p = 0; p < MAXX; ++p)                                                              \
             if (p < npx && tid + p * 256 < nx) *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + xl[p]) = prex[p]; \
         _Pragma("unroll") for (int q = 0; q < NTW; ++q)                                                               \
@@ -910,7 +941,14 @@ WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t
     a.wi_valid = p.wi_valid > 0 ? p.wi_valid : g.wi; a.pad_ = 0;
     const int WK = 4 / p.WCI;
     a.lds_bytes = (int)std::max<size_t>(2 * (size_t)(a.x_bytes + a.y_bytes), (size_t)(WK - 1) * p.WCI * 9 * p.NTW * 4 * 64 * 4);
+    a.xf_stat_off = -1; a.xf_mask_off = -1; a.xf_C = 0; a.xf_groups = 1; a.xf_npg = 1; a.pad2_ = 0;     // plain X (wgrad_job_set_xf)
     return a;
+}
+
+// X of this job is the producer's raw conv output (virtual activation): its published table, masks and BatchNorm groups
+void wgrad_job_set_xf(WgradJob& a, int64_t stat_off, int64_t mask_off, int C, int groups, int npg) {
+    a.xf_stat_off = stat_off; a.xf_mask_off = mask_off; a.xf_C = C; a.xf_groups = groups; a.xf_npg = npg;
+    a.lds_bytes = std::max(a.lds_bytes, 2 * (a.x_bytes + a.y_bytes) + groups * 2 * C * 4);
 }
 
 #define WG_DISPATCH(W_, N_, T_, WHAT)                                       \
@@ -1014,10 +1052,11 @@ struct ConvSmallArgs {
     long long* stat_acc;   // nullable: BatchNorm forward accumulators int64 [BN_REP][groups][2][cpad] (common.h)
     int cpad;
     int tap[9];            // packed taps (fill_taps)
+    XfSrc xf;              // XF kernels: `in` is the producer's raw conv output (see k_conv_res)
 };
 
-template <int NT, int KSMAX>
-__global__ void __launch_bounds__(256)
+template <int NT, int KSMAX, bool XF = false>
+__global__ void __launch_bounds__(256, (XF && NT == 1 && KSMAX == 5) ? 3 : 1)
 k_conv_small(const ConvSmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1091,26 +1130,58 @@ k_conv_small(const ConvSmallArgs a) {
         n_ += dn;
     };
     uint4 pre[MAXP];
+    unsigned xf_ok = 0;                                                  // XF: bit p = piece p of the fetched tile lies inside the image
+    float4 xf_m0 = make_float4(1.f, 1.f, 1.f, 1.f), xf_m1 = xf_m0;      // XF: Dropout2d factors of the fetched tile's (image, 8 channels)
+    float xf_sc[8], xf_sh[8];                                            // XF: this thread's 8 channels (tid % nch8 is the same for every piece)
+    const int xch = (tid % nch8) * 8;
     auto fetch = [&](int n_, int y_, int x_) {
         const int gy0 = y_ * 8 * is, gx0 = x_ * 16 * is;
         const bf16* org = a.in + (((int64_t)n_ * a.g.hi + gy0) * a.g.wi + gx0) * a.g.ldi;
+        if constexpr (XF) xf_ok = 0;
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
             const unsigned gy = (unsigned)(gy0 + phy[p]), gx = (unsigned)(gx0 + phx[p]);
             pre[p] = make_uint4(0, 0, 0, 0);
-            if (gy < (unsigned)a.g.hi && gx < (unsigned)a.g.wi) pre[p] = *reinterpret_cast<const uint4*>(org + poff[p]);
+            if (gy < (unsigned)a.g.hi && gx < (unsigned)a.g.wi) {
+                pre[p] = *reinterpret_cast<const uint4*>(org + poff[p]);
+                if constexpr (XF) xf_ok |= 1u << p;
+            }
+        }
+        if constexpr (XF) {
+            if (a.xf.mask) {
+                const float4* mp = reinterpret_cast<const float4*>(a.xf.mask + (int64_t)n_ * a.xf.C + xch);
+                xf_m0 = mp[0]; xf_m1 = mp[1];
+            }
         }
     };
     auto stash = [&](int buf_) {
+        if constexpr (XF) {
+            const float mk[8] = {xf_m0.x, xf_m0.y, xf_m0.z, xf_m0.w, xf_m1.x, xf_m1.y, xf_m1.z, xf_m1.w};
 #pragma unroll
-        for (int p = 0; p < MAXP; ++p) {
-            const int i = tid + p * 256;
-            if (i < npieces) *reinterpret_cast<uint4*>(halo0 + buf_ * halo_elems + i * 8) = pre[p];
+            for (int p = 0; p < MAXP; ++p) {
+                const int i = tid + p * 256;
+                if (i < npieces) *reinterpret_cast<uint4*>(halo0 + buf_ * halo_elems + i * 8) = xf_act8(pre[p], xf_sc, xf_sh, mk, (xf_ok >> p) & 1u);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < MAXP; ++p) {
+                const int i = tid + p * 256;
+                if (i < npieces) *reinterpret_cast<uint4*>(halo0 + buf_ * halo_elems + i * 8) = pre[p];
+            }
         }
     };
 
     int buf = 0;
-    if (tile < tile_end) { fetch(tn, tty, ttx); stash(0); }
+    if (tile < tile_end) fetch(tn, tty, ttx);
+    if constexpr (XF) {      // the producer's scale / shift (block 0 publishes them and updates the running statistics); a block walks
+        float* tab = reinterpret_cast<float*>(smem + 2 * a.halo_bytes);      // tiles of ONE group: its 8 channels stay in registers
+        bn_fwd_table(tab, a.xf.facc, a.xf.gamma, a.xf.beta, a.xf.rmean, a.xf.rvar, a.xf.stat, a.xf.C, a.xf.groups, a.xf.ppg,
+                     a.xf.momentum, a.xf.eps, a.xf.publish != 0 && blockIdx.x == 0);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xf_sc[j] = tab[(grp * 2 + 0) * a.xf.C + xch + j]; xf_sh[j] = tab[(grp * 2 + 1) * a.xf.C + xch + j]; }
+    }
+    if (tile < tile_end) stash(0);
     __syncthreads();
     const int base0 = ((wid * 2) * is * HWp + r * is) * Ci, rowstep = is * HWp * Ci;
     for (; tile < tile_end; tile += bpg, buf ^= 1) {
@@ -1239,7 +1310,7 @@ int conv_small_blocks(const stcd_conv_geom& g, int groups) {
 }
 
 int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_modeB, const float* bias, void* out,
-                      bool out_nchw, int groups, long long* stat_acc, int cpad, hipStream_t s) {
+                      bool out_nchw, int groups, long long* stat_acc, int cpad, hipStream_t s, const XfSrc* xf) {
     ConvSmallArgs a;
     a.g = g;
     a.in = (const bf16*)in; a.wf = (const bf16*)wf_modeB; a.bias = bias; a.out = out; a.out_nchw = out_nchw ? 1 : 0;
@@ -1262,7 +1333,13 @@ int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_mo
     if (g.n % groups != 0) return 1;
     const int blocks = conv_small_blocks(g, groups);
     size_t lds = std::max<size_t>(2 * (size_t)a.halo_bytes, 4 * 2 * 16 * 2 * 4 * 2);
-#define LAUNCH_SMALL(N_, K_) k_conv_small<N_, K_><<<blocks, 256, lds, s>>>(a)
+    const bool use_xf = xf && xf->on;
+    if (use_xf) {
+        if (xf->C != g.ci || xf->groups != groups) return 1;
+        a.xf = *xf;
+        lds = 2 * (size_t)a.halo_bytes + (size_t)xf->groups * 2 * xf->C * 4;
+    }
+#define LAUNCH_SMALL(N_, K_) do { if (use_xf) k_conv_small<N_, K_, true><<<blocks, 256, lds, s>>>(a); else k_conv_small<N_, K_, false><<<blocks, 256, lds, s>>>(a); } while (0)
     if (nt == 1) { if (a.KS <= 5) LAUNCH_SMALL(1, 5); else LAUNCH_SMALL(1, 9); }
     else { if (a.KS <= 5) LAUNCH_SMALL(2, 5); else LAUNCH_SMALL(2, 9); }
 #undef LAUNCH_SMALL
@@ -1296,6 +1373,7 @@ struct ConvResArgs {
     float s1_scale, s2_scale;
     unsigned in_bytes;     // size of the input tensor (buffer-load range check)
     int8_t tix[3][3];      // tap index of every (row shift, column shift)
+    XfSrc xf;              // XF kernels: `in` is the producer's raw conv output; BN-affine + ReLU + Dropout2d applied while staging
 };
 
 constexpr int RES_HW = 18;     // halo edge of the 16 x 16 output tile
@@ -1305,7 +1383,10 @@ constexpr int RES_HW = 18;     // halo edge of the 16 x 16 output tile
 // PIPE: the (32-channel chunk, column shift) stages of a step are software-pipelined -- the LDS reads of stage s + 1 (6 halo
 // fragments + 3 x NT filter fragments) are issued before the MFMAs of stage s, into a second register set; without it the
 // compiler issues every stage's reads right in front of their first use and the wave waits out the LDS latency 3-6 times per step.
-template <int NT, int CW, bool SH = false, bool PIPE = false>
+// XF: the input is a "virtual activation" (XfSrc, common.h): every staged 16-B piece goes through xf_act8 between its buffer load
+// and its LDS store; the producer's scale / shift table is built in the block's prologue (block 0 publishes it and updates the
+// running statistics, as k_bn_act's block 0 did), the Dropout2d factors of the step's image ride along with the halo loads.
+template <int NT, int CW, bool SH = false, bool PIPE = false, bool XF = false>
 __global__ void __launch_bounds__(256, (CW == 64 && NT == 4) ? 1 : 2)
 k_conv_res(const ConvResArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1318,6 +1399,7 @@ k_conv_res(const ConvResArgs a) {
     const int bl = blockIdx.x % P, rest = blockIdx.x / P, slice = rest % a.nslices, grp = rest / a.nslices;
     char* const filt = smem;                                  // [32-ch chunk][tap][NT][64 lanes][16 B]
     char* const halo0 = smem + a.filt_bytes;                  // two halo buffers, HALO_BYTES apart
+    float* const xf_tab = reinterpret_cast<float*>(smem + a.filt_bytes + (SH ? 1 : 2) * HALO_BYTES);   // XF: [groups][2][Ci] scale, shift
     const int ntaps = 9;
     const int nsteps = a.nchunks / KSC;                       // pipeline steps per tile (nchunks = Ci / 32)
 
@@ -1396,22 +1478,42 @@ k_conv_res(const ConvResArgs a) {
             (P_).n += dn;                                                                                              \
         }                                                                                                              \
     } while (0)
+    unsigned xf_ok = 0;            // XF: bit p = piece p of the fetched step lies inside the image
+    float4 xf_m0 = make_float4(1.f, 1.f, 1.f, 1.f), xf_m1 = xf_m0;      // XF: Dropout2d factors of the fetched step's (image, 8 channels)
 #define RES_FETCH(P_)                                                                                                  \
     do {                                                                                                               \
         const int gy0_ = (P_).y * 16, gx0_ = (P_).x * 16;                                                               \
         const unsigned soff_ = (unsigned)(((((int64_t)(P_).n * a.g.hi + gy0_) * a.g.wi + gx0_) * a.g.ldi + (P_).c * CW) * 2); \
+        if constexpr (XF) xf_ok = 0;                                                                                   \
         _Pragma("unroll") for (int p = 0; p < MAXP; ++p) {                                                             \
             const int hy_ = pyx[p] >> 16, hx_ = (int)(short)(pyx[p] & 0xffff);                                         \
             const bool ok_ = (unsigned)(gy0_ + hy_) < (unsigned)a.g.hi && (unsigned)(gx0_ + hx_) < (unsigned)a.g.wi;   \
             const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok_ ? (unsigned)poff[p] : 0x80000000u, soff_, 0); \
             pre[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                           \
+            if constexpr (XF) xf_ok |= ok_ ? (1u << p) : 0u;                                                           \
+        }                                                                                                              \
+        if constexpr (XF) {                                                                                            \
+            if (a.xf.mask) {                                                                                           \
+                const float4* mp_ = reinterpret_cast<const float4*>(a.xf.mask + (int64_t)(P_).n * a.xf.C + (P_).c * CW + ch * 8); \
+                xf_m0 = mp_[0]; xf_m1 = mp_[1];                                                                        \
+            }                                                                                                          \
         }                                                                                                              \
     } while (0)
-#define RES_STASH(BUF_)                                                                                                \
+#define RES_STASH(BUF_, P_)                                                                                            \
     do {                                                                                                               \
-        _Pragma("unroll") for (int p = 0; p < MAXP; ++p)                                                               \
-            if ((tid >> LG8) + p * PIXSTEP < RES_HW * RES_HW)                                                          \
-                *reinterpret_cast<uint4*>(halo0 + (BUF_) * HALO_BYTES + plds[p]) = pre[p];                             \
+        if constexpr (XF) {                                                                                            \
+            float sc_[8], sh_[8];                                                                                      \
+            const float mk_[8] = {xf_m0.x, xf_m0.y, xf_m0.z, xf_m0.w, xf_m1.x, xf_m1.y, xf_m1.z, xf_m1.w};             \
+            const float* tb_ = xf_tab + (grp * 2) * a.xf.C + (P_).c * CW + ch * 8;                                     \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) { sc_[j] = tb_[j]; sh_[j] = tb_[a.xf.C + j]; }               \
+            _Pragma("unroll") for (int p = 0; p < MAXP; ++p)                                                           \
+                if ((tid >> LG8) + p * PIXSTEP < RES_HW * RES_HW)                                                      \
+                    *reinterpret_cast<uint4*>(halo0 + (BUF_) * HALO_BYTES + plds[p]) = xf_act8(pre[p], sc_, sh_, mk_, (xf_ok >> p) & 1u); \
+        } else {                                                                                                       \
+            _Pragma("unroll") for (int p = 0; p < MAXP; ++p)                                                           \
+                if ((tid >> LG8) + p * PIXSTEP < RES_HW * RES_HW)                                                      \
+                    *reinterpret_cast<uint4*>(halo0 + (BUF_) * HALO_BYTES + plds[p]) = pre[p];                         \
+        }                                                                                                              \
     } while (0)
 
     f32x4 acc[4][NT];
@@ -1448,7 +1550,12 @@ k_conv_res(const ConvResArgs a) {
                 *reinterpret_cast<uint4*>(filt + ((int64_t)min(f0 + 4 * k, nfrag - 1) * 64 + lane) * 16) = v[k];
         }
     }
-    if (cur.tile < tile_end) RES_STASH(0);
+    if constexpr (XF) {      // the producer's scale / shift for this block's group(s), before the first transformed stash
+        bn_fwd_table(xf_tab, a.xf.facc, a.xf.gamma, a.xf.beta, a.xf.rmean, a.xf.rvar, a.xf.stat, a.xf.C, a.xf.groups, a.xf.ppg,
+                     a.xf.momentum, a.xf.eps, a.xf.publish != 0 && blockIdx.x == 0);
+        __syncthreads();
+    }
+    if (cur.tile < tile_end) RES_STASH(0, cur);
     __syncthreads();
     while (cur.tile < tile_end) {
         const bool have_next = nxt.tile < tile_end;
@@ -1512,7 +1619,7 @@ k_conv_res(const ConvResArgs a) {
             }
         }
         if constexpr (SH) barrier_lds();                  // one halo buffer: every wave is done reading it before it is refilled
-        if (have_next) RES_STASH(SH ? 0 : (buf ^ 1));
+        if (have_next) RES_STASH(SH ? 0 : (buf ^ 1), nxt);
         if (cur.c == nsteps - 1) {
             // ---- epilogue of this tile: lane (q, r) holds channels 4q..4q+3 of n-tile t2 at row 4*wid + m, column r
             const int mx = cur.x * 16 + r;
@@ -1660,7 +1767,7 @@ ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int gr
 
 int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvResPlan& rp, const void* in, const void* wf,
                     const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0, float s1_scale,
-                    float s2_scale) {
+                    float s2_scale, const XfSrc* xf) {
     if (!rp.ok) return 1;
     ConvResArgs a;
     a.g = g;
@@ -1672,24 +1779,25 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
     a.stat_acc = stat_acc; a.cpad = cpad; a.stat_c0 = stat_c0; a.s1_scale = s1_scale; a.s2_scale = s2_scale;
     a.in_bytes = (unsigned)((int64_t)g.n * g.hi * g.wi * g.ldi * 2);
     for (int t = 0; t < 9; ++t) a.tix[g.dy[t] + 1][g.dx[t] + 1] = (int8_t)t;
-#define LAUNCH_RES(N_, W_)                                                                                        \
+    const bool use_xf = xf && xf->on;
+    size_t lds = (size_t)rp.lds_bytes;
+    if (use_xf) {
+        if (rp.single_halo || xf->C != g.ci || xf->groups != groups) return 1;     // (the single-halo variant has no XF instantiation)
+        a.xf = *xf;
+        lds += (size_t)xf->groups * 2 * xf->C * 4;
+        if (lds > 160 * 1024) return 1;
+    }
+#define LAUNCH_RES_V(N_, W_, P_, X_)                                                                              \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
-            (void)hipFuncSetAttribute((const void*)k_conv_res<N_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void*)k_conv_res<N_, W_, false, P_, X_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        k_conv_res<N_, W_><<<(unsigned)rp.blocks, 256, (size_t)rp.lds_bytes, s>>>(a);                             \
+        k_conv_res<N_, W_, false, P_, X_><<<(unsigned)rp.blocks, 256, lds, s>>>(a);                               \
     } while (0)
-#define LAUNCH_RES_PIPE(N_, W_)                                                                                   \
-    do {                                                                                                          \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set) {                                                                                          \
-            (void)hipFuncSetAttribute((const void*)k_conv_res<N_, W_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr_set = true;                                                                                      \
-        }                                                                                                         \
-        k_conv_res<N_, W_, false, true><<<(unsigned)rp.blocks, 256, (size_t)rp.lds_bytes, s>>>(a);               \
-    } while (0)
+#define LAUNCH_RES(N_, W_) do { if (use_xf) LAUNCH_RES_V(N_, W_, false, true); else LAUNCH_RES_V(N_, W_, false, false); } while (0)
+#define LAUNCH_RES_PIPE(N_, W_) do { if (use_xf) LAUNCH_RES_V(N_, W_, true, true); else LAUNCH_RES_V(N_, W_, true, false); } while (0)
     // measured (SNUNet / SegCD, 16 x 256^2): <1, 64> 0.67 -> 0.58 ms per step (-13 %); the CW = 32 variants do not move (their
     // layers sit on the HBM roofline: 134 MB in + 134 MB out per 32 -> 32 full-resolution layer in 66 us), <2, 64> has no registers
     // left for the second fragment set.  Default: <1, 64> only; STCD_CONV_RES_PIPE=1 pipelines every variant that fits, 0 none.
@@ -1721,6 +1829,7 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
     }
 #undef LAUNCH_RES
 #undef LAUNCH_RES_PIPE
+#undef LAUNCH_RES_V
 #undef LAUNCH_RES_SH
     return 0;
 }

@@ -304,60 +304,7 @@ void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t p
 }
 
 
-// ---- consumer-side "finalize": every block of a kernel that APPLIES a BatchNorm derives the per-channel constants of all
-//      its channels from the integer accumulators (2*C*BN_REP loads per block) into an LDS table; block 0 also publishes
-//      them (stat, running statistics / dgamma, dbeta) for later kernels.  Same arithmetic as torch: biased variance for
-//      the normalisation, unbiased for running_var, momentum 0.1, double precision for the moments.
-// tab: [groups][2][C] = scale, shift.  Thread c handles channel c for all groups IN ORDER (the shared encoder BatchNorm
-// sees date 0 then date 1: /root/reference/models/SiamUnet_diff.py:99,123).
-__device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __restrict__ facc, const float* __restrict__ gamma,
-                                             const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
-                                             float* __restrict__ stat, int C, int groups, int64_t ppg, float momentum, float eps,
-                                             bool publish, int cbase = 0, int CS = 0, int g_first = 0) {
-    // channels [cbase, cbase + CS) only (CS == 0: all): wide layers give every block one 64-channel slab, so its prologue reads
-    // 64 channels' accumulators instead of up to 2048
-    if (CS == 0) CS = C;
-    for (int cl = threadIdx.x; cl < CS; cl += blockDim.x) {
-        const int c = cbase + cl;
-        if (facc) {
-            const float gam = gamma[c], bet = beta[c];
-            float rm = (publish && rmean) ? rmean[c] : 0.f, rv = (publish && rvar) ? rvar[c] : 0.f;
-            for (int gi = 0; gi < groups; ++gi) {      // the running statistics see the groups in the order the reference calls the
-                int g = gi + g_first;                   // BatchNorm on them: g_first, g_first + 1, ... (cyclic)
-                if (g >= groups) g -= groups;
-                const double s1 = bn_acc_get(facc, groups, C, g, 0, c, BN_FS1), s2 = bn_acc_get(facc, groups, C, g, 1, c, BN_FS2);
-                const double mean = s1 / (double)ppg;
-                double var = s2 / (double)ppg - mean * mean;
-                if (var < 0.0) var = 0.0;
-                const double invstd = 1.0 / sqrt(var + (double)eps);
-                const float sc = (float)(gam * invstd), sh = (float)(bet - mean * gam * invstd);
-                tab[(g * 2 + 0) * CS + cl] = sc;
-                tab[(g * 2 + 1) * CS + cl] = sh;
-                if (publish) {
-                    float* st = stat + (int64_t)g * 4 * C;
-                    st[c] = (float)mean; st[C + c] = (float)invstd; st[2 * C + c] = sc; st[3 * C + c] = sh;
-                    const double unb = ppg > 1 ? var * ((double)ppg / (double)(ppg - 1)) : var;
-                    rm = (float)((1.0 - momentum) * rm + momentum * mean);
-                    rv = (float)((1.0 - momentum) * rv + momentum * unb);
-                }
-            }
-            if (publish && rmean) rmean[c] = rm;
-            if (publish && rvar) rvar[c] = rv;
-        } else if (gamma) {      // eval mode: the running statistics (read-only), the arithmetic of k_bn_eval_prepare -- no launch for it
-            const float invstd = 1.f / sqrtf(rvar[c] + eps);
-            const float sc = gamma[c] * invstd, sh = beta[c] - rmean[c] * gamma[c] * invstd;
-            for (int g = 0; g < groups; ++g) {
-                tab[(g * 2 + 0) * CS + cl] = sc;
-                tab[(g * 2 + 1) * CS + cl] = sh;
-            }
-        } else {
-            for (int g = 0; g < groups; ++g) {
-                tab[(g * 2 + 0) * CS + cl] = stat[(int64_t)g * 4 * C + 2 * C + c];
-                tab[(g * 2 + 1) * CS + cl] = stat[(int64_t)g * 4 * C + 3 * C + c];
-            }
-        }
-    }
-}
+// (bn_fwd_table: common.h -- the convolution kernels that apply a BatchNorm while staging their input use it too)
 // tab: [groups][5][C] = (scale, shift, b, mean, c) of dY = scale*dz + b*(y - mean) + c  (see k_bn_bwd_apply)
 __device__ __forceinline__ void bn_bwd_table(float* tab, const long long* __restrict__ bacc, const float* __restrict__ stat,
                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int groups, int64_t ppg,

@@ -667,10 +667,116 @@ def g17_cf_base():
     save("g17_cf_base.npz", **d)
 
 
+# ------------------------------------------------------------------------------ G21
+class _DropRec(nn.Module):
+    """nn.Dropout replaced by an explicit element-wise mask (already divided by keep), recorded in the fixture"""
+    def __init__(self, store, name, keep, gen):
+        super().__init__()
+        self.store, self.name, self.keep, self.gen = store, name, keep, gen
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        m = (torch.rand(x.shape, generator=self.gen) < self.keep).float() / self.keep
+        self.store[self.name] = m
+        return x * m
+
+
+def g21_cf_decoder():
+    """ChangeFormer's decoder from the reference's OWN classes.  /root/reference/models/ChangeFormer.py does not import here
+    (timm at :10-11), but `resize` (:238-257), `DWConv` (:512-523), `MLP` (:677-688), `conv_diff` / `make_prediction` (:1138-1157)
+    and `DecoderTransformer_v3` (:1475-1631) use none of timm's names: their definitions are compiled from the file by `ast`
+    (the G8 recipe: those six nodes, nothing is copied into this repository) in a namespace of torch / nn / F / warnings plus the
+    importable models.ChangeFormerBaseNetworks classes.  No timm name is defined anywhere; the encoder classes (which call
+    trunc_normal_ at construction) stay out.  Two feature pyramids; eval mode, train mode with Dropout p = 0, and train mode with
+    the two nn.Dropout(0.6) sites of every conv_diff swapped for mask recorders: outputs (5 maps), a weighted-sum loss, every
+    parameter's gradient, the gradients of the ten input features, BatchNorm running statistics after the training forward."""
+    import ast
+    import warnings
+    from models.ChangeFormerBaseNetworks import ConvLayer, ResidualBlock, UpsampleConvLayer
+    print("G21 ChangeFormer decoder (reference classes by ast)")
+    path = "/root/reference/models/ChangeFormer.py"
+    want = {"resize", "DWConv", "MLP", "conv_diff", "make_prediction", "DecoderTransformer_v3"}
+    nodes = [n for n in ast.parse(open(path).read()).body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in want]
+    assert {n.name for n in nodes} == want
+    ns = {"torch": torch, "nn": nn, "F": F, "warnings": warnings, "ConvLayer": ConvLayer, "ResidualBlock": ResidualBlock,
+          "UpsampleConvLayer": UpsampleConvLayer}
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), path, "exec"), ns)
+    Dec, DW = ns["DecoderTransformer_v3"], ns["DWConv"]
+    d = {}
+    cases = {"a": dict(B=2, chans=[16, 24, 40, 48], emb=32, out=2, hw=(16, 16)),
+             "b": dict(B=1, chans=[8, 16, 24, 32], emb=16, out=1, hw=(24, 16))}
+    for tag, c in cases.items():
+        torch.manual_seed(2100 + ord(tag))
+        dec = Dec(input_transform="multiple_select", in_index=[0, 1, 2, 3], align_corners=False, in_channels=c["chans"],
+                  embedding_dim=c["emb"], output_nc=c["out"], decoder_softmax=False, feature_strides=[2, 4, 8, 16])
+        with torch.no_grad():       # BatchNorm / PReLU away from their trivial initial values
+            for k, v in dec.state_dict().items():
+                if k.endswith("running_mean"): v.normal_(0, 0.2)
+                elif k.endswith("running_var"): v.uniform_(0.5, 1.5)
+            for k, v in dec.named_parameters():
+                if v.dim() == 1 and "conv2d" not in k and "proj" not in k and v.numel() > 1: v.add_(torch.randn_like(v) * 0.1)
+        init = {k: v.clone() for k, v in dec.state_dict().items()}
+        for k, v in init.items():
+            d[f"{tag}/init/{k}"] = t2n(v)
+        h, w = c["hw"]
+        feats = [[torch.randn(c["B"], ch, h >> s, w >> s) for s, ch in enumerate(c["chans"])] for _ in range(2)]
+        for i in range(2):
+            for s in range(4):
+                d[f"{tag}/f{i + 1}_{s}"] = t2n(feats[i][s])
+        wts = [0.5, -0.25, 0.75, 1.0, 2.0]
+
+        def run(mode):
+            dec.load_state_dict(init)
+            f = [[x.clone().requires_grad_(True) for x in fs] for fs in feats]
+            outs = dec(f[0], f[1])
+            for i, o in enumerate(outs):
+                d[f"{tag}/{mode}/out{i}"] = t2n(o)
+            if mode == "eval":
+                return
+            loss = sum(wt * (o * torch.linspace(-1, 1, o.numel()).view_as(o)).sum() for wt, o in zip(wts, outs)) / 100.0
+            dec.zero_grad()
+            loss.backward()
+            d[f"{tag}/{mode}/loss"] = loss.item()
+            for k, v in dec.named_parameters():
+                d[f"{tag}/{mode}/g/{k}"] = t2n(v.grad)
+            for i in range(2):
+                for s in range(4):
+                    d[f"{tag}/{mode}/gf{i + 1}_{s}"] = t2n(f[i][s].grad)
+            for k, v in dec.state_dict().items():
+                if "running" in k or "num_batches" in k:
+                    d[f"{tag}/{mode}/bn/{k}"] = t2n(v)
+
+        dec.eval(); run("eval")
+        dec.train()
+        for m_ in dec.modules():
+            if isinstance(m_, nn.Dropout): m_.p = 0.0
+        run("train_p0")
+        store, gen = {}, torch.Generator().manual_seed(77)
+        for s in (1, 2, 3, 4):
+            seq = getattr(dec, f"diff_c{s}")
+            for idx in (3, 7):
+                seq[idx] = _DropRec(store, f"TDec_x2.diff_c{s}.{idx}", 0.4, gen)
+        dec.train(); run("train_masks")
+        for k, v in store.items():
+            d[f"{tag}/train_masks/mask/{k}"] = t2n(v)
+        d[f"{tag}/meta"] = np.array([c["B"], c["emb"], c["out"], h, w] + c["chans"], dtype=np.int64)
+    # DWConv (the depth-wise step of Mix-FFN): tokens [B, N, C] -> [B, N, C]
+    torch.manual_seed(2190)
+    dw = DW(24)
+    x = torch.randn(2, 6 * 5, 24, requires_grad=True)
+    y = dw(x, 6, 5)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    d["dw/x"], d["dw/y"], d["dw/gy"], d["dw/gx"] = t2n(x), t2n(y), t2n(gy), t2n(x.grad)
+    d["dw/w"], d["dw/b"], d["dw/gw"], d["dw/gb"] = t2n(dw.dwconv.weight), t2n(dw.dwconv.bias), t2n(dw.dwconv.weight.grad), t2n(dw.dwconv.bias.grad)
+    save("g21_cf_decoder.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
+    which = sys.argv[1:] or ["g1", "g2", "g2s", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
     fn = {"g1": g1_ops, "g2": g2_fcsiam, "g2s": g2_snunet, "g3": g3_cfg1, "g4": g4_traj, "g5": g5_metric, "g6": g6_odd,
           "g7": g7_train128, "g8": g8_contrastive, "g10": g10_segcd, "g11": g11_segcd, "g12": g12_segcd_r18, "g13": g13_segcd_r34,
-          "g14": g14_segcd_r101, "g15": g15_unetseg, "g16": g16_ffctlcd, "g17": g17_cf_base, "g18": g18_segcd_wide, "g19": g19_fcef, "g20": g20_xconc}
+          "g14": g14_segcd_r101, "g15": g15_unetseg, "g16": g16_ffctlcd, "g17": g17_cf_base, "g18": g18_segcd_wide, "g19": g19_fcef, "g20": g20_xconc, "g21": g21_cf_decoder}
     for w in which:
         fn[w]()

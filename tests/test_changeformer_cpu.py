@@ -40,6 +40,76 @@ def test_pinned_decoder_head_blocks_match_the_reference_vectors(golden):
             np.testing.assert_allclose(v.grad.numpy(), g[f"{tag}/g/{k}"], rtol=1e-4, atol=1e-4, err_msg=f"{tag} {k}")
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_decoder_matches_the_reference_classes(golden, tag):
+    """oracle.changeformer_ref.decoder (+ _conv_diff, _make_pred) == the reference's OWN DecoderTransformer_v3 / MLP / conv_diff /
+    make_prediction / resize (/root/reference/models/ChangeFormer.py:238-257,677-688,1138-1157,1475-1631), compiled from its file
+    by ast (tests/golden/make_golden.py g21; timm is never touched): the five output maps in eval mode, and in training mode --
+    Dropout p = 0, and with the recorded element-wise masks of the eight nn.Dropout(0.6) sites -- outputs, loss, every parameter's
+    gradient, the gradients of all eight input features and the BatchNorm running statistics, at 1e-5."""
+    g = golden("g21_cf_decoder.npz")
+    meta = g[f"{tag}/meta"]
+    B, emb, out, h, w = (int(v) for v in meta[:5])
+    cfg = R.CFConfig(out_ch=out)
+    feats = [[_t(g[f"{tag}/f{i + 1}_{s}"]) for s in range(4)] for i in range(2)]
+    wts = [0.5, -0.25, 0.75, 1.0, 2.0]
+
+    def state():
+        st = {"TDec_x2." + k[len(tag) + 6:]: _t(v).clone() for k, v in g.items() if k.startswith(f"{tag}/init/")}
+        for k, v in st.items():
+            if v.dtype.is_floating_point and "running" not in k:
+                v.requires_grad_(True)
+        return st
+
+    def close(a, b, what, rtol=1e-5, atol=1e-5):
+        np.testing.assert_allclose(a, b, rtol=rtol, atol=atol * max(1.0, float(np.abs(b).max())), err_msg=f"{tag} {what}")
+
+    st = state()
+    with torch.no_grad():
+        outs = R.decoder(cfg, st, feats[0], feats[1], False, None)
+    for i, o in enumerate(outs):
+        close(o.numpy(), g[f"{tag}/eval/out{i}"], f"eval out{i}")
+    for mode in ("train_p0", "train_masks"):
+        st = state()
+        f = [[x.clone().requires_grad_(True) for x in fs] for fs in feats]
+        masks = {} if mode == "train_p0" else {k[len(tag) + 18:]: _t(v) for k, v in g.items() if k.startswith(f"{tag}/train_masks/mask/")}
+        assert mode == "train_p0" or len(masks) == 8
+        outs = R.decoder(cfg, st, f[0], f[1], True, masks)
+        for i, o in enumerate(outs):
+            close(o.detach().numpy(), g[f"{tag}/{mode}/out{i}"], f"{mode} out{i}")
+        loss = sum(wt * (o * torch.linspace(-1, 1, o.numel()).view_as(o)).sum() for wt, o in zip(wts, outs)) / 100.0
+        assert abs(loss.item() - float(g[f"{tag}/{mode}/loss"])) <= 1e-5 * max(1.0, abs(float(g[f"{tag}/{mode}/loss"])))
+        loss.backward()
+        n = 0
+        for k, v in st.items():
+            key = f"{tag}/{mode}/g/{k[8:]}"
+            if key in g:
+                close(v.grad.numpy(), g[key], f"{mode} grad {k}", rtol=1e-4, atol=2e-5)
+                n += 1
+            bkey = f"{tag}/{mode}/bn/{k[8:]}"
+            if bkey in g:
+                close(v.detach().numpy().astype(np.float64), g[bkey].astype(np.float64), f"{mode} {k}")
+        assert n == sum(1 for k in g if k.startswith(f"{tag}/{mode}/g/")) and n > 60
+        for i in range(2):
+            for s in range(4):
+                close(f[i][s].grad.numpy(), g[f"{tag}/{mode}/gf{i + 1}_{s}"], f"{mode} d feature {i + 1}.{s}", rtol=1e-4, atol=2e-5)
+
+
+def test_depthwise_step_of_mix_ffn_matches_the_reference_class(golden):
+    """oracle.changeformer_ref.dwconv_tokens (the depth-wise step inside mix_ffn) == the reference's DWConv
+    (/root/reference/models/ChangeFormer.py:512-523, compiled from the file by ast): output and all three gradients."""
+    g = golden("g21_cf_decoder.npz")
+    x = _t(g["dw/x"]).clone().requires_grad_(True)
+    w = _t(g["dw/w"]).clone().requires_grad_(True)
+    b = _t(g["dw/b"]).clone().requires_grad_(True)
+    y = R.dwconv_tokens(x, w, b, 6, 5)
+    np.testing.assert_allclose(y.detach().numpy(), g["dw/y"], rtol=1e-5, atol=1e-6)
+    y.backward(_t(g["dw/gy"]))
+    np.testing.assert_allclose(x.grad.numpy(), g["dw/gx"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(w.grad.numpy(), g["dw/gw"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b.grad.numpy(), g["dw/gb"], rtol=1e-4, atol=1e-5)
+
+
 def test_parameter_table_engine_table_and_module_agree():
     """One order, three places: the oracle's table (the reference's registration order), the engine's flat layout
     (stcd_param_info) and the nn.Module's state_dict.  41 028 730 parameters: the figure the ChangeFormer paper quotes for V6."""

@@ -581,18 +581,43 @@ def test_fcsiam_every_layer_in_place(arch, dtype, B, H, W):
             worst[kind] = (r, name)
         assert r <= t_, (kind, name, r)
 
+    def bn_relu(pname, y_all):
+        """A = relu(BatchNorm_train(Y)) per BatchNorm group (encoder: one group per date), rounded as the engine stores / stages it"""
+        pbn = getattr(m, "bn" + pname[4:])
+        ng = 1 if pname.endswith("d") else 2
+        n_ = y_all.shape[0] // ng
+        outs = []
+        for gi in range(ng):
+            y = y_all[gi * n_:(gi + 1) * n_]
+            mu, var = y.mean(dim=(0, 2, 3), keepdim=True), y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+            outs.append(torch.relu((y - mu) * torch.rsqrt(var + 1e-5) * pbn.weight.detach().view(1, -1, 1, 1) + pbn.bias.detach().view(1, -1, 1, 1)))
+        a = torch.cat(outs)
+        return a.to(torch.bfloat16).float() if dtype == "bf16" else a
+
+    n_virt = 0
     for name in names:
         conv, bn = getattr(m, name), getattr(m, "bn" + name[4:])
-        X, Y, dY = nchw(ws[name + ".in"])[:, :conv.in_channels], nchw(ws[name + ".Y"]), nchw(ws[name + ".dY"])      # conv11: 3 of 8 padded channels
+        if name + ".in.virt" in ws:
+            # virtual activation (round 4): the layer reads its producer's RAW conv output and applies BN + ReLU (+ Dropout2d) while
+            # staging -- in the forward launch and in the weight gradient.  Both are checked against torch's convolution of the
+            # activation computed HERE from that raw tensor; the producer records no A of its own.
+            raw = ws[name + ".in.virt"]
+            prod = [k[:-2] for k in ws if k.endswith(".Y") and ws[k].data_ptr() == raw.data_ptr()]
+            assert len(prod) == 1 and not any(k.startswith(prod[0] + ".A.g") for k in ws), (name, prod)
+            X = bn_relu(prod[0], nchw(raw))
+            n_virt += 1
+        else:
+            X = nchw(ws[name + ".in"])[:, :conv.in_channels]      # conv11: 3 of 8 padded channels
+        Y, dY = nchw(ws[name + ".Y"]), nchw(ws[name + ".dY"])
         Wv = wq(conv.weight).requires_grad_(True)
         bv = conv.bias.detach().clone().requires_grad_(True)
         if isinstance(conv, torch.nn.ConvTranspose2d):
             Yt = torch.nn.functional.conv_transpose2d(X, Wv, bv, stride=1, padding=1)
         else:
             Yt = torch.nn.functional.conv2d(X, Wv, bv, padding=1)
-        chk("conv output", name, Y, Yt.detach())
+        chk("conv output" + (" (virtual input)" if name + ".in.virt" in ws else ""), name, Y, Yt.detach())
         Yt.backward(dY)
-        chk("weight gradient", name, conv.weight.grad, Wv.grad, 5e-6)      # fp32 accumulation of the same bf16 products on both sides
+        chk("weight gradient" + (" (virtual input)" if name + ".in.virt" in ws else ""), name, conv.weight.grad, Wv.grad, 5e-6)      # fp32 accumulation of the same bf16 products on both sides
         # a bias in front of a training-mode BatchNorm has a mathematically zero gradient (the per-date sums of dY vanish): both
         # sides are rounding noise, so bound them against the natural scale sum|dY| instead of against each other
         scale = float(dY.abs().sum(dim=(0, 2, 3)).max())
@@ -601,12 +626,18 @@ def test_fcsiam_every_layer_in_place(arch, dtype, B, H, W):
             worst["bias gradient / sum|dY|"] = max(worst.get("bias gradient / sum|dY|", (0.0, "")), (r, name + ":" + side))
             assert r <= (1e-5 if dtype == "fp32" else 4e-3), (name, side, r)
         groups = [k for k in ws if k.startswith(name + ".A.g")]
+        if not groups:
+            continue                               # a virtual layer: its activation exists only inside its consumer's staging (checked there)
         npg = Y.shape[0] // len(groups)
         for gi in range(len(groups)):
             y = Y[gi * npg:(gi + 1) * npg]
             mu, var = y.mean(dim=(0, 2, 3), keepdim=True), y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
             a = torch.relu((y - mu) * torch.rsqrt(var + 1e-5) * bn.weight.detach().view(1, -1, 1, 1) + bn.bias.detach().view(1, -1, 1, 1))
             chk("bn+relu", name, nchw(ws[f"{name}.A.g{gi}"]), a, 5e-6 if dtype == "fp32" else 4e-3)
+    if dtype == "bf16":
+        assert n_virt >= 9, n_virt          # 6 encoder + >= 3 decoder layers read a virtual activation in the bf16 plan
+    else:
+        assert n_virt == 0                  # the fp32 parity path materialises everything
     print(f"SiamUnet_{arch} {dtype} B={B} {H}x{W} layer-local worst relative l2: " + ", ".join(f"{k} {v[0]:.1e} ({v[1]})" for k, v in worst.items()))
 
 
@@ -671,3 +702,41 @@ def test_side_stream_weight_gradients_are_deterministic_and_match_the_serial_pla
         worst[1] = max(worst[1], rel)
         assert rel <= (2e-5 if arch != "changeformer" else 1e-4), f"{arch} {info.name}: side-stream plan vs serial plan rel-l2 {rel:.2e}"
     print(f"{arch}: worst rel-l2 between passes {worst[0]:.2e}, side-stream plan vs serial plan {worst[1]:.2e}")
+
+
+@pytest.mark.parametrize("arch,B,H,W", [("diff", 4, 64, 64), ("conc", 2, 48, 80), ("sub", 3, 32, 32), ("fcef", 2, 64, 64), ("diff", 2, 100, 100),
+                                        ("diff", 16, 256, 256)])
+def test_virtual_activations_equal_the_materialised_plan_bit_for_bit(monkeypatch, arch, B, H, W):
+    """Round 4: a non-skip conv -> BN -> ReLU -> Dropout2d layer whose only reader is the next conv of its stage never writes its
+    activation -- the reader's forward launch (k_conv_small / k_conv_res, XF variants) and its weight gradient (k_wgrad_group,
+    job.xf_*) apply scale / shift / ReLU / mask while staging the raw conv output (common.h XfSrc / xf_act8, the arithmetic of
+    k_bn_act).  The plan with every activation materialised (STCD_VIRT_ACT=0, rounds 1-3) must give the SAME bits: logits, loss,
+    every parameter gradient, BatchNorm running statistics (the consumer's block 0 publishes them now), in training mode with
+    Dropout2d active (odd sizes and the headline size included), and the eval-mode logits (running statistics path)."""
+    torch.manual_seed(5)
+    x1 = torch.randn(B, 3, H, W, device=DEV); x2 = torch.randn(B, 3, H, W, device=DEV)
+    tgt = (torch.rand(B, H, W, device=DEV) < 0.2).long()
+    st = R.synth_state(arch, 3, 2, 9)
+    res = []
+    for virt in ("1", "0"):
+        monkeypatch.setenv("STCD_VIRT_ACT", virt)
+        m = CLS[arch](3, 2, dtype="bf16")
+        m.load_state_dict(st)
+        m.to(DEV).train()
+        m._seed, m._steps = 123, 0                      # the same Dropout2d masks in both plans
+        out = unwrap(m(x1, x2))
+        loss = torch.nn.functional.cross_entropy(out, tgt)
+        loss.backward()
+        torch.cuda.synchronize()
+        nvirt = sum(1 for k in m._engine.ws_tensors() if k.endswith(".in.virt"))
+        m.eval()
+        with torch.no_grad():
+            ev = unwrap(m(x1, x2)).clone()
+        res.append((out.detach().clone(), loss.item(), m._flat_grads.clone(), m._flat_bn.clone(), ev, nvirt))
+    a, b = res
+    assert a[5] >= 9 and b[5] == 0, (a[5], b[5])
+    assert torch.equal(a[0], b[0]), float((a[0] - b[0]).abs().max())
+    assert a[1] == b[1]
+    assert torch.equal(a[2], b[2]), float((a[2] - b[2]).abs().max())
+    assert torch.equal(a[3], b[3]), float((a[3] - b[3]).abs().max())
+    assert torch.equal(a[4], b[4]), float((a[4] - b[4]).abs().max())
