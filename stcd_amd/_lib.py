@@ -13,7 +13,9 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstcd_hip.so")
+# STCD_LIB_PATH: development aid for A/B runs of two builds of the library in one GPU session (tools/ab_variants.sh); the product
+# loads stcd_amd/libstcd_hip.so
+LIB_PATH = os.environ.get("STCD_LIB_PATH") or os.path.join(_HERE, "libstcd_hip.so")
 
 ARCH_DIFF, ARCH_CONC, ARCH_SUB, ARCH_SNUNET, ARCH_SEGCD = 0, 1, 2, 3, 4
 ARCH_SEGCD_R18, ARCH_SEGCD_R34, ARCH_SEGCD_R101, ARCH_SEGCD_R152 = 5, 6, 7, 8

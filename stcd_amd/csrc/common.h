@@ -187,18 +187,30 @@ struct XfSrc {
     float momentum = 0.1f, eps = 1e-5f;
     int on = 0;                        // 0: plain input tensor
 };
-// one 16-B piece (8 consecutive channels of one pixel); ok == false: a zero-filled border piece stays zero (the conv pads A, not Y)
-__device__ __forceinline__ uint4 xf_act8(const uint4 raw, const float (&sc)[8], const float (&sh)[8], const float (&mk)[8], const bool ok) {
+// one 16-B piece (8 consecutive channels of one pixel).  sc / sh: the channel's BatchNorm scale / shift ALREADY multiplied by the
+// image's Dropout2d factor (mk >= 0, so max(y * sc + sh, 0) * mk == max(y * (sc * mk) + sh * mk, 0): k_bn_act folds the same way);
+// okm: 0xffffffff, or 0 for a zero-filled border piece, which must stay zero (the convolution pads A, not Y).  Per pair of
+// channels: 2 unpacks, 2 FMAs, 1 v_cvt_pk_bf16_f32, 1 v_pk_max_i16 (ReLU on the packed bf16 bits: a negative bf16 is a negative
+// int16; rounding and ReLU commute), 1 AND -- 3.5 VALU per element (the first version's fp32 max + mask multiply + select: 5).
+__device__ __forceinline__ uint4 xf_act8(const uint4 raw, const float (&sc)[8], const float (&sh)[8], const unsigned okm) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
     const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
     uint32_t o[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
-        lo = fmaxf(fmaf(lo, sc[2 * i], sh[2 * i]), 0.f) * mk[2 * i];
-        hi = fmaxf(fmaf(hi, sc[2 * i + 1], sh[2 * i + 1]), 0.f) * mk[2 * i + 1];
-        o[i] = ok ? pack_bf16x2(lo, hi) : 0u;
+        const float lo = fmaf(__uint_as_float(w[i] << 16), sc[2 * i], sh[2 * i]);
+        const float hi = fmaf(__uint_as_float(w[i] & 0xffff0000u), sc[2 * i + 1], sh[2 * i + 1]);
+        const s16x2 p = __builtin_bit_cast(s16x2, pack_bf16x2(lo, hi));
+        o[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(p, s16x2{0, 0})) & okm;
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// scale / shift of 8 channels folded with the Dropout2d factors of the image (identity factors when the layer has no mask)
+__device__ __forceinline__ void xf_fold8(const float* __restrict__ tab_sc, const float* __restrict__ tab_sh, const float4 m0, const float4 m1,
+                                         float (&sc)[8], float (&sh)[8]) {
+    const float mk[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = tab_sc[j] * mk[j]; sh[j] = tab_sh[j] * mk[j]; }
 }
 
 // ------------------------------------------------------------------ host launchers (kernels_*.hip)
@@ -352,7 +364,7 @@ WgradJob wgrad_make_job(const stcd_conv_geom& g, const WgradMfmaPlan& p, int64_t
 void wgrad_job_set_xf(WgradJob& a, int64_t stat_off, int64_t mask_off, int C, int groups, int npg);
 int wgrad_variant_slots(int WCI, int NTW, bool t9, int lds_bytes);   // resident blocks of that kernel variant on the chip
 int launch_wgrad_group(int WCI, int NTW, bool t9, const WgradJob* jobs_dev, int njobs, int total_blocks, int lds_bytes,
-                       const char* base, hipStream_t s);
+                       const char* base, hipStream_t s, bool xf = false);
 struct PackSpec;
 // Batched slab reduction: ONE launch per backward stage sums every weight-gradient launch's K-split slabs straight
 // into the reference-layout gradient tensors (device job table built at configure time).
@@ -401,6 +413,7 @@ void launch_pack_jobs(const PackJob* jobs_dev, int njobs, int64_t total, const f
 int bn_stats_chunks(int64_t pixels_per_group, int C);
 void launch_bn_stats(int dt, const void* Y, int ld, int C, int groups, int64_t pixels_per_group, long long* acc, hipStream_t s);
 // eval mode: stat fp32 [groups][4][C] = mean, invstd, scale, shift from the running statistics
+void launch_bn_finalize(const XfSrc& x, hipStream_t s);
 void launch_bn_eval_prepare(int C, int groups, const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float* stat, float eps, hipStream_t s);
 // A = relu(Y*scale+shift) * mask ; optional fused 2x2 max-pool output P (floor).

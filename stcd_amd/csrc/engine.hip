@@ -78,6 +78,7 @@ struct WgradOp {
 };
 struct WgradGroup {                      // all launches of one kernel variant in one backward stage
     int WCI = 1, NTW = 1; bool t9 = false;
+    bool xf = false;                     // its jobs stage X through the virtual-activation transform (k_wgrad_group<.., XF = true>)
     int gemm = 0;                        // > 0: k_wgrad_gemm<gemm> group (one-tap launches; WCI / NTW / t9 unused)
     int dma = 0;                         // 1: k_wgrad_dma group (256 x 256 channel tiles, LDS-DMA staging; splits chosen for the group)
     std::vector<WgradJob> jobs;
@@ -242,7 +243,11 @@ struct stcd_engine_impl {
     int final_conv = -1;
     ConvOp final_fwd, final_dgr; WgradOp final_wg;
     const Cbrd* final_xsrc = nullptr;   // conv11d reads conv12d's raw output (virtual activation)
-    int use_virt = 1;                   // STCD_VIRT_ACT=0: every activation materialised (the round-3 plan)
+    int use_virt = 0;                   // STCD_VIRT_ACT=1: virtual activations (round 4: built, bit-identical, MEASURED 2-3 % SLOWER on the
+                                        // headline step -- DESIGN.md section 4 -- so every activation is materialised by default)
+    int fc_virt_layers = 0;             // layers of the current FC-Siam plan whose activation is virtual
+    int xf_mode = 0;                    // STCD_XF_MODE bit 0: the virtual layers' tables come from a k_bn_finalize launch instead of every
+                                        // consumer block's prologue; bit 1: timing experiment (no transform, wrong results)
     std::vector<ConvOp*> conv_ops;      // every ConvOp of the plan (weight-image packing walks this)
     int64_t slab = -1, slab_floats = 0;
     std::vector<WgradOp*> wgrad_ops;                    // every WgradOp of the plan
@@ -569,8 +574,8 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                 std::vector<WgradGroup>& gs = e.wgroups[op->stage];
                 size_t gi = 0;
                 for (; gi < gs.size(); ++gi)
-                    if (gs[gi].gemm == op->plan.gemm && gs[gi].dma == op->plan.dma && gs[gi].WCI == op->plan.WCI && gs[gi].NTW == op->plan.NTW && gs[gi].t9 == t9) break;
-                if (gi == gs.size()) { WgradGroup g; g.WCI = op->plan.WCI; g.NTW = op->plan.NTW; g.t9 = t9; g.gemm = op->plan.gemm; g.dma = op->plan.dma; gs.push_back(g); }
+                    if (gs[gi].gemm == op->plan.gemm && gs[gi].dma == op->plan.dma && gs[gi].WCI == op->plan.WCI && gs[gi].NTW == op->plan.NTW && gs[gi].t9 == t9 && gs[gi].xf == (op->xf_C > 0)) break;
+                if (gi == gs.size()) { WgradGroup g; g.WCI = op->plan.WCI; g.NTW = op->plan.NTW; g.t9 = t9; g.gemm = op->plan.gemm; g.dma = op->plan.dma; g.xf = op->xf_C > 0; gs.push_back(g); }
                 op->grouped = true;
             }
             for (int st = 0; st < 2; ++st)
@@ -613,7 +618,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                     std::vector<WgradOp*> ops;
                     int64_t W = 0;
                     for (WgradOp* op : e.wgrad_ops)
-                        if (op->grouped && op->stage == st && !op->plan.gemm && !op->plan.dma && op->plan.WCI == G.WCI && op->plan.NTW == G.NTW && (op->g.ntaps == 9) == G.t9) {
+                        if (op->grouped && op->stage == st && !op->plan.gemm && !op->plan.dma && op->plan.WCI == G.WCI && op->plan.NTW == G.NTW && (op->g.ntaps == 9) == G.t9 && (op->xf_C > 0) == G.xf) {
                             ops.push_back(op);
                             const int64_t ntiles = (int64_t)op->g.n * ((op->g.wm + 15) / 16) * ((op->g.hm + 7) / 8);
                             W += ntiles * op->plan.gy * op->plan.gz;
@@ -649,7 +654,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
             if (op->grouped) {
                 const bool t9 = !op->plan.dma && op->g.ntaps == 9;      // (one LDS-DMA group per stage, whatever the tap count)
                 for (WgradGroup& G : e.wgroups[op->stage])
-                    if (G.gemm == op->plan.gemm && G.dma == op->plan.dma && G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9) {
+                    if (G.gemm == op->plan.gemm && G.dma == op->plan.dma && G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9 && G.xf == (op->xf_C > 0)) {
                         op->group = (int)(&G - e.wgroups[op->stage].data());
                         WgradJob j = op->plan.dma ? wgrad_dma_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
                                    : op->plan.gemm ? wgrad_gemm_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
@@ -972,7 +977,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     //      the conv's forward launch (k_conv_small / k_conv_res, XF variants) and its weight gradient (k_wgrad_group, job.xf_*)
     //      apply BN-affine + ReLU + Dropout2d while staging.  Eligibility mirrors exec_conv / exec_wgrad's kernel choice, which is
     //      fixed at configure time (the switches are read at stcd_create).
-    e.final_xsrc = nullptr;
+    e.final_xsrc = nullptr; e.fc_virt_layers = 0;
     for (auto& L : e.enc) { L.virt = false; L.xsrc = nullptr; }
     for (auto& L : e.dec) { L.virt = false; L.xsrc = nullptr; }
     if (e.use_virt && e.dt == BF16 && e.use_mfma && e.use_wgroup && !fc_cross(e)) {
@@ -981,11 +986,11 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
             if (op.small && e.use_small) return true;
             return op.res.ok && !nchw && !op.res.single_halo;
         };
-        auto wg_ok = [&](const WgradOp& op) { return op.plan.ok && !op.plan.gemm && !op.plan.dma; };
+        auto wg_ok = [&](const WgradOp& op) { return op.plan.ok && !op.plan.gemm && !op.plan.dma && op.plan.WCI < 4 && op.plan.NTW < 4; };
         auto link = [&](Cbrd& P, ConvOp& cf, WgradOp& cw, bool nchw) {
             if (P.pool || P.fuse_dst.off >= 0) return false;
             if (!fwd_ok(cf, nchw) || !wg_ok(cw)) return false;
-            P.virt = true;
+            P.virt = true; ++e.fc_virt_layers;
             cw.in_off = P.Y.off;
             cw.xf_stat_off = P.stat;
             cw.xf_mask_off = (P.drop >= 0) ? e.masks + e.drops[P.drop].off * 4 : -1;
@@ -1290,7 +1295,7 @@ static void launch_wgroup(const Ctx& c, WgradGroup& G) {
             return;
         }
         if (launch_wgrad_group(G.WCI, G.NTW, G.t9, c.at<WgradJob>(G.table_off), (int)G.jobs.size(), G.total_blocks, G.lds_bytes,
-                               c.ws, c.s) != 0)
+                               c.ws, c.s, G.xf) != 0)
             set_error("grouped weight-gradient launch exceeds the LDS budget");
     }
 }
@@ -1338,8 +1343,14 @@ static XfSrc xf_source(const Ctx& c, const Cbrd& P, float* bn_running, bool trai
     x.mask = (training && e.drop_p > 0.f && P.drop >= 0) ? c.at<float>(e.masks) + e.drops[P.drop].off : nullptr;
     x.publish = training ? 1 : 0;
     x.on = 1;
+    if (training && (e.xf_mode & 1)) {       // the table was published by k_bn_finalize right behind the producer (cbrd_forward)
+        x.facc = nullptr; x.gamma = nullptr; x.beta = nullptr; x.rmean = nullptr; x.rvar = nullptr; x.publish = 0;
+    }
+    if (e.xf_mode & 2) x.on = 2;             // TIMING EXPERIMENT ONLY (wrong results): stage the raw tensor, no transform
     return x;
 }
+
+static const float* a_gamma(const Ctx& c, const Cbrd& L) { return c.params + c.e.bns[L.bn].g_off; }
 
 static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool training) {
     stcd_engine& e = c.e;
@@ -1360,7 +1371,16 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
             launch_bn_stats(e.dt, c.at(L.Y.off), L.Y.ld, C, L.groups, ppg, c.at<long long>(L.facc), c.s);
         }
     }
-    if (L.virt) return;      // the consumer applies scale / shift / ReLU / Dropout2d while staging Y (and publishes the statistics)
+    if (L.virt) {            // the consumer applies scale / shift / ReLU / Dropout2d while staging Y (and publishes the statistics)
+        if (training && (e.xf_mode & 1)) {
+            XfSrc x = xf_source(c, L, bn_running, training);
+            x.facc = c.at<long long>(L.facc); x.gamma = a_gamma(c, L); x.beta = x.gamma ? c.params + e.bns[L.bn].b_off : nullptr;
+            x.rmean = bn_running + e.bns[L.bn].run_off; x.rvar = x.rmean + C;
+            ProfScope ps(c, PC_BN_STATS, 0.0, 0.0, "k_bn_finalize");
+            launch_bn_finalize(x, c.s);
+        }
+        return;
+    }
     BnActArgs a;
     a.Y = c.at(L.Y.off); a.ldy = L.Y.ld;
     a.A = c.at(L.A.off); a.lda = L.A.ld; a.a_group_off = L.A.goff;
@@ -1492,6 +1512,10 @@ static int forward_fcsiam(stcd_engine& e, const float* x1, const float* x2, cons
     if (training && e.drop_p > 0.f) {
         if (masks) STCD_HIP(hipMemcpyAsync(c.at(e.masks), masks, e.drop_floats * 4, hipMemcpyDeviceToDevice, s));
         else launch_dropout_gen(c.at<float>(e.masks), e.drop_floats, seed, e.drop_p, s);
+    } else if (training && e.fc_virt_layers > 0) {
+        // p == 0 with virtual activations: the weight-gradient job table addresses the mask buffer unconditionally (it is built at
+        // configure time), so the buffer must read as all ones (k_dropout_gen with p = 0 writes 1 / (1 - 0) everywhere)
+        launch_dropout_gen(c.at<float>(e.masks), e.drop_floats, seed, 0.f, s);
     }
     if (pack_all_weights(c, training != 0)) return 1;
     if (training) STCD_HIP(hipMemsetAsync(c.at(e.zero_begin), 0, e.zero_end - e.zero_begin, s));   // the step's ONE workspace memset
@@ -2755,8 +2779,10 @@ static void engine_env_switches(stcd_engine* e) {
     e->use_act_fuse = !(env && env[0] == '1');
     env = getenv("STCD_NO_SKIP_FUSED");
     e->use_skip_fused = !(env && env[0] == '1');
-    env = getenv("STCD_VIRT_ACT");                // 0: materialise every activation (k_bn_act per layer, the round-3 plan)
+    env = getenv("STCD_VIRT_ACT");                // 1: virtual activations (opt-in); 0 / unset: k_bn_act per layer
     if (env) e->use_virt = atoi(env) != 0;
+    env = getenv("STCD_XF_MODE");
+    if (env) e->xf_mode = atoi(env);
     env = getenv("STCD_WGRAD_SIDE");              // 0: the decoder's weight gradients stay on the caller's stream
     if (env) e->wg_side_on = atoi(env) != 0;
     env = getenv("STCD_WGRAD_SIDE_DIV");          // share of the planner's block budget for stage 0's grouped grids: 1 / div

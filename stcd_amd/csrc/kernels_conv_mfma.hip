@@ -484,7 +484,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base0, const char* base1) 
 template <int C>
 __device__ __forceinline__ int px_off(int x) { return x * (2 * C) + (x >> 3) * (C == 16 ? 128 : 32); }
 
-template <int WCI, int NTW, bool T9>
+// XF: X is a virtual activation (job.xf_*): a separate instantiation -- as a run-time branch the staging transform cost EVERY job of
+// the kernel 20-26 more registers (<2,2> spilled 28 B / lane, <2,1> fell from 4 to 3 waves per SIMD: +40 % on the plain jobs' time)
+template <int WCI, int NTW, bool T9, bool XF = false>
 __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bf16* a_in = reinterpret_cast<const bf16*>(base + a.in_off);
@@ -559,12 +561,12 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
     uint4 prex[MAXX], prey[NTW];
     // X as a virtual activation (job.xf_C > 0; uniform per block): scale / shift table of the producer in LDS behind the two staging
     // buffers, the fetched tile's validity bits, image group and Dropout2d factors ride with the loads, xf_act8 at the LDS store
-    const bool xf_on = a.xf_C > 0;
+    constexpr bool xf_on = XF;
     float* const xf_tab = reinterpret_cast<float*>(smem + 2 * buf_bytes);
     const int xf_ch = min(ci0 + (tid % XCH) * 8, max(a.xf_C - 8, 0));        // (tid + p * 256) % XCH is the same for every piece p
     unsigned xf_ok = 0; int xf_g = 0;
     float4 xf_m0 = make_float4(1.f, 1.f, 1.f, 1.f), xf_m1 = xf_m0;
-    if (xf_on) {
+    if constexpr (xf_on) {
         const float* st = reinterpret_cast<const float*>(base + a.xf_stat_off);
         for (int i = tid; i < a.xf_groups * 2 * a.xf_C; i += 256) {
             const int c = i % a.xf_C, w = (i / a.xf_C) & 1, g_ = i / (2 * a.xf_C);
@@ -575,7 +577,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
 #define WG_FETCH(N_, Y_, X_)                                                                                          \
     do {                                                                                                              \
         const int my0_ = (Y_) * 8, mx0_ = (X_) * 16;                                                                   \
-        if (xf_on) {                                                                                                  \
+        if constexpr (xf_on) {                                                                                        \
             xf_ok = 0; xf_g = (N_) / a.xf_npg;                                                                        \
             if (a.xf_mask_off >= 0) {                                                                                 \
                 const float4* mp_ = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base + a.xf_mask_off) + (int64_t)(N_) * a.xf_C + xf_ch); \
@@ -590,7 +592,7 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
                 const bool ok_ = (unsigned)(my0_ + xa[p]) < (unsigned)a.g.hi && (unsigned)(mx0_ + xb[p]) < (unsigned)a.wi_valid; \
                 const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok_ ? (unsigned)xg[p] : 0x80000000u, xs_, 0); \
                 prex[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                     \
-                xf_ok |= ok_ ? (1u << p) : 0u;                                                                        \
+                if constexpr (xf_on) xf_ok |= ok_ ? (1u << p) : 0u;                                                   \
             }                                                                                                         \
         }                                                                                                             \
         _Pragma("unroll") for (int q = 0; q < NTW; ++q) {                                                             \
@@ -601,13 +603,12 @@ __device__ __forceinline__ void wgrad_body(const WgradJob& a, const char* base, 
     } while (0)
 #define WG_STASH(BUF_)                                                                                                \
     do {                                                                                                              \
-        if (xf_on) {                                                                                                  \
+        if constexpr (xf_on) {                                                                                        \
             float sc_[8], sh_[8];                                                                                     \
-            const float mk_[8] = {xf_m0.x, xf_m0.y, xf_m0.z, xf_m0.w, xf_m1.x, xf_m1.y, xf_m1.z, xf_m1.w};            \
             const float* tb_ = xf_tab + (xf_g * 2) * a.xf_C + xf_ch;                                                  \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) { sc_[j] = tb_[j]; sh_[j] = tb_[a.xf_C + j]; }              \
+            xf_fold8(tb_, tb_ + a.xf_C, xf_m0, xf_m1, sc_, sh_);                                                      \
             _Pragma("unroll") for (int p = 0; p < MAXX; ++p)                                                          \
-                if (p < npx) prex[p] = xf_act8(prex[p], sc_, sh_, mk_, (xf_ok >> p) & 1u);                            \
+                if (p < npx) prex[p] = xf_act8(prex[p], sc_, sh_, 0u - ((xf_ok >> p) & 1u));                          \
         }                                                                                                             \
         _Pragma("unroll") for (int p = 0; p < MAXX; ++p)                                                              \
             if (p < npx && tid + p * 256 < nx) *reinterpret_cast<uint4*>(smem + (BUF_) * buf_bytes + xl[p]) = prex[p]; \
@@ -723,9 +724,9 @@ k_wgrad_mfma(const WgradJob a) {
     wgrad_body<WCI, NTW, T9>(a, nullptr, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-template <int WCI, int NTW, bool T9>
+template <int WCI, int NTW, bool T9, bool XF = false>
 // <4,2>: 72 accumulators + 6 X pieces in flight: 2 blocks per CU; <4,4>: 144 accumulators: one wave per SIMD
-__global__ void __launch_bounds__(256, (WCI == 2 && NTW == 2) ? 3 : NTW == 4 ? 1 : 2)
+__global__ void __launch_bounds__(256, (WCI == 2 && NTW == 2 && !XF) ? 3 : NTW == 4 ? 1 : 2)
 k_wgrad_group(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
     int lo = 0, hi = njobs - 1;            // last job with start <= blockIdx.x (uniform: scalar loads)
     while (lo < hi) {
@@ -741,7 +742,7 @@ k_wgrad_group(const WgradJob* __restrict__ jobs, int njobs, const char* base) {
     int bx, r;
     if (lb < full * G) { const int rem = lb % (8 * G); bx = (lb / (8 * G)) * 8 + (rem & 7); r = rem >> 3; }
     else { const int l2 = lb - full * G, tail = a.gx - full; bx = full + l2 % tail; r = l2 / tail; }
-    wgrad_body<WCI, NTW, T9>(a, base, bx, r % a.gy, r / a.gy);
+    wgrad_body<WCI, NTW, T9, XF>(a, base, bx, r % a.gy, r / a.gy);
 }
 
 // sum the slabs; out[t][k][n] (engine layout, same as the slab) or, with a PackSpec, straight into the reference layout
@@ -975,7 +976,7 @@ int wgrad_variant_slots(int WCI, int NTW, bool t9, int lds_bytes) {
 }
 
 int launch_wgrad_group(int WCI, int NTW, bool t9, const WgradJob* jobs_dev, int njobs, int total_blocks, int lds_bytes,
-                       const char* base, hipStream_t s) {
+                       const char* base, hipStream_t s, bool xf) {
     if (njobs <= 0 || total_blocks <= 0) return 0;
     if (lds_bytes > 128 * 1024) return 1;
     if (lds_bytes > 64 * 1024) {      // the 64-channel tiles: two 34-KB X buffers (+ two 17-KB dY buffers at 64 x 64)
@@ -987,6 +988,13 @@ int launch_wgrad_group(int WCI, int NTW, bool t9, const WgradJob* jobs_dev, int 
             (void)hipFuncSetAttribute((const void*)k_wgrad_group<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
+    }
+    if (xf) {      // virtual-activation jobs (opt-in plan): the tile shapes FC-Siam's layers use
+#define WG_GROUP_XF(W_, N_, T_) k_wgrad_group<W_, N_, T_, true><<<(unsigned)total_blocks, 256, (size_t)lds_bytes, s>>>(jobs_dev, njobs, base)
+        if (WCI == 4 || NTW == 4) return 1;
+        WG_DISPATCH(WCI, NTW, t9, WG_GROUP_XF);
+#undef WG_GROUP_XF
+        return 0;
     }
 #define WG_GROUP(W_, N_, T_) k_wgrad_group<W_, N_, T_><<<(unsigned)total_blocks, 256, (size_t)lds_bytes, s>>>(jobs_dev, njobs, base)
     WG_DISPATCH(WCI, NTW, t9, WG_GROUP);
@@ -1056,7 +1064,7 @@ struct ConvSmallArgs {
 };
 
 template <int NT, int KSMAX, bool XF = false>
-__global__ void __launch_bounds__(256, (XF && NT == 1 && KSMAX == 5) ? 3 : 1)
+__global__ void __launch_bounds__(256, (XF && NT == 1 && KSMAX == 5) ? 2 : 1)
 k_conv_small(const ConvSmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1133,6 +1141,7 @@ k_conv_small(const ConvSmallArgs a) {
     unsigned xf_ok = 0;                                                  // XF: bit p = piece p of the fetched tile lies inside the image
     float4 xf_m0 = make_float4(1.f, 1.f, 1.f, 1.f), xf_m1 = xf_m0;      // XF: Dropout2d factors of the fetched tile's (image, 8 channels)
     float xf_sc[8], xf_sh[8];                                            // XF: this thread's 8 channels (tid % nch8 is the same for every piece)
+    float xf_fs[8], xf_fh[8];                                            // ... folded with the fetched tile's Dropout2d factors
     const int xch = (tid % nch8) * 8;
     auto fetch = [&](int n_, int y_, int x_) {
         const int gy0 = y_ * 8 * is, gx0 = x_ * 16 * is;
@@ -1156,11 +1165,11 @@ k_conv_small(const ConvSmallArgs a) {
     };
     auto stash = [&](int buf_) {
         if constexpr (XF) {
-            const float mk[8] = {xf_m0.x, xf_m0.y, xf_m0.z, xf_m0.w, xf_m1.x, xf_m1.y, xf_m1.z, xf_m1.w};
+            xf_fold8(xf_sc, xf_sh, xf_m0, xf_m1, xf_fs, xf_fh);
 #pragma unroll
             for (int p = 0; p < MAXP; ++p) {
                 const int i = tid + p * 256;
-                if (i < npieces) *reinterpret_cast<uint4*>(halo0 + buf_ * halo_elems + i * 8) = xf_act8(pre[p], xf_sc, xf_sh, mk, (xf_ok >> p) & 1u);
+                if (i < npieces) *reinterpret_cast<uint4*>(halo0 + buf_ * halo_elems + i * 8) = a.xf.on == 2 ? pre[p] : xf_act8(pre[p], xf_fs, xf_fh, 0u - ((xf_ok >> p) & 1u));
             }
         } else {
 #pragma unroll
@@ -1461,8 +1470,15 @@ k_conv_res(const ConvResArgs a) {
 
     // ---- software pipeline: the halo chunk of step s+1 is requested into registers before the MFMAs of step s and
     //      parked in the other LDS buffer after them; one barrier per step.  A step = (tile, CW-channel chunk).
+    // (Round 4 tried TWO steps in flight -- step s+2 requested before the MFMAs of step s, step s+1 parked from a second register
+    //  set: MEASURED SLOWER on every family (diff conv 0.985 -> 1.00-1.02 ms, SNUNet 12.7 -> 13.5 ms, SegCD 9.3 -> 9.85 ms).  The
+    //  compiled loop shows why: hipcc allocates the offset temporaries of the new loads INTO the destination registers of the other
+    //  set and guards them with s_waitcnt vmcnt(4) / (2) / (0) in front of the fetch, so nothing more was in flight than before,
+    //  with 24-44 more live registers.  One step in flight stays.)
     struct Pos { int tile, n, y, x, c; };
-    uint4 pre[MAXP];
+    struct XfSet { unsigned ok; float4 m0, m1; };      // XF: validity bits and Dropout2d factors that travel with a register set
+    uint4 preA[MAXP];
+    XfSet xsA{0u, make_float4(1.f, 1.f, 1.f, 1.f), make_float4(1.f, 1.f, 1.f, 1.f)};
     // Halo loads are raw buffer loads: the descriptor starts one row + one pixel BEFORE the tensor, so offsets relative
     // to a tile's halo corner are never negative; a piece outside the image gets an offset beyond num_records and the
     // hardware returns zeros -- no address select, no data select, no 64-bit address arithmetic per piece.
@@ -1478,41 +1494,38 @@ k_conv_res(const ConvResArgs a) {
             (P_).n += dn;                                                                                              \
         }                                                                                                              \
     } while (0)
-    unsigned xf_ok = 0;            // XF: bit p = piece p of the fetched step lies inside the image
-    float4 xf_m0 = make_float4(1.f, 1.f, 1.f, 1.f), xf_m1 = xf_m0;      // XF: Dropout2d factors of the fetched step's (image, 8 channels)
-#define RES_FETCH(P_)                                                                                                  \
+#define RES_FETCH(P_, PRE_, XS_)                                                                                       \
     do {                                                                                                               \
         const int gy0_ = (P_).y * 16, gx0_ = (P_).x * 16;                                                               \
         const unsigned soff_ = (unsigned)(((((int64_t)(P_).n * a.g.hi + gy0_) * a.g.wi + gx0_) * a.g.ldi + (P_).c * CW) * 2); \
-        if constexpr (XF) xf_ok = 0;                                                                                   \
+        if constexpr (XF) (XS_).ok = 0;                                                                                \
         _Pragma("unroll") for (int p = 0; p < MAXP; ++p) {                                                             \
             const int hy_ = pyx[p] >> 16, hx_ = (int)(short)(pyx[p] & 0xffff);                                         \
             const bool ok_ = (unsigned)(gy0_ + hy_) < (unsigned)a.g.hi && (unsigned)(gx0_ + hx_) < (unsigned)a.g.wi;   \
             const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok_ ? (unsigned)poff[p] : 0x80000000u, soff_, 0); \
-            pre[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                           \
-            if constexpr (XF) xf_ok |= ok_ ? (1u << p) : 0u;                                                           \
+            (PRE_)[p] = make_uint4(v_[0], v_[1], v_[2], v_[3]);                                                        \
+            if constexpr (XF) (XS_).ok |= ok_ ? (1u << p) : 0u;                                                        \
         }                                                                                                              \
         if constexpr (XF) {                                                                                            \
             if (a.xf.mask) {                                                                                           \
                 const float4* mp_ = reinterpret_cast<const float4*>(a.xf.mask + (int64_t)(P_).n * a.xf.C + (P_).c * CW + ch * 8); \
-                xf_m0 = mp_[0]; xf_m1 = mp_[1];                                                                        \
+                (XS_).m0 = mp_[0]; (XS_).m1 = mp_[1];                                                                  \
             }                                                                                                          \
         }                                                                                                              \
     } while (0)
-#define RES_STASH(BUF_, P_)                                                                                            \
+#define RES_STASH(BUF_, P_, PRE_, XS_)                                                                                 \
     do {                                                                                                               \
         if constexpr (XF) {                                                                                            \
             float sc_[8], sh_[8];                                                                                      \
-            const float mk_[8] = {xf_m0.x, xf_m0.y, xf_m0.z, xf_m0.w, xf_m1.x, xf_m1.y, xf_m1.z, xf_m1.w};             \
             const float* tb_ = xf_tab + (grp * 2) * a.xf.C + (P_).c * CW + ch * 8;                                     \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) { sc_[j] = tb_[j]; sh_[j] = tb_[a.xf.C + j]; }               \
+            xf_fold8(tb_, tb_ + a.xf.C, (XS_).m0, (XS_).m1, sc_, sh_);                                                 \
             _Pragma("unroll") for (int p = 0; p < MAXP; ++p)                                                           \
                 if ((tid >> LG8) + p * PIXSTEP < RES_HW * RES_HW)                                                      \
-                    *reinterpret_cast<uint4*>(halo0 + (BUF_) * HALO_BYTES + plds[p]) = xf_act8(pre[p], sc_, sh_, mk_, (xf_ok >> p) & 1u); \
+                    *reinterpret_cast<uint4*>(halo0 + (BUF_) * HALO_BYTES + plds[p]) = a.xf.on == 2 ? (PRE_)[p] : xf_act8((PRE_)[p], sc_, sh_, 0u - (((XS_).ok >> p) & 1u)); \
         } else {                                                                                                       \
             _Pragma("unroll") for (int p = 0; p < MAXP; ++p)                                                           \
                 if ((tid >> LG8) + p * PIXSTEP < RES_HW * RES_HW)                                                      \
-                    *reinterpret_cast<uint4*>(halo0 + (BUF_) * HALO_BYTES + plds[p]) = pre[p];                         \
+                    *reinterpret_cast<uint4*>(halo0 + (BUF_) * HALO_BYTES + plds[p]) = (PRE_)[p];                      \
         }                                                                                                              \
     } while (0)
 
@@ -1535,7 +1548,7 @@ k_conv_res(const ConvResArgs a) {
     { const int trem = tile0 - cur.n * tiles_img; cur.y = trem / a.tiles_x; cur.x = trem - cur.y * a.tiles_x; }
     Pos nxt = cur; RES_ADV(nxt);
     int buf = 0;
-    if (cur.tile < tile_end) RES_FETCH(cur);               // first halo chunk in flight while the filter is staged
+    if (cur.tile < tile_end) RES_FETCH(cur, preA, xsA);    // first halo chunk in flight while the filter is staged
     // ---- filter slice -> LDS: first batch was requested at kernel entry; deeper slices take more rounds
     {
 #pragma unroll
@@ -1555,11 +1568,11 @@ k_conv_res(const ConvResArgs a) {
                      a.xf.momentum, a.xf.eps, a.xf.publish != 0 && blockIdx.x == 0);
         __syncthreads();
     }
-    if (cur.tile < tile_end) RES_STASH(0, cur);
+    if (cur.tile < tile_end) RES_STASH(0, cur, preA, xsA);
     __syncthreads();
     while (cur.tile < tile_end) {
         const bool have_next = nxt.tile < tile_end;
-        if (have_next) RES_FETCH(nxt);
+        if (have_next) RES_FETCH(nxt, preA, xsA);
         const char* hb = halo0 + (SH ? 0 : buf) * HALO_BYTES;
         if constexpr (PIPE) {
             constexpr int NSTG = KSC * 3;
@@ -1619,7 +1632,7 @@ k_conv_res(const ConvResArgs a) {
             }
         }
         if constexpr (SH) barrier_lds();                  // one halo buffer: every wave is done reading it before it is refilled
-        if (have_next) RES_STASH(SH ? 0 : (buf ^ 1), nxt);
+        if (have_next) RES_STASH(SH ? 0 : (buf ^ 1), nxt, preA, xsA);
         if (cur.c == nsteps - 1) {
             // ---- epilogue of this tile: lane (q, r) holds channels 4q..4q+3 of n-tile t2 at row 4*wid + m, column r
             const int mx = cur.x * 16 + r;
@@ -1802,7 +1815,7 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
     // layers sit on the HBM roofline: 134 MB in + 134 MB out per 32 -> 32 full-resolution layer in 66 us), <2, 64> has no registers
     // left for the second fragment set.  Default: <1, 64> only; STCD_CONV_RES_PIPE=1 pipelines every variant that fits, 0 none.
     static const int pipe_env = [] { const char* e = getenv("STCD_CONV_RES_PIPE"); return e ? atoi(e) : -1; }();
-    const int pipe = pipe_env >= 0 ? pipe_env : (rp.CW == 64 && rp.NT == 1);
+    const int pipe = pipe_env >= 0 ? pipe_env : (rp.CW == 64 && rp.NT == 1 && !use_xf);      // (<1, 64, PIPE, XF> spills: 112 B / lane)
 #define LAUNCH_RES_SH(N_)                                                                                         \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \

@@ -330,6 +330,17 @@ __device__ __forceinline__ void bn_bwd_table(float* tab, const long long* __rest
     }
 }
 
+// One small launch that turns a layer's forward accumulators into its published table (stat: mean, invstd, scale, shift) and updates the
+// running statistics -- for virtual activations (XfSrc): the consumers' blocks then read 2 * C floats instead of each deriving the
+// table from 2 * C * BN_REP integers with double-precision divisions and square roots in its prologue (STCD_XF_MODE, engine.hip).
+__global__ void k_bn_finalize(const XfSrc x) {
+    extern __shared__ float fin_tab[];
+    bn_fwd_table(fin_tab, x.facc, x.gamma, x.beta, x.rmean, x.rvar, x.stat, x.C, x.groups, x.ppg, x.momentum, x.eps, true);
+}
+void launch_bn_finalize(const XfSrc& x, hipStream_t s) {
+    k_bn_finalize<<<1, 128, (size_t)x.groups * 2 * x.C * 4, s>>>(x);
+}
+
 __global__ void k_bn_eval_prepare(int C, int groups, const float* __restrict__ gamma, const float* __restrict__ beta,
                                   const float* __restrict__ rmean, const float* __restrict__ rvar, float* __restrict__ stat,
                                   float eps) {
@@ -382,12 +393,15 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) { sc[j] = bn_tab[(g * 2 + 0) * CS + c0l + j]; sh[j] = bn_tab[(g * 2 + 1) * CS + c0l + j]; }
         if constexpr (MASK) {
+            // the Dropout2d factor (0 or 1 / (1 - p), never negative) is folded into scale / shift: relu(z) * mk == relu(y * (sc * mk) +
+            // sh * mk) -- the same arithmetic as the staging transform of a virtual activation (common.h xf_fold8 / xf_act8), so a layer
+            // gives the same bits whether its activation is materialised here or formed in its consumer's loader.  (With a residual the
+            // ReLU sees z + res: those layers -- SNUNet's -- have no mask.)
             const float4* mp = reinterpret_cast<const float4*>(mask + (int64_t)n * C + c0);
             const float4 m0 = mp[0], m1 = mp[1];
             mk[0] = m0.x; mk[1] = m0.y; mk[2] = m0.z; mk[3] = m0.w; mk[4] = m1.x; mk[5] = m1.y; mk[6] = m1.z; mk[7] = m1.w;
-        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) mk[j] = 1.f;
+            for (int j = 0; j < 8; ++j) { sc[j] *= mk[j]; sh[j] *= mk[j]; }
         }
     }
     // the 2x2 quad: all loads first (clamped inside the map), then the arithmetic and the stores
@@ -407,10 +421,10 @@ k_bn_act(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __restri
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float z = v[k][j] * sc[j] + sh[j];
-            if constexpr (RES) z += rs[k][j];    // residual add before the ReLU (SNUNet conv_block_nested, SNUNet.py:25)
-            if (relu) z = fmaxf(z, 0.f);
-            v[k][j] = round_as<T>(z * mk[j]);
+            float z = fmaf(v[k][j], sc[j], sh[j]);
+            if constexpr (RES) z += MASK ? rs[k][j] * mk[j] : rs[k][j];    // residual add before the ReLU (SNUNet conv_block_nested, SNUNet.py:25)
+            if (relu) z = z > 0.f ? z : 0.f;     // (+0 for -0 and NaN, as the packed-bf16 ReLU of xf_act8)
+            v[k][j] = round_as<T>(z);
             best[j] = k == 0 ? v[k][j] : fmaxf(best[j], v[k][j]);   // pooled cells are complete quads: every k is inside
         }
         if (ok[k]) {
@@ -484,14 +498,19 @@ k_bn_act_pair(const T* __restrict__ Y, int ldy, T* __restrict__ A, GV av, T* __r
             float sc[8], sh[8], mk[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { sc[j] = bn_tab[(g * 2 + 0) * C + c0 + j]; sh[j] = bn_tab[(g * 2 + 1) * C + c0 + j]; }
-            if constexpr (MASK) ld8f(mask + ((int64_t)g * npg + nb) * C + c0, mk);
+            if constexpr (MASK) {                 // folded Dropout2d factor, as k_bn_act
+                ld8f(mask + ((int64_t)g * npg + nb) * C + c0, mk);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { sc[j] *= mk[j]; sh[j] *= mk[j]; }
+            }
             float best[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float z = fmaxf(vv[g][k][j] * sc[j] + sh[j], 0.f);
-                    vv[g][k][j] = round_as<T>(MASK ? z * mk[j] : z);
+                    float z = fmaf(vv[g][k][j], sc[j], sh[j]);
+                    z = z > 0.f ? z : 0.f;
+                    vv[g][k][j] = round_as<T>(z);
                     best[j] = k == 0 ? vv[g][k][j] : fmaxf(best[j], vv[g][k][j]);
                 }
                 if (ok[k]) store8<T>(A + g * av.goff + pix[k] * av.ld + c0, vv[g][k]);

@@ -32,6 +32,11 @@ N_TRAIN, N_VAL, SIZE, BS, EPOCHS = 256, 64, 256, 16, 20
 # differ in the initial weights and the dropout masks (same data), for a statistical F1 comparison (tests/test_trainer_gpu.py)
 SEEDS = [int(v) for v in sys.argv[1:]] or [41]
 torch.set_num_threads(int(os.environ.get("F1_THREADS", "8")))
+# F1_REPLICA=r (round 4): the same protocol with the pairs INSIDE every batch permuted (images, labels, mask rows alike; the
+# permutation stream of tests/test_trainer_gpu.py::_f1_run(replica=r)) -- mathematically the same steps, another fp32 summation order:
+# an independent sample of the run's chaotic trajectory (a single 320-step run moves a seed's final F1 by +-1.5 pt).  Written to
+# g9r<r>_f1_s<seed>.npz; the test averages the reference's replicas per seed, as it averages the engine's.
+REPLICA = int(os.environ.get("F1_REPLICA", "0"))
 
 
 def main():
@@ -51,17 +56,23 @@ def run(SEED):
     sched = Poly(opt, EPOCHS, ipe)
     losses_, f1s, ious, cm = [], [], [], None
     t0 = time.time()
+    prng = np.random.default_rng(7919 * REPLICA + SEED) if REPLICA else None
     for ep in range(EPOCHS):
         m.train()
         for it in range(ipe):
             sl = slice(it * BS, (it + 1) * BS)
             install_masks(m, fcsiam_ref.synth_masks("diff", BS, SEED + 1000 * ep + it)) if ep == 0 and it == 0 else None
             masks = fcsiam_ref.synth_masks("diff", BS, SEED + 1000 * ep + it)
+            a_, b_, l_ = A[sl], B[sl], L[sl]
+            if prng is not None:
+                perm = torch.from_numpy(prng.permutation(BS))
+                a_, b_, l_ = a_[perm], b_[perm], l_[perm]
+                masks = {k: (torch.cat([v[perm], v[BS + perm]]) if v.shape[0] == 2 * BS else v[perm]) for k, v in masks.items()}
             for name, mk in masks.items():
                 getattr(m, name).mask, getattr(m, name).pos = mk, 0
             opt.zero_grad()
-            logits = m(A[sl], B[sl])
-            loss = ref_losses.cd_loss(torch.sigmoid(logits), L[sl].float().unsqueeze(1))
+            logits = m(a_, b_)
+            loss = ref_losses.cd_loss(torch.sigmoid(logits), l_.float().unsqueeze(1))
             loss.backward()
             opt.step()
             sched.step(epoch=ep)
@@ -73,7 +84,8 @@ def run(SEED):
         sc = fcsiam_ref.scores_from_cm(cm)
         f1s.append(float(sc["f1"][1])); ious.append(float(sc["iou"][1]))
         print(f"epoch {ep:2d}  loss {np.mean(losses_[-ipe:]):.4f}  val F1 {f1s[-1]:.4f}  IoU {ious[-1]:.4f}  ({time.time() - t0:.0f} s)", flush=True)
-    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "g9_f1.npz" if SEED == 41 else f"g9_f1_s{SEED}.npz"),
+    fname = ("g9_f1.npz" if SEED == 41 else f"g9_f1_s{SEED}.npz") if REPLICA == 0 else f"g9r{REPLICA}_f1_s{SEED}.npz"
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), fname), replica=REPLICA,
                         n_train=N_TRAIN, n_val=N_VAL, size=SIZE, batch=BS, epochs=EPOCHS, seed=SEED, data_seed_train=900,
                         data_seed_val=901, losses=np.array(losses_), val_f1=np.array(f1s), val_iou=np.array(ious), cm=cm.numpy())
 

@@ -119,3 +119,77 @@ def test_bf16_gradients_on_a_partly_trained_state(arch):
     assert vs_emul[0][0] >= 0.995, vs_emul[:4]
     assert vs_fp32[0][0] >= 0.98, vs_fp32[:4]
     assert abs(le - lf) < 5e-3
+
+
+def test_snunet_bf16_gradients_against_its_bf16_emulating_oracle():
+    """BASELINE.json configs[2] is SNUNet in bf16 (round-3 review, weak #2: its bf16 parity rested on fitted bounds -- rel-l2 0.32 /
+    cosine 0.95 against G7).  oracle/snunet_bf16.py rounds exactly what the engine stores (Y1 -- also the identity branch --, A1, Y2,
+    the block output, the transposed convs' outputs, Z; every stored gradient incl. the per-consumer contributions and their
+    once-more-rounded sum); from a partly-trained state (60 AdamW steps of the fp32 engine on LEVIR-shaped pairs) the bf16 engine
+    must agree with it tensor by tensor, and with the fp32 oracle at the bf16 bound."""
+    from oracle import snunet_bf16 as ES
+    from oracle import snunet_ref as S
+    from stcd_amd.modules import SNUNet_ECAM
+    B, Sz = 4, 64
+    a, b, lab = synth.make_batch(B, Sz, Sz, seed=91)
+    A, Bt, L = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), torch.from_numpy(lab).to(DEV)
+    m = SNUNet_ECAM(3, 2, dtype="fp32")
+    m.load_state_dict(S.synth_state(3, 2, 13))
+    m.to(DEV).train()
+    opt = FlatAdamW(m, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    for _ in range(60):
+        opt.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(_first(m(A, Bt)), L).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    st = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    a2, b2, lab2 = synth.make_batch(2, Sz, Sz, seed=92)
+    x1, x2, tgt = torch.from_numpy(a2), torch.from_numpy(b2), torch.from_numpy(lab2)
+
+    def oracle(emulate):
+        ref = {k: v.clone() for k, v in st.items()}
+        for k, v in ref.items():
+            if v.dtype.is_floating_point and "running" not in k:
+                v.requires_grad_(True)
+        logits = ES.forward(ref, x1, x2) if emulate else S.forward(ref, x1, x2, training=True)
+        loss = R.cross_entropy(logits, tgt)
+        loss.backward()
+        return loss.item(), logits.detach(), {k: v.grad for k, v in ref.items() if v.requires_grad}
+
+    e = SNUNet_ECAM(3, 2, dtype="bf16")
+    e.load_state_dict(st)
+    e.to(DEV).train()
+    logits = _first(e(x1.to(DEV), x2.to(DEV)))
+    loss = torch.nn.functional.cross_entropy(logits, tgt.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    le, oe, ge = loss.item(), logits.detach().cpu(), {k: p.grad.detach().cpu() for k, p in e.named_parameters()}
+    lm, om, gm = oracle(True)
+    lf, of_, gf = oracle(False)
+
+    def cosines(got, ref):
+        out = []
+        for k, g in ref.items():
+            # conv biases in front of a training-mode BatchNorm have mathematically zero gradients (conv2's; conv1's reaches the
+            # loss through the identity branch only and is real)
+            if (".conv2.bias" in k) or float(g.abs().max()) < 1e-9:
+                continue
+            rel, cos = _util.rel_l2_cos(got[k].numpy(), g.numpy())
+            out.append((cos, rel, k))
+        return sorted(out)
+    vs_emul, vs_fp32, emul_vs_fp32 = cosines(ge, gm), cosines(ge, gf), cosines(gm, gf)
+    print(f"snunet trained state: loss engine {le:.4f} emulation {lm:.4f} fp32 {lf:.4f} | engine vs emulation worst {vs_emul[0][0]:.4f} ({vs_emul[0][2]}) "
+          f"median {vs_emul[len(vs_emul) // 2][0]:.4f} | engine vs fp32 worst {vs_fp32[0][0]:.4f} ({vs_fp32[0][2]}) median {vs_fp32[len(vs_fp32) // 2][0]:.4f} | "
+          f"emulation vs fp32 worst {emul_vs_fp32[0][0]:.4f} median {emul_vs_fp32[len(emul_vs_fp32) // 2][0]:.4f}")
+    assert float((oe - om).abs().max()) <= 2e-2 * float(om.abs().max()) and abs(le - lm) < 2e-3
+    # Measured (MI355X): median 0.9998, every convolution / transposed-convolution / attention weight >= 0.995; the tensors below that
+    # are BatchNorm scale / shift gradients of the deepest nested blocks (conv0_3.bn2.weight 0.989, conv1_2.bn1.weight 0.991,
+    # conv0_3.bn1.weight 0.994): d(gamma) = sum(dz * xhat) over (n, h, w) is a sum of nearly cancelling terms in a trained network, so
+    # two bf16 evaluations that differ only in accumulation order agree less on it -- the emulation itself sits at 0.984 against the
+    # fp32 oracle on the same class, and the engine is no further from fp32 than the emulation is.
+    convs = [t for t in vs_emul if ".bn" not in t[2]]
+    bns = [t for t in vs_emul if ".bn" in t[2]]
+    print(f"  conv / attention weights worst {convs[0][0]:.4f} ({convs[0][2]}); BatchNorm parameters worst {bns[0][0]:.4f} ({bns[0][2]})")
+    assert convs[0][0] >= 0.995, convs[:6]
+    assert bns[0][0] >= 0.985, bns[:6]
+    assert vs_fp32[0][0] >= emul_vs_fp32[0][0] - 0.02, (vs_fp32[:4], emul_vs_fp32[:4])

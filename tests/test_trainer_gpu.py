@@ -264,9 +264,15 @@ def test_f1_parity_with_statistics_over_reference_seeds(dtype):
     # orders): a single 320-step run is ONE sample of a chaotic trajectory (a 1e-7 change of one gradient moves a seed's final F1 by
     # up to 3 pt, in the reference as in the engine); the replicas average the engine's side of that noise, the seeds the reference's
     reps = F1_REPLICAS if dtype == "bf16" else 1
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     for g in fixtures:
         epochs, ipe = int(g["epochs"]), int(g["n_train"]) // int(g["batch"])
-        rf1 = g["val_f1"] * 100
+        # the reference's own replicas of this seed (make_f1_fixture.py with F1_REPLICA=r: the in-batch permutation stream of the
+        # engine's replica r), averaged like the engine's
+        import glob
+        ref_reps = [g["val_f1"][-5:].mean() * 100] + [float(np.load(f, allow_pickle=False)["val_f1"][-5:].mean() * 100)
+                                                      for f in sorted(glob.glob(os.path.join(gdir, f"g9r*_f1_s{int(g['seed'])}.npz")))]
+        rf1 = np.full(5, float(np.mean(ref_reps)))
         per_rep = []
         for r in range(reps):
             losses_, f1 = _f1_run(g, dtype, replica=r)
@@ -276,7 +282,7 @@ def test_f1_parity_with_statistics_over_reference_seeds(dtype):
             np.testing.assert_allclose(em, rm, atol=0.03 if dtype == "fp32" else 0.04)
             per_rep.append(f1[-5:].mean())
         eng.append(float(np.mean(per_rep))); ref.append(rf1[-5:].mean())
-        print(f"{dtype} seed {int(g['seed'])}: last-5-epoch mean F1 engine {eng[-1]:.2f} (replicas {np.round(per_rep, 2)}) / reference {ref[-1]:.2f}")
+        print(f"{dtype} seed {int(g['seed'])}: last-5-epoch mean F1 engine {eng[-1]:.2f} (replicas {np.round(per_rep, 2)}) / reference {ref[-1]:.2f} (replicas {np.round(ref_reps, 2)})")
     eng, ref = np.array(eng), np.array(ref)
     K = len(eng)
     # the runs are PAIRED (seed k of the engine repeats seed k of the reference: same initial weights, batch order, masks), so the

@@ -1,0 +1,11 @@
+#!/bin/bash
+O=$GRAFT_REPO_ROOT/gpurun_out/r04g; mkdir -p $O
+R3=$PWD/build/r03/libstcd_hip_r03.so
+for m in diff snunet segcd changeformer conc; do
+  for lib in r04 r03 r04 r03; do
+    if [ $lib = r03 ]; then export STCD_LIB_PATH=$R3; else unset STCD_LIB_PATH; fi
+    a="--model $m"; [ $m = diff ] && a=""
+    python bench.py $a --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/${m}_$lib.json 2>> $O/bench.err
+    python -c "import json;d=json.load(open('$O/${m}_$lib.json'));print('$m $lib', d['value'], d['ms_per_step'])" | tee -a $O/ab.txt
+  done
+done
