@@ -146,7 +146,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="diff", choices=["diff", "conc", "sub", "fcef", "xconc", "snunet", "segcd", "unetseg", "ffctlcd", "changeformer"],
                     help="unetseg: the single-image UNet of train_sup.py (one 'pair' = one image); ffctlcd: SegCD's feature-level variant")
-    ap.add_argument("--encoder", default="resnet50", choices=sorted(SEGCD_ENCODERS), help="--model segcd: the ResNet encoder")
+    ap.add_argument("--encoder", default="resnet50", choices=sorted(SEGCD_ENCODERS) + ["mit_b0"],
+                    help="--model segcd: the ResNet encoder; --model changeformer --encoder mit_b0: the MiT-B0 widths BASELINE.json configs[4] names")
     ap.add_argument("--batch", type=int, default=16, help="image pairs per GPU per step")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -156,6 +157,9 @@ def parse():
                          "(stcd_pseudo_pair: blend + normalise + labels), then trains on them")
     ap.add_argument("--graph", action="store_true", help="replay the step as ONE captured hipGraph (stcd_amd.train_loop.GraphedTrainStep): "
                                                           "small batches of the SegCD family are host-bound otherwise")
+    ap.add_argument("--bucket-dtype", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="gradient buckets of the data-parallel all-reduce (N > 1): auto = bf16 payloads with fp32 accumulation for the families with "
+                         "large gradients (SNUNet 48 MB, ChangeFormer 164 MB: SURVEY 8e), fp32 for the rest (FC-Siam 5-6 MB: latency-bound either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16)     # bounded CPU sample: ~10-30 s of host work in total (16 = the GPU's batch)
@@ -362,7 +366,13 @@ def main():
             args.size = 512
         if args.batch == 16 and "--batch" not in sys.argv:
             args.batch = 4
-        model = ChangeFormerV6(3, 2, dtype=args.dtype).to(dev).train()
+        if args.encoder == "mit_b0":
+            from stcd_amd.changeformer import MIT_B0
+            model = ChangeFormerV6(3, 2, dtype=args.dtype, config=dict(MIT_B0)).to(dev).train()
+            NAMES["changeformer"] = "ChangeFormer(MiT-B0 encoder)"
+            args.no_cpu_baseline = True
+        else:
+            model = ChangeFormerV6(3, 2, dtype=args.dtype).to(dev).train()
     elif args.model == "segcd":       # train_pse_cd.py:426-431: SegCD(resnet50), 1 class, Adam(lr 1e-3), BCE+Dice on sigmoid(change)
         from stcd_amd.segcd import SegCD
         args.label = 1
@@ -386,7 +396,8 @@ def main():
     broadcast_parameters(model)
     # torch.optim.AdamW semantics, one launch (weight_decay 0 == the Adam the SegCD script uses)
     opt = FlatAdamW(model, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0 if args.model in ("segcd", "unetseg", "ffctlcd") else 0.01)
-    reducer = FlatGradReducer(model)  # noqa: F841  (installs the gradient hook when world > 1)
+    bucket_dtype = args.bucket_dtype if args.bucket_dtype != "auto" else ("bf16" if args.model in ("snunet", "changeformer") else "fp32")
+    reducer = FlatGradReducer(model, bucket_dtype=bucket_dtype)  # noqa: F841  (installs the gradient hook when world > 1)
 
     a, b, lab = synth.make_batch(args.batch, args.size, args.size, seed=1337 + rank)
     A, B, L = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(lab).to(dev)
@@ -483,13 +494,14 @@ def main():
                    "last_loss": round(last_loss, 5)},
         "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
         "collective_backend": dist.get_backend() if world > 1 else None,
+        "bucket_dtype": bucket_dtype if world > 1 else None,
         "pairs_per_sec_per_rank": [round(v, 2) for v in rank_rates],
         "graph_replay": bool(args.graph),
     }
     # whole-step roofline: SURVEY 8d's algorithmic figures per pair x pairs per step / measured step time (all ranks)
     seg_family = args.model in ("segcd", "unetseg", "ffctlcd")
     fl_pp, by_pp = (segcd_alg(args.encoder, dates=1 if args.model == "unetseg" else 2, ffc=args.model == "ffctlcd") if seg_family
-                    else changeformer_alg(args.size, args.size) if args.model == "changeformer" else ALG_PER_PAIR_256[args.model])
+                    else (changeformer_alg(args.size, args.size, E=(32, 64, 160, 256), depths=(2, 2, 2, 2), k=3) if args.encoder == "mit_b0" else changeformer_alg(args.size, args.size)) if args.model == "changeformer" else ALG_PER_PAIR_256[args.model])
     pmc_key = args.model if (not seg_family or args.encoder == "resnet50") else args.model + "_" + args.encoder
     sc = 1.0 if args.model == "changeformer" else (args.size / 256.0) ** 2
     step_s = elapsed / args.steps

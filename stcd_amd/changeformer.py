@@ -29,6 +29,12 @@ from .modules import HipChangeDetector
 
 V6 = dict(embed_dims=(64, 128, 320, 512), depths=(3, 3, 4, 3), num_heads=(1, 2, 4, 8), sr_ratios=(8, 4, 2, 1), mlp_ratio=4,
           patch1=7, patch=7, drop_rate=0.1, attn_drop=0.1, drop_path_rate=0.1)
+# The encoder BASELINE.json configs[4] names ("ChangeFormer (MiT-B0 encoder)"; SURVEY R10: not what the in-tree V6 builds): the mit_b0
+# entry of the reference's vendored encoder zoo, /root/reference/segmentation_models_pytorch/encoders/mix_transformer.py:497-511 --
+# widths [32, 64, 160, 256], depths [2, 2, 2, 2], heads [1, 2, 5, 8] (head dimension 32 everywhere), patch 7 / 3 / 3 / 3, drop 0.0,
+# drop_path 0.1.  ChangeFormerV6(config=MIT_B0) runs it under the same decoder.
+MIT_B0 = dict(embed_dims=(32, 64, 160, 256), depths=(2, 2, 2, 2), num_heads=(1, 2, 5, 8), sr_ratios=(8, 4, 2, 1), mlp_ratio=4,
+              patch1=7, patch=3, drop_rate=0.0, attn_drop=0.0, drop_path_rate=0.1)
 
 
 class DropPath(nn.Module):

@@ -211,13 +211,16 @@ def test_one_rank_rccl_group_runs_the_collective_path(family, overlap):
     np.testing.assert_array_equal(out[True], out[False])
 
 
-def test_bench_contract_under_torchrun_two_ranks_on_one_card(tmp_path):
+@pytest.mark.parametrize("model,want_bucket", [("diff", "fp32"), ("snunet", "bf16")])
+def test_bench_contract_under_torchrun_two_ranks_on_one_card(tmp_path, model, want_bucket):
     """The driver's multi-GPU launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N --steps K --warmup W`) rehearsed with N = 2 on this one-GPU box (STCD_DDP_REHEARSAL=1: both
     ranks share cuda:0 and meet over gloo -- RCCL cannot host two ranks on one device): exactly ONE JSON line from rank 0, n_gpus 2,
     value = global pairs / max-over-ranks time, per-rank rates present, the gradient buckets really averaged (the ranks end with the
     same loss trajectory on different data shards only if the parameters stayed in lock-step: checked through `last_loss` finiteness
-    and the collective backend field)."""
+    and the collective backend field).  `--bucket-dtype auto` (round 4): SNUNet (48 MB of gradients) and ChangeFormer (164 MB) travel
+    as bf16 buckets with fp32 accumulation, the FC-Siam family (5-6 MB) stays fp32 -- so the first multi-GPU run of the
+    driver exercises the path section 8e describes."""
     import json
     import socket
     import subprocess
@@ -228,7 +231,7 @@ def test_bench_contract_under_torchrun_two_ranks_on_one_card(tmp_path):
     env = dict(os.environ, STCD_DDP_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "4",
-           "--no-cpu-baseline", "--no-roofline"]
+           "--no-cpu-baseline", "--no-roofline"] + (["--model", model, "--size", "64"] if model != "diff" else [])
     out = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -236,6 +239,7 @@ def test_bench_contract_under_torchrun_two_ranks_on_one_card(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["collective_backend"] == "gloo" and d["rccl_ranks"] == 0
+    assert d["bucket_dtype"] == want_bucket
     assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
     assert len(d["pairs_per_sec_per_rank"]) == 2 and all(v > 0 for v in d["pairs_per_sec_per_rank"])
     assert abs(d["value"] - 2 * 4 * 4 / (d["ms_per_step"] * 4 / 1e3)) <= 0.01 * d["value"]        # whole-job rate over the max time
