@@ -245,6 +245,19 @@ __global__ void __launch_bounds__(256)
 k_conv_mfma_x4(const ConvMfmaArgs4 j) {
     conv_mfma_body<NT>(j.a[blockIdx.z], blockIdx.x, blockIdx.y);
 }
+// ... or all four phases of a tile in ONE block, back to back (large maps: >= 1024 tiles).  The phases read the same input tile
+// (one HBM fetch, three L2 hits instead of four fetches by blocks scattered over the XCDs) and write the interleaved halves /
+// quarters of the same output lines within microseconds of each other on one XCD, so its L2 merges them into whole-line writes
+// (a phase alone writes 32-B pieces at a 64-B stride on the 16-channel level).
+template <int NT>
+__global__ void __launch_bounds__(256)
+k_conv_mfma_x4s(const ConvMfmaArgs4 j) {
+#pragma unroll 1
+    for (int z = 0; z < 4; ++z) {
+        conv_mfma_body<NT>(j.a[z], blockIdx.x, blockIdx.y);
+        __syncthreads();       // the next phase rewrites the tap table and the halo
+    }
+}
 
 // ------------------------------------------------------------------ host side
 static void taps_extent(const stcd_conv_geom& g, int* dymin, int* dymax, int* dxmin, int* dxmax) {
@@ -433,15 +446,20 @@ int launch_conv_mfma_x4(const stcd_conv_geom g[4], const ConvMfmaPlan p[4], cons
         lds = std::max(lds, conv_mfma_args(g[k], p[k], in, wf[k], bias, out, false, j.a[k]));
     }
     if (lds > 160 * 1024) return 1;
-    dim3 grid((unsigned)(j.a[0].tiles_x * j.a[0].tiles_y * g[0].n), (unsigned)(p[0].NTtot / p[0].NT), 4);
+    const int64_t tiles = (int64_t)j.a[0].tiles_x * j.a[0].tiles_y * g[0].n * (p[0].NTtot / p[0].NT);
+    static const int seq_env = [] { const char* e = getenv("STCD_X4_SEQ"); return e ? atoi(e) : -1; }();      // 0 / 1 force; default: by size
+    const bool seq = seq_env >= 0 ? seq_env != 0 : tiles >= 1024;
+    dim3 grid((unsigned)(j.a[0].tiles_x * j.a[0].tiles_y * g[0].n), (unsigned)(p[0].NTtot / p[0].NT), seq ? 1 : 4);
 #define LAUNCH_X4(N_)                                                                                             \
     do {                                                                                                          \
         static bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
             (void)hipFuncSetAttribute((const void*)k_conv_mfma_x4<N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void*)k_conv_mfma_x4s<N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                      \
         }                                                                                                         \
-        k_conv_mfma_x4<N_><<<grid, 256, lds, s>>>(j);                                                             \
+        if (seq) k_conv_mfma_x4s<N_><<<grid, 256, lds, s>>>(j);                                                   \
+        else k_conv_mfma_x4<N_><<<grid, 256, lds, s>>>(j);                                                        \
     } while (0)
     switch (p[0].NT) {
         case 1: LAUNCH_X4(1); break;
@@ -1306,7 +1324,9 @@ bool conv_small_ok(const stcd_conv_geom& g, const ConvMfmaPlan& p) {
     const int HH = 7 * g.in_stride + (dymax - dymin) + 1, HWp = 15 * g.in_stride + (dxmax - dxmin) + 1;
     // measured: the register-resident filter only pays for one n-tile and <= 5 k-steps (Ci <= 16, Co <= 16);
     // wider cases run faster on the generic kernel (fewer registers, more waves)
-    return ks <= 5 && nt == 1 && g.ci <= 32 && HH * HWp * (g.ci / 8) <= 3 * 256;
+    // (STCD_SMALL_NT2=1: also two n-tiles, i.e. the 16 -> 32-channel layers -- re-measured in round 4)
+    static const int nt2 = [] { const char* e = getenv("STCD_SMALL_NT2"); return e ? atoi(e) : 0; }();
+    return ks <= 5 && nt <= (nt2 ? 2 : 1) && g.ci <= 32 && HH * HWp * (g.ci / 8) <= 3 * 256;
 }
 
 // blocks the launcher will use (the BN-partial slab is sized from this)
