@@ -447,8 +447,10 @@ int launch_conv_mfma_x4(const stcd_conv_geom g[4], const ConvMfmaPlan p[4], cons
     }
     if (lds > 160 * 1024) return 1;
     const int64_t tiles = (int64_t)j.a[0].tiles_x * j.a[0].tiles_y * g[0].n * (p[0].NTtot / p[0].NT);
-    static const int seq_env = [] { const char* e = getenv("STCD_X4_SEQ"); return e ? atoi(e) : -1; }();      // 0 / 1 force; default: by size
-    const bool seq = seq_env >= 0 ? seq_env != 0 : tiles >= 1024;
+    // MEASURED SLOWER (round 4, SiamUnet_diff 16 x 256^2: the four launches 0.088 -> 0.133 ms per step; SNUNet 12.94 -> 13.20 ms): a
+    // quarter of the blocks, each four times as long, fill the chip worse than the extra input fetches cost -- opt-in (STCD_X4_SEQ=1)
+    static const int seq_env = [] { const char* e = getenv("STCD_X4_SEQ"); return e ? atoi(e) : 0; }();
+    const bool seq = seq_env != 0 && tiles >= 1;
     dim3 grid((unsigned)(j.a[0].tiles_x * j.a[0].tiles_y * g[0].n), (unsigned)(p[0].NTtot / p[0].NT), seq ? 1 : 4);
 #define LAUNCH_X4(N_)                                                                                             \
     do {                                                                                                          \
@@ -1767,6 +1769,15 @@ ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int gr
         };
         const int ntmax = std::min(4, p.NT);
         NT = 0;
+        // STCD_CONV_RES_ONE=<tiles>: layers with at most that many 16 x 16 tiles take the widest slice that fits ONE block per CU
+        // (fewer, longer pipeline steps and fewer re-reads of the input per output slice) -- round-4 experiment, DESIGN.md section 4
+        static const int one_tiles = [] { const char* e = getenv("STCD_CONV_RES_ONE"); return e ? atoi(e) : 0; }();
+        {
+            const int64_t tiles_ = (int64_t)g.n * ((g.wm + 15) / 16) * ((g.hm + 15) / 16);
+            if (one_tiles > 0 && tiles_ <= one_tiles)
+                for (int nt = ntmax; nt >= 1 && !NT; nt >>= 1)
+                    if (fits(nt, 1)) NT = nt;
+        }
         for (int nt = ntmax; nt >= 1 && !NT; nt >>= 1)
             if (fits(nt, 2) && nchunks * 9 * nt <= conv_res_filter_budget()) NT = nt;
         for (int nt = ntmax; nt >= 1 && !NT; nt >>= 1)

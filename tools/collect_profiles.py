@@ -72,5 +72,21 @@ if dom and r.get("traffic") is None:      # a kernel CLASS of the engine's timer
 r["traffic_step"] = int(step_total); r["traffic_step_source"] = f"profiles/{tag}_pmc_traffic.txt"
 if "step" in r and r["step"].get("alg_bytes"):
     r["traffic_step_over_algorithmic"] = round(step_total / r["step"]["alg_bytes"], 3)
+# the dominant kernel's fraction must follow from the committed rocprof summary: merged AverageNs over its instantiations
+rk = collections.defaultdict(lambda: [0.0, 0])
+for row in csv.DictReader(l for l in open(f"{dst}/{tag}_kernel_stats.csv") if not l.startswith("#")):
+    nm = short(row["Name"])
+    rk[nm.split("<")[0]][0] += float(row["TotalDurationNs"]); rk[nm.split("<")[0]][1] += int(row["Calls"])
+if dom and dom.split("<")[0] in rk and r.get("alg_bytes_per_launch"):
+    tot_ns, calls = rk[dom.split("<")[0]]
+    avg_us = tot_ns / calls / 1e3
+    r["rocprof_avg_launch_us"] = round(avg_us, 3)
+    if r.get("bound") == "hbm":
+        r["rocprof_frac"] = round(r["alg_bytes_per_launch"] / (avg_us * 1e-6) / 1e9 / r["peak"], 4)
+    else:
+        r["rocprof_frac"] = round(r["alg_flops_per_launch"] / (avg_us * 1e-6) / 1e12 / r["peak"], 4)
+    r["rocprof_note"] = ("merged AverageNs of the dominant kernel's instantiations in profiles/%s_kernel_stats.csv (the same command; ALL its launches: "
+                         "warm-up and timed steps with the weight gradients on the side stream -- concurrent kernels stretch each other's durations -- "
+                         "plus the instrumented steps, which run on one stream)" % tag)
 open(f"{dst}/{tag}_bench.json", "w").write(json.dumps(d) + "\n")
-print("bench line:", {k: r.get(k) for k in ("kernel", "traffic", "traffic_step", "traffic_step_over_algorithmic")})
+print("bench line:", {k: r.get(k) for k in ("kernel", "frac", "avg_launch_us", "rocprof_avg_launch_us", "rocprof_frac", "traffic", "traffic_step", "traffic_step_over_algorithmic")})
