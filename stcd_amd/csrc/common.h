@@ -113,7 +113,15 @@ __device__ __forceinline__ double bn_acc_get(const long long* __restrict__ acc, 
     long long s = 0;
 #pragma unroll
     for (int r = 0; r < BN_REP; ++r) s += acc[(((int64_t)r * groups + g) * 2 + which) * C + c];
-    return (double)s / (double)scale;
+    return (double)s * (1.0 / (double)scale);      // (the scales are powers of two: exact, and no double-precision division)
+}
+// 1 / sqrt(x) in double without a double-precision square root or division (software sequences of ~40 instructions each on the
+// consumer blocks' critical path: every block of every kernel that applies a BatchNorm builds its table first): a float seed and two
+// Newton steps -- 2^-23 -> 2^-45 -> 2^-89 relative error
+__device__ __forceinline__ double bn_rsqrt(double x) {
+    double y = (double)__frsqrt_rn((float)x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y * (1.5 - 0.5 * x * y * y);
 }
 
 // ---- consumer-side "finalize": every block of a kernel that APPLIES a BatchNorm derives the per-channel constants of all
@@ -129,6 +137,7 @@ __device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __rest
     // channels [cbase, cbase + CS) only (CS == 0: all): wide layers give every block one 64-channel slab, so its prologue reads
     // 64 channels' accumulators instead of up to 2048
     if (CS == 0) CS = C;
+    const double inv_n = 1.0 / (double)ppg;            // the ONE double-precision division of a thread's table entries
     for (int cl = threadIdx.x; cl < CS; cl += blockDim.x) {
         const int c = cbase + cl;
         if (facc) {
@@ -138,10 +147,10 @@ __device__ __forceinline__ void bn_fwd_table(float* tab, const long long* __rest
                 int g = gi + g_first;                   // BatchNorm on them: g_first, g_first + 1, ... (cyclic)
                 if (g >= groups) g -= groups;
                 const double s1 = bn_acc_get(facc, groups, C, g, 0, c, BN_FS1), s2 = bn_acc_get(facc, groups, C, g, 1, c, BN_FS2);
-                const double mean = s1 / (double)ppg;
-                double var = s2 / (double)ppg - mean * mean;
+                const double mean = s1 * inv_n;
+                double var = s2 * inv_n - mean * mean;
                 if (var < 0.0) var = 0.0;
-                const double invstd = 1.0 / sqrt(var + (double)eps);
+                const double invstd = bn_rsqrt(var + (double)eps);
                 const float sc = (float)(gam * invstd), sh = (float)(bet - mean * gam * invstd);
                 tab[(g * 2 + 0) * CS + cl] = sc;
                 tab[(g * 2 + 1) * CS + cl] = sh;

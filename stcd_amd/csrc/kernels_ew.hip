@@ -310,6 +310,7 @@ __device__ __forceinline__ void bn_bwd_table(float* tab, const long long* __rest
                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int groups, int64_t ppg,
                                              bool publish, int cbase = 0, int CS = 0, float* __restrict__ dbeta_copy = nullptr) {
     if (CS == 0) CS = C;                         // channel slab [cbase, cbase + CS), see bn_fwd_table
+    const double inv_n = 1.0 / (double)ppg;
     for (int cl = threadIdx.x; cl < CS; cl += blockDim.x) {
         const int c = cbase + cl;
         double tg = 0.0, tb = 0.0;
@@ -317,7 +318,7 @@ __device__ __forceinline__ void bn_bwd_table(float* tab, const long long* __rest
             const double s1 = bn_acc_get(bacc, groups, C, g, 0, c, BN_BS), s2 = bn_acc_get(bacc, groups, C, g, 1, c, BN_BS);
             const float* st = stat + (int64_t)g * 4 * C;
             const double mean = st[c], invstd = st[C + c], scale = st[2 * C + c];
-            const double k1 = s1 / (double)ppg, k2 = s2 / (double)ppg;
+            const double k1 = s1 * inv_n, k2 = s2 * inv_n;
             float* bw = tab + (int64_t)g * 5 * CS;
             bw[cl] = (float)scale;
             bw[CS + cl] = st[3 * C + c];
