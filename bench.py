@@ -468,6 +468,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     last_loss = loss.item()
+    # the host's OWN cost of a step: enqueue time into an idle queue (a synchronize in front of every step).  `host_enqueue_ms_per_step`
+    # above is taken while the GPU is busy: once the hardware queue is full the enqueue blocks, so on a GPU-bound step it approaches
+    # the step time whatever the host costs (ChangeFormer: 19.3 ms of 25.1 with 3.9 ms of real host work per step)
+    idle = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step()
+        idle.append(time.perf_counter() - th)
+    torch.cuda.synchronize()
+    host_idle_ms = sorted(idle)[len(idle) // 2] * 1e3
     my_rate = args.batch * args.steps / own_elapsed
     rank_rates = [my_rate]
     if world > 1:      # self-check of the first multi-GPU run: every rank's own pairs/s and the collective backend in use
@@ -484,6 +495,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 4),     # << ms_per_step: the GPU is the bound, not the host
+        "host_ms_per_step_idle_queue": round(host_idle_ms, 4),                  # the host's own work per step (median of 5 steps, GPU idle)
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{NAMES[args.model]}(3,{args.label}) {args.size}x{args.size} full training step "

@@ -39,7 +39,7 @@ class _FlatAdamBase(torch.optim.Optimizer):
     # ---- flat state tied to the model's current flat buffers
     def _ensure_state(self):
         m = self._model
-        dev = next(m.parameters()).device
+        dev = m._flat_params.device if getattr(m, "_flat_params", None) is not None else next(m.parameters()).device
         if dev.type != "cuda":
             raise StcdError("move the model to the GPU before stepping / loading the flat optimizer (no CPU fallback)")
         m._ensure_flat(dev)                    # no-op once the flat views exist (also re-flattens after .to())
@@ -57,7 +57,7 @@ class _FlatAdamBase(torch.optim.Optimizer):
         copied into place first."""
         m = self._model
         fg = m._flat_grads
-        for p, info in zip(m.parameters(), m._engine.params):
+        for p, info in zip(m._live_params() or m.parameters(), m._engine.params):
             if p.grad is None:
                 raise StcdError("step() without gradients: call backward() first")
             if p.grad.data_ptr() != fg.data_ptr() + 4 * info.offset:
