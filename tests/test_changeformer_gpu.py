@@ -3,6 +3,8 @@ restated from /root/reference/models/ChangeFormer.py:195-358,472-523,1342-1701 -
 decoder-head blocks are pinned by tests/golden/g17_cf_base.npz).  fp32 engine: the five outputs and the loss at 1e-3, every
 parameter's gradient per tensor (relative l2 / cosine, tests/_util.py), BatchNorm running statistics; identical dropout masks on
 both sides (the engine's counter hash, reproduced by oracle.changeformer_ref.engine_masks from the engine's own site table)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -343,7 +345,7 @@ def test_backward_through_an_eval_forward_raises():
     assert torch.equal(outs2[-1], outs[-1].detach())
 
 
-@pytest.mark.parametrize("cfg_name,B,H,W", [("tiny", 2, 64, 64), ("v6", 1, 64, 64), ("mitb0", 2, 64, 64)])
+@pytest.mark.parametrize("cfg_name,B,H,W", [("tiny", 2, 64, 64), ("mitb0", 2, 64, 64)] + ([("v6", 1, 64, 64)] if os.environ.get("STCD_TEST_FULL") else []))
 def test_bf16_engine_against_the_bf16_emulating_oracle(cfg_name, B, H, W):
     """BASELINE.json configs[4] is ChangeFormer in bf16 (round-3 review, weak #2: its bf16 parity rested on fitted bounds, worst
     gradient cosine 0.89 against the fp32 oracle).  oracle/changeformer_bf16.py rounds exactly what the engine stores (every CfT
