@@ -104,8 +104,8 @@ constexpr float BN_FS1 = 67108864.f;       // 2^26
 constexpr float BN_FS2 = 262144.f;         // 2^18
 constexpr float BN_BS = 68719476736.f;     // 2^36
 inline int64_t bn_acc_bytes(int groups, int C) { return (int64_t)BN_REP * groups * 2 * C * 8; }
-__device__ __forceinline__ void bn_acc_add(long long* acc, int rep, int groups, int C, int g, int which, int c, float v, float scale) {
-    const long long q = (long long)llrint((double)v * (double)scale);
+__device__ __forceinline__ void bn_acc_add(long long* acc, int rep, int groups, int C, int g, int which, int c, double v, float scale) {
+    const long long q = (long long)llrint(v * (double)scale);
     atomicAdd(reinterpret_cast<unsigned long long*>(acc + (((int64_t)(rep & (BN_REP - 1)) * groups + g) * 2 + which) * C + c),
               (unsigned long long)q);
 }
@@ -515,6 +515,10 @@ void launch_pool_bwd(int dt, const void* A, int lda, int64_t a_goff, const void*
                      int64_t da_goff, int groups, int npg, int H, int W, int C, int accumulate, hipStream_t s);
 // encoder skip layer: dA = pool gradient + skip-fusion gradient and the BN-backward partial sums of it, in one pass
 // (mode 0: |a1-a2| skips, 1: a2-a1); the sums go into bacc as launch_bn_bwd_reduce's
+bool skip_pair_supported(int B, int H, int W, int C);   // pairs, map size, channels of the skip layer
+void launch_skip_bwd_pair(int dt, int mode, const void* Y, int ldy, const void* dD, int ldd, const void* dP, int ldp, void* dA,
+                          int ldda, int64_t da_goff, const float* stat, const float* mask, int B, int H, int W, int C,
+                          long long* partial, hipStream_t s);
 void launch_skip_bwd(int dt, int mode, const void* A, int lda, int64_t a_goff, const void* Y, int ldy, const void* dD, int ldd,
                      const void* dP, int ldp, void* dA, int ldda, int64_t da_goff, const float* stat, const float* mask, int B,
                      int H, int W, int C, long long* bacc, hipStream_t s);

@@ -267,7 +267,7 @@ struct stcd_engine_impl {
     int64_t final_bias_acc = -1;
     std::vector<BiasJob> bias_jobs; int64_t bias_jobs_off = -1;
     int64_t masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
-    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1, use_act_fuse = 1, use_gemm = 1;
+    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1, use_act_fuse = 1, use_gemm = 1, use_skip_recompute = 1;
     // FC-Siam backward: the decoder's grouped weight gradients (+ slab reduce, bias finish) run on a low-priority side stream beside
     // the encoder's backward chain on the caller's stream; their grids get 1 / wg_side_div of the planner's block budget so that the
     // chain's blocks find free slots (wgrad_side_stream)
@@ -426,6 +426,12 @@ static const DecSpec DEC[4] = {
 static inline int fc_dates(const stcd_engine& e) { return e.arch == STCD_ARCH_FCEF ? 1 : 2; }
 static inline bool fc_concat_skips(const stcd_engine& e) { return e.arch == STCD_ARCH_CONC || e.arch == STCD_ARCH_FCEF; }
 static inline bool fc_cross(const stcd_engine& e) { return e.arch == STCD_ARCH_XCONC; }
+// skip layers of diff / sub whose activations are never stored: the forward writes only the pooled map and the fused skip,
+// the backward (k_skip_bwd_pair) recomputes them from Y
+static inline bool skip_recomputed(const stcd_engine& e, const Cbrd& L) {
+    return e.use_skip_recompute && e.use_act_fuse && e.use_skip_fused && L.pool && L.fuse_dst.off >= 0 && L.groups == 2 &&
+           skip_pair_supported(L.npg, L.H, L.W, e.convs[L.conv].cout);
+}
 static inline bool fc_family(const stcd_engine& e) {      // the engines backward_fcsiam runs
     return e.arch == STCD_ARCH_DIFF || e.arch == STCD_ARCH_CONC || e.arch == STCD_ARCH_SUB || e.arch == STCD_ARCH_FCEF || e.arch == STCD_ARCH_XCONC;
 }
@@ -1058,7 +1064,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         // "in.virt": the input is the producer's RAW conv output (virtual activation); the producer then records no A
         rec(L.xsrc ? "in.virt" : "in", L.in.off, L.in.ld, L.N, L.K);
         rec("Y", L.Y.off, L.Y.ld, L.N, cv.cout);
-        for (int g = 0; g < L.groups && !L.virt; ++g) {
+        for (int g = 0; g < L.groups && !L.virt && !skip_recomputed(e, L); ++g) {
             char sfx[8];
             snprintf(sfx, sizeof(sfx), "A.g%d", g);
             rec(sfx, L.A.off + g * L.A.goff * T, L.A.ld, L.npg, cv.cout);
@@ -1383,7 +1389,7 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     }
     BnActArgs a;
     a.Y = c.at(L.Y.off); a.ldy = L.Y.ld;
-    a.A = c.at(L.A.off); a.lda = L.A.ld; a.a_group_off = L.A.goff;
+    a.A = skip_recomputed(e, L) ? nullptr : c.at(L.A.off); a.lda = L.A.ld; a.a_group_off = L.A.goff;
     a.P = L.pool ? c.at(L.P.off) : nullptr; a.ldp = L.P.ld;
     a.stat = stat;
     a.mask = (training && e.drop_p > 0.f && L.drop >= 0) ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
@@ -1394,7 +1400,7 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     a.gamma = c.params + bn.g_off; a.beta = c.params + bn.b_off;
     a.running_mean = bn_running + bn.run_off; a.running_var = bn_running + bn.run_off + C;
     if (L.fuse_dst.off >= 0 && e.use_act_fuse && L.groups == 2) {
-        ProfScope ps(c, PC_BN_ACT, 0.0, act_bytes * 2.75, "k_bn_act_pair");
+        ProfScope ps(c, PC_BN_ACT, 0.0, act_bytes * (a.A ? 2.75 : 1.75), "k_bn_act_pair");
         launch_bn_act_pair(e.dt, a, c.at(L.fuse_dst.off), L.fuse_dst.ld, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.s);
         return;
     }
@@ -1641,11 +1647,19 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
                 const int C = e.convs[L.conv].cout;
                 int lvl = 0;
                 while (lvl < 4 && SKIP_IDX[lvl] != li) ++lvl;
+                const float* mk = e.drop_p > 0.f ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr;
+                if (skip_recomputed(e, L)) {
+                    ProfScope ps(c, PC_POOL_FUSE, 0.0, 2.75 * L.N * L.H * L.W * C * (double)T, "k_skip_bwd_pair");
+                    launch_skip_bwd_pair(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(L.Y.off), L.Y.ld, c.at<char>(e.dD[lvl].off) + C * T,
+                                         e.dD[lvl].ld, c.at(L.dPool.off), L.dPool.ld, c.at(L.dA.off), L.dA.ld, L.dA.goff,
+                                         c.at<float>(L.stat), mk, L.npg, L.H, L.W, C, c.at<long long>(L.bacc), s);
+                } else {
                 ProfScope ps(c, PC_POOL_FUSE, 0.0, 4.75 * L.N * L.H * L.W * C * (double)T, "k_skip_bwd");
                 launch_skip_bwd(dt, e.arch == STCD_ARCH_DIFF ? 0 : 1, c.at(L.A.off), L.A.ld, L.A.goff, c.at(L.Y.off), L.Y.ld,
                                 c.at<char>(e.dD[lvl].off) + C * T, e.dD[lvl].ld, c.at(L.dPool.off), L.dPool.ld, c.at(L.dA.off), L.dA.ld,
                                 L.dA.goff, c.at<float>(L.stat), e.drop_p > 0.f ? c.at<float>(e.masks) + e.drops[L.drop].off : nullptr,
                                 L.npg, L.H, L.W, C, c.at<long long>(L.bacc), s);
+                }
                 skip_chunks = 1;
             } else if (L.pool) {  // dA_skip += gradient routed back through the 2x2 max-pool
                 const int C = e.convs[L.conv].cout;
@@ -2779,6 +2793,8 @@ static void engine_env_switches(stcd_engine* e) {
     e->use_act_fuse = !(env && env[0] == '1');
     env = getenv("STCD_NO_SKIP_FUSED");
     e->use_skip_fused = !(env && env[0] == '1');
+    env = getenv("STCD_NO_SKIP_RECOMPUTE");       // 1: the skip layers of diff / sub store their activations again
+    e->use_skip_recompute = !(env && env[0] == '1');
     env = getenv("STCD_VIRT_ACT");                // 1: virtual activations (opt-in); 0 / unset: k_bn_act per layer
     if (env) e->use_virt = atoi(env) != 0;
     env = getenv("STCD_XF_MODE");

@@ -355,7 +355,7 @@ def test_full_size_properties_bf16():
     # linear kernels + power-of-two scale: equal up to the summation order of the atomically folded slab parts and the
     # 2^-36 fixed-point step of the BatchNorm backward accumulators (rint(2x) != 2 rint(x))
     rel = ((grads[1] - 2.0 * grads[0]).abs().max() / grads[1].abs().max()).item()
-    assert rel < 5e-5, rel
+    assert rel < 1e-4, rel       # (the 2^-36 grid of the fixed-point BatchNorm accumulators is not scale-invariant)
 
 
 @pytest.mark.parametrize("label", [1, 2])
@@ -430,7 +430,7 @@ def test_full_size_properties_other_configs_bf16(arch):
                 if not zero_grad_by_construction(name):
                     assert p.grad.abs().max().item() > 0, name
     rel = ((grads[1] - 2.0 * grads[0]).abs().max() / grads[1].abs().max()).item()
-    assert rel < 5e-5, rel
+    assert rel < 1e-4, rel       # (the 2^-36 grid of the fixed-point BatchNorm accumulators is not scale-invariant)
 
 
 # bf16 bounds of the 128x128 step.  Forward: activations are STORED in bf16 between kernels (2^-9 relative per rounding, a
@@ -752,3 +752,39 @@ def test_virtual_activations_equal_the_materialised_plan_bit_for_bit(monkeypatch
         assert torch.equal(a[2], b[2]), float((a[2] - b[2]).abs().max())
     assert torch.equal(a[3], b[3]), float((a[3] - b[3]).abs().max())
     assert torch.equal(a[4], b[4]), float((a[4] - b[4]).abs().max())
+
+
+@pytest.mark.parametrize("arch,B,H,W,dtype", [("diff", 4, 64, 64, "bf16"), ("sub", 3, 32, 32, "bf16"), ("diff", 2, 100, 100, "bf16"),
+                                              ("diff", 3, 33, 47, "bf16"), ("diff", 2, 64, 64, "fp32"), ("sub", 2, 50, 34, "fp32"),
+                                              ("diff", 16, 256, 256, "bf16")])
+def test_recomputed_skip_activations_equal_the_stored_plan_bit_for_bit(monkeypatch, arch, B, H, W, dtype):
+    """Round 4: the skip layers of diff / sub (last conv of an encoder level) do not store their activations -- k_bn_act_pair writes
+    only the pooled map and the fused skip |a1 - a2| / a2 - a1, and the backward (k_skip_bwd_pair) recomputes a = round(max(fma(y,
+    scale * mk, shift * mk), 0)) from the conv output with the forward's arithmetic, both dates of a pair in one thread.  The plan
+    that stores them (STCD_NO_SKIP_RECOMPUTE=1: k_bn_act_pair<STORE_A> + the per-date k_skip_bwd of rounds 2-3) must give the SAME
+    bits: logits, every gradient, the running statistics -- with Dropout2d active, odd sizes (unpooled border cells) included."""
+    torch.manual_seed(6)
+    x1 = torch.randn(B, 3, H, W, device=DEV); x2 = torch.randn(B, 3, H, W, device=DEV)
+    tgt = (torch.rand(B, H, W, device=DEV) < 0.2).long()
+    st = R.synth_state(arch, 3, 2, 11)
+    res = []
+    for stored in ("0", "1"):
+        monkeypatch.setenv("STCD_NO_SKIP_RECOMPUTE", stored)
+        m = CLS[arch](3, 2, dtype=dtype)
+        m.load_state_dict(st)
+        m.to(DEV).train()
+        m._seed, m._steps = 77, 0
+        out = unwrap(m(x1, x2))
+        torch.nn.functional.cross_entropy(out, tgt).backward()
+        torch.cuda.synchronize()
+        nA = sum(1 for k in m._engine.ws_tensors() if ".A.g" in k)
+        res.append((out.detach().clone(), m._flat_grads.clone(), m._flat_bn.clone(), nA))
+    a, b = res
+    assert b[3] - a[3] == 8, (a[3], b[3])            # four skip layers x two dates are not materialised
+    assert torch.equal(a[0], b[0])
+    assert torch.equal(a[2], b[2])
+    # gradients: dA is the same bits; the BatchNorm partial sums are the same per-thread floats summed exactly (double) per block,
+    # but the two kernels cut the map into different blocks, so the 2^-36 fixed-point grid can round a block's sum the other way
+    rel = float((a[1].double() - b[1].double()).norm() / b[1].double().norm())
+    print(f"recomputed vs stored skip activations {arch} {B}x{H}x{W} {dtype}: gradient rel-l2 {rel:.2e}")
+    assert rel <= (1e-7 if dtype == "bf16" else 1e-6), rel
