@@ -342,7 +342,8 @@ int stcd_op_bn_act(int dtype, const stcd_map_geom* g, const void* y, int ldy, co
                    float* running_mean, float* running_var, const float* mask, int relu, int training, void* a, int lda,
                    void* pool, int ldp, float* stat, void* scratch, int64_t scratch_bytes, void* hip_stream);
 /* the same for the last conv of an encoder level (groups == 2, training, ReLU), both dates in one pass, also writing the
- * bi-temporal skip fused = |a1 - a2| (fuse_mode 0, SiamUnet_diff.py:150) or a2 - a1 (1, SiamUnet_sub.py:150): [n/2] images */
+ * bi-temporal skip fused = |a1 - a2| (fuse_mode 0, SiamUnet_diff.py:150) or a2 - a1 (1, SiamUnet_sub.py:150): [n/2] images.
+ * a == NULL: the activations themselves are not written (only pool and fused; see stcd_op_skip_bwd) */
 int stcd_op_bn_act_pair(int dtype, const stcd_map_geom* g, const void* y, int ldy, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, const float* mask, int fuse_mode, void* a, int lda, void* pool,
                         int ldp, void* fused, int ldf, float* stat, void* scratch, int64_t scratch_bytes, void* hip_stream);
@@ -375,7 +376,9 @@ int stcd_op_fuse_bwd(int dtype, int mode, const stcd_map_geom* g, const void* a,
 int stcd_op_rep_pad(int dtype, const stcd_map_geom* g, void* d, int ld, int h0, int w0, void* hip_stream);
 int stcd_op_rep_pad_bwd(int dtype, const stcd_map_geom* g, void* dd, int ld, int h0, int w0, void* hip_stream);
 /* backward of an encoder level's last conv in one pass (groups == 2): da = max-pool gradient of dpool + skip-fusion
- * gradient of dd, then the BatchNorm backward of it: dy, dgamma, dbeta */
+ * gradient of dd, then the BatchNorm backward of it: dy, dgamma, dbeta.  a == NULL: the activations were not stored
+ * (stcd_op_bn_act_pair with a == NULL; the engine's default plan for diff / sub) and are recomputed from y, stat and mask with
+ * the forward's arithmetic -- channels a multiple of 8 and a power of two <= 256 */
 int stcd_op_skip_bwd(int dtype, int mode, const stcd_map_geom* g, const void* a, int lda, const void* y, int ldy, const void* dd,
                      int ldd, const void* dpool, int ldp, const float* stat, const float* mask, void* da, int ldda, void* dy,
                      int lddy, float* dgamma, float* dbeta, void* scratch, int64_t scratch_bytes, void* hip_stream);

@@ -73,12 +73,15 @@ struct WgradOp {
     int group = -1;                      // index of its WgradGroup inside e.wgroups[stage]
     // X is a virtual activation (the producer's raw conv output, transformed while staged: XfSrc / wgrad_job_set_xf); xf_C == 0: plain
     int64_t xf_stat_off = -1, xf_mask_off = -1; int xf_C = 0, xf_groups = 1, xf_npg = 1;
+    bool tail = false;                   // the network's first conv: its dY is the LAST tensor of the backward, so it gets a group of
+                                         // its own -- its stage-mates' grid goes out as soon as THEY are ready, not with it
     bool own_taps = false;               // filter taps (ky, kx) of this launch given here instead of conv.fwd.ky/kx[tap0 + t]
     int8_t oky[9] = {0}, okx[9] = {0};   // (the 7x7 stem: 49 taps spread over 7 launches)
 };
 struct WgradGroup {                      // all launches of one kernel variant in one backward stage
     int WCI = 1, NTW = 1; bool t9 = false;
     bool xf = false;                     // its jobs stage X through the virtual-activation transform (k_wgrad_group<.., XF = true>)
+    bool tail = false;                   // holds only the network's first conv (WgradOp::tail)
     int gemm = 0;                        // > 0: k_wgrad_gemm<gemm> group (one-tap launches; WCI / NTW / t9 unused)
     int dma = 0;                         // 1: k_wgrad_dma group (256 x 256 channel tiles, LDS-DMA staging; splits chosen for the group)
     std::vector<WgradJob> jobs;
@@ -267,7 +270,7 @@ struct stcd_engine_impl {
     int64_t final_bias_acc = -1;
     std::vector<BiasJob> bias_jobs; int64_t bias_jobs_off = -1;
     int64_t masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
-    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1, use_act_fuse = 1, use_gemm = 1, use_skip_recompute = 1;
+    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1, use_act_fuse = 1, use_gemm = 1, use_skip_recompute = 1, wg_tail_split = 0;
     // FC-Siam backward: the decoder's grouped weight gradients (+ slab reduce, bias finish) run on a low-priority side stream beside
     // the encoder's backward chain on the caller's stream; their grids get 1 / wg_side_div of the planner's block budget so that the
     // chain's blocks find free slots (wgrad_side_stream)
@@ -580,8 +583,8 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                 std::vector<WgradGroup>& gs = e.wgroups[op->stage];
                 size_t gi = 0;
                 for (; gi < gs.size(); ++gi)
-                    if (gs[gi].gemm == op->plan.gemm && gs[gi].dma == op->plan.dma && gs[gi].WCI == op->plan.WCI && gs[gi].NTW == op->plan.NTW && gs[gi].t9 == t9 && gs[gi].xf == (op->xf_C > 0)) break;
-                if (gi == gs.size()) { WgradGroup g; g.WCI = op->plan.WCI; g.NTW = op->plan.NTW; g.t9 = t9; g.gemm = op->plan.gemm; g.dma = op->plan.dma; g.xf = op->xf_C > 0; gs.push_back(g); }
+                    if (gs[gi].gemm == op->plan.gemm && gs[gi].dma == op->plan.dma && gs[gi].WCI == op->plan.WCI && gs[gi].NTW == op->plan.NTW && gs[gi].t9 == t9 && gs[gi].xf == (op->xf_C > 0) && gs[gi].tail == op->tail) break;
+                if (gi == gs.size()) { WgradGroup g; g.WCI = op->plan.WCI; g.NTW = op->plan.NTW; g.t9 = t9; g.gemm = op->plan.gemm; g.dma = op->plan.dma; g.xf = op->xf_C > 0; g.tail = op->tail; gs.push_back(g); }
                 op->grouped = true;
             }
             for (int st = 0; st < 2; ++st)
@@ -624,7 +627,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
                     std::vector<WgradOp*> ops;
                     int64_t W = 0;
                     for (WgradOp* op : e.wgrad_ops)
-                        if (op->grouped && op->stage == st && !op->plan.gemm && !op->plan.dma && op->plan.WCI == G.WCI && op->plan.NTW == G.NTW && (op->g.ntaps == 9) == G.t9 && (op->xf_C > 0) == G.xf) {
+                        if (op->grouped && op->stage == st && !op->plan.gemm && !op->plan.dma && op->plan.WCI == G.WCI && op->plan.NTW == G.NTW && (op->g.ntaps == 9) == G.t9 && (op->xf_C > 0) == G.xf && op->tail == G.tail) {
                             ops.push_back(op);
                             const int64_t ntiles = (int64_t)op->g.n * ((op->g.wm + 15) / 16) * ((op->g.hm + 7) / 8);
                             W += ntiles * op->plan.gy * op->plan.gz;
@@ -660,7 +663,7 @@ static void build_pack_jobs(stcd_engine& e, Bump& ws) {
             if (op->grouped) {
                 const bool t9 = !op->plan.dma && op->g.ntaps == 9;      // (one LDS-DMA group per stage, whatever the tap count)
                 for (WgradGroup& G : e.wgroups[op->stage])
-                    if (G.gemm == op->plan.gemm && G.dma == op->plan.dma && G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9 && G.xf == (op->xf_C > 0)) {
+                    if (G.gemm == op->plan.gemm && G.dma == op->plan.dma && G.WCI == op->plan.WCI && G.NTW == op->plan.NTW && G.t9 == t9 && G.xf == (op->xf_C > 0) && G.tail == op->tail) {
                         op->group = (int)(&G - e.wgroups[op->stage].data());
                         WgradJob j = op->plan.dma ? wgrad_dma_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
                                    : op->plan.gemm ? wgrad_gemm_make_job(op->g, op->plan, op->in_off, op->dout_off, op->slab, cv.fwd.kpad, cv.fwd.wld)
@@ -951,6 +954,8 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     for (auto& L : e.enc) bind_cbrd(L);
     for (auto& L : e.dec) bind_cbrd(L);
     for (auto& X : e.xc) bind_cbrd(X.res);
+    for (auto& L : e.enc) L.wg.tail = false;
+    if (e.wg_tail_split && !e.enc.empty()) e.enc[0].wg.tail = true;
     for (auto& U : e.ups) {
         const ConvW& cv = e.convs[U.conv];
         for (int ph = 0; ph < 4; ++ph) {
@@ -2795,6 +2800,8 @@ static void engine_env_switches(stcd_engine* e) {
     e->use_skip_fused = !(env && env[0] == '1');
     env = getenv("STCD_NO_SKIP_RECOMPUTE");       // 1: the skip layers of diff / sub store their activations again
     e->use_skip_recompute = !(env && env[0] == '1');
+    env = getenv("STCD_WGRAD_TAIL_SPLIT");        // 1: the first conv's weight gradient gets a grid of its own, so its stage-mates' grid
+    e->wg_tail_split = env && env[0] == '1';      //    goes out ~120 us earlier (measured neutral: the step is HBM-bound)
     env = getenv("STCD_VIRT_ACT");                // 1: virtual activations (opt-in); 0 / unset: k_bn_act per layer
     if (env) e->use_virt = atoi(env) != 0;
     env = getenv("STCD_XF_MODE");

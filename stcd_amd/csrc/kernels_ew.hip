@@ -42,6 +42,41 @@ template <> struct Raw8<float> {
     __device__ __forceinline__ void get(float (&o)[8]) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
 };
 
+// V (4 or 8) consecutive values: the narrower piece halves a thread's registers where a kernel holds many pieces at once
+template <typename T, int V> struct RawV;
+template <typename T> struct RawV<T, 8> : Raw8<T> {};
+template <> struct RawV<bf16, 4> {
+    uint2 v;
+    __device__ __forceinline__ void opaque() { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+    __device__ __forceinline__ void ld(const bf16* p) { v = *reinterpret_cast<const uint2*>(p); }
+    __device__ __forceinline__ void get(float (&o)[4]) const {
+        o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+};
+template <> struct RawV<float, 4> {
+    float4 a;
+    __device__ __forceinline__ void opaque() {}
+    __device__ __forceinline__ void ld(const float* p) { a = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void get(float (&o)[4]) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; }
+};
+template <int V> __device__ __forceinline__ void ldVf(const float* p, float (&v)[V]) {
+#pragma unroll
+    for (int i = 0; i < V / 4; ++i) {
+        const float4 a = *reinterpret_cast<const float4*>(p + 4 * i);
+        v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
+    }
+}
+template <typename T, int V> __device__ __forceinline__ void storeV(T* p, const float (&v)[V]);
+template <> __device__ __forceinline__ void storeV<bf16, 8>(bf16* p, const float (&v)[8]) { store8<bf16>(p, v); }
+template <> __device__ __forceinline__ void storeV<float, 8>(float* p, const float (&v)[8]) { store8<float>(p, v); }
+template <> __device__ __forceinline__ void storeV<bf16, 4>(bf16* p, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+template <> __device__ __forceinline__ void storeV<float, 4>(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // grid of the kernels that build a per-block BatchNorm table in their prologue: capped at ~2 resident rounds of the
 // chip so the table (one dependent round trip + a few double operations per channel) is built <= 2048 times per launch
@@ -169,7 +204,7 @@ void launch_unpack_dw(const PackSpec& ps, const double* dwe, float* gsrc, hipStr
 // Block reduction of per-thread partial sums s1[8], s2[8] (8 consecutive channels of channel block threadIdx.x % cb; pixel lane
 // threadIdx.x / cb; 256 threads).  Returns n and leaves in red[(w * cb + b) * 16 + which * 8 + j], w < n, partial sums such that
 // output (which, c) = sum over w < n of red[(w * cb + (c >> 3)) * 16 + which * 8 + (c & 7)]  (block_reduce16_get).
-// cb a power of two <= 32: a butterfly over the wave's lanes with xor masks >= cb (ds_bpermute, log2(64 / cb) steps), then one
+// cb a power of two, cb * V <= 256 (V = 8 values per thread and sum; block_reduce2<V>: 4 as well): a butterfly over the wave's lanes with xor masks >= cb (ds_bpermute, log2(64 / cb) steps), then one
 // LDS slot per wave and channel block -- IN DOUBLE: the threads' float partials are summed exactly (to 2^-53), so the block's sum
 // does not depend on the summation tree, and the 64-bit fixed-point accumulators behind it are exact anyway.  What remains in
 // float is each thread's own partial over its <= 32 values.  (A float tree gave results ~1 ulp apart from the serial walk it
@@ -177,39 +212,47 @@ void launch_unpack_dw(const PackSpec& ps, const double* dwe, float* gsrc, hipStr
 // The earlier epilogue had 2 * CS threads each walk 256 / cb LDS slots serially: 128 dependent-latency reads at 16 channels, ~5 us
 // per block with the other 224 threads idle -- at 2048+ blocks per launch the largest term of k_skip_bwd / k_bn_reduce at the
 // full-resolution levels.  red: 256 * 16 floats == 256 * 8 doubles.
-__device__ __forceinline__ int block_reduce16(const float (&s1)[8], const float (&s2)[8], const int cb, double* __restrict__ red) {
-    if ((cb & (cb - 1)) == 0 && cb <= 32) {
-        double d[16];
+template <int V>
+__device__ __forceinline__ int block_reduce2(const float (&s1)[V], const float (&s2)[V], const int cb, double* __restrict__ red) {
+    if ((cb & (cb - 1)) == 0 && cb * V <= 256) {
+        double d[2 * V];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { d[j] = (double)s1[j]; d[8 + j] = (double)s2[j]; }
+        for (int j = 0; j < V; ++j) { d[j] = (double)s1[j]; d[V + j] = (double)s2[j]; }
         for (int m = 32; m >= cb; m >>= 1) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) d[j] += __shfl_xor(d[j], m);
+            for (int j = 0; j < 2 * V; ++j) d[j] += __shfl_xor(d[j], m);
         }
         const int wl = threadIdx.x & 63, w = threadIdx.x >> 6;
         if (wl < cb) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) red[(w * cb + wl) * 16 + j] = d[j];
+            for (int j = 0; j < 2 * V; ++j) red[(w * cb + wl) * 2 * V + j] = d[j];
         }
         return 4;
     }
     float* redf = reinterpret_cast<float*>(red);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { redf[threadIdx.x * 16 + j] = s1[j]; redf[threadIdx.x * 16 + 8 + j] = s2[j]; }
+    for (int j = 0; j < V; ++j) { redf[threadIdx.x * 2 * V + j] = s1[j]; redf[threadIdx.x * 2 * V + V + j] = s2[j]; }
     return 256 / cb;
 }
-__device__ __forceinline__ double block_reduce16_get(const double* __restrict__ red, const int n, const int cb, const int which, const int c) {
+template <int V>
+__device__ __forceinline__ double block_reduce2_get(const double* __restrict__ red, const int n, const int cb, const int which, const int c) {
     double a = 0.0;
     if (n == 4) {
 #pragma unroll
-        for (int l = 0; l < 4; ++l) a += red[(l * cb + (c >> 3)) * 16 + which * 8 + (c & 7)];
+        for (int l = 0; l < 4; ++l) a += red[(l * cb + c / V) * 2 * V + which * V + (c % V)];
     } else {
         const float* redf = reinterpret_cast<const float*>(red);
         float af = 0.f;
-        for (int l = 0; l < n; ++l) af += redf[(l * cb + (c >> 3)) * 16 + which * 8 + (c & 7)];
+        for (int l = 0; l < n; ++l) af += redf[(l * cb + c / V) * 2 * V + which * V + (c % V)];
         a = (double)af;
     }
     return a;
+}
+__device__ __forceinline__ int block_reduce16(const float (&s1)[8], const float (&s2)[8], const int cb, double* __restrict__ red) {
+    return block_reduce2<8>(s1, s2, cb, red);
+}
+__device__ __forceinline__ double block_reduce16_get(const double* __restrict__ red, const int n, const int cb, const int which, const int c) {
+    return block_reduce2_get<8>(red, n, cb, which, c);
 }
 
 // ------------------------------------------------------------------ batch-norm statistics
@@ -827,8 +870,8 @@ k_skip_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ Y, in
 // predicates; the skip gradient sign(a0 - a1) * g is formed ONCE per pair element (date 1 uses its negative); a running
 // arg-max instead of a second walk.  Partial sums: the same per-thread values as the per-date kernel and an exact (double)
 // block sum, so both plans give the same BatchNorm sums.  thread = one 2x2 quad x 8 channels of a PAIR.
-template <typename T, bool MASK, int MODE, bool EVEN>
-__global__ void __launch_bounds__(256)
+template <typename T, bool MASK, int MODE, bool EVEN, int V>
+__global__ void __launch_bounds__(256, (V == 4 && sizeof(T) == 2) ? 4 : 1)
 k_skip_bwd_pair(const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int ldd, const T* __restrict__ dP, int ldp,
                 T* __restrict__ dA, GV dav, const float* __restrict__ stat, const float* __restrict__ mask, int B, int H, int W,
                 int C, int lcb, long long* __restrict__ bacc) {
@@ -836,17 +879,17 @@ k_skip_bwd_pair(const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int 
     const int cb = 1 << lcb, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
     const int yc = blockIdx.y, nb = blockIdx.z;
     const int tx = blockIdx.x * 256 + threadIdx.x;
-    const int xc = tx >> lcb, c0 = (tx & (cb - 1)) * 8;
-    float s1[2][8], s2[2][8];
+    const int xc = tx >> lcb, c0 = (tx & (cb - 1)) * V;
+    float s1[2][V], s2[2][V];
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s1[g][j] = s2[g][j] = 0.f;
+        for (int j = 0; j < V; ++j) s1[g][j] = s2[g][j] = 0.f;
     if (xc < Wc) {
         const bool pooled = EVEN || (yc < Hp && xc < Wp);
         bool ok[4];
         uint32_t pix[4];
-        Raw8<T> ry[2][4], rg[4], rp[2];
+        RawV<T, V> ry[2][4], rg[4], rp[2];
         const uint32_t gstride = (uint32_t)B * H * W;        // pixels per date (the launcher checks 2 * B * H * W < 2^31)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -861,34 +904,34 @@ k_skip_bwd_pair(const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int 
         for (int g = 0; g < 2; ++g)     // an un-pooled border cell re-reads cell (0, 0) of its image and ignores it
             rp[g].ld(dP + (uint64_t)((((uint32_t)g * B + nb) * Hp + (pooled ? yc : 0)) * Wp + (pooled ? xc : 0)) * ldp + c0);
         // ---- phase A: the forward's activations of both dates, pixel by pixel -> skip gradient t, running arg-max
-        float t[4][8], best[2][8];
-        int bk[2][8];
+        float t[4][V], best[2][V];
+        int bk[2][V];
         {
-            float sc[2][8], sh[2][8];
+            float sc[2][V], sh[2][V];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const float* st = stat + (g * 4 + 2) * C + c0;
-                ld8f(st, sc[g]); ld8f(st + C, sh[g]);
+                ldVf<V>(st, sc[g]); ldVf<V>(st + C, sh[g]);
                 if constexpr (MASK) {
-                    float mk[8];
-                    ld8f(mask + ((int64_t)g * B + nb) * C + c0, mk);
+                    float mk[V];
+                    ldVf<V>(mask + ((int64_t)g * B + nb) * C + c0, mk);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { sc[g][j] *= mk[j]; sh[g][j] *= mk[j]; }
+                    for (int j = 0; j < V; ++j) { sc[g][j] *= mk[j]; sh[g][j] *= mk[j]; }
                 }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float a[2][8], gk[8];
+                float a[2][V], gk[V];
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    float y[8];
+                    float y[V];
                     ry[g][k].get(y);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) a[g][j] = round_as<T>(fmaxf(fmaf(y[j], sc[g][j], sh[g][j]), 0.f));
+                    for (int j = 0; j < V; ++j) a[g][j] = round_as<T>(fmaxf(fmaf(y[j], sc[g][j], sh[g][j]), 0.f));
                 }
                 rg[k].get(gk);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < V; ++j) {
                     // date 0 receives +sign(a0 - a1) * g, date 1 the negative; "sub" (f2 - f1): date 0 gets -g, date 1 +g
                     if constexpr (MODE == 0) {
                         const float d = a[0][j] - a[1][j];          // branch-free: g with d's sign bit flipped in, 0 where d == 0
@@ -907,18 +950,18 @@ k_skip_bwd_pair(const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int 
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             __builtin_amdgcn_sched_barrier(0);      // keep each date's table loads behind the previous phase (register budget)
-            float mean[8], invstd[8], scale[8], shift[8], mk[8], gp[8];
+            float mean[V], invstd[V], scale[V], shift[V], mk[V], gp[V];
             const float* st = stat + (int64_t)g * 4 * C + c0;
-            ld8f(st, mean); ld8f(st + C, invstd); ld8f(st + 2 * C, scale); ld8f(st + 3 * C, shift);
-            if constexpr (MASK) ld8f(mask + ((int64_t)g * B + nb) * C + c0, mk);
+            ldVf<V>(st, mean); ldVf<V>(st + C, invstd); ldVf<V>(st + 2 * C, scale); ldVf<V>(st + 3 * C, shift);
+            if constexpr (MASK) ldVf<V>(mask + ((int64_t)g * B + nb) * C + c0, mk);
             rp[g].get(gp);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float v[8], y[8];
+                float v[V], y[V];
                 ry[g][k].opaque();
                 ry[g][k].get(y);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < V; ++j) {
                     float da = g ? -t[k][j] : t[k][j];
                     if (pooled && bk[g][j] == k) da += gp[j];
                     da = round_as<T>(da);
@@ -929,7 +972,7 @@ k_skip_bwd_pair(const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int 
                     s1[g][j] += dz;
                     s2[g][j] = fmaf(__fmul_rn(dz, y[j] - mean[j]), invstd[j], s2[g][j]);
                 }
-                if (ok[k]) store8<T>(dA + g * dav.goff + (uint64_t)pix[k] * dav.ld + c0, v);
+                if (ok[k]) storeV<T, V>(dA + g * dav.goff + (uint64_t)pix[k] * dav.ld + c0, v);
             }
         }
     }
@@ -937,11 +980,11 @@ k_skip_bwd_pair(const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int 
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         if (g) __syncthreads();
-        const int nred = block_reduce16(s1[g], s2[g], cb, red);
+        const int nred = block_reduce2<V>(s1[g], s2[g], cb, red);
         __syncthreads();
         for (int o = threadIdx.x; o < 2 * C; o += 256) {
             const int which = o / C, c = o - which * C;
-            const double a_ = block_reduce16_get(red, nred, cb, which, c);
+            const double a_ = block_reduce2_get<V>(red, nred, cb, which, c);
             bn_acc_add(bacc, rep, 2, C, g, which, c, a_, BN_BS);
         }
     }
@@ -1578,32 +1621,42 @@ void launch_skip_bwd(int dt, int mode, const void* A, int lda, int64_t a_goff, c
 #undef SKIP_BWD_K
 }
 
+// channels per thread: 8 (2 waves / SIMD, fewer instructions per element) or 4 (4 waves / SIMD).  Measured at 16 pairs of 256 x 256
+// (us, V = 8 / V = 4): level 1 (16 ch, 256^2) 75.3 / 60.4; level 2 32.1 / 32.0; level 3 23.1 / 27.5; level 4 13.4 / 19.4 -- the
+// narrow piece pays where the map is large enough for the latency hiding to matter.  STCD_SKIP_PAIR_V=4|8 forces one.
+static int skip_pair_v(int B, int H, int W, int C) {
+    static const int env = [] { const char* e = getenv("STCD_SKIP_PAIR_V"); return e ? atoi(e) : 0; }();
+    if (env == 4 || env == 8) return env;
+    return (int64_t)B * H * W * C >= ((int64_t)12 << 20) ? 4 : 8;
+}
 bool skip_pair_supported(int B, int H, int W, int C) {
-    const int cb = C / 8;
-    return C % 8 == 0 && cb >= 1 && cb <= 32 && (cb & (cb - 1)) == 0 && (int64_t)2 * B * H * W < ((int64_t)1 << 31) && B <= 65535 &&
-           (H + 1) / 2 <= 65535;
+    const int V = skip_pair_v(B, H, W, C), cb = C / V;
+    return C % 8 == 0 && cb >= 1 && cb * V <= 256 && (cb & (cb - 1)) == 0 && (int64_t)2 * B * H * W < ((int64_t)1 << 31) &&
+           B <= 65535 && (H + 1) / 2 <= 65535;
 }
 void launch_skip_bwd_pair(int dt, int mode, const void* Y, int ldy, const void* dD, int ldd, const void* dP, int ldp, void* dA,
                           int ldda, int64_t da_goff, const float* stat, const float* mask, int B, int H, int W, int C,
                           long long* partial, hipStream_t s) {
-    const int cb = C / 8;
+    const int V = skip_pair_v(B, H, W, C), cb = C / V;
     int lcb = 0;
     while ((1 << lcb) < cb) ++lcb;
     if (!skip_pair_supported(B, H, W, C))
     {   // (skip_pair_supported(): the engine plans this kernel only for shapes that pass)
-        set_error("launch_skip_bwd_pair: channels / 8 must be a power of two <= 32 and 2 * B * H * W < 2^31");
+        set_error("launch_skip_bwd_pair: channels per thread-slab must be a power of two, channels <= 256, 2 * B * H * W < 2^31");
         return;
     }
     GV dav{ldda, da_goff};
     const dim3 grid((unsigned)cdiv((int64_t)((W + 1) / 2) * cb, 256), (unsigned)((H + 1) / 2), (unsigned)B);
     const bool even = !(H & 1) && !(W & 1);
 #define SKIP_PAIR(T_, M_) do { if (mode == 0) SKIP_PAIR_E(T_, M_, 0); else SKIP_PAIR_E(T_, M_, 1); } while (0)
-#define SKIP_PAIR_E(T_, M_, MODE_) do { if (even) SKIP_PAIR_K(T_, M_, MODE_, true); else SKIP_PAIR_K(T_, M_, MODE_, false); } while (0)
-#define SKIP_PAIR_K(T_, M_, MODE_, E_) k_skip_bwd_pair<T_, M_, MODE_, E_><<<grid, 256, 0, s>>>((const T_*)Y, ldy, (const T_*)dD, ldd, (const T_*)dP, ldp, (T_*)dA, dav, stat, mask, B, H, W, C, lcb, partial)
+#define SKIP_PAIR_E(T_, M_, MODE_) do { if (even) SKIP_PAIR_V(T_, M_, MODE_, true); else SKIP_PAIR_V(T_, M_, MODE_, false); } while (0)
+#define SKIP_PAIR_V(T_, M_, MODE_, E_) do { if (V == 8) SKIP_PAIR_K(T_, M_, MODE_, E_, 8); else SKIP_PAIR_K(T_, M_, MODE_, E_, 4); } while (0)
+#define SKIP_PAIR_K(T_, M_, MODE_, E_, V_) k_skip_bwd_pair<T_, M_, MODE_, E_, V_><<<grid, 256, 0, s>>>((const T_*)Y, ldy, (const T_*)dD, ldd, (const T_*)dP, ldp, (T_*)dA, dav, stat, mask, B, H, W, C, lcb, partial)
     if (dt == BF16) { if (mask) SKIP_PAIR(bf16, true); else SKIP_PAIR(bf16, false); }
     else { if (mask) SKIP_PAIR(float, true); else SKIP_PAIR(float, false); }
 #undef SKIP_PAIR
 #undef SKIP_PAIR_E
+#undef SKIP_PAIR_V
 #undef SKIP_PAIR_K
 }
 

@@ -69,7 +69,7 @@ int stcd_op_bn_act_pair(int dtype, const stcd_map_geom* g, const void* y, int ld
     if (check_map(g)) return 1;
     STCD_CHECK(dtype == STCD_DTYPE_F32 || dtype == STCD_DTYPE_BF16, "unknown dtype");
     STCD_CHECK(g->groups == 2, "the pair kernel handles the two dates of a pair: groups must be 2");
-    STCD_CHECK(y && gamma && beta && running_mean && running_var && a && fused && stat && scratch, "null pointer argument");
+    STCD_CHECK(y && gamma && beta && running_mean && running_var && fused && stat && scratch, "null pointer argument");
     STCD_CHECK(fuse_mode == 0 || fuse_mode == 1, "fuse_mode must be 0 (|a1-a2|) or 1 (a2-a1)");
     STCD_CHECK(scratch_bytes >= stcd_op_ew_scratch_bytes(g), "scratch too small");
     hipStream_t s = (hipStream_t)hip_stream;
@@ -213,15 +213,19 @@ int stcd_op_skip_bwd(int dtype, int mode, const stcd_map_geom* g, const void* a,
                      int lddy, float* dgamma, float* dbeta, void* scratch, int64_t scratch_bytes, void* hip_stream) {
     if (check_map(g)) return 1;
     STCD_CHECK(g->groups == 2 && (mode == 0 || mode == 1), "groups must be 2, mode 0 or 1");
-    STCD_CHECK(a && y && dd && dpool && stat && da && dy && dgamma && dbeta && scratch, "null pointer argument");
+    STCD_CHECK(y && dd && dpool && stat && da && dy && dgamma && dbeta && scratch, "null pointer argument");
     STCD_CHECK(scratch_bytes >= stcd_op_ew_scratch_bytes(g), "scratch too small");
     hipStream_t s = (hipStream_t)hip_stream;
     const int b = g->n / 2;
+    STCD_CHECK(a || skip_pair_supported(b, g->h, g->w, g->c), "a == NULL (recompute the activations from y): unsupported shape");
     const int64_t HW = (int64_t)g->h * g->w, ppg = b * HW;
     long long* acc = (long long*)scratch;
     STCD_HIP(hipMemsetAsync(acc, 0, (size_t)acc_bytes(*g), s));
-    launch_skip_bwd(dtype, mode, a, lda, ppg * lda, y, ldy, dd, ldd, dpool, ldp, da, ldda, ppg * ldda, stat, mask, b, g->h, g->w, g->c,
-                    acc, s);
+    if (a)
+        launch_skip_bwd(dtype, mode, a, lda, ppg * lda, y, ldy, dd, ldd, dpool, ldp, da, ldda, ppg * ldda, stat, mask, b, g->h, g->w,
+                        g->c, acc, s);
+    else        // the engine's default plan: the forward stored no activations, k_skip_bwd_pair recomputes them from y
+        launch_skip_bwd_pair(dtype, mode, y, ldy, dd, ldd, dpool, ldp, da, ldda, ppg * ldda, stat, mask, b, g->h, g->w, g->c, acc, s);
     launch_bn_bwd_apply(dtype, da, ldda, ppg * ldda, dy, lddy, y, ldy, stat, acc, dgamma, dbeta, mask, g->c, 2, b, HW, 1, s);
     STCD_HIP(hipGetLastError());
     return 0;

@@ -315,7 +315,8 @@ def test_replication_pad_against_reference_vectors(golden, dtype):
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("b,c,h,w", [(2, 16, 12, 10), (1, 32, 7, 9), (3, 8, 16, 16), (2, 128, 4, 4)])
+@pytest.mark.parametrize("b,c,h,w", [(2, 16, 12, 10), (1, 32, 7, 9), (3, 8, 16, 16), (2, 128, 4, 4), (2, 128, 32, 32), (1, 16, 96, 256),
+                                     (1, 64, 33, 71)])
 def test_encoder_skip_layer_forward_and_backward_vs_oracle(dtype, mode, b, c, h, w):
     """Last conv of an encoder level, both dates in one pass.  Forward (stcd_op_bn_act_pair): BN(train) per date + ReLU +
     Dropout2d + pool + the skip |a1-a2| / a2-a1.  Backward (stcd_op_skip_bwd): pool gradient (first maximum) + fusion
@@ -370,6 +371,27 @@ def test_encoder_skip_layer_forward_and_backward_vs_oracle(dtype, mode, b, c, h,
     scale = max(1.0, float(np.abs(dg_ref).max()))
     np.testing.assert_allclose(dg.cpu().numpy()[:c] / scale, dg_ref / scale, **SUM_TOL[dtype])
     np.testing.assert_allclose(db.cpu().numpy()[:c] / scale, db_ref / scale, **SUM_TOL[dtype])
+
+    # the engine's default plan (round 4): the forward writes no activations (a == NULL), the backward recomputes them from y
+    # (k_skip_bwd_pair, both dates in one thread) -- the same pooled map, fused skip, dA and dY bit for bit, the same sums
+    if cp & (cp - 1) == 0:
+        P2, F2 = torch.zeros_like(Pt), torch.zeros_like(F)
+        stat2 = torch.zeros_like(stat)
+        rm2, rv2 = f32(pad1(rm, cp)), f32(pad1(rv, cp, 1.0))
+        _lib.check(l.stcd_op_bn_act_pair(DT[dtype][0], C.byref(geo), P(Y), cp, P(gm), P(bt), P(rm2), P(rv2), P(mk), mode, None, cp, P(P2), cp,
+                                         P(F2), cp, P(stat2), P(sc), nb, stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(P2, Pt) and torch.equal(F2, F) and torch.equal(stat2, stat)
+        dA2 = torch.full_like(A, float("nan"))
+        dY2 = torch.zeros_like(A)
+        dg2, db2 = torch.zeros_like(dg), torch.zeros_like(db)
+        _lib.check(l.stcd_op_skip_bwd(DT[dtype][0], mode, C.byref(geo), None, cp, P(Y), cp, P(dD), cp, P(dP), cp, P(stat), P(mk), P(dA2), cp,
+                                      P(dY2), cp, P(dg2), P(db2), P(sc), nb, stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(dA2, dA), float((dA2.float() - dA.float()).abs().max())
+        np.testing.assert_allclose(dg2.cpu().numpy(), dg.cpu().numpy(), rtol=1e-6, atol=1e-7 * scale)
+        np.testing.assert_allclose(db2.cpu().numpy(), db.cpu().numpy(), rtol=1e-6, atol=1e-7 * scale)
+        np.testing.assert_allclose(dY2.float().cpu().numpy(), dY.float().cpu().numpy(), rtol=1e-2 if dtype == "bf16" else 1e-5, atol=1e-6 * scale)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
