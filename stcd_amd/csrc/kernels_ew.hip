@@ -261,7 +261,8 @@ __device__ __forceinline__ double block_reduce16_get(const double* __restrict__ 
 // chunks per group: ~2048 16-byte pieces (8 per thread) per block, so small-spatial / wide-channel layers still
 // spread over the whole chip (a 32x32x128-channel map used to get 16 blocks)
 int bn_stats_chunks(int64_t ppg, int C) {
-    int64_t c = ppg * (C / 8) / 2048;
+    static const int per = [] { const char* e = getenv("STCD_BN_CHUNK_PIECES"); return e && atoi(e) >= 256 ? atoi(e) : 2048; }();
+    int64_t c = ppg * (C / 8) / per;
     if (c < 1) c = 1;
     if (c > 1024) c = 1024;
     return (int)c;

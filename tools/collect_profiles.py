@@ -10,7 +10,7 @@ usage: python tools/collect_profiles.py r01
 import collections, csv, glob, json, os, re, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-STEPS = 4            # bench.py --steps 3 --warmup 1 in the --pmc passes of tools/profile_round.sh
+STEPS = 9            # bench.py --steps 3 --warmup 1 in the --pmc passes of tools/profile_round.sh, + the 5 idle-queue steps every run appends
 src, dst = f"gpurun_out/{tag}", "profiles"
 os.makedirs(dst, exist_ok=True)
 line = [l for l in open(f"{src}/bench.json") if l.startswith("{")][-1]
