@@ -201,57 +201,33 @@ void launch_unpack_dw(const PackSpec& ps, const double* dwe, float* gsrc, hipStr
     k_unpack_dw<<<cdiv(total, 256), 256, 0, s>>>(ps, dwe, gsrc);
 }
 
-// Block reduction of per-thread partial sums s1[8], s2[8] (8 consecutive channels of channel block threadIdx.x % cb; pixel lane
-// threadIdx.x / cb; 256 threads).  Returns n and leaves in red[(w * cb + b) * 16 + which * 8 + j], w < n, partial sums such that
-// output (which, c) = sum over w < n of red[(w * cb + (c >> 3)) * 16 + which * 8 + (c & 7)]  (block_reduce16_get).
-// cb a power of two, cb * V <= 256 (V = 8 values per thread and sum; block_reduce2<V>: 4 as well): a butterfly over the wave's lanes with xor masks >= cb (ds_bpermute, log2(64 / cb) steps), then one
-// LDS slot per wave and channel block -- IN DOUBLE: the threads' float partials are summed exactly (to 2^-53), so the block's sum
-// does not depend on the summation tree, and the 64-bit fixed-point accumulators behind it are exact anyway.  What remains in
-// float is each thread's own partial over its <= 32 values.  (A float tree gave results ~1 ulp apart from the serial walk it
-// replaced, which the reference's tiny-batch fixtures -- BatchNorm over 8 values, variance << mean^2 -- amplify to 1e-2.)
-// The earlier epilogue had 2 * CS threads each walk 256 / cb LDS slots serially: 128 dependent-latency reads at 16 channels, ~5 us
-// per block with the other 224 threads idle -- at 2048+ blocks per launch the largest term of k_skip_bwd / k_bn_reduce at the
-// full-resolution levels.  red: 256 * 16 floats == 256 * 8 doubles.
+// Block reduction of per-thread partial sums s1[V], s2[V] (V consecutive channels of channel block threadIdx.x % cb; pixel lane
+// threadIdx.x / cb; 256 threads): every thread parks its partials, then 2 * CS threads each walk the 256 / cb lanes of one channel in
+// lane order -- a fixed serial float sum.  Output (which, c) = block_reduce2_get(...).
+// Round 4 tried a butterfly over the wave's lanes (ds_bpermute) + one LDS slot per wave instead of the serial walk (128 dependent LDS
+// reads at 16 channels).  Time: neutral (small launches 10 -> 9 us; the large ones are bound by instruction issue / HBM, not by this
+// epilogue).  Numerics: every variant is a valid sum, but (a) a FLOAT tree differs from the serial walk by an ulp, which the
+// reference's tiny-batch fixtures (BatchNorm over 8 values, variance << mean^2) amplify to 1e-2; (b) an exact DOUBLE sum handed to the
+// 2^-36 fixed-point accumulators leaves a sub-grid remainder that is not invariant under scaling the gradients by a power of two --
+// through flipped bf16 roundings it grew to 1e-2 along SegCD's 50 BatchNorm layers (test_segcd_full_size_properties_bf16); (c) the
+// exact sum rounded to float once restores (b) and moves the bf16 engine away from its emulating oracle on ChangeFormer's 2 x 2 maps
+// (0.985 -> 0.93).  None is more right than the serial walk every bound of tests/ was measured with; it stays.
 template <int V>
-__device__ __forceinline__ int block_reduce2(const float (&s1)[V], const float (&s2)[V], const int cb, double* __restrict__ red) {
-    if ((cb & (cb - 1)) == 0 && cb * V <= 256) {
-        double d[2 * V];
+__device__ __forceinline__ int block_reduce2(const float (&s1)[V], const float (&s2)[V], const int cb, float* __restrict__ red) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) { d[j] = (double)s1[j]; d[V + j] = (double)s2[j]; }
-        for (int m = 32; m >= cb; m >>= 1) {
-#pragma unroll
-            for (int j = 0; j < 2 * V; ++j) d[j] += __shfl_xor(d[j], m);
-        }
-        const int wl = threadIdx.x & 63, w = threadIdx.x >> 6;
-        if (wl < cb) {
-#pragma unroll
-            for (int j = 0; j < 2 * V; ++j) red[(w * cb + wl) * 2 * V + j] = d[j];
-        }
-        return 4;
-    }
-    float* redf = reinterpret_cast<float*>(red);
-#pragma unroll
-    for (int j = 0; j < V; ++j) { redf[threadIdx.x * 2 * V + j] = s1[j]; redf[threadIdx.x * 2 * V + V + j] = s2[j]; }
+    for (int j = 0; j < V; ++j) { red[threadIdx.x * 2 * V + j] = s1[j]; red[threadIdx.x * 2 * V + V + j] = s2[j]; }
     return 256 / cb;
 }
 template <int V>
-__device__ __forceinline__ double block_reduce2_get(const double* __restrict__ red, const int n, const int cb, const int which, const int c) {
-    double a = 0.0;
-    if (n == 4) {
-#pragma unroll
-        for (int l = 0; l < 4; ++l) a += red[(l * cb + c / V) * 2 * V + which * V + (c % V)];
-    } else {
-        const float* redf = reinterpret_cast<const float*>(red);
-        float af = 0.f;
-        for (int l = 0; l < n; ++l) af += redf[(l * cb + c / V) * 2 * V + which * V + (c % V)];
-        a = (double)af;
-    }
+__device__ __forceinline__ float block_reduce2_get(const float* __restrict__ red, const int n, const int cb, const int which, const int c) {
+    float a = 0.f;
+    for (int l = 0; l < n; ++l) a += red[(l * cb + c / V) * 2 * V + which * V + (c % V)];
     return a;
 }
-__device__ __forceinline__ int block_reduce16(const float (&s1)[8], const float (&s2)[8], const int cb, double* __restrict__ red) {
+__device__ __forceinline__ int block_reduce16(const float (&s1)[8], const float (&s2)[8], const int cb, float* __restrict__ red) {
     return block_reduce2<8>(s1, s2, cb, red);
 }
-__device__ __forceinline__ double block_reduce16_get(const double* __restrict__ red, const int n, const int cb, const int which, const int c) {
+__device__ __forceinline__ float block_reduce16_get(const float* __restrict__ red, const int n, const int cb, const int which, const int c) {
     return block_reduce2_get<8>(red, n, cb, which, c);
 }
 
@@ -276,7 +252,7 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
             const float* __restrict__ mask, const T* __restrict__ res, int ldres, int C, int npg, int64_t HW, int relu,
             int64_t ppg, int nchunk, long long* __restrict__ acc, const SliceViews xs, int base_valid, T* __restrict__ dA_sum,
             int nslab) {
-    __shared__ double red[256 * 8];          // block_reduce16 (== 256 * 16 floats)
+    __shared__ float red[256 * 16];
     // block -> (channel slab, pixel chunk): wide layers give a block 64 channels (one 128-B line per pixel) of many pixels, so
     // it ends with 128 atomic adds instead of 2*C
     const int CS = C / nslab, slab = blockIdx.x % nslab, cbase = slab * CS;
@@ -379,7 +355,7 @@ k_bn_reduce(const T* __restrict__ Y, int ldy, const T* __restrict__ dA, GV dav, 
     __syncthreads();
     for (int o = threadIdx.x; o < 2 * CS; o += 256) {
         int which = o / CS, c = o - which * CS;
-        const double a_ = block_reduce16_get(red, nred, cb, which, c);
+        const float a_ = block_reduce16_get(red, nred, cb, which, c);
         bn_acc_add(acc, chunk, gridDim.y, C, g, which, cbase + c, a_, MODE == 0 ? (which ? BN_FS2 : BN_FS1) : BN_BS);
     }
 }
@@ -777,7 +753,7 @@ __global__ void __launch_bounds__(256)
 k_skip_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int ldd,
            const T* __restrict__ dP, int ldp, T* __restrict__ dA, GV dav, const float* __restrict__ stat,
            const float* __restrict__ mask, int B, int H, int W, int C, int64_t total, long long* __restrict__ bacc) {
-    __shared__ double red[256 * 8];
+    __shared__ float red[256 * 16];
     const int g = blockIdx.y;
     const int cb = C >> 3, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
     const int lanes = 256 / cb, mycb = threadIdx.x % cb, lane = threadIdx.x / cb;
@@ -855,7 +831,7 @@ k_skip_bwd(int mode, const T* __restrict__ A, GV av, const T* __restrict__ Y, in
     __syncthreads();
     for (int o = threadIdx.x; o < 2 * C; o += 256) {
         const int which = o / C, c = o - which * C;
-        const double a_ = block_reduce16_get(red, nred, cb, which, c);
+        const float a_ = block_reduce16_get(red, nred, cb, which, c);
         bn_acc_add(bacc, blockIdx.x, 2, C, g, which, c, a_, BN_BS);
     }
 }
@@ -876,7 +852,7 @@ __global__ void __launch_bounds__(256, (V == 4 && sizeof(T) == 2) ? 4 : 1)
 k_skip_bwd_pair(const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int ldd, const T* __restrict__ dP, int ldp,
                 T* __restrict__ dA, GV dav, const float* __restrict__ stat, const float* __restrict__ mask, int B, int H, int W,
                 int C, int lcb, long long* __restrict__ bacc) {
-    __shared__ double red[256 * 8];
+    __shared__ float red[256 * 16];
     const int cb = 1 << lcb, Wc = (W + 1) >> 1, Hp = H >> 1, Wp = W >> 1;
     const int yc = blockIdx.y, nb = blockIdx.z;
     const int tx = blockIdx.x * 256 + threadIdx.x;
@@ -985,7 +961,7 @@ k_skip_bwd_pair(const T* __restrict__ Y, int ldy, const T* __restrict__ dD, int 
         __syncthreads();
         for (int o = threadIdx.x; o < 2 * C; o += 256) {
             const int which = o / C, c = o - which * C;
-            const double a_ = block_reduce2_get<V>(red, nred, cb, which, c);
+            const float a_ = block_reduce2_get<V>(red, nred, cb, which, c);
             bn_acc_add(bacc, rep, 2, C, g, which, c, a_, BN_BS);
         }
     }

@@ -355,7 +355,7 @@ def test_full_size_properties_bf16():
     # linear kernels + power-of-two scale: equal up to the summation order of the atomically folded slab parts and the
     # 2^-36 fixed-point step of the BatchNorm backward accumulators (rint(2x) != 2 rint(x))
     rel = ((grads[1] - 2.0 * grads[0]).abs().max() / grads[1].abs().max()).item()
-    assert rel < 1e-4, rel       # (the 2^-36 grid of the fixed-point BatchNorm accumulators is not scale-invariant)
+    assert rel < 5e-5, rel
 
 
 @pytest.mark.parametrize("label", [1, 2])
@@ -430,7 +430,7 @@ def test_full_size_properties_other_configs_bf16(arch):
                 if not zero_grad_by_construction(name):
                     assert p.grad.abs().max().item() > 0, name
     rel = ((grads[1] - 2.0 * grads[0]).abs().max() / grads[1].abs().max()).item()
-    assert rel < 1e-4, rel       # (the 2^-36 grid of the fixed-point BatchNorm accumulators is not scale-invariant)
+    assert rel < 5e-5, rel
 
 
 # bf16 bounds of the 128x128 step.  Forward: activations are STORED in bf16 between kernels (2^-9 relative per rounding, a
@@ -783,12 +783,12 @@ def test_recomputed_skip_activations_equal_the_stored_plan(monkeypatch, arch, B,
     assert b[3] - a[3] == 8, (a[3], b[3])            # four skip layers x two dates are not materialised
     assert torch.equal(a[0], b[0])
     assert torch.equal(a[2], b[2])
-    # gradients: dA is the same bits (tests/test_ew_ops_gpu.py checks that per op); the BatchNorm partial sums are the same per-thread
-    # floats summed exactly (double) per block, but the two kernels cut the map into different blocks, so the 2^-36 fixed-point grid
-    # of the accumulators rounds the block sums differently.  At the headline size (per-element gradients ~1e-7, 4096 blocks) that
-    # is ~1e-6 relative on a level-4 sum, and every later bf16 re-rounding of dY that it flips is a 4e-3 step on that element: the
-    # encoder's gradients of two equally valid plans then differ like two bf16 roundings of the same numbers do (measured: 3e-6 at
-    # conv43, 3.6e-3 at conv11, 7e-5 over all parameters)
+    # gradients: dA is the same bits (tests/test_ew_ops_gpu.py checks that per op, and the sums to 1e-6); the BatchNorm partial sums
+    # are the same per-thread floats, summed exactly per block and rounded to float once -- but the two kernels cut the map into
+    # different blocks, so the level's sums differ by float roundings (~1e-7).  In fp32 mode that is where it stays; in bf16 mode every
+    # re-rounding of dY that such a difference flips downstream is a 4e-3 step on that element, so the encoder's gradients of two
+    # equally valid plans end up as far apart as two bf16 roundings of the same numbers (measured 1e-9 ... 5e-4 over all parameters,
+    # 3e-6 at conv43 growing to 3.6e-3 at conv11 at the headline size)
     rel = float((a[1].double() - b[1].double()).norm() / b[1].double().norm())
     print(f"recomputed vs stored skip activations {arch} {B}x{H}x{W} {dtype}: gradient rel-l2 {rel:.2e}")
-    assert rel <= (1e-3 if B * H * W >= (1 << 20) else 1e-7 if dtype == "bf16" else 1e-6), rel
+    assert rel <= (2e-3 if dtype == "bf16" else 1e-5), rel

@@ -373,7 +373,8 @@ def test_encoder_skip_layer_forward_and_backward_vs_oracle(dtype, mode, b, c, h,
     np.testing.assert_allclose(db.cpu().numpy()[:c] / scale, db_ref / scale, **SUM_TOL[dtype])
 
     # the engine's default plan (round 4): the forward writes no activations (a == NULL), the backward recomputes them from y
-    # (k_skip_bwd_pair, both dates in one thread) -- the same pooled map, fused skip, dA and dY bit for bit, the same sums
+    # (k_skip_bwd_pair, both dates in one thread) -- the same pooled map, fused skip and dA bit for bit, the same sums and dY up to the
+    # summation order of the block partials
     if cp & (cp - 1) == 0:
         P2, F2 = torch.zeros_like(Pt), torch.zeros_like(F)
         stat2 = torch.zeros_like(stat)
@@ -389,8 +390,9 @@ def test_encoder_skip_layer_forward_and_backward_vs_oracle(dtype, mode, b, c, h,
                                       P(dY2), cp, P(dg2), P(db2), P(sc), nb, stream()))
         torch.cuda.synchronize()
         assert torch.equal(dA2, dA), float((dA2.float() - dA.float()).abs().max())
-        np.testing.assert_allclose(dg2.cpu().numpy(), dg.cpu().numpy(), rtol=1e-6, atol=1e-7 * scale)
-        np.testing.assert_allclose(db2.cpu().numpy(), db.cpu().numpy(), rtol=1e-6, atol=1e-7 * scale)
+        # (float sums of the same per-thread partials over differently cut blocks)
+        np.testing.assert_allclose(dg2.cpu().numpy(), dg.cpu().numpy(), rtol=3e-5, atol=1e-6 * scale)
+        np.testing.assert_allclose(db2.cpu().numpy(), db.cpu().numpy(), rtol=3e-5, atol=1e-6 * scale)
         np.testing.assert_allclose(dY2.float().cpu().numpy(), dY.float().cpu().numpy(), rtol=1e-2 if dtype == "bf16" else 1e-5, atol=1e-6 * scale)
 
 
