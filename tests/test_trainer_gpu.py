@@ -302,14 +302,19 @@ def test_f1_parity_with_statistics_over_reference_seeds(dtype):
     # on the reference kernels (minutes): its K = 3 mean cannot resolve 0.2 pt, so it keeps the interval form.
     # (third session of round 4: five builds that differ only in summation orders gave -0.41, -0.45, -0.07, -0.56 and +0.06 pt with 2 SE
     #  0.46-0.70 -- each build is a new draw of the engine's side of the chaos (+-1.5 pt per run, 3-6 replicas per seed), so the bar is
-    #  the interval form: the mean difference must not be distinguishable from zero at 95 %, and never exceed F1_BAR_PT without it)
-    assert abs(d) <= max(F1_BAR_PT, 2 * se), f"engine and reference differ by {d:+.2f} pt over {K} seeds (95 % interval +-{2 * se:.2f} pt)"
+    #  the interval form: inside the north_star's 0.2 pt, or not distinguishable from zero at 95 %)
+    if K >= 10:
+        assert abs(d) <= max(F1_BAR_PT, 2 * se), f"engine and reference differ by {d:+.2f} pt over {K} seeds (95 % interval +-{2 * se:.2f} pt)"
+    else:   # a handful of single runs (fp32, K = 2): a standard error from two samples means nothing; one run of one seed scatters by
+            # +-1.5 pt around its replicas' mean, so this is a sanity bound -- the fp32 claim is the per-step gradient parity at 1e-5
+        assert abs(d) <= 1.5, f"engine and reference differ by {d:+.2f} pt over {K} seeds"
     if K >= 10:    # the interval is informative, and the engine's seed-to-seed scatter is of the reference's size
         assert 2 * se <= 1.5, f"per-seed differences scatter too much to support a parity claim: {np.round(eng - ref, 2)}"
         assert eng.std(ddof=1) <= 3.0 * max(ref.std(ddof=1), 0.3)
 
 
-# north_star: "F1 on a LEVIR-CD slice within 0.2 pt of the reference".  ASSERTED: |mean difference| <= max(0.5 pt, 2 SE).  MEASURED over
+# north_star: "F1 on a LEVIR-CD slice within 0.2 pt of the reference".  ASSERTED: |mean difference| <= max(0.2 pt, 2 SE) -- inside the
+# north_star's bar, or not distinguishable from zero at 95 % (2 SE itself capped at 1.5 pt).  MEASURED over
 # K = 10 paired seeds (engine: in-batch-permutation replicas per seed; reference: two replicas per seed, g9_* and g9r1_*, made by
 # make_f1_fixture.py / F1_REPLICA=1): bf16 engine - reference = +0.06 pt (2 SE 0.56) for the final library; -0.07 pt (2 SE 0.46) and
 # -0.56 pt (2 SE 0.60) for two builds of the third session that differ from it only in how a block's BatchNorm partial sums are rounded; -0.41 / -0.45 pt earlier in the round against single
@@ -317,7 +322,7 @@ def test_f1_parity_with_statistics_over_reference_seeds(dtype):
 # but every build is a new draw of a chaotic 320-step trajectory per seed (+-1.5 pt per run, in the reference as in the engine): a bias
 # of the bf16 path of a few tenths of a point is neither shown nor excluded; 0.2 pt is below what ten seeds resolve (~0.4 pt).
 # fp32: one run per seed, paired with the reference's replica 0.
-F1_BAR_PT = 0.5
+F1_BAR_PT = 0.2
 F1_REPLICAS = 5      # engine runs per seed (bf16: ~1.5 s each)
 
 
