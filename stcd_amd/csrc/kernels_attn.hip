@@ -36,7 +36,7 @@ __device__ __forceinline__ s16x4 ld4(const bf16* p) { return *reinterpret_cast<c
 // grid (query blocks, heads, images); 4 waves, each walks 16-query tiles; K [Nkv][D + 8] and V^T [D][Nkv16 + 8] of the (image, head)
 // stay in LDS for the whole block (Nkv <= 256).
 template <int DT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_attn_fwd_mfma(const bf16* __restrict__ q, int ldq, const bf16* __restrict__ kv, int ldkv, bf16* __restrict__ out, int ldo, float* __restrict__ lse,
                 int N, int Nkv, int heads, float scale, DropSite drop) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -147,7 +147,7 @@ k_attn_rowdot(const bf16* __restrict__ o, int ldo, const bf16* __restrict__ dout
 // grid (query splits, key blocks of 128, images * heads); wave w owns keys [128 kb + 32 w, + 32); all four waves work on the SAME
 // 16-query tile.  Partial results: dq_part [key blocks][n * N][C] fp32 (summed over the key blocks), dkv_part [query splits][n * Nkv][2C].
 template <int DT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, DT <= 4 ? 2 : 1)     // <= 256 registers where they suffice: VGPR-form MFMAs (kernels_conv_mfma.hip, k_conv_small)
 k_attn_bwd_mfma(const bf16* __restrict__ q, int ldq, const bf16* __restrict__ kv, int ldkv, const bf16* __restrict__ dout, int lddo,
                 const float* __restrict__ lse, const float* __restrict__ Drow, float* __restrict__ dq_part, float* __restrict__ dkv_part, int n, int N,
                 int Nkv, int heads, float scale, DropSite drop, int qper) {

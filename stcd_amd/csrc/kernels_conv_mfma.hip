@@ -232,7 +232,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvMfmaArgs& a, const int 
 }
 
 template <int NT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)     // <= 256 registers: hipcc then selects the VGPR form of the MFMAs (see k_conv_small)
 k_conv_mfma(const ConvMfmaArgs a) {
     conv_mfma_body<NT>(a, blockIdx.x, blockIdx.y);
 }
@@ -241,7 +241,7 @@ k_conv_mfma(const ConvMfmaArgs a) {
 // grid shape): blockIdx.z picks the phase's argument block from the kernarg segment
 struct ConvMfmaArgs4 { ConvMfmaArgs a[4]; };
 template <int NT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)     // <= 256 registers: hipcc then selects the VGPR form of the MFMAs (see k_conv_small)
 k_conv_mfma_x4(const ConvMfmaArgs4 j) {
     conv_mfma_body<NT>(j.a[blockIdx.z], blockIdx.x, blockIdx.y);
 }
@@ -250,7 +250,7 @@ k_conv_mfma_x4(const ConvMfmaArgs4 j) {
 // quarters of the same output lines within microseconds of each other on one XCD, so its L2 merges them into whole-line writes
 // (a phase alone writes 32-B pieces at a 64-B stride on the 16-channel level).
 template <int NT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)     // <= 256 registers: hipcc then selects the VGPR form of the MFMAs (see k_conv_small)
 k_conv_mfma_x4s(const ConvMfmaArgs4 j) {
 #pragma unroll 1
     for (int z = 0; z < 4; ++z) {
@@ -1083,9 +1083,19 @@ struct ConvSmallArgs {
     XfSrc xf;              // XF kernels: `in` is the producer's raw conv output (see k_conv_res)
 };
 
-template <int NT, int KSMAX, bool XF = false>
-__global__ void __launch_bounds__(256, (XF && NT == 1 && KSMAX == 5) ? 2 : 1)
+// __launch_bounds__(256, 2), i.e. at most 256 registers per lane: with the default bound (512 = 256 VGPRs + 256 AGPRs) hipcc selects the
+// AGPR form of every MFMA, and wherever an accumulator crosses a basic block (the run-time `ks < KS` tests here, the run-time tap /
+// k-step loops of k_conv_mfma) it lives in VGPRs and is copied to and from the AGPRs around each MFMA: 8 v_accvgpr_write + 8
+// v_accvgpr_read + an s_nop for the MFMA result per k-step -- 80 of the ~210 VALU instructions of a tile here, 12-15 per MFMA in
+// k_conv_mfma, and a fully serialised MFMA chain.  With <= 256 registers the compiler takes the VGPR form and the copies vanish.
+// EXACT: the layer has exactly KSMAX k-steps -- the k-loop unrolls without the run-time tests (3 k-steps: 8 -> 16 channels, 5:
+// 16 -> 16, 9: 32 -> 16).
+// FAST == 2: additionally the map is a whole number of 8 x 16 tiles, every n-tile has its 16 channels and the output is NHWC bf16: the
+// epilogue loses its five run-time branches per row (border, layout, channel tail).
+template <int NT, int KSMAX, bool XF = false, int FAST = 0>
+__global__ void __launch_bounds__(256, 2)
 k_conv_small(const ConvSmallArgs a) {
+    constexpr bool EXACT = FAST >= 1, FULL = FAST == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int q = lane >> 4, r = lane & 15;
@@ -1102,7 +1112,7 @@ k_conv_small(const ConvSmallArgs a) {
     // multiplied (the MFMA section tests ks < KS), their registers just hold a copy of the last step.
 #pragma unroll
     for (int ks = 0; ks < KSMAX; ++ks) {
-        const int kk = min(ks, KS - 1);
+        const int kk = EXACT ? ks : min(ks, KS - 1);
 #pragma unroll
         for (int t2 = 0; t2 < NT; ++t2)
             wreg[ks][t2] = *reinterpret_cast<const bf16x8*>(a.wf + ((int64_t)(kk * a.NTtot + t2) * 64 + lane) * 8);
@@ -1227,7 +1237,7 @@ k_conv_small(const ConvSmallArgs a) {
         const bf16* hb = halo0 + buf * halo_elems;
 #pragma unroll
         for (int ks = 0; ks < KSMAX; ++ks) {
-            if (ks < KS) {
+            if (EXACT || ks < KS) {
                 const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(hb + base0 + aoff[ks]);
                 const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(hb + base0 + rowstep + aoff[ks]);
 #pragma unroll
@@ -1245,6 +1255,22 @@ k_conv_small(const ConvSmallArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int my = tty * 8 + wid * 2 + m;
+            if constexpr (FULL) {
+                const int oy = my * a.g.out_stride + a.g.oy0, ox = mx * a.g.out_stride + a.g.ox0;
+                bf16* orow = reinterpret_cast<bf16*>(a.out) + (((int64_t)tn * a.g.ho + oy) * a.g.wo + ox) * a.g.ldo + 4 * q;
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(acc[m][t2][0] + bv[t2][0], acc[m][t2][1] + bv[t2][1]);
+                    pk.y = pack_bf16x2(acc[m][t2][2] + bv[t2][2], acc[m][t2][3] + bv[t2][3]);
+                    *reinterpret_cast<uint2*>(orow + t2 * 16) = pk;
+                    const float rv[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
+                                         __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};     // the rounded outputs
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s1[t2][j] += rv[j]; s2[t2][j] += rv[j] * rv[j]; }
+                }
+                continue;
+            }
             if (my >= a.g.hm || mx >= a.g.wm) continue;
             const int oy = my * a.g.out_stride + a.g.oy0, ox = mx * a.g.out_stride + a.g.ox0;
             if (a.out_nchw) {
@@ -1370,9 +1396,20 @@ int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_mo
         a.xf = *xf;
         lds = 2 * (size_t)a.halo_bytes + (size_t)xf->groups * 2 * xf->C * 4;
     }
-#define LAUNCH_SMALL(N_, K_) do { if (use_xf) k_conv_small<N_, K_, true><<<blocks, 256, lds, s>>>(a); else k_conv_small<N_, K_, false><<<blocks, 256, lds, s>>>(a); } while (0)
-    if (nt == 1) { if (a.KS <= 5) LAUNCH_SMALL(1, 5); else LAUNCH_SMALL(1, 9); }
-    else { if (a.KS <= 5) LAUNCH_SMALL(2, 5); else LAUNCH_SMALL(2, 9); }
+    // STCD_SMALL_FAST=0: the generic kernel for every layer; 1: exact k-step count only; 2 (default): + full-tile NHWC epilogue
+    static const int fast_on = [] { const char* e = getenv("STCD_SMALL_FAST"); return e ? atoi(e) : 2; }();
+    const bool full = fast_on >= 2 && !out_nchw && g.co == nt * 16 && g.hm % 8 == 0 && g.wm % 16 == 0;
+#define LAUNCH_SMALL(N_, K_, F_) do { if (use_xf) k_conv_small<N_, K_, true, F_><<<blocks, 256, lds, s>>>(a); else k_conv_small<N_, K_, false, F_><<<blocks, 256, lds, s>>>(a); } while (0)
+#define LAUNCH_SMALL_K(N_, K_) do { if (full) LAUNCH_SMALL(N_, K_, 2); else LAUNCH_SMALL(N_, K_, 1); } while (0)
+#define LAUNCH_SMALL_N(N_) do { \
+        if (fast_on >= 1 && a.KS == 3) LAUNCH_SMALL_K(N_, 3); \
+        else if (fast_on >= 1 && a.KS == 5) LAUNCH_SMALL_K(N_, 5); \
+        else if (a.KS <= 5) LAUNCH_SMALL(N_, 5, 0); \
+        else if (fast_on >= 1 && a.KS == 9) LAUNCH_SMALL_K(N_, 9); \
+        else LAUNCH_SMALL(N_, 9, 0); } while (0)
+    if (nt == 1) LAUNCH_SMALL_N(1); else LAUNCH_SMALL_N(2);
+#undef LAUNCH_SMALL_K
+#undef LAUNCH_SMALL_N
 #undef LAUNCH_SMALL
     return 0;
 }
