@@ -315,8 +315,9 @@ def test_f1_parity_with_statistics_over_reference_seeds(dtype):
 
 # north_star: "F1 on a LEVIR-CD slice within 0.2 pt of the reference".  ASSERTED: |mean difference| <= max(0.2 pt, 2 SE) -- inside the
 # north_star's bar, or not distinguishable from zero at 95 % (2 SE itself capped at 1.5 pt).  MEASURED over
-# K = 10 paired seeds (engine: in-batch-permutation replicas per seed; reference: two replicas per seed, g9_* and g9r1_*, made by
-# make_f1_fixture.py / F1_REPLICA=1): bf16 engine - reference = +0.06 pt (2 SE 0.56) for the final library; -0.07 pt (2 SE 0.46) and
+# K = 10 paired seeds (engine: five in-batch-permutation replicas per seed; reference: three replicas per seed, g9_*, g9r1_*, g9r2_*, made
+# by make_f1_fixture.py / F1_REPLICA=1, 2): bf16 engine - reference = -0.12 pt (2 SE 0.51) for the final library (+0.06 pt, 2 SE 0.56,
+# against two reference replicas per seed); -0.07 pt (2 SE 0.46) and
 # -0.56 pt (2 SE 0.60) for two builds of the third session that differ from it only in how a block's BatchNorm partial sums are rounded; -0.41 / -0.45 pt earlier in the round against single
 # reference runs; -0.70 pt from single runs on both sides.  The statistic is one number per build (the engine is bit-reproducible)
 # but every build is a new draw of a chaotic 320-step trajectory per seed (+-1.5 pt per run, in the reference as in the engine): a bias
