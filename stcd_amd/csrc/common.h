@@ -318,8 +318,19 @@ int launch_conv_dma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvDm
 // uses the mode-B fragment image of conv_mfma_plan.
 bool conv_small_ok(const stcd_conv_geom& g, const ConvMfmaPlan& p);
 int conv_small_blocks(const stcd_conv_geom& g, int groups);
+// A data-gradient launch that also forms the BatchNorm-backward partial sums of the layer whose output gradient dA it writes
+// (sum(dz), sum(dz * xhat), dz = dA * mask * (z > 0): what k_bn_reduce<T, 1> would compute from a second pass over dA and Y).
+struct BwdSum {
+    const void* Y = nullptr; int ldy = 0;          // that layer's conv output (same map, same channels as dA)
+    const float* stat = nullptr;                   // its published [groups][4][C] (mean, invstd, scale, shift)
+    const float* mask = nullptr;                   // its Dropout2d factors [N][C] or nullptr
+    long long* acc = nullptr;                      // its backward accumulators (scale BN_BS)
+    int groups = 1;
+};
 int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_modeB, const float* bias, void* out,
-                      bool out_nchw_f32, int groups, long long* stat_acc, int cpad, hipStream_t s, const XfSrc* xf = nullptr);
+                      bool out_nchw_f32, int groups, long long* stat_acc, int cpad, hipStream_t s, const XfSrc* xf = nullptr,
+                      const BwdSum* bs = nullptr);
+bool conv_small_bwdsum_ok(const stcd_conv_geom& g);      // shapes the fused form handles (16 channels out, whole 8 x 16 tiles, 3 / 5 k-steps)
 struct WgradMfmaPlan {
     int WCI = 1, NTW = 1, gx = 1, gy = 1, gz = 1;
     int64_t slab_floats = 0;

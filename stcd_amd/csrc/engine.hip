@@ -100,6 +100,8 @@ struct Cbrd {                         // conv -> BN -> ReLU -> Dropout2d [-> poo
     GRef dA; TRef dY; TRef dIn; bool has_dIn = false;
     int64_t stat = -1;
     int64_t facc = -1, bacc = -1;     // BatchNorm accumulators (forward statistics / backward sums), see common.h
+    const Cbrd* dgr_bwd = nullptr;    // this layer's data-gradient launch also forms the BatchNorm-backward sums of THAT layer (BwdSum)
+    bool bwd_sums_fused = false;      // ... and that layer then skips its k_bn_reduce launch
     int64_t dgr_sum_acc = -1; int dgr_sum_c0 = 0, dgr_sum_C = 0;   // the data-gradient launch also sums a channel slice of its
                                                                     // output (bias gradient of the transposed conv feeding it)
     TRef fuse_dst;                    // skip layers of diff / sub: the decoder's concat slice that receives |a1-a2| / a2-a1
@@ -245,6 +247,7 @@ struct stcd_engine_impl {
     std::vector<UpConv> ups;
     int final_conv = -1;
     ConvOp final_fwd, final_dgr; WgradOp final_wg;
+    const Cbrd* final_dgr_bwd = nullptr;                // the last decoder layer, when final_dgr also forms its BatchNorm-backward sums
     const Cbrd* final_xsrc = nullptr;   // conv11d reads conv12d's raw output (virtual activation)
     int use_virt = 0;                   // STCD_VIRT_ACT=1: virtual activations (round 4: built, bit-identical, MEASURED 2-3 % SLOWER on the
                                         // headline step -- DESIGN.md section 4 -- so every activation is materialised by default)
@@ -270,7 +273,7 @@ struct stcd_engine_impl {
     int64_t final_bias_acc = -1;
     std::vector<BiasJob> bias_jobs; int64_t bias_jobs_off = -1;
     int64_t masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
-    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1, use_act_fuse = 1, use_gemm = 1, use_skip_recompute = 1, wg_tail_split = 0;
+    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1, use_act_fuse = 1, use_gemm = 1, use_skip_recompute = 1, wg_tail_split = 0, use_bwdsum = 1;
     // FC-Siam backward: the decoder's grouped weight gradients (+ slab reduce, bias finish) run on a low-priority side stream beside
     // the encoder's backward chain on the caller's stream; their grids get 1 / wg_side_div of the planner's block budget so that the
     // chain's blocks find free slots (wgrad_side_stream)
@@ -984,6 +987,30 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     }
     e.slab = ws.take(e.slab_floats * 4);
 
+    // ---- BatchNorm-backward sums inside the data gradient that produces dA (k_conv_small<.., BWD>): layer N's data gradient writes
+    //      dA of layer P (plain buffer, same map, 16 channels); P then skips its k_bn_reduce launch.  Level-1 layers only (the
+    //      small-channel kernel): conv12 -> conv11, conv11d -> conv12d, the final conv -> conv11d.
+    for (auto& L : e.enc) { L.dgr_bwd = nullptr; L.bwd_sums_fused = false; }
+    for (auto& L : e.dec) { L.dgr_bwd = nullptr; L.bwd_sums_fused = false; }
+    e.final_dgr_bwd = nullptr;
+    if (e.use_bwdsum && e.dt == BF16 && e.use_mfma && e.use_small && !e.use_virt) {
+        auto dest_ok = [&](const Cbrd& P, const ConvOp& dgr, int64_t dIn_off, int dIn_ld, int N) {
+            return !P.pool && P.fuse_dst.off < 0 && !P.virt && dgr.small && dgr.wf >= 0 && dIn_off == P.dA.off && dIn_ld == P.dA.ld &&
+                   e.convs[P.conv].cout == dgr.g.co && P.N == N && N % P.groups == 0 && conv_small_bwdsum_ok(dgr.g) &&
+                   (P.groups == 1 || P.dA.goff == (int64_t)P.npg * P.H * P.W * P.dA.ld);
+        };
+        auto scan = [&](std::vector<Cbrd>& v) {
+            for (size_t i = 1; i < v.size(); ++i) {
+                Cbrd& N = v[i]; Cbrd& P = v[i - 1];
+                if (N.has_dIn && N.dgr_sum_acc < 0 && dest_ok(P, N.dgr, N.dIn.off, N.dIn.ld, N.N)) { N.dgr_bwd = &P; P.bwd_sums_fused = true; }
+            }
+        };
+        scan(e.enc); scan(e.dec);
+        if (!e.dec.empty() && dest_ok(e.dec.back(), e.final_dgr, e.dFinalIn.off, e.dFinalIn.ld, e.dec.back().N)) {
+            e.final_dgr_bwd = &e.dec.back(); e.dec.back().bwd_sums_fused = true;
+        }
+    }
+
     // ---- virtual activations: a non-skip layer whose ONLY reader is the next conv of its stage hands that conv its raw output Y;
     //      the conv's forward launch (k_conv_small / k_conv_res, XF variants) and its weight gradient (k_wgrad_group, job.xf_*)
     //      apply BN-affine + ReLU + Dropout2d while staging.  Eligibility mirrors exec_conv / exec_wgrad's kernel choice, which is
@@ -1131,7 +1158,7 @@ struct StatReq { long long* acc = nullptr; int groups = 1; int c0 = 0; int C = 0
 // *fused receives 1 when the kernel delivered the sums, 0 when the caller must run the separate pass.
 static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const float* bias, void* out, bool nchw,
                       const StatReq* sr = nullptr, int* stat_chunks = nullptr, const ConvEpi* epi = nullptr, int* epi_fused = nullptr,
-                      const XfSrc* xf = nullptr) {
+                      const XfSrc* xf = nullptr, const BwdSum* bs = nullptr) {
     const int stat_groups = (sr && sr->acc) ? sr->groups : 0;
     long long* stat_acc = sr ? sr->acc : nullptr;
     const bool bn_form = sr && sr->c0 == 0 && sr->C == op.g.co && sr->s1 == BN_FS1 && sr->s2 == BN_FS2;
@@ -1152,6 +1179,12 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     else if (small_path) snprintf(kname, sizeof(kname), "k_conv_small<1, %d>", (op.g.ntaps * op.g.ci + 31) / 32 <= 5 ? 5 : 9);
     else if (mfma_path) snprintf(kname, sizeof(kname), "k_conv_mfma<%d>", op.plan.NT);
     else snprintf(kname, sizeof(kname), "k_conv_ref");
+    if (bs) {      // planned at configure time for exactly this kernel (dest_ok): anything else is a plan error
+        ProfScope ps2(c, PC_CONV, fl, by + (double)op.g.n * op.g.ho * op.g.wo * op.g.co * 2.0, "k_conv_small<bwd>");
+        if (launch_conv_small(op.g, in, c.at(op.wf), bias, out, nchw, bs->groups, nullptr, op.g.co, c.s, nullptr, bs) != 0)
+            set_error("fused BatchNorm-backward sums: the data-gradient launch does not fit k_conv_small<.., BWD>");
+        return;
+    }
     ProfScope prof(c, PC_CONV, fl, by, kname);
     if (stat_chunks) *stat_chunks = 0;
     if (epi_fused) *epi_fused = 0;
@@ -1413,6 +1446,16 @@ static void cbrd_forward(const Ctx& c, const Cbrd& L, float* bn_running, bool tr
     launch_bn_act(e.dt, a, c.s);
 }
 
+// the BatchNorm-backward sums of layer P as a data-gradient launch forms them (BwdSum, common.h)
+static BwdSum bwd_sum_of(const Ctx& c, const Cbrd& P) {
+    stcd_engine& e = c.e;
+    BwdSum b;
+    b.Y = c.at(P.Y.off); b.ldy = P.Y.ld; b.stat = c.at<float>(P.stat);
+    b.mask = (e.drop_p > 0.f && P.drop >= 0) ? c.at<float>(e.masks) + e.drops[P.drop].off : nullptr;
+    b.acc = c.at<long long>(P.bacc); b.groups = P.groups;
+    return b;
+}
+
 // skip_chunks > 0: dA and the BN partial sums were already produced by launch_skip_bwd (that many rows per date)
 static void cbrd_backward(const Ctx& c, const Cbrd& L, int skip_chunks = 0) {
     stcd_engine& e = c.e;
@@ -1425,7 +1468,7 @@ static void cbrd_backward(const Ctx& c, const Cbrd& L, int skip_chunks = 0) {
     long long* bacc = c.at<long long>(L.bacc);
     const double act_bytes = (double)L.N * HW * C * (double)dsize(e.dt);
     (void)ppg;
-    if (!skip_chunks) {
+    if (!skip_chunks && !L.bwd_sums_fused) {
         ProfScope ps(c, PC_BN_BWD_REDUCE, 0.0, 2.0 * act_bytes);
         launch_bn_bwd_reduce(e.dt, c.at(L.dA.off), L.dA.ld, L.dA.goff, c.at(L.Y.off), L.Y.ld, stat, mask, C, L.groups, L.npg, HW, 1,
                              bacc, c.s);
@@ -1440,7 +1483,10 @@ static void cbrd_backward(const Ctx& c, const Cbrd& L, int skip_chunks = 0) {
     if (L.has_dIn) {
         StatReq sr;
         if (L.dgr_sum_acc >= 0) { sr.acc = c.at<long long>(L.dgr_sum_acc); sr.groups = 1; sr.c0 = L.dgr_sum_c0; sr.C = L.dgr_sum_C; sr.s1 = sr.s2 = BN_BS; }
-        exec_conv(c, L.dgr, c.at(L.dY.off), nullptr, c.at(L.dIn.off), false, L.dgr_sum_acc >= 0 ? &sr : nullptr);
+        BwdSum bs;
+        if (L.dgr_bwd) bs = bwd_sum_of(c, *L.dgr_bwd);
+        exec_conv(c, L.dgr, c.at(L.dY.off), nullptr, c.at(L.dIn.off), false, L.dgr_sum_acc >= 0 ? &sr : nullptr, nullptr, nullptr, nullptr, nullptr,
+                  L.dgr_bwd ? &bs : nullptr);
     }
 }
 
@@ -1613,7 +1659,12 @@ static int backward_fcsiam(stcd_engine& e, const float* grad_logits, const float
         // conv11d: its bias gradient = per-channel sum of d(logits), formed while the gradient is packed
         launch_gout_pack(dt, grad_logits, c.at(e.G.off), B, e.label, e.H, e.W, s, c.at<long long>(e.final_bias_acc));
         exec_wgrad(c, e.final_wg, c.at(e.finalIn.off), c.at(e.G.off));
-        exec_conv(c, e.final_dgr, c.at(e.G.off), nullptr, c.at(e.dFinalIn.off), false);
+        {
+            BwdSum bs;
+            if (e.final_dgr_bwd) bs = bwd_sum_of(c, *e.final_dgr_bwd);
+            exec_conv(c, e.final_dgr, c.at(e.G.off), nullptr, c.at(e.dFinalIn.off), false, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      e.final_dgr_bwd ? &bs : nullptr);
+        }
         int di = (int)e.dec.size() - 1;
         for (int k = 3; k >= 0; --k) {
             int nb = 0;
@@ -2802,6 +2853,8 @@ static void engine_env_switches(stcd_engine* e) {
     e->use_skip_recompute = !(env && env[0] == '1');
     env = getenv("STCD_WGRAD_TAIL_SPLIT");        // 1: the first conv's weight gradient gets a grid of its own, so its stage-mates' grid
     e->wg_tail_split = env && env[0] == '1';      //    goes out ~120 us earlier (measured neutral: the step is HBM-bound)
+    env = getenv("STCD_NO_BWDSUM_FUSE");          // 1: every layer runs its own k_bn_reduce (no sums in k_conv_small data gradients)
+    e->use_bwdsum = !(env && env[0] == '1');
     env = getenv("STCD_VIRT_ACT");                // 1: virtual activations (opt-in); 0 / unset: k_bn_act per layer
     if (env) e->use_virt = atoi(env) != 0;
     env = getenv("STCD_XF_MODE");

@@ -1081,6 +1081,9 @@ struct ConvSmallArgs {
     int cpad;
     int tap[9];            // packed taps (fill_taps)
     XfSrc xf;              // XF kernels: `in` is the producer's raw conv output (see k_conv_res)
+    // BWD kernels (a data gradient that also sums the BatchNorm backward of the layer it writes dA for, see BwdSum)
+    const bf16* bw_Y; int bw_ldy; const float* bw_stat; const float* bw_mask;
+    float s1_scale, s2_scale;
 };
 
 // __launch_bounds__(256, 2), i.e. at most 256 registers per lane: with the default bound (512 = 256 VGPRs + 256 AGPRs) hipcc selects the
@@ -1092,10 +1095,14 @@ struct ConvSmallArgs {
 // 16 -> 16, 9: 32 -> 16).
 // FAST == 2: additionally the map is a whole number of 8 x 16 tiles, every n-tile has its 16 channels and the output is NHWC bf16: the
 // epilogue loses its five run-time branches per row (border, layout, channel tail).
-template <int NT, int KSMAX, bool XF = false, int FAST = 0>
+// BWD (with FAST == 2, NT == 1): the launch is a data gradient whose output dA belongs to a conv -> BN -> ReLU -> Dropout2d layer; its
+// epilogue also loads that layer's Y at the tile's positions and accumulates sum(dz) and sum(dz * xhat) of the ROUNDED dA it stores --
+// k_bn_reduce<T, 1>'s second pass over dA and Y (and its launch) disappears.
+template <int NT, int KSMAX, bool XF = false, int FAST = 0, bool BWD = false>
 __global__ void __launch_bounds__(256, 2)
 k_conv_small(const ConvSmallArgs a) {
     constexpr bool EXACT = FAST >= 1, FULL = FAST == 2;
+    static_assert(!BWD || (FULL && NT == 1 && !XF), "BWD: full-tile single-n-tile data gradients only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int q = lane >> 4, r = lane & 15;
@@ -1156,6 +1163,13 @@ k_conv_small(const ConvSmallArgs a) {
             const int cb = t2 * 16 + 4 * q + j;
             bv[t2][j] = (a.bias && cb < a.g.co) ? a.bias[cb] : 0.f;
         }
+    // BWD: this lane's four channels of the destination layer's published statistics (the block walks tiles of ONE group)
+    float bw_mean[4], bw_inv[4], bw_sc[4], bw_sh[4];
+    if constexpr (BWD) {
+        const float* st = a.bw_stat + (int64_t)grp * 4 * a.g.co + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bw_mean[j] = st[j]; bw_inv[j] = st[a.g.co + j]; bw_sc[j] = st[2 * a.g.co + j]; bw_sh[j] = st[3 * a.g.co + j]; }
+    }
     // tile walk: tile -> (n, ty, tx) advanced incrementally by bpg
     const int tiles_img = a.tiles_x * a.tiles_y;
     const int dn = bpg / tiles_img, drem = bpg - dn * tiles_img, dty = drem / a.tiles_x, dtx = drem - dty * a.tiles_x;
@@ -1228,6 +1242,14 @@ k_conv_small(const ConvSmallArgs a) {
         advance(nn, ny, nx);
         const bool have_next = tile + bpg < tile_end;
         if (have_next) fetch(nn, ny, nx);
+        uint2 bw_y[2];                     // BWD: Y of this tile's two rows (this lane's 4 channels), in flight under the MFMAs
+        float4 bw_mk = make_float4(1.f, 1.f, 1.f, 1.f);
+        if constexpr (BWD) {
+            const bf16* yrow = a.bw_Y + (((int64_t)tn * a.g.ho + tty * 8 + wid * 2) * a.g.wo + ttx * 16 + r) * a.bw_ldy + 4 * q;
+            bw_y[0] = *reinterpret_cast<const uint2*>(yrow);
+            bw_y[1] = *reinterpret_cast<const uint2*>(yrow + (int64_t)a.g.wo * a.bw_ldy);
+            if (a.bw_mask) bw_mk = *reinterpret_cast<const float4*>(a.bw_mask + (int64_t)tn * a.g.co + 4 * q);
+        }
         // ---- MFMAs of this tile
         f32x4 acc[2][NT];
 #pragma unroll
@@ -1266,8 +1288,22 @@ k_conv_small(const ConvSmallArgs a) {
                     *reinterpret_cast<uint2*>(orow + t2 * 16) = pk;
                     const float rv[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
                                          __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};     // the rounded outputs
+                    if constexpr (BWD) {
+                        const float y[4] = {__uint_as_float(bw_y[m].x << 16), __uint_as_float(bw_y[m].x & 0xffff0000u),
+                                            __uint_as_float(bw_y[m].y << 16), __uint_as_float(bw_y[m].y & 0xffff0000u)};
+                        const float mk[4] = {bw_mk.x, bw_mk.y, bw_mk.z, bw_mk.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { s1[t2][j] += rv[j]; s2[t2][j] += rv[j] * rv[j]; }
+                        for (int j = 0; j < 4; ++j) {       // the arithmetic of k_bn_reduce<T, 1>
+                            const float z = y[j] * bw_sc[j] + bw_sh[j];
+                            float dz = rv[j] * mk[j];
+                            if (!(z > 0.f)) dz = 0.f;
+                            s1[t2][j] += dz;
+                            s2[t2][j] += dz * (y[j] - bw_mean[j]) * bw_inv[j];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { s1[t2][j] += rv[j]; s2[t2][j] += rv[j] * rv[j]; }
+                    }
                 }
                 continue;
             }
@@ -1337,7 +1373,7 @@ k_conv_small(const ConvSmallArgs a) {
             float acc_ = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) acc_ += red[(((w * NT + t2) * 4 + qq) * 4 + j) * 2 + which];
-            if (c < a.cpad) bn_acc_add(a.stat_acc, bl, a.groups, a.cpad, grp, which, c, acc_, which ? BN_FS2 : BN_FS1);
+            if (c < a.cpad) bn_acc_add(a.stat_acc, bl, a.groups, a.cpad, grp, which, c, acc_, which ? a.s2_scale : a.s1_scale);
         }
     }
 }
@@ -1366,9 +1402,15 @@ int conv_small_blocks(const stcd_conv_geom& g, int groups) {
     return (int)(bpg * groups);
 }
 
+bool conv_small_bwdsum_ok(const stcd_conv_geom& g) {
+    const int ks = (g.ntaps * g.ci + 31) / 32;
+    return g.co == 16 && g.hm % 8 == 0 && g.wm % 16 == 0 && g.hm == g.ho && g.wm == g.wo && g.out_stride == 1 && g.oy0 == 0 && g.ox0 == 0 &&
+           (ks == 3 || ks == 5);
+}
 int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_modeB, const float* bias, void* out,
-                      bool out_nchw, int groups, long long* stat_acc, int cpad, hipStream_t s, const XfSrc* xf) {
+                      bool out_nchw, int groups, long long* stat_acc, int cpad, hipStream_t s, const XfSrc* xf, const BwdSum* bs) {
     ConvSmallArgs a;
+    a.bw_Y = nullptr; a.bw_ldy = 0; a.bw_stat = nullptr; a.bw_mask = nullptr; a.s1_scale = BN_FS1; a.s2_scale = BN_FS2;
     a.g = g;
     a.in = (const bf16*)in; a.wf = (const bf16*)wf_modeB; a.bias = bias; a.out = out; a.out_nchw = out_nchw ? 1 : 0;
     a.Ci = g.ci;
@@ -1395,6 +1437,14 @@ int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_mo
         if (xf->C != g.ci || xf->groups != groups) return 1;
         a.xf = *xf;
         lds = 2 * (size_t)a.halo_bytes + (size_t)xf->groups * 2 * xf->C * 4;
+    }
+    if (bs) {      // fused BatchNorm-backward sums: the tiles are partitioned by the DESTINATION layer's groups
+        if (!conv_small_bwdsum_ok(g) || out_nchw || use_xf || nt != 1 || stat_acc || bs->groups != groups || !bs->acc) return 1;
+        a.bw_Y = (const bf16*)bs->Y; a.bw_ldy = bs->ldy; a.bw_stat = bs->stat; a.bw_mask = bs->mask;
+        a.stat_acc = bs->acc; a.cpad = g.co; a.s1_scale = BN_BS; a.s2_scale = BN_BS;
+        if (a.KS == 3) k_conv_small<1, 3, false, 2, true><<<blocks, 256, lds, s>>>(a);
+        else k_conv_small<1, 5, false, 2, true><<<blocks, 256, lds, s>>>(a);
+        return 0;
     }
     // STCD_SMALL_FAST=0: the generic kernel for every layer; 1: exact k-step count only; 2 (default): + full-tile NHWC epilogue
     static const int fast_on = [] { const char* e = getenv("STCD_SMALL_FAST"); return e ? atoi(e) : 2; }();
