@@ -265,9 +265,19 @@ struct ConvResPlan {
     bool ok = false;
 };
 ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int groups);
+// A data-gradient launch that also forms the BatchNorm-backward partial sums of the layer whose output gradient dA it writes
+// (sum(dz), sum(dz * xhat), dz = dA * mask * (z > 0): what k_bn_reduce<T, 1> would compute from a second pass over dA and Y).
+struct BwdSum {
+    const void* Y = nullptr; int ldy = 0;          // that layer's conv output (same map, same channels as dA)
+    const float* stat = nullptr;                   // its published [groups][4][C] (mean, invstd, scale, shift)
+    const float* mask = nullptr;                   // its Dropout2d factors [N][C] or nullptr
+    long long* acc = nullptr;                      // its backward accumulators (scale BN_BS)
+    int groups = 1;
+};
 int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvResPlan& rp, const void* in, const void* wf,
                     const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0 = 0,
-                    float s1_scale = BN_FS1, float s2_scale = BN_FS2, const XfSrc* xf = nullptr);
+                    float s1_scale = BN_FS1, float s2_scale = BN_FS2, const XfSrc* xf = nullptr, const BwdSum* bs = nullptr);
+bool conv_res_bwdsum_ok(const stcd_conv_geom& g, const ConvResPlan& rp);
 // Tap-list convolutions with Ci % 64 == 0, Co % 64 == 0 as a tiled GEMM [positions x (taps * Ci)] . [(taps * Ci) x Co]: 128x128
 // or 64x64 block tiles staged through LDS in (64-channel chunk, tap) steps, fused bias + BN statistics, LDS-transposed 16-B
 // output stores.  1x1 convolutions of any stride, and the wide layers the resident-filter kernel cannot take.
@@ -318,15 +328,6 @@ int launch_conv_dma(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvDm
 // uses the mode-B fragment image of conv_mfma_plan.
 bool conv_small_ok(const stcd_conv_geom& g, const ConvMfmaPlan& p);
 int conv_small_blocks(const stcd_conv_geom& g, int groups);
-// A data-gradient launch that also forms the BatchNorm-backward partial sums of the layer whose output gradient dA it writes
-// (sum(dz), sum(dz * xhat), dz = dA * mask * (z > 0): what k_bn_reduce<T, 1> would compute from a second pass over dA and Y).
-struct BwdSum {
-    const void* Y = nullptr; int ldy = 0;          // that layer's conv output (same map, same channels as dA)
-    const float* stat = nullptr;                   // its published [groups][4][C] (mean, invstd, scale, shift)
-    const float* mask = nullptr;                   // its Dropout2d factors [N][C] or nullptr
-    long long* acc = nullptr;                      // its backward accumulators (scale BN_BS)
-    int groups = 1;
-};
 int launch_conv_small(const stcd_conv_geom& g, const void* in, const void* wf_modeB, const float* bias, void* out,
                       bool out_nchw_f32, int groups, long long* stat_acc, int cpad, hipStream_t s, const XfSrc* xf = nullptr,
                       const BwdSum* bs = nullptr);

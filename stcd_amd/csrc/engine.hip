@@ -951,8 +951,9 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         const ConvW& cv = e.convs[L.conv];
         bind_conv(L.fwd, geom3(L.N, L.H, L.W, L.K, L.in.ld, cv.cout, L.Y.ld), L.conv, false, 0, cv.cin, cv.cout, L.groups);
         bind_wgrad(L.wg, geom3(L.N, L.H, L.W, L.K, L.in.ld, cv.cout, L.dY.ld), L.conv, 0, cv.cin, cv.cout, L.in.off, L.dY.off);
-        if (L.has_dIn)
-            bind_conv(L.dgr, geom3(L.N, L.H, L.W, cv.dgrad.kpad, L.dY.ld, cv.cin, L.dIn.ld), L.conv, true, 0, cv.cout, cv.cin);
+        if (L.has_dIn)      // (tiles partitioned by the layer's BatchNorm groups: its data gradient may carry the previous layer's backward sums)
+            bind_conv(L.dgr, geom3(L.N, L.H, L.W, cv.dgrad.kpad, L.dY.ld, cv.cin, L.dIn.ld), L.conv, true, 0, cv.cout, cv.cin,
+                      e.use_bwdsum ? L.groups : 1);
     };
     for (auto& L : e.enc) bind_cbrd(L);
     for (auto& L : e.dec) bind_cbrd(L);
@@ -994,9 +995,16 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
     for (auto& L : e.dec) { L.dgr_bwd = nullptr; L.bwd_sums_fused = false; }
     e.final_dgr_bwd = nullptr;
     if (e.use_bwdsum && e.dt == BF16 && e.use_mfma && e.use_small && !e.use_virt) {
+        // STCD_BWDSUM_RES=1: also the layers behind a k_conv_res data gradient (k_conv_res<.., BWD>, one or two n-tiles).  Measured: eight
+        // more launches gone (114 -> 106), bn_bwd_reduce 0.150 -> 0.055 ms, conv 0.970 -> 1.052 ms: the step 2.094 -> 2.114 ms (diff), conc
+        // 2.433 -> 2.475 -- the resident-filter kernel pays more for 56 extra registers and the Y loads than the small launches cost.  Opt-in.
+        static const int res_too = [] { const char* v = getenv("STCD_BWDSUM_RES"); return v ? atoi(v) : 0; }();
         auto dest_ok = [&](const Cbrd& P, const ConvOp& dgr, int64_t dIn_off, int dIn_ld, int N) {
-            return !P.pool && P.fuse_dst.off < 0 && !P.virt && dgr.small && dgr.wf >= 0 && dIn_off == P.dA.off && dIn_ld == P.dA.ld &&
-                   e.convs[P.conv].cout == dgr.g.co && P.N == N && N % P.groups == 0 && conv_small_bwdsum_ok(dgr.g) &&
+            const bool kern = (dgr.small && conv_small_bwdsum_ok(dgr.g)) ||
+                              (res_too && !dgr.small && !dgr.gemm.ok && e.use_res && dgr.res.ok && dgr.res_groups == P.groups &&
+                               conv_res_bwdsum_ok(dgr.g, dgr.res));
+            return !P.pool && P.fuse_dst.off < 0 && !P.virt && kern && dgr.wf >= 0 && dIn_off == P.dA.off && dIn_ld == P.dA.ld &&
+                   e.convs[P.conv].cout == dgr.g.co && P.N == N && N % P.groups == 0 &&
                    (P.groups == 1 || P.dA.goff == (int64_t)P.npg * P.H * P.W * P.dA.ld);
         };
         auto scan = [&](std::vector<Cbrd>& v) {
@@ -1180,9 +1188,11 @@ static void exec_conv(const Ctx& c, const ConvOp& op, const void* in, const floa
     else if (mfma_path) snprintf(kname, sizeof(kname), "k_conv_mfma<%d>", op.plan.NT);
     else snprintf(kname, sizeof(kname), "k_conv_ref");
     if (bs) {      // planned at configure time for exactly this kernel (dest_ok): anything else is a plan error
-        ProfScope ps2(c, PC_CONV, fl, by + (double)op.g.n * op.g.ho * op.g.wo * op.g.co * 2.0, "k_conv_small<bwd>");
-        if (launch_conv_small(op.g, in, c.at(op.wf), bias, out, nchw, bs->groups, nullptr, op.g.co, c.s, nullptr, bs) != 0)
-            set_error("fused BatchNorm-backward sums: the data-gradient launch does not fit k_conv_small<.., BWD>");
+        ProfScope ps2(c, PC_CONV, fl, by + (double)op.g.n * op.g.ho * op.g.wo * op.g.co * 2.0, small_path ? "k_conv_small<bwd>" : "k_conv_res<bwd>");
+        const int rc = small_path ? launch_conv_small(op.g, in, c.at(op.wf), bias, out, nchw, bs->groups, nullptr, op.g.co, c.s, nullptr, bs)
+                                  : launch_conv_res(op.g, op.plan, op.res, in, c.at(op.wf), bias, out, op.res_groups, nullptr, op.g.co, c.s, 0,
+                                                    BN_BS, BN_BS, nullptr, bs);
+        if (rc != 0) set_error("fused BatchNorm-backward sums: the data-gradient launch does not fit its BWD kernel");
         return;
     }
     ProfScope prof(c, PC_CONV, fl, by, kname);

@@ -1492,6 +1492,8 @@ struct ConvResArgs {
     unsigned in_bytes;     // size of the input tensor (buffer-load range check)
     int8_t tix[3][3];      // tap index of every (row shift, column shift)
     XfSrc xf;              // XF kernels: `in` is the producer's raw conv output; BN-affine + ReLU + Dropout2d applied while staging
+    // BWD kernels: a data gradient that also forms the BatchNorm-backward sums of the layer it writes dA for (BwdSum, common.h)
+    const bf16* bw_Y; int bw_ldy; const float* bw_stat; const float* bw_mask;
 };
 
 constexpr int RES_HW = 18;     // halo edge of the 16 x 16 output tile
@@ -1504,9 +1506,12 @@ constexpr int RES_HW = 18;     // halo edge of the 16 x 16 output tile
 // XF: the input is a "virtual activation" (XfSrc, common.h): every staged 16-B piece goes through xf_act8 between its buffer load
 // and its LDS store; the producer's scale / shift table is built in the block's prologue (block 0 publishes it and updates the
 // running statistics, as k_bn_act's block 0 did), the Dropout2d factors of the step's image ride along with the halo loads.
-template <int NT, int CW, bool SH = false, bool PIPE = false, bool XF = false>
+// BWD: see k_conv_small -- the epilogue also loads the destination layer's Y at the tile's positions and accumulates sum(dz),
+// sum(dz * xhat) of the rounded dA it stores (the statistics registers and their block reduction are the forward's).
+template <int NT, int CW, bool SH = false, bool PIPE = false, bool XF = false, bool BWD = false>
 __global__ void __launch_bounds__(256, (CW == 64 && NT == 4) ? 1 : 2)
 k_conv_res(const ConvResArgs a) {
+    static_assert(!BWD || (NT <= 2 && !SH && !XF), "BWD: one or two n-tiles, double halo, plain input");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KSC = CW / 32, CH8 = CW / 8, LG8 = CW == 64 ? 3 : 2, SW = CH8 - 1;
     constexpr int HALO_BYTES = RES_HW * RES_HW * CW * 2;
@@ -1570,6 +1575,16 @@ k_conv_res(const ConvResArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) s1[t2][j] = s2[t2][j] = 0.f;
 
+    // BWD: this lane's channels of the destination layer's published statistics (the block walks tiles of ONE group)
+    float bw_mean[NT][4], bw_inv[NT][4], bw_sc[NT][4], bw_sh[NT][4];
+    if constexpr (BWD) {
+#pragma unroll
+        for (int t2 = 0; t2 < NT; ++t2) {
+            const float* st = a.bw_stat + (int64_t)grp * 4 * a.g.co + (slice * NT + t2) * 16 + 4 * q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bw_mean[t2][j] = st[j]; bw_inv[t2][j] = st[a.g.co + j]; bw_sc[t2][j] = st[2 * a.g.co + j]; bw_sh[t2][j] = st[3 * a.g.co + j]; }
+        }
+    }
     // tile walk inside the group: tiles bl, bl + P, ...
     const int tpg = a.ntiles / a.groups;
     const int tiles_img = a.tiles_x * a.tiles_y;
@@ -1682,6 +1697,25 @@ k_conv_res(const ConvResArgs a) {
     while (cur.tile < tile_end) {
         const bool have_next = nxt.tile < tile_end;
         if (have_next) RES_FETCH(nxt, preA, xsA);
+        uint2 bw_y[4][NT];                 // BWD: Y of this tile's four rows (this lane's channels), in flight under the last step's MFMAs
+        float4 bw_mk[NT];
+        if constexpr (BWD) {
+            if (cur.c == nsteps - 1) {
+                const int mxb = cur.x * 16 + r;
+                const bf16* yb = a.bw_Y + (((int64_t)cur.n * a.g.ho + cur.y * 16 + wid * 4) * a.g.wo + mxb) * a.bw_ldy + slice * NT * 16 + 4 * q;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const bool in_ = cur.y * 16 + wid * 4 + m < a.g.hm && mxb < a.g.wm;
+#pragma unroll
+                    for (int t2 = 0; t2 < NT; ++t2)
+                        bw_y[m][t2] = in_ ? *reinterpret_cast<const uint2*>(yb + (int64_t)m * a.g.wo * a.bw_ldy + t2 * 16) : make_uint2(0u, 0u);
+                }
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2)
+                    bw_mk[t2] = a.bw_mask ? *reinterpret_cast<const float4*>(a.bw_mask + (int64_t)cur.n * a.g.co + (slice * NT + t2) * 16 + 4 * q)
+                                          : make_float4(1.f, 1.f, 1.f, 1.f);
+            }
+        }
         const char* hb = halo0 + (SH ? 0 : buf) * HALO_BYTES;
         if constexpr (PIPE) {
             constexpr int NSTG = KSC * 3;
@@ -1772,7 +1806,20 @@ k_conv_res(const ConvResArgs a) {
                         for (int j = 0; j < 4; ++j)
                             if (cb + j < a.g.co) o[j] = (bf16)v[j];
                     }
-                    if (want_stats) {
+                    if constexpr (BWD) {
+                        const float y[4] = {__uint_as_float(bw_y[m][t2].x << 16), __uint_as_float(bw_y[m][t2].x & 0xffff0000u),
+                                            __uint_as_float(bw_y[m][t2].y << 16), __uint_as_float(bw_y[m][t2].y & 0xffff0000u)};
+                        const float mk[4] = {bw_mk[t2].x, bw_mk[t2].y, bw_mk[t2].z, bw_mk[t2].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {       // the arithmetic of k_bn_reduce<T, 1> on the rounded dA
+                            const float rv = round_as<bf16>(v[j]);
+                            const float z = y[j] * bw_sc[t2][j] + bw_sh[t2][j];
+                            float dz = rv * mk[j];
+                            if (!(z > 0.f)) dz = 0.f;
+                            s1[t2][j] += dz;
+                            s2[t2][j] += dz * (y[j] - bw_mean[t2][j]) * bw_inv[t2][j];
+                        }
+                    } else if (want_stats) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float rv = round_as<bf16>(v[j]);
@@ -1896,11 +1943,20 @@ ConvResPlan conv_res_plan(const stcd_conv_geom& g, const ConvMfmaPlan& p, int gr
     return rp;
 }
 
+bool conv_res_bwdsum_ok(const stcd_conv_geom& g, const ConvResPlan& rp) {
+    return rp.ok && !rp.single_halo && rp.NT <= 2 && g.co % (rp.NT * 16) == 0 && g.out_stride == 1 && g.oy0 == 0 && g.ox0 == 0;
+}
 int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvResPlan& rp, const void* in, const void* wf,
                     const float* bias, void* out, int groups, long long* stat_acc, int cpad, hipStream_t s, int stat_c0, float s1_scale,
-                    float s2_scale, const XfSrc* xf) {
+                    float s2_scale, const XfSrc* xf, const BwdSum* bs) {
     if (!rp.ok) return 1;
     ConvResArgs a;
+    a.bw_Y = nullptr; a.bw_ldy = 0; a.bw_stat = nullptr; a.bw_mask = nullptr;
+    if (bs) {
+        if (!conv_res_bwdsum_ok(g, rp) || stat_acc || (xf && xf->on) || bs->groups != groups || !bs->acc) return 1;
+        a.bw_Y = (const bf16*)bs->Y; a.bw_ldy = bs->ldy; a.bw_stat = bs->stat; a.bw_mask = bs->mask;
+        stat_acc = bs->acc; cpad = g.co; stat_c0 = 0; s1_scale = BN_BS; s2_scale = BN_BS;
+    }
     a.g = g;
     a.in = (const bf16*)in; a.wf = (const bf16*)wf; a.bias = bias; a.out = (bf16*)out;
     a.NTtot = p.NTtot; a.KSp = p.CiB / 32; a.nchunks = g.ci / 32;
@@ -1943,7 +1999,20 @@ int launch_conv_res(const stcd_conv_geom& g, const ConvMfmaPlan& p, const ConvRe
         }                                                                                                         \
         k_conv_res<N_, 32, true><<<(unsigned)rp.blocks, 256, (size_t)rp.lds_bytes, s>>>(a);                       \
     } while (0)
-    if (rp.single_halo) {
+    if (bs) {
+#define LAUNCH_RES_BWD(N_, W_, P_)                                                                                \
+    do {                                                                                                          \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute((const void*)k_conv_res<N_, W_, false, P_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        k_conv_res<N_, W_, false, P_, false, true><<<(unsigned)rp.blocks, 256, lds, s>>>(a);                      \
+    } while (0)
+        if (rp.CW == 64) { if (rp.NT == 1) LAUNCH_RES_BWD(1, 64, false); else LAUNCH_RES_BWD(2, 64, false); }
+        else { if (rp.NT == 1) LAUNCH_RES_BWD(1, 32, false); else LAUNCH_RES_BWD(2, 32, false); }
+#undef LAUNCH_RES_BWD
+    } else if (rp.single_halo) {
         if (rp.NT == 2) LAUNCH_RES_SH(2); else LAUNCH_RES_SH(4);
     } else if (rp.CW == 64) {
         switch (rp.NT) {
