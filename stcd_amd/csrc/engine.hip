@@ -432,6 +432,7 @@ static const DecSpec DEC[4] = {
 static inline int fc_dates(const stcd_engine& e) { return e.arch == STCD_ARCH_FCEF ? 1 : 2; }
 static inline bool fc_concat_skips(const stcd_engine& e) { return e.arch == STCD_ARCH_CONC || e.arch == STCD_ARCH_FCEF; }
 static inline bool fc_cross(const stcd_engine& e) { return e.arch == STCD_ARCH_XCONC; }
+static inline int bwdsum_res_on() { static const int v = [] { const char* x = getenv("STCD_BWDSUM_RES"); return x ? atoi(x) : 0; }(); return v; }
 // skip layers of diff / sub whose activations are never stored: the forward writes only the pooled map and the fused skip,
 // the backward (k_skip_bwd_pair) recomputes them from Y
 static inline bool skip_recomputed(const stcd_engine& e, const Cbrd& L) {
@@ -953,7 +954,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         bind_wgrad(L.wg, geom3(L.N, L.H, L.W, L.K, L.in.ld, cv.cout, L.dY.ld), L.conv, 0, cv.cin, cv.cout, L.in.off, L.dY.off);
         if (L.has_dIn)      // (tiles partitioned by the layer's BatchNorm groups: its data gradient may carry the previous layer's backward sums)
             bind_conv(L.dgr, geom3(L.N, L.H, L.W, cv.dgrad.kpad, L.dY.ld, cv.cin, L.dIn.ld), L.conv, true, 0, cv.cout, cv.cin,
-                      e.use_bwdsum ? L.groups : 1);
+                      (e.use_bwdsum && bwdsum_res_on()) ? L.groups : 1);
     };
     for (auto& L : e.enc) bind_cbrd(L);
     for (auto& L : e.dec) bind_cbrd(L);
@@ -998,7 +999,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         // STCD_BWDSUM_RES=1: also the layers behind a k_conv_res data gradient (k_conv_res<.., BWD>, one or two n-tiles).  Measured: eight
         // more launches gone (114 -> 106), bn_bwd_reduce 0.150 -> 0.055 ms, conv 0.970 -> 1.052 ms: the step 2.094 -> 2.114 ms (diff), conc
         // 2.433 -> 2.475 -- the resident-filter kernel pays more for 56 extra registers and the Y loads than the small launches cost.  Opt-in.
-        static const int res_too = [] { const char* v = getenv("STCD_BWDSUM_RES"); return v ? atoi(v) : 0; }();
+        const int res_too = bwdsum_res_on();
         auto dest_ok = [&](const Cbrd& P, const ConvOp& dgr, int64_t dIn_off, int dIn_ld, int N) {
             const bool kern = (dgr.small && conv_small_bwdsum_ok(dgr.g)) ||
                               (res_too && !dgr.small && !dgr.gemm.ok && e.use_res && dgr.res.ok && dgr.res_groups == P.groups &&
