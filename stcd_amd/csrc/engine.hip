@@ -273,7 +273,7 @@ struct stcd_engine_impl {
     int64_t final_bias_acc = -1;
     std::vector<BiasJob> bias_jobs; int64_t bias_jobs_off = -1;
     int64_t masks = -1, dwe_begin = -1, dwe_end = -1, scratch8 = -1;
-    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1, use_act_fuse = 1, use_gemm = 1, use_skip_recompute = 1, wg_tail_split = 0, use_bwdsum = 1;
+    int use_mfma = 1, use_small = 1, use_wgroup = 1, wgroup_min_tiles = 8, wgroup_rounds = 1, use_res = 1, use_skip_fused = 1, use_act_fuse = 1, use_gemm = 1, use_skip_recompute = 1, wg_tail_split = 0, use_bwdsum = 1, use_bwdsum_res = 0;
     // FC-Siam backward: the decoder's grouped weight gradients (+ slab reduce, bias finish) run on a low-priority side stream beside
     // the encoder's backward chain on the caller's stream; their grids get 1 / wg_side_div of the planner's block budget so that the
     // chain's blocks find free slots (wgrad_side_stream)
@@ -432,7 +432,6 @@ static const DecSpec DEC[4] = {
 static inline int fc_dates(const stcd_engine& e) { return e.arch == STCD_ARCH_FCEF ? 1 : 2; }
 static inline bool fc_concat_skips(const stcd_engine& e) { return e.arch == STCD_ARCH_CONC || e.arch == STCD_ARCH_FCEF; }
 static inline bool fc_cross(const stcd_engine& e) { return e.arch == STCD_ARCH_XCONC; }
-static inline int bwdsum_res_on() { static const int v = [] { const char* x = getenv("STCD_BWDSUM_RES"); return x ? atoi(x) : 0; }(); return v; }
 // skip layers of diff / sub whose activations are never stored: the forward writes only the pooled map and the fused skip,
 // the backward (k_skip_bwd_pair) recomputes them from Y
 static inline bool skip_recomputed(const stcd_engine& e, const Cbrd& L) {
@@ -954,7 +953,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         bind_wgrad(L.wg, geom3(L.N, L.H, L.W, L.K, L.in.ld, cv.cout, L.dY.ld), L.conv, 0, cv.cin, cv.cout, L.in.off, L.dY.off);
         if (L.has_dIn)      // (tiles partitioned by the layer's BatchNorm groups: its data gradient may carry the previous layer's backward sums)
             bind_conv(L.dgr, geom3(L.N, L.H, L.W, cv.dgrad.kpad, L.dY.ld, cv.cin, L.dIn.ld), L.conv, true, 0, cv.cout, cv.cin,
-                      (e.use_bwdsum && bwdsum_res_on()) ? L.groups : 1);
+                      (e.use_bwdsum && e.use_bwdsum_res) ? L.groups : 1);
     };
     for (auto& L : e.enc) bind_cbrd(L);
     for (auto& L : e.dec) bind_cbrd(L);
@@ -999,7 +998,7 @@ static int configure_fcsiam(stcd_engine& e, int B, int H, int W) {
         // STCD_BWDSUM_RES=1: also the layers behind a k_conv_res data gradient (k_conv_res<.., BWD>, one or two n-tiles).  Measured: eight
         // more launches gone (114 -> 106), bn_bwd_reduce 0.150 -> 0.055 ms, conv 0.970 -> 1.052 ms: the step 2.094 -> 2.114 ms (diff), conc
         // 2.433 -> 2.475 -- the resident-filter kernel pays more for 56 extra registers and the Y loads than the small launches cost.  Opt-in.
-        const int res_too = bwdsum_res_on();
+        const int res_too = e.use_bwdsum_res;
         auto dest_ok = [&](const Cbrd& P, const ConvOp& dgr, int64_t dIn_off, int dIn_ld, int N) {
             const bool kern = (dgr.small && conv_small_bwdsum_ok(dgr.g)) ||
                               (res_too && !dgr.small && !dgr.gemm.ok && e.use_res && dgr.res.ok && dgr.res_groups == P.groups &&
@@ -2866,6 +2865,8 @@ static void engine_env_switches(stcd_engine* e) {
     e->wg_tail_split = env && env[0] == '1';      //    goes out ~120 us earlier (measured neutral: the step is HBM-bound)
     env = getenv("STCD_NO_BWDSUM_FUSE");          // 1: every layer runs its own k_bn_reduce (no sums in k_conv_small data gradients)
     e->use_bwdsum = !(env && env[0] == '1');
+    env = getenv("STCD_BWDSUM_RES");              // 1: also the layers behind a k_conv_res data gradient (measured slower, see configure_fcsiam)
+    e->use_bwdsum_res = env && env[0] == '1';
     env = getenv("STCD_VIRT_ACT");                // 1: virtual activations (opt-in); 0 / unset: k_bn_act per layer
     if (env) e->use_virt = atoi(env) != 0;
     env = getenv("STCD_XF_MODE");
